@@ -1,0 +1,180 @@
+"""Synthetic factor graphs for the measurement workloads of SURVEY.md 8(d).
+
+The MRF layout mirrors how LP_MP-MRF's FMC_SRMP uses the reference containers (SURVEY.md A.5 and
+Appendix B): factor type 0 = unary simplex, factor type 1 = pairwise (dense or Potts); two message
+types, one per pairwise side, unary = left factor, schedule ``left``, unary side variable count,
+pairwise side exactly 1; relations ``u_i -> p_ij -> u_j`` for i < j in the variable order.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import model as M
+
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def u01(n: int, seed: int, first: int = 0) -> np.ndarray:
+    """Counter-based uniforms in [0,1): splitmix64 finaliser of seed + (first+i+1)*GOLDEN.
+    Bit-identical to the engine's device generator (lpmp_synth_fill) and the oracle's orc_synth_u01."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (np.arange(first + 1, first + n + 1, dtype=np.uint64)) * _GOLD
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def mrf_mtypes():
+    return [M.MsgType(0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, M.M_UNARY_PAIRWISE, 0),
+            M.MsgType(0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, M.M_UNARY_PAIRWISE, 1)]
+
+
+def grid_variable_order(H: int, W: int, order: str) -> np.ndarray:
+    """var[r, c] = index of the variable in the insertion / relation order."""
+    if order == "row_major":
+        return np.arange(H * W, dtype=np.int64).reshape(H, W)
+    if order == "colour_major":
+        rr, cc = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        black = ((rr + cc) % 2 == 0).reshape(-1)
+        var = np.empty(H * W, np.int64)
+        nb = int(black.sum())
+        var[black] = np.arange(nb)
+        var[~black] = nb + np.arange(H * W - nb)
+        return var.reshape(H, W)
+    raise ValueError(order)
+
+
+def grid_edges(H: int, W: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Edges in row-major node order, right edge then down edge per node; returns (a, b) as flat r*W+c."""
+    rr, cc = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    node = (rr * W + cc)
+    right_ok = cc < W - 1
+    down_ok = rr < H - 1
+    # interleave: for each node, right then down
+    a = np.stack([node, node], -1).reshape(-1)
+    b = np.stack([node + 1, node + W], -1).reshape(-1)
+    ok = np.stack([right_ok, down_ok], -1).reshape(-1)
+    return a[ok], b[ok]
+
+
+def mrf_model(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, unaries: np.ndarray,
+              tables: Optional[np.ndarray] = None, potts: Optional[np.ndarray] = None,
+              device_const: bool = False) -> M.FlatModel:
+    """MRF over variables 0..n_vars-1 (already in variable order) with edges (i<j required).
+    ``tables`` [E,L,L] (T[e,a,b]: a = label of i) or ``potts`` [E] diffs. With ``device_const`` the dense
+    tables are not materialised on the host (they are generated in HBM; see Engine.upload)."""
+    edge_i = np.asarray(edge_i, np.int64)
+    edge_j = np.asarray(edge_j, np.int64)
+    assert np.all(edge_i < edge_j)
+    b = M.ModelBuilder(2, mrf_mtypes())
+    b.skip_const = device_const
+    u = b.add_vector_factors(0, np.asarray(unaries, np.float64).reshape(n_vars, L))
+    E = edge_i.shape[0]
+    if potts is not None:
+        assert not device_const
+        p = b.add_potts_pairwise(1, L, potts)
+    elif device_const:
+        p = b.add_dense_pairwise(1, None, n=E, dims=(L, L))
+    else:
+        p = b.add_dense_pairwise(1, np.asarray(tables, np.float64).reshape(E, L, L))
+    # add_message<ML>(u_i, p); add_message<MR>(u_j, p) per edge, interleaved like the reference's MRF constructor
+    mt = np.tile(np.array([0, 1], np.int32), E)
+    left = np.stack([u[edge_i], u[edge_j]], 1).reshape(-1)
+    right = np.repeat(p, 2)
+    b.add_interleaved_messages(mt, left, right)
+    # AddFactorRelation(u_i, p); AddFactorRelation(p, u_j)
+    f1 = np.stack([u[edge_i], p], 1).reshape(-1)
+    f2 = np.stack([p, u[edge_j]], 1).reshape(-1)
+    b.add_relations(f1, f2)
+    return b.finish()
+
+
+def grid_model(H: int, W: int, L: int, pairwise: str = "dense", order: str = "row_major", seed: int = 1,
+               unaries: Optional[np.ndarray] = None, tables: Optional[np.ndarray] = None,
+               potts: Optional[np.ndarray] = None, device_const: bool = False) -> M.FlatModel:
+    """H x W grid MRF.  Random costs are U(0,1) from the counter-based generator: unaries first
+    (variable order), then the pairwise data edge by edge (edge order of grid_edges)."""
+    var = grid_variable_order(H, W, order).reshape(-1)
+    a, bb = grid_edges(H, W)
+    va, vb = var[a], var[bb]
+    i, j = np.minimum(va, vb), np.maximum(va, vb)
+    n = H * W
+    E = i.shape[0]
+    if unaries is None:
+        unaries = u01(n * L, seed, 0)
+    if pairwise == "dense":
+        if tables is None and not device_const:
+            tables = u01(E * L * L, seed, n * L)
+        return mrf_model(n, L, i, j, unaries, tables=tables, device_const=device_const)
+    if pairwise == "potts":
+        if potts is None:
+            potts = u01(E, seed, n * L)
+        return mrf_model(n, L, i, j, unaries, potts=potts)
+    raise ValueError(pairwise)
+
+
+def chain_model(n: int, L: int, diff: float = 1.0, seed: int = 1) -> M.FlatModel:
+    """C1: Potts chain, n variables, L labels (BASELINE.json configs[0])."""
+    i = np.arange(n - 1)
+    return mrf_model(n, L, i, i + 1, u01(n * L, seed, 0), potts=np.full(n - 1, diff))
+
+
+def random_graph_model(n: int, m: int, L: int, seed: int = 1, pairwise: str = "dense") -> M.FlatModel:
+    """C4-style G(n, m): m distinct uniform random edges without self loops, variable order = index."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    got = np.zeros((0, 2), np.int64)
+    while got.shape[0] < m:
+        need = int((m - got.shape[0]) * 1.2) + 16
+        e = rng.integers(0, n, size=(need, 2))
+        e = e[e[:, 0] != e[:, 1]]
+        e = np.stack([e.min(1), e.max(1)], 1)
+        got = np.unique(np.concatenate([got, e]), axis=0)
+    perm = rng.permutation(got.shape[0])[:m]
+    e = got[np.sort(perm)]
+    un = u01(n * L, seed, 0)
+    if pairwise == "dense":
+        return mrf_model(n, L, e[:, 0], e[:, 1], un, tables=u01(m * L * L, seed, n * L))
+    return mrf_model(n, L, e[:, 0], e[:, 1], un, potts=u01(m, seed, n * L))
+
+
+# ---- labeling-list (multicut-style) models: reference include/factors/labeling_list_factor.hxx ----
+EDGE_LABELINGS = [(1,)]
+TRIPLET_LABELINGS = [(0, 1, 1), (1, 0, 1), (1, 1, 0), (1, 1, 1)]
+
+
+def multicut_mtypes():
+    """edge factor (type 0, left) <-> triplet factor (type 1, right), one message type per triplet position;
+    tables are added in the same order by multicut_builder."""
+    return [M.MsgType(0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, M.M_LABELING, k) for k in range(3)]
+
+
+def multicut_builder() -> M.ModelBuilder:
+    b = M.ModelBuilder(2, multicut_mtypes())
+    for k in range(3):
+        b.add_labeling_table(EDGE_LABELINGS, TRIPLET_LABELINGS, (k,))
+    return b
+
+
+def multicut_triangle_model(n_nodes: int, n_triangles: int, seed: int = 1) -> M.FlatModel:
+    """Random multicut-style instance: edge factors (1 labeling, implicit origin) on the edges of random
+    triangles, triplet factors (4 labelings, implicit origin), costs U(-1,1)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tris = np.sort(np.stack([rng.choice(n_nodes, 3, replace=False) for _ in range(n_triangles)]), 1)
+    edges = {}
+    for t in tris:
+        for (x, y) in ((t[0], t[1]), (t[0], t[2]), (t[1], t[2])):
+            edges.setdefault((int(x), int(y)), len(edges))
+    b = multicut_builder()
+    ecost = 2.0 * u01(len(edges), seed, 0) - 1.0
+    e_ids = b.add_vector_factors(0, ecost.reshape(-1, 1), implicit_origin=True)
+    tcost = np.zeros((n_triangles, 4))
+    t_ids = b.add_vector_factors(1, tcost, implicit_origin=True)
+    for ti, t in enumerate(tris):
+        for k, (x, y) in enumerate(((t[0], t[1]), (t[0], t[2]), (t[1], t[2]))):
+            e = e_ids[edges[(int(x), int(y))]]
+            b.add_messages(k, e, t_ids[ti])
+            b.add_relations(e, t_ids[ti])
+    return b.finish()
