@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — message updates/sec of the LP_MP dual block-coordinate-ascent sweep on MI355X.
+
+One "step" = one LP::ComputePass (forward + backward sweep, reference include/LP_MP.h:869-887) over the
+workload of BASELINE.json configs[2]: 1024x1024 grid MRF, 32 labels, dense pairwise tables, anisotropic
+weights.  One message update = one executed receive or send.  Inputs are generated
+in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 1024] [--labels 32]
+                    [--order colour_major|row_major] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=1024)
+    ap.add_argument("--labels", type=int, default=32)
+    ap.add_argument("--pairwise", default="dense", choices=["dense", "potts"])
+    ap.add_argument("--order", default="colour_major", choices=["colour_major", "row_major"])
+    ap.add_argument("--mode", default="anisotropic")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-grid", type=int, default=256)
+    ap.add_argument("--also-row-major", action="store_true", help="also time the row-major ordering (extra key)")
+    return ap.parse_args()
+
+
+def build_device_grid(torch, H, W, L, pairwise, order, seed, engine_mod, synthetic, stream_ptr):
+    """Model structure on the host, costs generated directly in HBM (counter-based generator)."""
+    import numpy as np
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = H * W
+    n_e = len(synthetic.grid_edges(H, W)[0])
+    if pairwise == "dense":
+        m = synthetic.grid_model(H, W, L, order=order, seed=seed, device_const=True)
+        const = torch.empty(n_e * L * L, dtype=torch.float64, device=dev)
+        dual = torch.zeros(n * L + n_e * 2 * L, dtype=torch.float64, device=dev)
+    else:
+        m = synthetic.grid_model(H, W, L, pairwise="potts", order=order, seed=seed)
+        const = torch.empty(n_e, dtype=torch.float64, device=dev)
+        dual = torch.zeros(n * L + n_e * 2 * L, dtype=torch.float64, device=dev)
+    engine_mod.synth_fill(const.data_ptr(), const.numel(), seed, n * L, stream_ptr)
+    engine_mod.synth_fill(dual.data_ptr(), n * L, seed, 0, stream_ptr)
+    torch.cuda.synchronize()
+    return m, const, dual
+
+
+def time_passes(torch, dist, eng, steps, warmup, world):
+    eng.compute_pass(warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.compute_pass(steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(args, synthetic, M):
+    """The oracle (single-threaded C restatement of the reference sweep; the reference sweep is
+    single-threaded too) on a bounded sample of the same workload."""
+    from oracle.binding import Oracle
+    g = min(args.cpu_sample_grid, args.grid)
+    m = synthetic.grid_model(g, g, args.labels, pairwise=args.pairwise, order=args.order, seed=1)
+    o = Oracle(m)
+    o.set_reparametrization(M.REPAM_NAMES[args.mode])
+    o.ComputePass(1)
+    r0, s0 = o.counters()
+    passes = 0
+    t0 = time.perf_counter()
+    while True:
+        o.ComputePass(1)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or passes >= 50:
+            break
+    r1, s1 = o.counters()
+    return {"value": (r1 - r0 + s1 - s0) / dt, "unit": "msg-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{g}x{g} grid, {args.labels} labels, {args.pairwise} pairwise, {args.order}, {passes} passes, "
+                      f"oracle/lpmp_oracle.c single thread"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from lp_mp_amd import engine as E, model as M, synthetic as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    mode = M.REPAM_NAMES[args.mode]
+    H = W = args.grid
+    L = args.labels
+    stream_ptr = torch.cuda.current_stream().cuda_stream
+
+    if world == 1:
+        m, const, dual = build_device_grid(torch, H, W, L, args.pairwise, args.order, 1, E, S, stream_ptr)
+        eng = E.Engine(torch.cuda.current_device())
+        eng.set_stream(stream_ptr)
+        eng.upload(m, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual))
+        eng.set_reparametrization(mode)
+        runner = eng
+        info = [eng.plan.schedule_info(d, mode) for d in (0, 1)]
+        updates_per_pass = sum(i["n_receives"] + i["n_sends"] for i in info)
+        bytes_per_pass = sum(i["algorithmic_bytes"] for i in info)
+        levels = [i["n_levels"] for i in info]
+        parallelism = "1 GPU"
+    else:
+        from lp_mp_amd import multi_gpu as MG
+        runner = MG.StripSweep(torch, dist, H, W, L, args.pairwise, args.order, mode, seed=1)
+        updates_per_pass = runner.global_updates_per_pass
+        bytes_per_pass = runner.global_bytes_per_pass
+        levels = runner.levels
+        eng = runner.engine
+        parallelism = f"{world} row strips of {H}x{W}, cut-edge exchange once per sweep"
+
+    lb0 = runner.lower_bound()
+    dt = time_passes(torch, dist, runner, args.steps, args.warmup, world)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    lb1 = runner.lower_bound()
+
+    # roofline leg: the same passes again with every launch bracketed by HIP events on the engine's stream
+    eng.reset_kernel_timing()
+    eng.enable_kernel_timing(True)
+    runner.compute_pass(args.steps)
+    torch.cuda.synchronize()
+    kt = eng.kernel_timing()
+    eng.enable_kernel_timing(False)
+
+    out = None
+    if rank == 0:
+        value = updates_per_pass * args.steps / dt
+        dom = max(kt.items(), key=lambda kv: kv[1]["ms"]) if kt else None
+        roof = None
+        if dom:
+            k = dom[1]
+            avg_ms = k["ms"] / k["launches"]
+            achieved = (k["bytes"] / k["launches"]) / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": k["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "launches": k["launches"], "algorithmic_bytes_per_launch": k["bytes"] / k["launches"]}
+        out = {
+            "metric": "message updates/sec, 32-label grid MRF sweep (LP::ComputePass)" if L == 32 else "message updates/sec, grid MRF sweep (LP::ComputePass)",
+            "value": value, "unit": "msg-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{H}x{W} grid per GPU, {L} labels, {args.pairwise} pairwise, {args.mode} weights, "
+                                   f"{args.order} order", "parallelism": parallelism,
+                       "levels_per_direction": levels, "msg_updates_per_pass": updates_per_pass,
+                       "algorithmic_bytes_per_pass": bytes_per_pass},
+            "pass_algorithmic_GBps": bytes_per_pass * args.steps / dt / 1e9,
+            "lower_bound_before": lb0, "lower_bound_after": lb1,
+            "kernels": kt,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, S, M)
+    if world == 1 and args.also_row_major and args.order != "row_major":
+        del eng, runner
+        m, const, dual = build_device_grid(torch, H, W, L, args.pairwise, "row_major", 1, E, S, stream_ptr)
+        e2 = E.Engine(torch.cuda.current_device())
+        e2.set_stream(stream_ptr)
+        e2.upload(m, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual))
+        e2.set_reparametrization(mode)
+        i2 = [e2.plan.schedule_info(d, mode) for d in (0, 1)]
+        dt2 = time_passes(torch, dist, e2, args.steps, args.warmup, 1)
+        upd2 = sum(i["n_receives"] + i["n_sends"] for i in i2)
+        out["row_major"] = {"value": upd2 * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3,
+                            "levels_per_direction": [i["n_levels"] for i in i2], "lower_bound_after": e2.lower_bound()}
+        e2.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+/*
+ * lpmp_engine.h — C ABI of the MI355X sweep engine (liblpmp_engine.so).
+ *
+ * This is the drop-in boundary for ONE path of pawelswoboda/LP_MP: the dual block-coordinate-ascent
+ * sweep LP<FMC>::ComputePass and the dual bound LP<FMC>::LowerBound.  The reference's plug-in API is
+ * compile-time C++ (FactorContainer / MessageContainer / LP<FMC> templates); the host-side mirrors
+ * (lp_mp_amd/include/LP_gpu.hxx for C++, lp_mp_amd/lp.py for Python) keep that surface and talk to the
+ * device through the functions below.  Plain pointers and sizes only; no exceptions cross this
+ * boundary; every function returns 0 on success or a negative lpmp_status and sets
+ * lpmp_last_error().  The host-side mirrors re-throw std::runtime_error, the type the reference throws
+ * (reference include/LP_MP.h:458, include/topological_sort.hxx:115).
+ *
+ * Conventions (mirroring how the reference is used):
+ *   - single caller thread per handle (the reference's Solve loop is single-threaded and its static
+ *     arenas are not thread-safe, include/factors_messages.hxx:3369-3370);
+ *   - host arrays passed in are borrowed for the duration of the call; device arrays passed to
+ *     lpmp_upload_model with LPMP_MEM_DEVICE are borrowed until lpmp_destroy / the next upload;
+ *   - any structural change on the host side (everything that calls set_flags_dirty in the reference,
+ *     include/LP_MP.h:1623) requires a new lpmp_upload_model.
+ *
+ * Citations are relative to /root/reference.
+ */
+#ifndef LPMP_ENGINE_H
+#define LPMP_ENGINE_H
+
+#include <stdint.h>
+#include "lpmp_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lpmp_engine lpmp_engine;
+typedef struct lpmp_plan lpmp_plan;
+
+enum lpmp_status {
+  LPMP_OK = 0,
+  LPMP_ERR_INVALID = -1,     /* bad argument / malformed model (reference: assert / runtime_error) */
+  LPMP_ERR_UNSUPPORTED = -2, /* valid in the reference but not executable on the device */
+  LPMP_ERR_DEVICE = -3,      /* HIP error, or no GPU */
+  LPMP_ERR_STATE = -4        /* call order (e.g. ComputePass before set_reparametrization, LP_MP.h:414,458) */
+};
+
+enum lpmp_mem { LPMP_MEM_HOST = 0, LPMP_MEM_DEVICE = 1 };
+
+const char* lpmp_last_error(void);
+const char* lpmp_version(void);
+
+/* ---- host-only analysis (no GPU needed) -------------------------------------------------------
+ * Replaces LP::SortFactors (include/LP_MP.h:730-797), LP::get_omega (:412-460) and the weight
+ * routines (:1086-1154, :1232-1449, :1489-1505); FactorContainer::get_messages
+ * (include/factors_messages.hxx:3339-3365).  The cost arrays of the model are not read. */
+int lpmp_plan_create(const lpmp_model* m, lpmp_plan** out);
+void lpmp_plan_destroy(lpmp_plan* p);
+int64_t lpmp_plan_n_factors(const lpmp_plan* p);
+int64_t lpmp_plan_n_updated(const lpmp_plan* p, int direction);
+int lpmp_plan_get_order(const lpmp_plan* p, int direction, int32_t* out /*[n_factors]*/);          /* forwardOrdering_ */
+int lpmp_plan_get_update_order(const lpmp_plan* p, int direction, int32_t* out /*[n_updated]*/);  /* forwardUpdateOrdering_ */
+int64_t lpmp_plan_omega_nnz(lpmp_plan* p, int direction);
+int64_t lpmp_plan_mask_nnz(lpmp_plan* p, int direction);
+int lpmp_plan_get_omega(lpmp_plan* p, int direction, int mode, int64_t* off /*[n_updated+1]*/, double* data);
+int lpmp_plan_get_mask(lpmp_plan* p, int direction, int mode, int64_t* off /*[n_updated+1]*/, uint8_t* data);
+int lpmp_plan_get_msg_lists(const lpmp_plan* p, int64_t* off /*[n_factors+1]*/, int64_t* entries /*[2*n_messages]: msg*2+role*/);
+/* ComputeAnisotropicWeights on an arbitrary ordered factor list (include/LP_MP.h:1232-1415, incl. the
+ * strict-subset rules); rows = updated members of the list.  Call with om == NULL to query sizes. */
+int lpmp_plan_anisotropic_weights(const lpmp_plan* p, int64_t n, const int32_t* factors, int64_t* n_rows,
+                                  int64_t* om_nnz, int64_t* mk_nnz, int64_t* om_off, double* om, int64_t* mk_off,
+                                  uint8_t* mk);
+/* level schedule of a built-in sweep: levels = dependent steps, launches = kernel launches */
+int lpmp_plan_schedule_info(lpmp_plan* p, int direction, int mode, int64_t* n_levels, int64_t* n_launches,
+                            int64_t* n_receives, int64_t* n_sends, int64_t* algorithmic_bytes);
+
+/* ---- device engine --------------------------------------------------------------------------- */
+/* LP<FMC>::LP(cmd) (include/LP_MP.h:589-593).  device = HIP device ordinal. */
+int lpmp_create(int device, lpmp_engine** out);
+void lpmp_destroy(lpmp_engine* e);
+/* run all work on this hipStream_t (default: a stream owned by the engine) */
+int lpmp_set_stream(lpmp_engine* e, void* hip_stream);
+
+/* add_factor / add_message / AddFactorRelation, flattened (include/LP_MP.h:239-285, :698-702), plus the
+ * packed duals as serialize_dual lists them (include/factors_messages.hxx:3196-3223).
+ * const_mem / dual_mem say where m->const_data / m->dual_data live. */
+int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int dual_mem);
+
+int lpmp_set_reparametrization(lpmp_engine* e, int mode);   /* LP::set_reparametrization, LP_MP.h:330 */
+int lpmp_compute_pass(lpmp_engine* e, int n_passes);        /* LP::ComputePass, LP_MP.h:869-887 ('shared') */
+int lpmp_compute_forward_pass(lpmp_engine* e);              /* LP::ComputeForwardPass, LP_MP.h:889-900 */
+int lpmp_compute_backward_pass(lpmp_engine* e);             /* LP::ComputeBackwardPass, LP_MP.h:902-911 */
+/* LP::ComputePass(factorIt, factorItEnd, omegaIt, receive_it), LP_MP.h:981-1005: any factor list with
+ * any weights / masks (one row per listed factor). */
+int lpmp_compute_pass_custom(lpmp_engine* e, int64_t n, const int32_t* factors, const int64_t* om_off,
+                             const double* om, const int64_t* mk_off, const uint8_t* mk);
+int lpmp_lower_bound(lpmp_engine* e, double* out);          /* LP::LowerBound, LP_MP.h:1507-1518 */
+int lpmp_factor_lower_bounds(lpmp_engine* e, double* out /*[n_factors], host*/); /* FactorTypeAdapter::LowerBound */
+int lpmp_synchronize(lpmp_engine* e);
+
+int64_t lpmp_dual_size(const lpmp_engine* e);
+/* serialize_dual + save_archive / load_archive (include/serialization.hxx:228-424): packed duals */
+int lpmp_download_duals(lpmp_engine* e, double* host_out);
+int lpmp_upload_duals(lpmp_engine* e, const double* host_in);
+void* lpmp_device_duals(lpmp_engine* e);   /* device pointer of the packed duals (for zero-copy exchange) */
+
+const lpmp_plan* lpmp_engine_plan(const lpmp_engine* e);
+lpmp_plan* lpmp_engine_plan_mut(lpmp_engine* e);
+
+/* kernel timing with HIP events on the engine's stream (bench.py roofline leg).  While enabled every
+ * sweep launch is bracketed by an event pair.  Classes: enum KClass in lp_mp_amd/csrc/plan.hpp. */
+int lpmp_enable_kernel_timing(lpmp_engine* e, int on);
+int lpmp_get_kernel_timing(lpmp_engine* e, int n_classes, double* ms /*[n]*/, int64_t* launches /*[n]*/,
+                           int64_t* factors /*[n]*/, int64_t* receives /*[n]*/, int64_t* bytes /*[n]*/);
+int lpmp_reset_kernel_timing(lpmp_engine* e);
+
+/* synthetic workloads: out[i] = u01(splitmix64(seed + (first+i+1)*GOLDEN)) written on the device */
+int lpmp_synth_fill(void* device_ptr, int64_t n, uint64_t seed, uint64_t first, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPMP_ENGINE_H */

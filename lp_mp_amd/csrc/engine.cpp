@@ -1,0 +1,552 @@
+// engine.cpp — the C ABI of include/lpmp_engine.h: device memory, schedules, launches.
+// Host code only; the kernels are in kernels.hip.  There is NO CPU execution path: every compute
+// entry point needs a HIP device and fails with LPMP_ERR_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/lpmp_engine.h"
+#include "plan.hpp"
+
+namespace lpmp {
+void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
+                  int64_t first, int64_t count, hipStream_t s);
+void launch_factor_lb(const void* recs, const double* dual, const double* cdata, double* out, int64_t count, hipStream_t s);
+bool launch_dense_lb(int L, const void* recs, const double* dual, const double* cdata, double* out, int64_t first, int64_t count, hipStream_t s);
+void launch_sum_stage(const double* in, double* out, int64_t n, int64_t per_block, int64_t n_blocks, hipStream_t s);
+void launch_synth_fill(double* out, int64_t n, uint64_t seed, uint64_t first, hipStream_t s);
+int generic_max_dual();
+struct LbRecHost { int64_t dual_off; int64_t const_off; int32_t d0, d1; int32_t kind_flags; int32_t pad; };
+}  // namespace lpmp
+
+using namespace lpmp;
+
+static thread_local std::string g_error;
+const char* lpmp_last_error(void) { return g_error.c_str(); }
+const char* lpmp_version(void) { return "lp_mp_amd 0.1 (gfx950)"; }
+
+namespace {
+
+struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct StateError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct UnsupportedError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw DeviceError(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <class F>
+int guarded(F&& f) {
+  try { f(); return LPMP_OK; }
+  catch (const DeviceError& e) { g_error = e.what(); return LPMP_ERR_DEVICE; }
+  catch (const StateError& e) { g_error = e.what(); return LPMP_ERR_STATE; }
+  catch (const UnsupportedError& e) { g_error = e.what(); return LPMP_ERR_UNSUPPORTED; }
+  catch (const std::bad_alloc&) { g_error = "out of host memory"; return LPMP_ERR_INVALID; }
+  catch (const std::exception& e) { g_error = e.what(); return LPMP_ERR_INVALID; }
+}
+
+struct DevSchedule {
+  UpdRec* recs = nullptr;
+  Op* ops = nullptr;
+  std::vector<LevelRange> launches;
+  int64_t n_levels = 0, n_recv = 0, n_send = 0, alg_bytes = 0;
+  hipGraphExec_t graph = nullptr;
+  void release() {
+    if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
+    if (recs) { (void)hipFree(recs); recs = nullptr; }
+    if (ops) { (void)hipFree(ops); ops = nullptr; }
+    launches.clear();
+  }
+};
+
+struct ClassTiming { double ms = 0; int64_t launches = 0, factors = 0, receives = 0, bytes = 0; };
+
+}  // namespace
+
+struct lpmp_plan { Plan p; Schedule sched_cache[2][LPMP_REPAM_COUNT]; bool have_sched[2][LPMP_REPAM_COUNT] = {{false}}; };
+
+static void plan_schedule(lpmp_plan* pl, int d, int mode) {
+  if (pl->have_sched[d][mode]) return;
+  pl->p.ensure_weights(mode);
+  const auto& om = pl->p.omega[d][mode];
+  const auto& mk = pl->p.mask[d][mode];
+  pl->p.make_schedule(pl->p.upd[d].data(), (int64_t)pl->p.upd[d].size(), om.off.data(), om.data.data(), mk.off.data(),
+                      mk.data.data(), pl->sched_cache[d][mode]);
+  pl->have_sched[d][mode] = true;
+}
+
+struct lpmp_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::unique_ptr<lpmp_plan> plan;
+  double* d_dual = nullptr; bool own_dual = false;
+  double* d_const = nullptr; bool own_const = false;
+  int32_t* d_tabs = nullptr;
+  LbRecHost* d_lbrecs = nullptr;
+  double* d_lb = nullptr; double* d_part = nullptr; double* h_part = nullptr;
+  struct LbRun { int cls; int64_t first, count; };
+  std::vector<LbRun> lb_runs;
+  DevSchedule sched[2][LPMP_REPAM_COUNT];
+  bool have_sched[LPMP_REPAM_COUNT] = {false, false, false, false};
+  int mode = -1;
+  bool use_graph = true;
+  bool timing = false;
+  ClassTiming ct[KC_COUNT];
+  struct Pending { hipEvent_t a, b; int cls; int64_t factors, receives, bytes; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+
+  void release_model() {
+    for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m) sched[d][m].release();
+    for (int m = 0; m < LPMP_REPAM_COUNT; ++m) have_sched[m] = false;
+    if (own_dual && d_dual) (void)hipFree(d_dual);
+    if (own_const && d_const) (void)hipFree(d_const);
+    d_dual = nullptr; d_const = nullptr; own_dual = own_const = false;
+    if (d_tabs) { (void)hipFree(d_tabs); d_tabs = nullptr; }
+    if (d_lbrecs) { (void)hipFree(d_lbrecs); d_lbrecs = nullptr; }
+    if (d_lb) { (void)hipFree(d_lb); d_lb = nullptr; }
+    if (d_part) { (void)hipFree(d_part); d_part = nullptr; }
+    if (h_part) { (void)hipHostFree(h_part); h_part = nullptr; }
+    lb_runs.clear();
+    plan.reset();
+    mode = -1;
+  }
+  hipEvent_t get_event() {
+    if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+    hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
+  }
+  void drain_timing() {
+    for (auto& p : pending) {
+      HIP_CHECK(hipEventSynchronize(p.b));
+      float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+      ClassTiming& c = ct[p.cls];
+      c.ms += ms; c.launches++; c.factors += p.factors; c.receives += p.receives; c.bytes += p.bytes;
+      event_pool.push_back(p.a); event_pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+};
+
+namespace {
+
+void upload_schedule(const Schedule& s, DevSchedule& d) {
+  d.release();
+  d.launches = s.launches; d.n_levels = s.n_levels; d.n_recv = s.n_recv; d.n_send = s.n_send; d.alg_bytes = s.alg_bytes;
+  if (!s.recs.empty()) {
+    HIP_CHECK(hipMalloc((void**)&d.recs, s.recs.size() * sizeof(UpdRec)));
+    HIP_CHECK(hipMemcpy(d.recs, s.recs.data(), s.recs.size() * sizeof(UpdRec), hipMemcpyHostToDevice));
+  }
+  if (!s.ops.empty()) {
+    HIP_CHECK(hipMalloc((void**)&d.ops, s.ops.size() * sizeof(Op)));
+    HIP_CHECK(hipMemcpy(d.ops, s.ops.data(), s.ops.size() * sizeof(Op), hipMemcpyHostToDevice));
+  }
+}
+
+void check_generic_limits(const Plan& p, const Schedule& s) {
+  const int lim = generic_max_dual();
+  for (const auto& lr : s.launches) {
+    if (lr.kclass != KC_GENERIC) continue;
+    for (int64_t i = lr.begin; i < lr.end; ++i) {
+      const UpdRec& r = s.recs[i];
+      const int own = (r.kind_flags & 15) == LPMP_F_VECTOR ? r.d0 : r.d0 + r.d1;
+      if (own > lim) throw UnsupportedError("factor " + std::to_string(r.factor) + ": dual size " + std::to_string(own) + " exceeds the device limit " + std::to_string(lim));
+      for (int k = 0; k < r.n_recv + r.n_send; ++k)
+        if (s.ops[r.op_begin + k].len > lim) throw UnsupportedError("message too long for the device kernels");
+    }
+  }
+  (void)p;
+}
+
+void ensure_device_schedules(lpmp_engine* e, int mode) {
+  if (e->have_sched[mode]) return;
+  for (int d = 0; d < 2; ++d) {
+    plan_schedule(e->plan.get(), d, mode);
+    check_generic_limits(e->plan->p, e->plan->sched_cache[d][mode]);
+    upload_schedule(e->plan->sched_cache[d][mode], e->sched[d][mode]);
+  }
+  e->have_sched[mode] = true;
+}
+
+void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed) {
+  for (const auto& lr : s.launches) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (timed) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, e->stream)); }
+    launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, lr.begin, lr.end - lr.begin, e->stream);
+    if (timed) {
+      HIP_CHECK(hipEventRecord(b, e->stream));
+      e->pending.push_back({a, b, lr.kclass, lr.end - lr.begin, lr.n_recv, lr.bytes});
+    }
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+// one sweep over a device schedule; long launch chains (row-major grids: one launch per anti-diagonal)
+// are captured once into a hipGraph and replayed
+void run_schedule(lpmp_engine* e, DevSchedule& s) {
+  if (s.launches.empty()) return;
+  if (e->timing) { issue_launches(e, s, true); if (e->pending.size() > 4096) e->drain_timing(); return; }
+  if (e->use_graph && s.launches.size() > 8) {
+    if (!s.graph) {
+      hipGraph_t g = nullptr;
+      HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+      try { issue_launches(e, s, false); }
+      catch (...) { (void)hipStreamEndCapture(e->stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
+      HIP_CHECK(hipStreamEndCapture(e->stream, &g));
+      HIP_CHECK(hipGraphInstantiate(&s.graph, g, nullptr, nullptr, 0));
+      HIP_CHECK(hipGraphDestroy(g));
+    }
+    HIP_CHECK(hipGraphLaunch(s.graph, e->stream));
+    return;
+  }
+  issue_launches(e, s, false);
+}
+
+void require_model(const lpmp_engine* e) { if (!e || !e->plan) throw StateError("no model uploaded"); }
+void require_mode(const lpmp_engine* e) {
+  require_model(e);
+  if (e->mode < 0) throw StateError("no reparametrization mode set");   // reference LP_MP.h:414,458
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- plan -----------------------------------------------------------------------------------------
+int lpmp_plan_create(const lpmp_model* m, lpmp_plan** out) {
+  return guarded([&] {
+    if (!m || !out) throw std::runtime_error("null argument");
+    auto p = std::make_unique<lpmp_plan>();
+    p->p.build(*m);
+    *out = p.release();
+  });
+}
+void lpmp_plan_destroy(lpmp_plan* p) { delete p; }
+int64_t lpmp_plan_n_factors(const lpmp_plan* p) { return p ? p->p.nf : 0; }
+int64_t lpmp_plan_n_updated(const lpmp_plan* p, int d) { return p && (d == 0 || d == 1) ? (int64_t)p->p.upd[d].size() : 0; }
+int lpmp_plan_get_order(const lpmp_plan* p, int d, int32_t* out) {
+  return guarded([&] {
+    if (!p || !out || d < 0 || d > 1) throw std::runtime_error("bad argument");
+    std::memcpy(out, p->p.order[d].data(), p->p.order[d].size() * sizeof(int32_t));
+  });
+}
+int lpmp_plan_get_update_order(const lpmp_plan* p, int d, int32_t* out) {
+  return guarded([&] {
+    if (!p || !out || d < 0 || d > 1) throw std::runtime_error("bad argument");
+    std::memcpy(out, p->p.upd[d].data(), p->p.upd[d].size() * sizeof(int32_t));
+  });
+}
+int64_t lpmp_plan_omega_nnz(lpmp_plan* p, int d) {
+  int64_t s = 0;
+  if (p && (d == 0 || d == 1)) for (int32_t f : p->p.upd[d]) s += p->p.row_sends(f);
+  return s;
+}
+int64_t lpmp_plan_mask_nnz(lpmp_plan* p, int d) {
+  int64_t s = 0;
+  if (p && (d == 0 || d == 1)) for (int32_t f : p->p.upd[d]) s += p->p.row_receives(f);
+  return s;
+}
+int lpmp_plan_get_omega(lpmp_plan* p, int d, int mode, int64_t* off, double* data) {
+  return guarded([&] {
+    if (!p || !off || d < 0 || d > 1) throw std::runtime_error("bad argument");
+    p->p.ensure_weights(mode);
+    const auto& c = p->p.omega[d][mode];
+    std::memcpy(off, c.off.data(), c.off.size() * sizeof(int64_t));
+    if (!c.data.empty()) std::memcpy(data, c.data.data(), c.data.size() * sizeof(double));
+  });
+}
+int lpmp_plan_get_mask(lpmp_plan* p, int d, int mode, int64_t* off, uint8_t* data) {
+  return guarded([&] {
+    if (!p || !off || d < 0 || d > 1) throw std::runtime_error("bad argument");
+    p->p.ensure_weights(mode);
+    const auto& c = p->p.mask[d][mode];
+    std::memcpy(off, c.off.data(), c.off.size() * sizeof(int64_t));
+    if (!c.data.empty()) std::memcpy(data, c.data.data(), c.data.size());
+  });
+}
+int lpmp_plan_get_msg_lists(const lpmp_plan* p, int64_t* off, int64_t* entries) {
+  return guarded([&] {
+    if (!p || !off || !entries) throw std::runtime_error("bad argument");
+    std::memcpy(off, p->p.fm_off.data(), p->p.fm_off.size() * sizeof(int64_t));
+    for (size_t i = 0; i < p->p.fm.size(); ++i) entries[i] = (int64_t)p->p.fm[i].msg * 2 + p->p.fm[i].role;
+  });
+}
+int lpmp_plan_anisotropic_weights(const lpmp_plan* p, int64_t n, const int32_t* factors, int64_t* n_rows, int64_t* om_nnz,
+                                  int64_t* mk_nnz, int64_t* om_off, double* om, int64_t* mk_off, uint8_t* mk) {
+  return guarded([&] {
+    if (!p || !factors || n < 0) throw std::runtime_error("bad argument");
+    Csr<double> a; Csr<uint8_t> b;
+    p->p.anisotropic_weights(factors, n, a, b);
+    if (n_rows) *n_rows = a.rows();
+    if (om_nnz) *om_nnz = (int64_t)a.data.size();
+    if (mk_nnz) *mk_nnz = (int64_t)b.data.size();
+    if (om_off && om && mk_off && mk) {
+      std::memcpy(om_off, a.off.data(), a.off.size() * sizeof(int64_t));
+      std::memcpy(mk_off, b.off.data(), b.off.size() * sizeof(int64_t));
+      if (!a.data.empty()) std::memcpy(om, a.data.data(), a.data.size() * sizeof(double));
+      if (!b.data.empty()) std::memcpy(mk, b.data.data(), b.data.size());
+    }
+  });
+}
+int lpmp_plan_schedule_info(lpmp_plan* p, int d, int mode, int64_t* n_levels, int64_t* n_launches, int64_t* n_recv,
+                            int64_t* n_send, int64_t* alg_bytes) {
+  return guarded([&] {
+    if (!p || d < 0 || d > 1 || mode < 0 || mode >= LPMP_REPAM_COUNT) throw std::runtime_error("bad argument");
+    plan_schedule(p, d, mode);
+    const Schedule& s = p->sched_cache[d][mode];
+    if (n_levels) *n_levels = s.n_levels;
+    if (n_launches) *n_launches = (int64_t)s.launches.size();
+    if (n_recv) *n_recv = s.n_recv;
+    if (n_send) *n_send = s.n_send;
+    if (alg_bytes) *alg_bytes = s.alg_bytes;
+  });
+}
+
+// ---- engine ---------------------------------------------------------------------------------------
+int lpmp_create(int device, lpmp_engine** out) {
+  return guarded([&] {
+    if (!out) throw std::runtime_error("null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw DeviceError("no HIP device available: the engine has no CPU path");
+    if (device < 0 || device >= n) throw DeviceError("device ordinal out of range");
+    HIP_CHECK(hipSetDevice(device));
+    auto e = std::make_unique<lpmp_engine>();
+    e->device = device;
+    HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+    const char* ng = std::getenv("LPMP_NO_GRAPH");
+    e->use_graph = !(ng && ng[0] == '1');
+    *out = e.release();
+  });
+}
+
+void lpmp_destroy(lpmp_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  for (auto& p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
+  e->release_model();
+  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int lpmp_set_stream(lpmp_engine* e, void* s) {
+  return guarded([&] {
+    if (!e) throw std::runtime_error("null engine");
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m)
+      if (e->sched[d][m].graph) { (void)hipGraphExecDestroy(e->sched[d][m].graph); e->sched[d][m].graph = nullptr; }
+    if (e->own_stream && e->stream) { HIP_CHECK(hipStreamDestroy(e->stream)); }
+    e->stream = (hipStream_t)s; e->own_stream = false;
+  });
+}
+
+int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int dual_mem) {
+  return guarded([&] {
+    if (!e || !m) throw std::runtime_error("null argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->release_model();
+    auto pl = std::make_unique<lpmp_plan>();
+    pl->p.build(*m);
+    const Plan& p = pl->p;
+    const int64_t n_const = p.f_coff[p.nf], n_dual = p.f_doff[p.nf];
+    if ((n_const > 0 && !m->const_data) || !m->dual_data) throw std::runtime_error("cost arrays missing");
+    if (const_mem == LPMP_MEM_DEVICE) {
+      e->d_const = const_cast<double*>(m->const_data);
+      if (((uintptr_t)e->d_const & 15) != 0) throw std::runtime_error("device const buffer must be 16-byte aligned");
+    } else if (n_const > 0) {
+      HIP_CHECK(hipMalloc((void**)&e->d_const, (size_t)n_const * sizeof(double)));
+      e->own_const = true;
+      HIP_CHECK(hipMemcpy(e->d_const, m->const_data, (size_t)n_const * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (dual_mem == LPMP_MEM_DEVICE) {
+      e->d_dual = const_cast<double*>(m->dual_data);
+    } else {
+      HIP_CHECK(hipMalloc((void**)&e->d_dual, (size_t)n_dual * sizeof(double)));
+      e->own_dual = true;
+      HIP_CHECK(hipMemcpy(e->d_dual, m->dual_data, (size_t)n_dual * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (!p.tab_data.empty()) {
+      HIP_CHECK(hipMalloc((void**)&e->d_tabs, p.tab_data.size() * sizeof(int32_t)));
+      HIP_CHECK(hipMemcpy(e->d_tabs, p.tab_data.data(), p.tab_data.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    // lower-bound records, in factor order, and runs of factors the streaming dense kernel can take
+    std::vector<LbRecHost> lb(p.nf);
+    auto lb_class = [&](int64_t f) {
+      if (p.f_kind[f] == LPMP_F_PAIRWISE_DENSE && p.f_dim0[f] == p.f_dim1[f] && (p.f_coff[f] % 2) == 0 &&
+          (p.f_dim0[f] == 8 || p.f_dim0[f] == 16 || p.f_dim0[f] == 32)) return p.f_dim0[f];
+      return 0;
+    };
+    for (int64_t f = 0; f < p.nf; ++f) {
+      lb[f] = {p.f_doff[f], p.f_kind[f] == LPMP_F_VECTOR ? -1 : p.f_coff[f], p.f_dim0[f], p.f_dim1[f], p.f_kind[f] | (p.f_flags[f] << 4), 0};
+      const int c = lb_class(f);
+      if (e->lb_runs.empty() || e->lb_runs.back().cls != c) e->lb_runs.push_back({c, f, 1}); else e->lb_runs.back().count++;
+    }
+    HIP_CHECK(hipMalloc((void**)&e->d_lbrecs, (size_t)p.nf * sizeof(LbRecHost)));
+    HIP_CHECK(hipMemcpy(e->d_lbrecs, lb.data(), (size_t)p.nf * sizeof(LbRecHost), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc((void**)&e->d_lb, (size_t)p.nf * sizeof(double)));
+    HIP_CHECK(hipMalloc((void**)&e->d_part, 1024 * sizeof(double)));
+    HIP_CHECK(hipHostMalloc((void**)&e->h_part, 1024 * sizeof(double), hipHostMallocDefault));
+    e->plan = std::move(pl);
+  });
+}
+
+int lpmp_set_reparametrization(lpmp_engine* e, int mode) {
+  return guarded([&] {
+    require_model(e);
+    if (mode == LPMP_REPAM_MIXED) throw UnsupportedError("mixed reparametrization is assert(false) in the reference (LP_MP.h:1455)");
+    if (mode < 0 || mode >= LPMP_REPAM_COUNT) throw std::runtime_error("unknown reparametrization mode");
+    HIP_CHECK(hipSetDevice(e->device));
+    ensure_device_schedules(e, mode);
+    e->mode = mode;
+  });
+}
+
+int lpmp_compute_forward_pass(lpmp_engine* e) {
+  return guarded([&] { require_mode(e); HIP_CHECK(hipSetDevice(e->device)); run_schedule(e, e->sched[0][e->mode]); });
+}
+int lpmp_compute_backward_pass(lpmp_engine* e) {
+  return guarded([&] { require_mode(e); HIP_CHECK(hipSetDevice(e->device)); run_schedule(e, e->sched[1][e->mode]); });
+}
+int lpmp_compute_pass(lpmp_engine* e, int n) {
+  return guarded([&] {
+    require_mode(e);
+    HIP_CHECK(hipSetDevice(e->device));
+    for (int i = 0; i < n; ++i) { run_schedule(e, e->sched[0][e->mode]); run_schedule(e, e->sched[1][e->mode]); }
+  });
+}
+
+int lpmp_compute_pass_custom(lpmp_engine* e, int64_t n, const int32_t* factors, const int64_t* om_off, const double* om,
+                             const int64_t* mk_off, const uint8_t* mk) {
+  return guarded([&] {
+    require_model(e);
+    if (n < 0 || (n > 0 && (!factors || !om_off || !mk_off))) throw std::runtime_error("bad argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    Schedule s;
+    static const double dz = 0; static const uint8_t uz = 0;
+    e->plan->p.make_schedule(factors, n, om_off, om ? om : &dz, mk_off, mk ? mk : &uz, s);
+    check_generic_limits(e->plan->p, s);
+    DevSchedule d;
+    try {
+      upload_schedule(s, d);
+      const bool g = e->use_graph; e->use_graph = false;
+      run_schedule(e, d);
+      e->use_graph = g;
+      HIP_CHECK(hipStreamSynchronize(e->stream));
+    } catch (...) { d.release(); throw; }
+    d.release();
+  });
+}
+
+static void compute_factor_lbs(lpmp_engine* e) {
+  for (const auto& r : e->lb_runs) {
+    if (r.cls == 0 || !launch_dense_lb(r.cls, e->d_lbrecs, e->d_dual, e->d_const, e->d_lb, r.first, r.count, e->stream))
+      launch_factor_lb(e->d_lbrecs + r.first, e->d_dual, e->d_const, e->d_lb + r.first, r.count, e->stream);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+int lpmp_lower_bound(lpmp_engine* e, double* out) {
+  return guarded([&] {
+    require_model(e);
+    if (!out) throw std::runtime_error("null argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    compute_factor_lbs(e);
+    const int64_t nf = e->plan->p.nf;
+    int64_t nb = std::min<int64_t>(1024, (nf + 255) / 256);
+    const int64_t per = (nf + nb - 1) / nb;
+    nb = (nf + per - 1) / per;
+    launch_sum_stage(e->d_lb, e->d_part, nf, per, nb, e->stream);
+    HIP_CHECK(hipMemcpyAsync(e->h_part, e->d_part, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    double lb = e->plan->p.constant;
+    for (int64_t i = 0; i < nb; ++i) lb += e->h_part[i];
+    *out = lb;
+  });
+}
+
+int lpmp_factor_lower_bounds(lpmp_engine* e, double* out) {
+  return guarded([&] {
+    require_model(e);
+    if (!out) throw std::runtime_error("null argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    compute_factor_lbs(e);
+    HIP_CHECK(hipMemcpyAsync(out, e->d_lb, (size_t)e->plan->p.nf * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+  });
+}
+
+int lpmp_synchronize(lpmp_engine* e) {
+  return guarded([&] { if (!e) throw std::runtime_error("null engine"); HIP_CHECK(hipSetDevice(e->device)); HIP_CHECK(hipStreamSynchronize(e->stream)); if (e->timing) e->drain_timing(); });
+}
+
+int64_t lpmp_dual_size(const lpmp_engine* e) { return e && e->plan ? e->plan->p.f_doff[e->plan->p.nf] : 0; }
+
+int lpmp_download_duals(lpmp_engine* e, double* out) {
+  return guarded([&] {
+    require_model(e);
+    if (!out) throw std::runtime_error("null argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    HIP_CHECK(hipMemcpyAsync(out, e->d_dual, (size_t)lpmp_dual_size(e) * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+  });
+}
+int lpmp_upload_duals(lpmp_engine* e, const double* in) {
+  return guarded([&] {
+    require_model(e);
+    if (!in) throw std::runtime_error("null argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    HIP_CHECK(hipMemcpyAsync(e->d_dual, in, (size_t)lpmp_dual_size(e) * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+  });
+}
+void* lpmp_device_duals(lpmp_engine* e) { return e ? e->d_dual : nullptr; }
+const lpmp_plan* lpmp_engine_plan(const lpmp_engine* e) { return e ? e->plan.get() : nullptr; }
+lpmp_plan* lpmp_engine_plan_mut(lpmp_engine* e) { return e ? e->plan.get() : nullptr; }
+
+int lpmp_enable_kernel_timing(lpmp_engine* e, int on) {
+  return guarded([&] {
+    if (!e) throw std::runtime_error("null engine");
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (e->timing) e->drain_timing();
+    e->timing = on != 0;
+  });
+}
+int lpmp_get_kernel_timing(lpmp_engine* e, int n, double* ms, int64_t* launches, int64_t* factors, int64_t* receives, int64_t* bytes) {
+  return guarded([&] {
+    if (!e) throw std::runtime_error("null engine");
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->drain_timing();
+    for (int c = 0; c < n && c < KC_COUNT; ++c) {
+      if (ms) ms[c] = e->ct[c].ms;
+      if (launches) launches[c] = e->ct[c].launches;
+      if (factors) factors[c] = e->ct[c].factors;
+      if (receives) receives[c] = e->ct[c].receives;
+      if (bytes) bytes[c] = e->ct[c].bytes;
+    }
+  });
+}
+int lpmp_reset_kernel_timing(lpmp_engine* e) {
+  return guarded([&] {
+    if (!e) throw std::runtime_error("null engine");
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->drain_timing();
+    for (auto& c : e->ct) c = ClassTiming();
+  });
+}
+
+int lpmp_synth_fill(void* p, int64_t n, uint64_t seed, uint64_t first, void* stream) {
+  return guarded([&] {
+    if (!p && n > 0) throw std::runtime_error("null argument");
+    launch_synth_fill((double*)p, n, seed, first, (hipStream_t)stream);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
+}  // extern "C"

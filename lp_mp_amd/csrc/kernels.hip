@@ -1,0 +1,533 @@
+// kernels.hip — hand-written gfx950 (CDNA4) kernels of the LP_MP dual block-coordinate-ascent sweep.
+//
+// What one launch does: every wavefront (or sub-wave lane group) takes ONE updated factor of the
+// current level and executes the reference's FactorContainer::UpdateFactor on it
+// (reference include/factors_messages.hxx:2256-2261): pull a weight-1 message through every active
+// receiving message, then push omega-weighted messages through every active sending message, all
+// computed from the factor state after the receives (the reference's tmp_factor copy, :2799-2805).
+// Factors of one level touch disjoint memory (plan.cpp, level scheduling), so the result equals the
+// sequential sweep of LP::ComputePass (reference include/LP_MP.h:981-1005).
+//
+// The inner op is min-plus over doubles: no MFMA.  The kernels are HBM-bound streams of pairwise
+// tables (dense) or short vectors (Potts); they are built around coalesced 16-B-per-lane loads of the
+// tables, LDS staging of the label vectors, and DPP / permute min-reductions inside 64-wide waves.
+// All arithmetic is IEEE double without contraction (-ffp-contract=off) so that duals are
+// bit-identical to the sequential CPU semantics (min and + are exact; evaluation order is copied).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "plan.hpp"
+
+namespace lpmp {
+
+#define LPMP_INF (__builtin_inf())
+constexpr int GEN_MAXD = 512;       // generic kernel: max dual size / message length held in LDS per wave
+constexpr int GEN_WAVES = 4;
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, mask, 64);
+  hi = __shfl_xor(hi, mask, 64);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl(lo, src, 64);
+  hi = __shfl(hi, src, 64);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmin(v, shfl_xor_f64(v, m));
+  return v;
+}
+// min over aligned groups of G lanes (G power of two <= 64)
+template <int G>
+__device__ __forceinline__ double group_min(double v) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) v = fmin(v, shfl_xor_f64(v, m));
+  return v;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Generic kernel: any factor kind, any message kind, either role.  One wave per updated factor.
+// -------------------------------------------------------------------------------------------------
+struct GenLds {
+  double own[GEN_MAXD];
+  double snap[GEN_MAXD];
+  double dl[GEN_MAXD];
+  double val[GEN_MAXD];
+};
+
+// pairwise cost T(a,b) of a pairwise factor (dense table or Potts scalar)
+__device__ __forceinline__ double pw_cost(const double* __restrict__ cdata, int64_t coff, int kind, int d1, int a, int b) {
+  if (kind == LPMP_F_PAIRWISE_DENSE) return cdata[coff + (int64_t)a * d1 + b];
+  return a == b ? 0.0 : cdata[coff];
+}
+
+// dl[x] = omega * (m_s[x] + min_y (T + m_o[y])) for side s of a pairwise factor whose message vectors are
+// read through pointer m (global: live peer, or LDS: own snapshot)
+template <class MPtr>
+__device__ void pw_min_marginal(GenLds& L, const double* __restrict__ cdata, int64_t coff, int kind, int d0, int d1,
+                                MPtr m, int side, double omega, int lane) {
+  if (side == 0) {
+    for (int a = 0; a < d0; ++a) {
+      double v = LPMP_INF;
+      for (int b = lane; b < d1; b += 64) v = fmin(v, pw_cost(cdata, coff, kind, d1, a, b) + m[d0 + b]);
+      v = wave_min(v);
+      if (lane == 0) L.dl[a] = omega * (m[a] + v);
+    }
+  } else {
+    for (int b = lane; b < d1; b += 64) {
+      double v = LPMP_INF;
+      for (int a = 0; a < d0; ++a) v = fmin(v, pw_cost(cdata, coff, kind, d1, a, b) + m[a]);
+      L.dl[b] = omega * (m[d0 + b] + v);
+    }
+  }
+  wave_sync();
+}
+
+// labeling_message::compute_msg (reference labeling_list_factor.hxx:411-443): dl[l] = omega*(min_{r:tab[r]==l} R[r] - not_taken)
+template <class RPtr>
+__device__ void labeling_to_left(GenLds& L, RPtr R, int nr, const int32_t* __restrict__ tab, int nl, int implicit_origin,
+                                 double omega, int lane) {
+  double nt = implicit_origin ? 0.0 : LPMP_INF;
+  for (int r = 0; r < nr; ++r) if (tab[r] >= nl) nt = fmin(nt, R[r]);
+  for (int l = lane; l < nl; l += 64) {
+    double v = LPMP_INF;
+    for (int r = 0; r < nr; ++r) if (tab[r] == l) v = fmin(v, R[r]);
+    L.dl[l] = omega * (v - nt);
+  }
+  wave_sync();
+}
+
+template <class SPtr>
+__device__ void minnorm_delta(GenLds& L, SPtr src, int n, double omega, int lane) {
+  double mn = LPMP_INF;
+  for (int i = lane; i < n; i += 64) mn = fmin(mn, src[i]);
+  mn = wave_min(mn);
+  for (int i = lane; i < n; i += 64) L.dl[i] = omega * (src[i] - mn);
+  wave_sync();
+}
+
+__global__ void __launch_bounds__(64 * GEN_WAVES)
+sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+                     const double* __restrict__ cdata, const int32_t* __restrict__ tabs, int64_t first, int64_t count) {
+  __shared__ GenLds lds[GEN_WAVES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t idx = (int64_t)blockIdx.x * GEN_WAVES + wave;
+  if (idx >= count) return;
+  GenLds& L = lds[wave];
+  const UpdRec rec = recs[first + idx];
+  const int okind = rec.kind_flags & 15;
+  const int oflags = rec.kind_flags >> 4;
+  const int on = okind == LPMP_F_VECTOR ? rec.d0 : rec.d0 + rec.d1;   // own dual size
+  double* own_g = dual + rec.dual_off;
+  for (int i = lane; i < on; i += 64) L.own[i] = own_g[i];
+  wave_sync();
+
+  const int n_ops = rec.n_recv + rec.n_send;
+  for (int k = 0; k < n_ops; ++k) {
+    if (k == rec.n_recv) {   // state after the receives: what every send is computed from
+      for (int i = lane; i < on; i += 64) L.snap[i] = L.own[i];
+      wave_sync();
+    }
+    const Op op = ops[rec.op_begin + k];
+    const bool recv = k < rec.n_recv;
+    const int code = op.info & 15, role = (op.info >> 4) & 1, side = (op.info >> 5) & 1, imp = (op.info >> 6) & 1;
+    const int pkind = (op.info >> 8) & 15;
+    double* peer = dual + op.peer_dual;
+    const int len = op.len;
+    // ---- compute delta (into L.dl) ------------------------------------------------------------
+    // the message is computed by the peer for a receive and by the updated factor for a send
+    const bool by_right = recv ? (role == 0) : (role == 1);
+    if (code == OP_UP) {
+      if (by_right) {   // min-marginal of the pairwise (right) factor
+        if (recv) pw_min_marginal(L, cdata, op.peer_const, pkind, op.pd0, op.pd1, (const double*)peer, side, op.omega, lane);
+        else pw_min_marginal(L, cdata, rec.const_off, okind, rec.d0, rec.d1, (const double*)L.snap, side, op.omega, lane);
+      } else {          // omega * theta of the unary (left) factor
+        for (int i = lane; i < len; i += 64) L.dl[i] = op.omega * (recv ? peer[i] : L.snap[i]);
+        wave_sync();
+      }
+    } else if (code == OP_LABELING) {
+      const int32_t* tab = tabs + op.peer_const;
+      if (by_right) {
+        if (recv) labeling_to_left(L, (const double*)peer, op.pd0, tab, op.pd1, imp, op.omega, lane);
+        else labeling_to_left(L, (const double*)L.snap, rec.d0, tab, op.pd1, imp, op.omega, lane);
+      } else {
+        for (int i = lane; i < len; i += 64) L.dl[i] = op.omega * (recv ? peer[i] : L.snap[i]);
+        wave_sync();
+      }
+    } else {            // OP_MINNORM
+      if (recv) minnorm_delta(L, (const double*)peer, len, op.omega, lane);
+      else minnorm_delta(L, (const double*)L.snap, len, op.omega, lane);
+    }
+    // ---- apply: +delta to the side that did not compute it, -delta to the side that did ----------
+    // (reference MessageContainerView::operator-=, factors_messages.hxx:495-508)
+    // which of {own, peer} is the left factor?
+    const bool own_is_left = role == 0;
+    const double s_left = by_right ? +1.0 : -1.0, s_right = -s_left;
+    // left factor is always a vector of length len
+    if (own_is_left) { for (int i = lane; i < len; i += 64) L.own[i] += s_left * L.dl[i]; }
+    else { for (int i = lane; i < len; i += 64) peer[i] += s_left * L.dl[i]; }
+    // right factor
+    if (code == OP_UP) {
+      if (own_is_left) { double* m = peer + (side == 0 ? 0 : op.pd0); for (int i = lane; i < len; i += 64) m[i] += s_right * L.dl[i]; }
+      else { double* m = L.own + (side == 0 ? 0 : rec.d0); for (int i = lane; i < len; i += 64) m[i] += s_right * L.dl[i]; }
+    } else if (code == OP_LABELING) {
+      const int32_t* tab = tabs + op.peer_const;
+      const int nl = op.pd1;
+      if (own_is_left) { for (int r = lane; r < op.pd0; r += 64) if (tab[r] < nl) peer[r] += s_right * L.dl[tab[r]]; }
+      else { for (int r = lane; r < rec.d0; r += 64) if (tab[r] < nl) L.own[r] += s_right * L.dl[tab[r]]; }
+    } else {
+      if (own_is_left) { for (int i = lane; i < len; i += 64) peer[i] += s_right * L.dl[i]; }
+      else { for (int i = lane; i < len; i += 64) L.own[i] += s_right * L.dl[i]; }
+    }
+    wave_sync();
+    (void)oflags;
+  }
+  for (int i = lane; i < on; i += 64) own_g[i] = L.own[i];
+}
+
+// -------------------------------------------------------------------------------------------------
+// Dense fast path: unary simplex factor with L labels whose active messages all go to dense L x L
+// pairwise factors.  G lanes per factor; each lane keeps NL double2 of the table in registers, loaded
+// as one coalesced 16-B-per-lane stream (2G doubles per load step = RPL rows).
+//   lane g: column pair c2 = g % (L/2) (columns 2*c2, 2*c2+1), row-in-step rl = g / (L/2)
+//   element of load step i: row = i*RPL + rl
+// side 0 (own label = row a):    q[a] = min_b T[a][b] + m2[b]  -> reduce over the L/2 lanes of a row
+// side 1 (own label = column b): q[b] = min_a T[a][b] + m1[a]  -> local over steps, reduce over the RPL row-lanes
+// Vectors (theta, m1, m2, delta) live one element per lane (lane g < L) and are transposed through LDS.
+// -------------------------------------------------------------------------------------------------
+template <int L> struct DenseCfg;
+template <> struct DenseCfg<32> { static constexpr int G = 64; };
+template <> struct DenseCfg<16> { static constexpr int G = 16; };
+template <> struct DenseCfg<8>  { static constexpr int G = 8; };
+template <> struct DenseCfg<4>  { static constexpr int G = 4; };
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+template <int L>
+__global__ void __launch_bounds__(256)
+sweep_dense_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+                   const double* __restrict__ cdata, int64_t first, int64_t count) {
+  constexpr int G = DenseCfg<L>::G;
+  constexpr int CL = L / 2;            // lanes per table row
+  constexpr int RPL = 2 * G / L;       // rows per load step
+  constexpr int NL = L / RPL;          // load steps
+  constexpr int GPB = 256 / G;         // groups (factors) per block
+  static_assert(G >= L / 2 && (2 * G) % L == 0 && L % RPL == 0, "bad dense config");
+  // LDS: per group  mo[L] (other-side vector) + q[L] (min result), one group-private slab
+  __shared__ double lds_mo[GPB][L];
+  __shared__ double lds_q[GPB][L];
+  const int grp = threadIdx.x / G, g = threadIdx.x % G;
+  const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
+  const bool live = idx < count;
+  const int c2 = g % CL, rl = g / CL;
+  UpdRec rec;
+  if (live) rec = recs[first + idx]; else { rec.n_recv = 0; rec.n_send = 0; rec.dual_off = 0; rec.op_begin = 0; }
+  double* own_g = dual + rec.dual_off;
+  const bool vl = live && g < L;        // this lane holds vector element g
+  double theta = vl ? own_g[g] : 0.0;
+  // every lane of a wave must run the same number of iterations (cross-lane ops inside)
+  int n_recv = rec.n_recv;
+  int max_recv = n_recv;
+  if (G < 64) {
+#pragma unroll
+    for (int m = 32; m >= G; m >>= 1) max_recv = max(max_recv, __shfl_xor(max_recv, m, 64));
+  }
+  for (int k = 0; k < max_recv; ++k) {
+    const bool act = k < n_recv;
+    Op op;
+    if (act) op = ops[rec.op_begin + k]; else { op.peer_dual = rec.dual_off; op.peer_const = 0; op.info = 0; }
+    const int side = (op.info >> 5) & 1;
+    const double* T = cdata + op.peer_const;
+    double* ms = dual + op.peer_dual + (side == 0 ? 0 : L);
+    const double* mo = dual + op.peer_dual + (side == 0 ? L : 0);
+    double2_t t[NL];
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) t[i] = *reinterpret_cast<const double2_t*>(T + (int64_t)i * 2 * G + 2 * g);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) t[i] = double2_t{0.0, 0.0};
+    }
+    const double ms_v = (act && g < L) ? ms[g] : 0.0;
+    const double mo_v = (act && g < L) ? mo[g] : 0.0;
+    if (g < L) lds_mo[grp][g] = mo_v;
+    wave_sync();
+    if (side == 0) {
+      // lane needs m2[2*c2], m2[2*c2+1]
+      const double2_t mv = *reinterpret_cast<const double2_t*>(&lds_mo[grp][2 * c2]);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        double v = fmin(t[i].x + mv.x, t[i].y + mv.y);
+#pragma unroll
+        for (int m = CL / 2; m >= 1; m >>= 1) v = fmin(v, shfl_xor_f64(v, m));
+        if (c2 == 0) lds_q[grp][i * RPL + rl] = v;
+      }
+    } else {
+      double vx = LPMP_INF, vy = LPMP_INF;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const double m1v = lds_mo[grp][i * RPL + rl];
+        vx = fmin(vx, t[i].x + m1v);
+        vy = fmin(vy, t[i].y + m1v);
+      }
+#pragma unroll
+      for (int m = G / 2; m >= CL; m >>= 1) { vx = fmin(vx, shfl_xor_f64(vx, m)); vy = fmin(vy, shfl_xor_f64(vy, m)); }
+      if (rl == 0) { lds_q[grp][2 * c2] = vx; lds_q[grp][2 * c2 + 1] = vy; }
+    }
+    wave_sync();
+    if (act && g < L) {
+      const double delta = ms_v + lds_q[grp][g];   // omega = 1: delta = min-marginal
+      theta += delta;                                // RepamLeft(+delta)
+      ms[g] = ms_v - delta;                          // RepamRight(-delta)
+    }
+    wave_sync();
+  }
+  // sends: delta = omega * theta_snapshot; peer += delta; theta -= delta
+  if (vl) {
+    const double snap = theta;
+    for (int k = 0; k < rec.n_send; ++k) {
+      const Op op = ops[rec.op_begin + rec.n_recv + k];
+      const int side = (op.info >> 5) & 1;
+      double* ms = dual + op.peer_dual + (side == 0 ? 0 : L);
+      const double delta = op.omega * snap;
+      ms[g] += delta;
+      theta -= delta;
+    }
+    own_g[g] = theta;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Potts fast path: L lanes per unary factor; peers are pairwise_potts_factor(L, diff).
+// min_b (diff*[a!=b] + m_o[b]) = min(m_o[a], diff + min_{b != a} m_o[b]), with min_{b != a} from the two
+// smallest entries of m_o (reference vector::two_min, vector.hxx:348-443).
+// -------------------------------------------------------------------------------------------------
+template <int L>
+__global__ void __launch_bounds__(256)
+sweep_potts_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+                   const double* __restrict__ cdata, int64_t first, int64_t count) {
+  constexpr int GPB = 256 / L;
+  const int grp = threadIdx.x / L, g = threadIdx.x % L;
+  const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
+  const bool live = idx < count;
+  UpdRec rec;
+  if (live) rec = recs[first + idx]; else { rec.n_recv = 0; rec.n_send = 0; rec.dual_off = 0; rec.op_begin = 0; }
+  double* own_g = dual + rec.dual_off;
+  double theta = live ? own_g[g] : 0.0;
+  int n_recv = rec.n_recv, max_recv = rec.n_recv;
+#pragma unroll
+  for (int m = 32; m >= L; m >>= 1) max_recv = max(max_recv, __shfl_xor(max_recv, m, 64));
+  for (int k = 0; k < max_recv; ++k) {
+    const bool act = k < n_recv;
+    Op op;
+    if (act) op = ops[rec.op_begin + k]; else { op.peer_dual = rec.dual_off; op.peer_const = 0; op.info = 0; }
+    const int side = (op.info >> 5) & 1;
+    double* ms = dual + op.peer_dual + (side == 0 ? 0 : L);
+    const double* mo = dual + op.peer_dual + (side == 0 ? L : 0);
+    const double diff = act ? cdata[op.peer_const] : 0.0;
+    const double ms_v = act ? ms[g] : 0.0;
+    const double mo_v = act ? mo[g] : 0.0;
+    // two smallest of mo over the group (multiset semantics)
+    double a1 = mo_v, a2 = LPMP_INF;
+#pragma unroll
+    for (int m = L / 2; m >= 1; m >>= 1) {
+      const double b1 = shfl_xor_f64(a1, m), b2 = shfl_xor_f64(a2, m);
+      const double n1 = fmin(a1, b1);
+      const double n2 = fmin(fmax(a1, b1), fmin(a2, b2));
+      a1 = n1; a2 = n2;
+    }
+    // exactly one lane may take the role of "the" minimum: the lowest lane holding a1
+    const unsigned long long holders = __ballot(mo_v == a1);
+    const int grp_shift = (threadIdx.x & 63) - g;
+    const unsigned long long gmask = (L == 64 ? ~0ull : ((1ull << L) - 1ull)) << grp_shift;
+    const int first_holder = __ffsll((long long)(holders & gmask)) - 1;
+    const double min_except = ((int)(threadIdx.x & 63) == first_holder) ? a2 : a1;
+    if (act) {
+      const double q = fmin(0.0 + mo_v, diff + min_except);
+      const double delta = ms_v + q;
+      theta += delta;
+      ms[g] = ms_v - delta;
+    }
+  }
+  if (live) {
+    const double snap = theta;
+    for (int k = 0; k < rec.n_send; ++k) {
+      const Op op = ops[rec.op_begin + rec.n_recv + k];
+      const int side = (op.info >> 5) & 1;
+      double* ms = dual + op.peer_dual + (side == 0 ? 0 : L);
+      const double delta = op.omega * snap;
+      ms[g] += delta;
+      theta -= delta;
+    }
+    own_g[g] = theta;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Lower bound (reference LP::LowerBound, LP_MP.h:1507-1518): per-factor bound, then a fixed-order sum.
+// -------------------------------------------------------------------------------------------------
+struct LbRec { int64_t dual_off; int64_t const_off; int32_t d0, d1; int32_t kind_flags; int32_t pad; };
+
+// one wave per factor, any kind
+__global__ void __launch_bounds__(256)
+factor_lb_kernel(const LbRec* __restrict__ recs, const double* __restrict__ dual, const double* __restrict__ cdata,
+                 double* __restrict__ out, int64_t count) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t f = (int64_t)blockIdx.x * 4 + wave;
+  if (f >= count) return;
+  const LbRec r = recs[f];
+  const int kind = r.kind_flags & 15, flags = r.kind_flags >> 4;
+  const double* d = dual + r.dual_off;
+  double lb;
+  if (kind == LPMP_F_VECTOR) {
+    double v = LPMP_INF;
+    for (int i = lane; i < r.d0; i += 64) v = fmin(v, d[i]);
+    lb = wave_min(v);
+    if ((flags & LPMP_FF_IMPLICIT_ORIGIN) && 0.0 < lb) lb = 0.0;
+  } else {
+    // min_a ( m1[a] + min_b (T[a][b] + m2[b]) ): lanes sweep the table row-major (coalesced)
+    const int d0 = r.d0, d1 = r.d1;
+    double best = LPMP_INF;
+    if (kind == LPMP_F_PAIRWISE_DENSE) {
+      const double* T = cdata + r.const_off;
+      for (int a = 0; a < d0; ++a) {
+        double v = LPMP_INF;
+        for (int b = lane; b < d1; b += 64) v = fmin(v, T[(int64_t)a * d1 + b] + d[d0 + b]);
+        v = wave_min(v);
+        best = fmin(best, d[a] + v);
+      }
+    } else {
+      const double diff = cdata[r.const_off];
+      for (int a = 0; a < d0; ++a) {
+        double v = LPMP_INF;
+        for (int b = lane; b < d1; b += 64) v = fmin(v, (a == b ? 0.0 : diff) + d[d0 + b]);
+        v = wave_min(v);
+        best = fmin(best, d[a] + v);
+      }
+    }
+    lb = best;
+  }
+  if (lane == 0) out[f] = lb;
+}
+
+// dense L x L pairwise bound with the streaming layout of sweep_dense_kernel (G lanes per factor)
+template <int L>
+__global__ void __launch_bounds__(256)
+dense_lb_kernel(const LbRec* __restrict__ recs, const double* __restrict__ dual, const double* __restrict__ cdata,
+                double* __restrict__ out, int64_t first, int64_t count) {
+  constexpr int G = DenseCfg<L>::G;
+  constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
+  __shared__ double lds_m[GPB][2 * L];
+  const int grp = threadIdx.x / G, g = threadIdx.x % G;
+  const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
+  const bool live = idx < count;
+  const int c2 = g % CL, rl = g / CL;
+  LbRec r;
+  if (live) r = recs[first + idx]; else { r.dual_off = 0; r.const_off = 0; }
+  const double* T = cdata + r.const_off;
+  const double* d = dual + r.dual_off;
+  double2_t t[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) t[i] = live ? *reinterpret_cast<const double2_t*>(T + (int64_t)i * 2 * G + 2 * g) : double2_t{0.0, 0.0};
+  for (int i = g; i < 2 * L; i += G) lds_m[grp][i] = live ? d[i] : 0.0;
+  wave_sync();
+  const double2_t m2 = *reinterpret_cast<const double2_t*>(&lds_m[grp][L + 2 * c2]);
+  double best = LPMP_INF;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    double v = fmin(t[i].x + m2.x, t[i].y + m2.y);
+#pragma unroll
+    for (int m = CL / 2; m >= 1; m >>= 1) v = fmin(v, shfl_xor_f64(v, m));
+    best = fmin(best, lds_m[grp][i * RPL + rl] + v);
+  }
+#pragma unroll
+  for (int m = G / 2; m >= CL; m >>= 1) best = fmin(best, shfl_xor_f64(best, m));
+  if (live && g == 0) out[first + idx] = best;
+}
+
+// deterministic two-stage sum: block b sums a fixed contiguous slice in a fixed tree order
+__global__ void __launch_bounds__(256)
+sum_stage_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n, int64_t per_block) {
+  __shared__ double sh[256];
+  const int64_t b0 = (int64_t)blockIdx.x * per_block;
+  const int64_t b1 = b0 + per_block < n ? b0 + per_block : n;
+  double s = 0.0;
+  for (int64_t i = b0 + threadIdx.x; i < b1; i += 256) s += in[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+// counter-based generator of the synthetic workloads: bit-identical to lp_mp_amd.synthetic.u01
+__global__ void synth_fill_kernel(double* __restrict__ out, int64_t n, uint64_t seed, uint64_t first) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint64_t z = seed + (first + (uint64_t)i + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    out[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+  }
+}
+
+// ---- launch wrappers (called from engine.cpp) -----------------------------------------------------
+void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
+                  int64_t first, int64_t count, hipStream_t s) {
+  if (count <= 0) return;
+  auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
+  switch (kclass) {
+    case KC_DENSE_32: hipLaunchKernelGGL(sweep_dense_kernel<32>, blocks(256 / DenseCfg<32>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
+    case KC_DENSE_16: hipLaunchKernelGGL(sweep_dense_kernel<16>, blocks(256 / DenseCfg<16>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
+    case KC_DENSE_8: hipLaunchKernelGGL(sweep_dense_kernel<8>, blocks(256 / DenseCfg<8>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
+    case KC_DENSE_4: hipLaunchKernelGGL(sweep_dense_kernel<4>, blocks(256 / DenseCfg<4>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
+    case KC_POTTS_32: hipLaunchKernelGGL(sweep_potts_kernel<32>, blocks(256 / 32), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
+    case KC_POTTS_16: hipLaunchKernelGGL(sweep_potts_kernel<16>, blocks(256 / 16), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
+    case KC_POTTS_8: hipLaunchKernelGGL(sweep_potts_kernel<8>, blocks(256 / 8), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
+    case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
+    default: hipLaunchKernelGGL(sweep_generic_kernel, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, first, count); break;
+  }
+}
+
+void launch_factor_lb(const void* recs, const double* dual, const double* cdata, double* out, int64_t count, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(factor_lb_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, (const LbRec*)recs, dual, cdata, out, count);
+}
+
+bool launch_dense_lb(int L, const void* recs, const double* dual, const double* cdata, double* out, int64_t first, int64_t count, hipStream_t s) {
+  if (count <= 0) return true;
+  auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
+  switch (L) {
+    case 32: hipLaunchKernelGGL(dense_lb_kernel<32>, blocks(256 / DenseCfg<32>::G), dim3(256), 0, s, (const LbRec*)recs, dual, cdata, out, first, count); return true;
+    case 16: hipLaunchKernelGGL(dense_lb_kernel<16>, blocks(256 / DenseCfg<16>::G), dim3(256), 0, s, (const LbRec*)recs, dual, cdata, out, first, count); return true;
+    case 8: hipLaunchKernelGGL(dense_lb_kernel<8>, blocks(256 / DenseCfg<8>::G), dim3(256), 0, s, (const LbRec*)recs, dual, cdata, out, first, count); return true;
+    default: return false;
+  }
+}
+
+void launch_sum_stage(const double* in, double* out, int64_t n, int64_t per_block, int64_t n_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(sum_stage_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, in, out, n, per_block);
+}
+
+void launch_synth_fill(double* out, int64_t n, uint64_t seed, uint64_t first, hipStream_t s) {
+  if (n <= 0) return;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, seed, first);
+}
+
+int generic_max_dual() { return GEN_MAXD; }
+
+}  // namespace lpmp

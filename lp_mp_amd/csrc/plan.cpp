@@ -1,0 +1,483 @@
+// plan.cpp — see plan.hpp.  Host restatement of the reference's ordering / weight rules, plus the
+// level scheduling that makes the Gauss-Seidel sweep executable as a few wide kernel launches.
+#include "plan.hpp"
+
+#include <algorithm>
+#include <limits>
+#include <numeric>
+#include <stdexcept>
+
+namespace lpmp {
+
+namespace {
+
+// message_passing_schedule -> what each side does (reference factors_messages.hxx:1530-1545)
+struct SchedCaps { bool to_left, to_right, from_left, from_right; };
+SchedCaps caps(int s) {
+  switch (s) {
+    case LPMP_SCHED_LEFT: return {false, true, false, true};
+    case LPMP_SCHED_RIGHT: return {true, false, true, false};
+    case LPMP_SCHED_FULL: return {true, true, true, true};
+    case LPMP_SCHED_ONLY_SEND: return {true, true, false, false};
+    default: return {false, false, false, false};
+  }
+}
+
+[[noreturn]] void fail(const std::string& s) { throw std::runtime_error(s); }
+
+// reference topological_sort.hxx:100-144 — DFS, roots by index, successors by insertion, reversed post-order
+std::vector<int32_t> reference_topological_order(int64_t nf, const int32_t* rel, int64_t n_rel) {
+  std::vector<int64_t> head(nf + 1, 0);
+  for (int64_t i = 0; i < n_rel; ++i) {
+    const int32_t a = rel[2 * i], b = rel[2 * i + 1];
+    if (a < 0 || a >= nf || b < 0 || b >= nf) fail("factor relation out of range");
+    head[a + 1]++;
+  }
+  std::partial_sum(head.begin(), head.end(), head.begin());
+  std::vector<int32_t> succ(n_rel);
+  {
+    std::vector<int64_t> cur(head.begin(), head.end() - 1);
+    for (int64_t i = 0; i < n_rel; ++i) succ[cur[rel[2 * i]]++] = rel[2 * i + 1];
+  }
+  std::vector<uint8_t> seen(nf, 0);
+  std::vector<int32_t> post;
+  post.reserve(nf);
+  struct Frame { int32_t node; int64_t next; };
+  std::vector<Frame> st;
+  for (int64_t root = 0; root < nf; ++root) {
+    if (seen[root]) continue;
+    seen[root] = 1;
+    st.push_back({(int32_t)root, head[root]});
+    while (!st.empty()) {
+      Frame& fr = st.back();
+      const int64_t end = head[fr.node + 1];
+      while (fr.next != end && seen[succ[fr.next]]) ++fr.next;
+      if (fr.next == end) {
+        post.push_back(fr.node);
+        st.pop_back();
+      } else {
+        const int32_t nx = succ[fr.next++];
+        seen[nx] = 1;
+        st.push_back({nx, head[nx]});
+      }
+    }
+  }
+  std::reverse(post.begin(), post.end());
+  return post;
+}
+
+}  // namespace
+
+int64_t Plan::row_sends(int32_t f) const {
+  int64_t s = 0;
+  for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) s += fm[j].sends;
+  return s;
+}
+int64_t Plan::row_receives(int32_t f) const {
+  int64_t s = 0;
+  for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) s += fm[j].receives;
+  return s;
+}
+
+void Plan::build(const lpmp_model& m) {
+  if (m.n_ftypes <= 0 || m.n_factors <= 0) fail("model has no factors");
+  if (m.n_factors > std::numeric_limits<int32_t>::max() || m.n_messages > std::numeric_limits<int32_t>::max() / 2)
+    fail("model too large for 32-bit factor/message indices");
+  n_ftypes = m.n_ftypes; n_mtypes = m.n_mtypes; n_tables = m.n_tables;
+  ftype_primal.assign(n_ftypes, 0);
+  if (m.ftype_computes_primal) ftype_primal.assign(m.ftype_computes_primal, m.ftype_computes_primal + n_ftypes);
+  mtypes.assign(m.mtypes, m.mtypes + n_mtypes);
+  if (n_tables > 0) {
+    tab_off.assign(m.tab_off, m.tab_off + n_tables + 1);
+    tab_data.assign(m.tab_data, m.tab_data + tab_off[n_tables]);
+    tab_nleft.assign(m.tab_nleft, m.tab_nleft + n_tables);
+  }
+  nf = m.n_factors; nm = m.n_messages; constant = m.constant;
+  f_type.assign(m.f_type, m.f_type + nf);
+  f_kind.assign(m.f_kind, m.f_kind + nf);
+  if (m.f_flags) f_flags.assign(m.f_flags, m.f_flags + nf); else f_flags.assign(nf, 0);
+  f_dim0.assign(m.f_dim0, m.f_dim0 + nf);
+  if (m.f_dim1) f_dim1.assign(m.f_dim1, m.f_dim1 + nf); else f_dim1.assign(nf, 0);
+  f_coff.assign(nf + 1, 0); f_doff.assign(nf + 1, 0);
+  max_dual = 1;
+  for (int64_t f = 0; f < nf; ++f) {
+    if (f_kind[f] > LPMP_F_PAIRWISE_POTTS) fail("factor " + std::to_string(f) + ": unknown kind");
+    if (f_type[f] < 0 || f_type[f] >= n_ftypes) fail("factor " + std::to_string(f) + ": type out of range");
+    if (f_dim0[f] <= 0 || (f_kind[f] == LPMP_F_PAIRWISE_DENSE && f_dim1[f] <= 0)) fail("factor " + std::to_string(f) + ": bad dimension");
+    if (f_kind[f] == LPMP_F_PAIRWISE_POTTS) f_dim1[f] = f_dim0[f];
+    if (f_kind[f] == LPMP_F_VECTOR) f_dim1[f] = 0;
+    f_coff[f + 1] = f_coff[f] + lpmp_factor_const_size(f_kind[f], f_dim0[f], f_dim1[f]);
+    const int64_t ds = lpmp_factor_dual_size(f_kind[f], f_dim0[f], f_dim1[f]);
+    f_doff[f + 1] = f_doff[f] + ds;
+    max_dual = std::max<int64_t>(max_dual, ds);
+  }
+  m_type.assign(m.m_type, m.m_type + nm);
+  m_left.assign(m.m_left, m.m_left + nm);
+  m_right.assign(m.m_right, m.m_right + nm);
+  for (int t = 0; t < n_mtypes; ++t) {
+    const auto& mt = mtypes[t];
+    if (mt.left_ftype < 0 || mt.left_ftype >= n_ftypes || mt.right_ftype < 0 || mt.right_ftype >= n_ftypes)
+      fail("message type " + std::to_string(t) + ": factor type out of range");
+    if (mt.schedule < 0 || mt.schedule > LPMP_SCHED_NONE) fail("message type " + std::to_string(t) + ": bad schedule");
+    if (mt.kind < 0 || mt.kind > LPMP_M_MINNORM) fail("message type " + std::to_string(t) + ": unknown kind");
+  }
+  for (int64_t i = 0; i < nm; ++i) {
+    const int t = m_type[i];
+    const int32_t l = m_left[i], r = m_right[i];
+    if (t < 0 || t >= n_mtypes || l < 0 || l >= nf || r < 0 || r >= nf || l == r) fail("message " + std::to_string(i) + ": index out of range");
+    const auto& mt = mtypes[t];
+    bool ok = f_type[l] == mt.left_ftype && f_type[r] == mt.right_ftype && f_kind[l] == LPMP_F_VECTOR;
+    if (ok && mt.kind == LPMP_M_UNARY_PAIRWISE)
+      ok = f_kind[r] != LPMP_F_VECTOR && (mt.param == 0 || mt.param == 1) && f_dim0[l] == (mt.param == 0 ? f_dim0[r] : f_dim1[r]);
+    if (ok && mt.kind == LPMP_M_LABELING)
+      ok = f_kind[r] == LPMP_F_VECTOR && mt.param >= 0 && mt.param < n_tables && tab_nleft[mt.param] == f_dim0[l] &&
+           tab_off[mt.param + 1] - tab_off[mt.param] == f_dim0[r];
+    if (ok && mt.kind == LPMP_M_MINNORM) ok = f_kind[r] == LPMP_F_VECTOR && f_dim0[r] == f_dim0[l];
+    if (!ok) fail("message " + std::to_string(i) + ": factors do not fit the message type");
+  }
+
+  // ---- per-factor message lists: dispatcher order = left-role types in MessageList order, then right-role
+  std::vector<int32_t> rank_l(n_mtypes), rank_r(n_mtypes);
+  for (int k = 0; k < n_ftypes; ++k) {
+    int r = 0;
+    for (int t = 0; t < n_mtypes; ++t) if (mtypes[t].left_ftype == k) rank_l[t] = r++;
+    for (int t = 0; t < n_mtypes; ++t) if (mtypes[t].right_ftype == k) rank_r[t] = r++;
+  }
+  fm_off.assign(nf + 1, 0);
+  for (int64_t i = 0; i < nm; ++i) { fm_off[m_left[i] + 1]++; fm_off[m_right[i] + 1]++; }
+  std::partial_sum(fm_off.begin(), fm_off.end(), fm_off.begin());
+  fm.resize(2 * nm);
+  struct Tmp { int32_t rank; int32_t msg; uint8_t role; };
+  std::vector<Tmp> tmp(2 * nm);
+  {
+    std::vector<int64_t> cur(fm_off.begin(), fm_off.end() - 1);
+    for (int64_t i = 0; i < nm; ++i) {   // insertion order inside each factor
+      tmp[cur[m_left[i]]++] = {rank_l[m_type[i]], (int32_t)i, 0};
+      tmp[cur[m_right[i]]++] = {rank_r[m_type[i]], (int32_t)i, 1};
+    }
+  }
+  updated.assign(nf, 0);
+  for (int64_t f = 0; f < nf; ++f) {
+    Tmp* b = tmp.data() + fm_off[f];
+    Tmp* e = tmp.data() + fm_off[f + 1];
+    std::stable_sort(b, e, [](const Tmp& x, const Tmp& y) { return x.rank < y.rank; });
+    for (Tmp* p = b; p != e;) {          // runs of one dispatcher; LIFO storages iterate newest first
+      Tmp* q = p;
+      while (q != e && q->rank == p->rank) ++q;
+      const auto& mt = mtypes[m_type[p->msg]];
+      const bool lifo = p->role == 0 ? (mt.n_left == 0 && mt.n_right != 0) : (mt.n_right == 0 && mt.n_left != 0);
+      if (lifo) std::reverse(p, q);
+      p = q;
+    }
+    bool upd_f = ftype_primal[f_type[f]] != 0;
+    for (Tmp* p = b; p != e; ++p) {
+      const SchedCaps c = caps(mtypes[m_type[p->msg]].schedule);
+      MsgEntry& en = fm[fm_off[f] + (p - b)];
+      en.msg = p->msg; en.role = p->role;
+      if (p->role == 0) {
+        en.adjacent = m_right[p->msg];
+        en.sends = c.to_right; en.receives = c.from_right; en.adj_sends = c.to_left; en.adj_receives = c.from_left;
+      } else {
+        en.adjacent = m_left[p->msg];
+        en.sends = c.to_left; en.receives = c.from_left; en.adj_sends = c.to_right; en.adj_receives = c.from_right;
+      }
+      upd_f = upd_f || en.sends || en.receives;
+    }
+    updated[f] = upd_f;
+  }
+
+  // ---- orderings
+  const int32_t* rels[2] = {m.rel_fwd, m.rel_bwd};
+  const int64_t nrels[2] = {m.n_rel_fwd, m.n_rel_bwd};
+  for (int d = 0; d < 2; ++d) {
+    order[d] = reference_topological_order(nf, rels[d], nrels[d]);
+    upd[d].clear();
+    for (int32_t f : order[d]) if (updated[f]) upd[d].push_back(f);
+  }
+}
+
+// rows for the updated members of a list (reference allocate_omega / allocate_receive_mask)
+static void shape_rows(const Plan& p, const int32_t* list, int64_t n, Csr<double>& om, Csr<uint8_t>& mk) {
+  om.off.assign(1, 0); mk.off.assign(1, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    if (!p.updated[list[i]]) continue;
+    om.off.push_back(om.off.back() + p.row_sends(list[i]));
+    mk.off.push_back(mk.off.back() + p.row_receives(list[i]));
+  }
+  om.data.assign(om.off.back(), 0.0);
+  mk.data.assign(mk.off.back(), 0);
+}
+
+// reference LP_MP.h:1232-1415
+void Plan::anisotropic_weights(const int32_t* list, int64_t n, Csr<double>& om, Csr<uint8_t>& mk) const {
+  constexpr int64_t NONE = -1, INF = std::numeric_limits<int64_t>::max();
+  std::vector<int64_t> pos(nf, NONE);
+  for (int64_t i = 0; i < n; ++i) {
+    if (list[i] < 0 || list[i] >= nf) fail("factor index out of range");
+    pos[list[i]] = i;
+  }
+  std::vector<int64_t> n_later(n, 0), last(n, 0), first(n, INF);
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t f = list[i];
+    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
+      const MsgEntry& e = fm[j];
+      const int64_t a = pos[e.adjacent];
+      if (a != NONE && e.adj_receives && a > i) {
+        ++n_later[i];
+        last[i] = std::max(last[i], a);
+        first[i] = std::min(first[i], a);
+      }
+    }
+  }
+  // factors outside the list: only those adjacent to >= 2 members get real values, all others read the
+  // value-initialised 0 of the reference's unordered_map::operator[] (LP_MP.h:1283-1303, :1322, :1342)
+  std::vector<int64_t> out_min_send, out_max_recv;
+  if (n < nf) {
+    out_min_send.assign(nf, 0); out_max_recv.assign(nf, 0);
+    std::vector<int32_t> touch(nf, 0);
+    for (int64_t i = 0; i < n; ++i)
+      for (int64_t j = fm_off[list[i]]; j < fm_off[list[i] + 1]; ++j)
+        if (pos[fm[j].adjacent] == NONE) ++touch[fm[j].adjacent];
+    for (int64_t g = 0; g < nf; ++g) {
+      if (touch[g] < 2) continue;
+      int64_t mn = INF, mx = 0;
+      for (int64_t j = fm_off[g]; j < fm_off[g + 1]; ++j) {
+        const int64_t a = pos[fm[j].adjacent];
+        if (a == NONE) continue;
+        if (fm[j].adj_sends) mn = std::min(mn, a);
+        if (fm[j].adj_receives) mx = std::max(mx, a);
+      }
+      out_min_send[g] = mn; out_max_recv[g] = mx;
+    }
+  }
+  shape_rows(*this, list, n, om, mk);
+  int64_t row = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t f = list[i];
+    if (!updated[f]) continue;
+    double* o = om.data.data() + om.off[row];
+    uint8_t* r = mk.data.data() + mk.off[row];
+    int64_t ns = 0, na = 0, nr = 0;
+    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
+      const MsgEntry& e = fm[j];
+      const int64_t a = pos[e.adjacent];
+      if (e.sends) {
+        const bool s = a != NONE ? ((i < a && updated[e.adjacent]) || last[a] > i) : (i < out_max_recv[e.adjacent]);
+        o[ns++] = s ? 1.0 : 0.0;
+        na += s;
+      }
+      if (e.receives) r[nr++] = a != NONE ? (a < i || first[a] < i) : (out_min_send[e.adjacent] < i);
+    }
+    if (na > 0) {
+      const double w = 1.0 / double(n_later[i] + std::max(na, ns - na));   // srmp_weight, :1397
+      for (int64_t k = 0; k < ns; ++k) if (o[k] > 0) o[k] *= w;
+    }
+    ++row;
+  }
+}
+
+void Plan::ensure_weights(int mode) {
+  if (mode < 0 || mode >= LPMP_REPAM_COUNT) fail("no reparametrization mode set");
+  if (have[mode]) return;
+  for (int d = 0; d < 2; ++d) {
+    Csr<double>& om = omega[d][mode];
+    Csr<uint8_t>& mk = mask[d][mode];
+    const std::vector<int32_t>& ord = order[d];
+    if (mode == LPMP_REPAM_ANISOTROPIC) {
+      anisotropic_weights(ord.data(), nf, om, mk);
+    } else if (mode == LPMP_REPAM_ANISOTROPIC2) {   // reference LP_MP.h:1086-1154
+      std::vector<int64_t> inv(nf), later(nf, 0);
+      for (int64_t i = 0; i < nf; ++i) inv[ord[i]] = i;
+      for (int64_t i = 0; i < nm; ++i) {
+        const SchedCaps c = caps(mtypes[m_type[i]].schedule);
+        const int64_t il = inv[m_left[i]], ir = inv[m_right[i]];
+        if (c.to_right && il < ir) ++later[il];
+        if (c.to_left && ir < il) ++later[ir];
+      }
+      shape_rows(*this, ord.data(), nf, om, mk);
+      int64_t row = 0;
+      for (int64_t i = 0; i < nf; ++i) {
+        const int32_t f = ord[i];
+        if (!updated[f]) continue;
+        int64_t ks = om.off[row], kr = mk.off[row];
+        for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
+          const int64_t a = inv[fm[j].adjacent];
+          if (fm[j].sends) om.data[ks++] = i < a ? 1.0 / double(later[i]) : 0.0;
+          if (fm[j].receives) mk.data[kr++] = a < i;
+        }
+        ++row;
+      }
+    } else {   // uniform / damped uniform, reference LP_MP.h:1422-1449 with leave_weight 0 / 1, full mask :1489
+      const double leave = mode == LPMP_REPAM_DAMPED_UNIFORM ? 1.0 : 0.0;
+      shape_rows(*this, ord.data(), nf, om, mk);
+      for (int64_t r = 0; r < om.rows(); ++r) {
+        const double w = 1.0 / (double(om.off[r + 1] - om.off[r]) + leave);
+        std::fill(om.data.begin() + om.off[r], om.data.begin() + om.off[r + 1], w);
+      }
+      std::fill(mk.data.begin(), mk.data.end(), 1);
+    }
+  }
+  have[mode] = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level scheduling.  The reference sweep is strictly sequential (LP_MP.h:989-992).  Two updates
+// commute exactly when they touch disjoint factors, so update u gets
+//   level(u) = 1 + max(level of the latest earlier update that touched u or one of the factors u touches)
+// and all updates of one level run concurrently with a result identical to the sequential sweep.
+void Plan::make_schedule(const int32_t* factors, int64_t n, const int64_t* om_off, const double* om,
+                         const int64_t* mk_off, const uint8_t* mk, Schedule& out) const {
+  out = Schedule();
+  std::vector<int32_t> level(n, 0), kclass(n, KC_GENERIC);
+  std::vector<int32_t> last_touch(nf, 0);
+  std::vector<int64_t> n_ops(n, 0);
+  int32_t max_level = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t f = factors[i];
+    if (f < 0 || f >= nf) fail("factor index out of range");
+    if (om_off[i + 1] - om_off[i] != row_sends(f) || mk_off[i + 1] - mk_off[i] != row_receives(f))
+      fail("row " + std::to_string(i) + ": omega / receive mask length does not match the factor's messages");
+    int32_t lv = last_touch[f];
+    int64_t ks = om_off[i], kr = mk_off[i], cnt = 0;
+    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
+      const MsgEntry& e = fm[j];
+      bool active = false;
+      if (e.receives) active = mk[kr++] != 0;
+      if (e.sends) { const double w = om[ks++]; if (w < 0) fail("negative send weight"); active = active || w != 0.0; }
+      if (active) lv = std::max(lv, last_touch[e.adjacent]);
+    }
+    // count ops
+    ks = om_off[i]; kr = mk_off[i];
+    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
+      const MsgEntry& e = fm[j];
+      if (e.receives && mk[kr++]) ++cnt;
+      if (e.sends && om[ks++] != 0.0) ++cnt;
+    }
+    n_ops[i] = cnt;
+    level[i] = lv + 1;
+    max_level = std::max(max_level, level[i]);
+    last_touch[f] = level[i];
+    ks = om_off[i]; kr = mk_off[i];
+    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
+      const MsgEntry& e = fm[j];
+      bool active = false;
+      if (e.receives) active = mk[kr++] != 0;
+      if (e.sends) active = (om[ks++] != 0.0) || active;
+      if (active) last_touch[e.adjacent] = level[i];
+    }
+  }
+  out.n_levels = max_level;
+
+  // build records + ops in list order first, then bucket by (level, class)
+  std::vector<UpdRec> recs(n);
+  std::vector<int64_t> rec_bytes(n, 0);
+  std::vector<int64_t> op_start(n + 1, 0);
+  for (int64_t i = 0; i < n; ++i) op_start[i + 1] = op_start[i] + n_ops[i];
+  if (op_start[n] > std::numeric_limits<int32_t>::max()) fail("too many active message operations for one schedule");
+  std::vector<Op> ops(op_start[n]);
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t f = factors[i];
+    UpdRec& r = recs[i];
+    r.dual_off = f_doff[f];
+    r.const_off = f_kind[f] == LPMP_F_VECTOR ? -1 : f_coff[f];
+    r.d0 = f_dim0[f]; r.d1 = f_dim1[f];
+    r.factor = f;
+    r.kind_flags = f_kind[f] | (f_flags[f] << 4);
+    Op* o = ops.data() + op_start[i];
+    int64_t nrecv = 0, nsend = 0;
+    bool all_dense = f_kind[f] == LPMP_F_VECTOR, all_potts = all_dense;
+    auto fill = [&](const MsgEntry& e, double w) {
+      const auto& mt = mtypes[m_type[e.msg]];
+      const int32_t peer = e.adjacent;
+      Op op{};
+      op.peer_dual = f_doff[peer];
+      op.omega = w;
+      op.msg = e.msg;
+      op.len = f_dim0[m_left[e.msg]];
+      op.pd0 = f_dim0[peer]; op.pd1 = f_dim1[peer];
+      const int32_t right = m_right[e.msg];
+      int side = 0, imp = 0;
+      if (mt.kind == LPMP_M_UNARY_PAIRWISE) {
+        side = mt.param;
+        op.peer_const = e.role == 0 ? f_coff[peer] : -1;
+        if (!(e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && f_dim0[peer] == r.d0 && f_dim1[peer] == r.d0 && (f_coff[peer] % 2) == 0)) all_dense = false;
+        if (!(e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == r.d0)) all_potts = false;
+      } else {
+        all_dense = all_potts = false;
+        if (mt.kind == LPMP_M_LABELING) {
+          op.peer_const = tab_off[mt.param];
+          op.pd1 = tab_nleft[mt.param];
+          imp = (f_flags[right] & LPMP_FF_IMPLICIT_ORIGIN) ? 1 : 0;
+        }
+      }
+      op.info = mt.kind | (e.role << 4) | (side << 5) | (imp << 6) | (f_kind[peer] << 8);
+      return op;
+    };
+    int64_t ks = om_off[i], kr = mk_off[i];
+    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {   // receives first, list order
+      const MsgEntry& e = fm[j];
+      if (e.receives && mk[kr++]) { *o++ = fill(e, 1.0); ++nrecv; }
+    }
+    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {   // then sends, list order
+      const MsgEntry& e = fm[j];
+      if (e.sends) { const double w = om[ks++]; if (w != 0.0) { *o++ = fill(e, w); ++nsend; } }
+    }
+    if (nrecv > 32767 || nsend > 32767) fail("factor has too many messages");
+    r.op_begin = (int32_t)op_start[i];
+    r.n_recv = (int16_t)nrecv; r.n_send = (int16_t)nsend;
+    // the reference snapshots the factor only when it has more than one send CALL (all sending messages,
+    // active or not, factors_messages.hxx:2544-2558,2799-2805); with a single one it sends from the live
+    // factor, which gives the same numbers, so the kernels always send from the post-receive state.
+    out.n_recv += nrecv; out.n_send += nsend;
+    // algorithmic bytes: own dual read + written once, per receive the peer's table and both
+    // message vectors read and one written, per send one peer vector read and written
+    const int64_t own = f_doff[f + 1] - f_doff[f];
+    const int64_t bytes_before = out.alg_bytes;
+    out.alg_bytes += 16 * own;
+    for (int64_t k = 0; k < nrecv + nsend; ++k) {
+      const Op& op = ops[op_start[i] + k];
+      const int code = op.info & 15;
+      const int pk = (op.info >> 8) & 15;
+      const bool recv = k < nrecv;
+      if (code == LPMP_M_UNARY_PAIRWISE) {
+        const int64_t L = op.len;
+        if (recv) out.alg_bytes += 24 * L + (pk == LPMP_F_PAIRWISE_DENSE ? 8 * (int64_t)op.pd0 * op.pd1 : (pk == LPMP_F_PAIRWISE_POTTS ? 8 : 0));
+        else out.alg_bytes += 16 * L;
+      } else {
+        out.alg_bytes += 16 * (int64_t)op.pd0;
+      }
+    }
+    rec_bytes[i] = out.alg_bytes - bytes_before;
+    const int n_all = (int)(nrecv + nsend);
+    if (n_all == 0) { out.alg_bytes = bytes_before; rec_bytes[i] = 0; }
+    if (n_all > 0 && all_dense && (r.d0 == 4 || r.d0 == 8 || r.d0 == 16 || r.d0 == 32))
+      kclass[i] = r.d0 == 4 ? KC_DENSE_4 : r.d0 == 8 ? KC_DENSE_8 : r.d0 == 16 ? KC_DENSE_16 : KC_DENSE_32;
+    else if (n_all > 0 && all_potts && (r.d0 == 4 || r.d0 == 8 || r.d0 == 16 || r.d0 == 32))
+      kclass[i] = r.d0 == 4 ? KC_POTTS_4 : r.d0 == 8 ? KC_POTTS_8 : r.d0 == 16 ? KC_POTTS_16 : KC_POTTS_32;
+  }
+  // bucket sort by (level, class); factors without any active op touch nothing and are dropped
+  const int64_t n_keys = (int64_t)max_level * KC_COUNT;
+  std::vector<int64_t> key_count(n_keys + 1, 0), key_recv(n_keys, 0), key_send(n_keys, 0), key_bytes(n_keys, 0);
+  auto key = [&](int64_t i) { return (int64_t)(level[i] - 1) * KC_COUNT + kclass[i]; };
+  for (int64_t i = 0; i < n; ++i) {
+    if (n_ops[i] == 0) continue;
+    ++key_count[key(i) + 1];
+    key_recv[key(i)] += recs[i].n_recv; key_send[key(i)] += recs[i].n_send; key_bytes[key(i)] += rec_bytes[i];
+  }
+  std::partial_sum(key_count.begin(), key_count.end(), key_count.begin());
+  out.recs.resize(key_count[n_keys]);
+  {
+    std::vector<int64_t> cur(key_count.begin(), key_count.end() - 1);
+    for (int64_t i = 0; i < n; ++i) if (n_ops[i] > 0) out.recs[cur[key(i)]++] = recs[i];
+  }
+  for (int64_t k = 0; k < n_keys; ++k)
+    if (key_count[k + 1] > key_count[k]) {
+      LevelRange lr;
+      lr.kclass = (int32_t)(k % KC_COUNT); lr.begin = key_count[k]; lr.end = key_count[k + 1];
+      lr.n_recv = key_recv[k]; lr.n_send = key_send[k]; lr.bytes = key_bytes[k];
+      out.launches.push_back(lr);
+    }
+  out.ops = std::move(ops);
+}
+
+}  // namespace lpmp

@@ -1,0 +1,117 @@
+// plan.hpp — host-side analysis of a flat LP_MP model: per-factor message lists, update ordering,
+// send weights / receive masks for every reparametrisation mode, and the level schedule the HIP
+// sweep kernels execute.  Pure C++17 (no HIP): the same code runs in the CPU-only test container.
+//
+// Reference behaviour restated here (paths relative to /root/reference):
+//   message lists  include/factors_messages.hxx:3339-3365, :3402-3419, storage order :2081-2119, :2030-2041
+//   FactorUpdated  include/factors_messages.hxx:3125-3140
+//   ordering       include/LP_MP.h:730-797, include/topological_sort.hxx:100-144
+//   weights        include/LP_MP.h:1232-1415 (anisotropic), :1086-1154 (anisotropic2), :1422-1449 (uniform),
+//                  :1489-1505 (full receive mask)
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/lpmp_model.h"
+
+namespace lpmp {
+
+struct MsgEntry {          // one element of FactorContainer::get_messages()
+  int32_t msg;
+  int32_t adjacent;
+  uint8_t role;            // 0: this factor is the message's left factor, 1: right
+  uint8_t sends, receives, adj_sends, adj_receives;
+};
+
+template <class T>
+struct Csr {
+  std::vector<int64_t> off{0};
+  std::vector<T> data;
+  int64_t rows() const { return (int64_t)off.size() - 1; }
+};
+
+// Device-side records (plain structs shared with kernels.hip) -----------------------------------
+enum OpCode : int32_t { OP_UP = 0, OP_LABELING = 1, OP_MINNORM = 2 };
+
+struct alignas(16) UpdRec {   // one updated factor
+  int64_t dual_off;   // own dual start
+  int64_t const_off;  // own const start (pairwise) or -1
+  int32_t d0, d1;     // own dims (vector: d0 = n, d1 = 0)
+  int32_t op_begin;   // first op
+  int16_t n_recv, n_send;
+  int32_t factor;
+  int32_t kind_flags; // own kind (bits 0-3) | flags << 4
+};
+static_assert(sizeof(UpdRec) == 48, "UpdRec layout");
+
+struct alignas(16) Op {       // one active receive or send
+  int64_t peer_dual;  // peer dual start
+  int64_t peer_const; // peer const start (pairwise peer), or offset of the match table in tab_data (labeling)
+  double omega;       // send weight (receives: 1.0)
+  int32_t info;       // opcode | role<<4 | side<<5 | peer_implicit_origin<<6 | peer_kind<<8
+  int32_t pd0;        // peer dim0
+  int32_t pd1;        // peer dim1 (dense pairwise peer) / n_left of the table (labeling)
+  int32_t msg;        // message index (diagnostics)
+  int32_t len;        // message length (= dim of the left factor's variable)
+  int32_t pad;
+};
+static_assert(sizeof(Op) == 48, "Op layout");
+
+// kernel classes: which kernel runs an updated factor
+enum KClass : int32_t {
+  KC_GENERIC = 0,
+  KC_DENSE_4, KC_DENSE_8, KC_DENSE_16, KC_DENSE_32,
+  KC_POTTS_4, KC_POTTS_8, KC_POTTS_16, KC_POTTS_32,
+  KC_COUNT
+};
+
+struct LevelRange {            // one kernel launch: a range of UpdRec indices of one level and class
+  int32_t kclass; int64_t begin, end;
+  int64_t n_recv = 0, n_send = 0, bytes = 0;   // active receives / sends / algorithmic bytes of the range
+};
+
+struct Schedule {             // executable form of one (factor list, omega, mask) sweep
+  std::vector<UpdRec> recs;   // sorted by (level, kclass)
+  std::vector<Op> ops;
+  std::vector<LevelRange> launches;   // in execution order
+  int64_t n_levels = 0;
+  int64_t n_recv = 0, n_send = 0;     // active receives / sends = message updates per sweep
+  int64_t alg_bytes = 0;              // algorithmic HBM bytes per sweep (DESIGN.md accounting)
+};
+
+struct Plan {
+  // copied structure (no cost data)
+  int32_t n_ftypes = 0, n_mtypes = 0, n_tables = 0;
+  std::vector<uint8_t> ftype_primal;
+  std::vector<lpmp_msg_type> mtypes;
+  std::vector<int64_t> tab_off;
+  std::vector<int32_t> tab_data, tab_nleft;
+  int64_t nf = 0, nm = 0;
+  std::vector<int32_t> f_type, f_dim0, f_dim1;
+  std::vector<uint8_t> f_kind, f_flags;
+  std::vector<int64_t> f_coff, f_doff;   // [nf+1]
+  std::vector<int32_t> m_type, m_left, m_right;
+  double constant = 0;
+  // derived
+  std::vector<int64_t> fm_off;
+  std::vector<MsgEntry> fm;
+  std::vector<uint8_t> updated;
+  std::vector<int32_t> order[2], upd[2];
+  Csr<double> omega[2][LPMP_REPAM_COUNT];
+  Csr<uint8_t> mask[2][LPMP_REPAM_COUNT];
+  bool have[LPMP_REPAM_COUNT] = {false, false, false, false};
+  int max_dual = 1;
+
+  // throws std::runtime_error on invalid input (the reference throws too, LP_MP.h:458)
+  void build(const lpmp_model& m);
+  void ensure_weights(int mode);
+  void anisotropic_weights(const int32_t* list, int64_t n, Csr<double>& om, Csr<uint8_t>& mk) const;
+  // turn a factor list + rows into levels/records/ops; rows are indexed like the list's updated factors
+  void make_schedule(const int32_t* factors, int64_t n, const int64_t* om_off, const double* om,
+                     const int64_t* mk_off, const uint8_t* mk, Schedule& out) const;
+  int64_t row_sends(int32_t f) const;
+  int64_t row_receives(int32_t f) const;
+};
+
+}  // namespace lpmp

@@ -1,0 +1,282 @@
+"""ctypes binding of the C ABI in include/lpmp_engine.h (liblpmp_engine.so).
+
+No CPU fallback: ``Engine`` raises if the HIP extension is missing or no GPU is present.
+``Plan`` (host-only analysis: ordering, weights, level schedule) works without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+from .model import FlatModel
+
+_LIB = None
+N_KCLASS = 9
+KCLASS_NAMES = ["generic", "dense4", "dense8", "dense16", "dense32", "potts4", "potts8", "potts16", "potts32"]
+KERNEL_NAMES = ["sweep_generic_kernel", "sweep_dense_kernel<4>", "sweep_dense_kernel<8>", "sweep_dense_kernel<16>",
+                "sweep_dense_kernel<32>", "sweep_potts_kernel<4>", "sweep_potts_kernel<8>", "sweep_potts_kernel<16>",
+                "sweep_potts_kernel<32>"]
+MEM_HOST, MEM_DEVICE = 0, 1
+
+EXPORTS = [
+    "lpmp_last_error", "lpmp_version", "lpmp_plan_create", "lpmp_plan_destroy", "lpmp_plan_n_factors",
+    "lpmp_plan_n_updated", "lpmp_plan_get_order", "lpmp_plan_get_update_order", "lpmp_plan_omega_nnz",
+    "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
+    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
+    "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_compute_pass", "lpmp_compute_forward_pass",
+    "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
+    "lpmp_synchronize", "lpmp_dual_size", "lpmp_download_duals", "lpmp_upload_duals", "lpmp_device_duals",
+    "lpmp_engine_plan", "lpmp_engine_plan_mut", "lpmp_enable_kernel_timing", "lpmp_get_kernel_timing",
+    "lpmp_reset_kernel_timing", "lpmp_synth_fill",
+]
+
+
+def library_path() -> str:
+    return _build.SO
+
+
+def lib():
+    """Loads the HIP extension; raises (never falls back) if it is not built."""
+    global _LIB
+    if _LIB is None:
+        so = library_path()
+        if not os.path.exists(so):
+            raise RuntimeError(f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the engine has no CPU fallback)")
+        L = C.CDLL(so)
+        L.lpmp_last_error.restype = C.c_char_p
+        L.lpmp_version.restype = C.c_char_p
+        for n in ("lpmp_plan_n_factors", "lpmp_dual_size"):
+            getattr(L, n).restype = C.c_int64
+            getattr(L, n).argtypes = [C.c_void_p]
+        for n in ("lpmp_plan_n_updated", "lpmp_plan_omega_nnz", "lpmp_plan_mask_nnz"):
+            getattr(L, n).restype = C.c_int64
+            getattr(L, n).argtypes = [C.c_void_p, C.c_int]
+        L.lpmp_plan_create.argtypes = [C.c_void_p, C.c_void_p]
+        L.lpmp_plan_destroy.argtypes = [C.c_void_p]
+        L.lpmp_plan_get_order.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.lpmp_plan_get_update_order.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.lpmp_plan_get_omega.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.lpmp_plan_get_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.lpmp_plan_get_msg_lists.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lpmp_plan_anisotropic_weights.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
+        L.lpmp_plan_schedule_info.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.lpmp_create.argtypes = [C.c_int, C.c_void_p]
+        L.lpmp_destroy.argtypes = [C.c_void_p]
+        L.lpmp_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.lpmp_upload_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.lpmp_set_reparametrization.argtypes = [C.c_void_p, C.c_int]
+        L.lpmp_compute_pass.argtypes = [C.c_void_p, C.c_int]
+        L.lpmp_compute_forward_pass.argtypes = [C.c_void_p]
+        L.lpmp_compute_backward_pass.argtypes = [C.c_void_p]
+        L.lpmp_compute_pass_custom.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+        L.lpmp_lower_bound.argtypes = [C.c_void_p, C.c_void_p]
+        L.lpmp_factor_lower_bounds.argtypes = [C.c_void_p, C.c_void_p]
+        L.lpmp_synchronize.argtypes = [C.c_void_p]
+        L.lpmp_download_duals.argtypes = [C.c_void_p, C.c_void_p]
+        L.lpmp_upload_duals.argtypes = [C.c_void_p, C.c_void_p]
+        L.lpmp_device_duals.restype = C.c_void_p
+        L.lpmp_device_duals.argtypes = [C.c_void_p]
+        L.lpmp_engine_plan.restype = C.c_void_p
+        L.lpmp_engine_plan.argtypes = [C.c_void_p]
+        L.lpmp_engine_plan_mut.restype = C.c_void_p
+        L.lpmp_engine_plan_mut.argtypes = [C.c_void_p]
+        L.lpmp_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        L.lpmp_get_kernel_timing.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.lpmp_reset_kernel_timing.argtypes = [C.c_void_p]
+        L.lpmp_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class EngineError(RuntimeError):
+    """Mirrors the std::runtime_error the reference throws (LP_MP.h:458)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+def _chk(rc: int):
+    if rc != 0:
+        raise EngineError(rc, lib().lpmp_last_error().decode())
+
+
+class Plan:
+    """Host-only analysis of a model: orderings, weights, level schedule (no GPU needed)."""
+
+    def __init__(self, model: Optional[FlatModel] = None, _handle=None, _owner=None):
+        self.L = lib()
+        self._owner = _owner
+        if _handle is not None:
+            self.h = _handle
+            self._own = False
+        else:
+            cs = model.c_struct()
+            h = C.c_void_p()
+            _chk(self.L.lpmp_plan_create(C.addressof(cs), C.addressof(h)))
+            self.h = h.value
+            self._own = True
+
+    def __del__(self):
+        if getattr(self, "_own", False) and getattr(self, "h", None):
+            self.L.lpmp_plan_destroy(self.h)
+            self.h = None
+
+    @property
+    def n_factors(self) -> int:
+        return self.L.lpmp_plan_n_factors(self.h)
+
+    def order(self, d: int) -> np.ndarray:
+        out = np.empty(self.n_factors, np.int32)
+        _chk(self.L.lpmp_plan_get_order(self.h, d, out.ctypes.data))
+        return out
+
+    def update_order(self, d: int) -> np.ndarray:
+        out = np.empty(self.L.lpmp_plan_n_updated(self.h, d), np.int32)
+        _chk(self.L.lpmp_plan_get_update_order(self.h, d, out.ctypes.data))
+        return out
+
+    def omega(self, d: int, mode: int):
+        off = np.empty(self.L.lpmp_plan_n_updated(self.h, d) + 1, np.int64)
+        data = np.empty(self.L.lpmp_plan_omega_nnz(self.h, d), np.float64)
+        _chk(self.L.lpmp_plan_get_omega(self.h, d, mode, off.ctypes.data, data.ctypes.data))
+        return off, data
+
+    def mask(self, d: int, mode: int):
+        off = np.empty(self.L.lpmp_plan_n_updated(self.h, d) + 1, np.int64)
+        data = np.empty(self.L.lpmp_plan_mask_nnz(self.h, d), np.uint8)
+        _chk(self.L.lpmp_plan_get_mask(self.h, d, mode, off.ctypes.data, data.ctypes.data))
+        return off, data
+
+    def msg_lists(self, n_messages: int):
+        off = np.empty(self.n_factors + 1, np.int64)
+        ent = np.empty(2 * n_messages, np.int64)
+        _chk(self.L.lpmp_plan_get_msg_lists(self.h, off.ctypes.data, ent.ctypes.data))
+        return off, ent
+
+    def anisotropic_weights(self, factors):
+        factors = np.ascontiguousarray(factors, np.int32)
+        nr, a, b = C.c_int64(), C.c_int64(), C.c_int64()
+        _chk(self.L.lpmp_plan_anisotropic_weights(self.h, factors.shape[0], factors.ctypes.data, C.addressof(nr),
+                                                  C.addressof(a), C.addressof(b), None, None, None, None))
+        om_off, mk_off = np.empty(nr.value + 1, np.int64), np.empty(nr.value + 1, np.int64)
+        om, mk = np.empty(a.value, np.float64), np.empty(b.value, np.uint8)
+        _chk(self.L.lpmp_plan_anisotropic_weights(self.h, factors.shape[0], factors.ctypes.data, None, None, None,
+                                                  om_off.ctypes.data, om.ctypes.data, mk_off.ctypes.data, mk.ctypes.data))
+        return om_off, om, mk_off, mk
+
+    def schedule_info(self, d: int, mode: int) -> dict:
+        v = [C.c_int64() for _ in range(5)]
+        _chk(self.L.lpmp_plan_schedule_info(self.h, d, mode, *[C.addressof(x) for x in v]))
+        return dict(zip(("n_levels", "n_launches", "n_receives", "n_sends", "algorithmic_bytes"), [x.value for x in v]))
+
+
+class Engine:
+    """Device engine. ``const_dev`` / ``dual_dev``: optional device pointers (ints) of caller-owned HBM
+    buffers holding the packed pairwise tables / duals (zero-copy; the caller keeps them alive)."""
+
+    def __init__(self, device: int = 0):
+        self.L = lib()
+        h = C.c_void_p()
+        _chk(self.L.lpmp_create(int(device), C.addressof(h)))
+        self.h = h.value
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lpmp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_stream(self, stream_ptr: int):
+        _chk(self.L.lpmp_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def upload(self, model: FlatModel, const_dev: Optional[int] = None, dual_dev: Optional[int] = None, keep=None):
+        cs = model.c_struct()
+        if const_dev is not None:
+            cs.const_data = const_dev
+        if dual_dev is not None:
+            cs.dual_data = dual_dev
+        self._keep = keep
+        self.model = model
+        _chk(self.L.lpmp_upload_model(self.h, C.addressof(cs), MEM_DEVICE if const_dev is not None else MEM_HOST,
+                                      MEM_DEVICE if dual_dev is not None else MEM_HOST))
+
+    @property
+    def plan(self) -> Plan:
+        return Plan(_handle=self.L.lpmp_engine_plan_mut(self.h), _owner=self)
+
+    def set_reparametrization(self, mode: int):
+        _chk(self.L.lpmp_set_reparametrization(self.h, int(mode)))
+
+    def compute_pass(self, n: int = 1):
+        _chk(self.L.lpmp_compute_pass(self.h, int(n)))
+
+    def forward_pass(self):
+        _chk(self.L.lpmp_compute_forward_pass(self.h))
+
+    def backward_pass(self):
+        _chk(self.L.lpmp_compute_backward_pass(self.h))
+
+    def compute_pass_custom(self, factors, om_off, om, mk_off, mk):
+        factors = np.ascontiguousarray(factors, np.int32)
+        om_off = np.ascontiguousarray(om_off, np.int64)
+        om = np.ascontiguousarray(om, np.float64)
+        mk_off = np.ascontiguousarray(mk_off, np.int64)
+        mk = np.ascontiguousarray(mk, np.uint8)
+        _chk(self.L.lpmp_compute_pass_custom(self.h, factors.shape[0], factors.ctypes.data, om_off.ctypes.data,
+                                             om.ctypes.data, mk_off.ctypes.data, mk.ctypes.data))
+
+    def lower_bound(self) -> float:
+        out = C.c_double()
+        _chk(self.L.lpmp_lower_bound(self.h, C.addressof(out)))
+        return out.value
+
+    def factor_lower_bounds(self) -> np.ndarray:
+        out = np.empty(self.model.n_factors, np.float64)
+        _chk(self.L.lpmp_factor_lower_bounds(self.h, out.ctypes.data))
+        return out
+
+    def synchronize(self):
+        _chk(self.L.lpmp_synchronize(self.h))
+
+    def download_duals(self) -> np.ndarray:
+        out = np.empty(self.L.lpmp_dual_size(self.h), np.float64)
+        _chk(self.L.lpmp_download_duals(self.h, out.ctypes.data))
+        return out
+
+    def upload_duals(self, d: np.ndarray):
+        d = np.ascontiguousarray(d, np.float64)
+        assert d.shape[0] == self.L.lpmp_dual_size(self.h)
+        _chk(self.L.lpmp_upload_duals(self.h, d.ctypes.data))
+
+    def device_duals_ptr(self) -> int:
+        return self.L.lpmp_device_duals(self.h)
+
+    def enable_kernel_timing(self, on: bool):
+        _chk(self.L.lpmp_enable_kernel_timing(self.h, 1 if on else 0))
+
+    def reset_kernel_timing(self):
+        _chk(self.L.lpmp_reset_kernel_timing(self.h))
+
+    def kernel_timing(self) -> dict:
+        ms = np.zeros(N_KCLASS, np.float64)
+        arrs = [np.zeros(N_KCLASS, np.int64) for _ in range(4)]
+        _chk(self.L.lpmp_get_kernel_timing(self.h, N_KCLASS, ms.ctypes.data, *[a.ctypes.data for a in arrs]))
+        out = {}
+        for c in range(N_KCLASS):
+            if arrs[0][c] > 0:
+                out[KCLASS_NAMES[c]] = dict(kernel=KERNEL_NAMES[c], ms=float(ms[c]), launches=int(arrs[0][c]),
+                                            factors=int(arrs[1][c]), receives=int(arrs[2][c]), bytes=int(arrs[3][c]))
+        return out
+
+
+def synth_fill(device_ptr: int, n: int, seed: int, first: int = 0, stream_ptr: int = 0):
+    _chk(lib().lpmp_synth_fill(C.c_void_p(device_ptr), n, C.c_uint64(seed), C.c_uint64(first), C.c_void_p(stream_ptr)))

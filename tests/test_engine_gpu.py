@@ -1,0 +1,320 @@
+"""Parity of the HIP sweep (through the C ABI) against the CPU oracle, plus size-independent
+properties at BASELINE.json's full sizes.  Tolerance of the north star: lower bound within 1e-5
+relative after the same number of passes on identical inputs; the duals themselves are required to
+match to 1e-12 absolute (they are bit-identical in practice: min and + are exact and the evaluation
+order is copied)."""
+import numpy as np
+import pytest
+
+from lp_mp_amd import model as M
+from lp_mp_amd import synthetic as S
+from lp_mp_amd import engine as E
+from oracle.binding import Oracle
+
+pytestmark = pytest.mark.gpu
+
+LB_RTOL = 1e-5          # BASELINE.json north_star
+DUAL_ATOL = 1e-12
+MODES = (M.REPAM_ANISOTROPIC, M.REPAM_ANISOTROPIC2, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = E.Engine(0)
+    yield e
+    e.close()
+
+
+def _check(eng, m, mode, passes, exact=True):
+    o = Oracle(m)
+    o.set_reparametrization(mode)
+    eng.upload(m)
+    eng.set_reparametrization(mode)
+    lb0 = eng.lower_bound()
+    assert abs(lb0 - o.LowerBound()) <= LB_RTOL * max(1.0, abs(lb0))
+    prev = lb0
+    for _ in range(passes):
+        o.ComputePass(1)
+        eng.compute_pass(1)
+        lb, lbo = eng.lower_bound(), o.LowerBound()
+        assert abs(lb - lbo) <= LB_RTOL * max(1.0, abs(lbo)), (lb, lbo)
+        assert lb >= prev - 1e-8 * max(1.0, abs(prev))          # dual ascent
+        prev = lb
+    d, do = eng.download_duals(), o.duals()
+    assert np.max(np.abs(d - do)) <= DUAL_ATOL
+    if exact:
+        assert np.array_equal(d, do)
+    flb = eng.factor_lower_bounds()
+    oflb = np.array([o.factor_lower_bound(f) for f in range(min(m.n_factors, 400))])
+    assert np.max(np.abs(flb[:oflb.shape[0]] - oflb)) <= DUAL_ATOL
+    return prev
+
+
+# ---- every kernel class x every weight mode ---------------------------------------------------
+@pytest.mark.parametrize("L", [4, 8, 16, 32])
+@pytest.mark.parametrize("order", ["row_major", "colour_major"])
+def test_dense_fast_path(eng, L, order):
+    m = S.grid_model(13, 11, L, order=order, seed=L)
+    for mode in MODES:
+        _check(eng, m, mode, 3)
+    info = eng.plan.schedule_info(M.FORWARD, M.REPAM_ANISOTROPIC)
+    assert info["n_levels"] == (2 if order == "colour_major" else 13 + 11 - 1)
+
+
+@pytest.mark.parametrize("L", [4, 8, 16, 32])
+@pytest.mark.parametrize("order", ["row_major", "colour_major"])
+def test_potts_fast_path(eng, L, order):
+    m = S.grid_model(12, 15, L, pairwise="potts", order=order, seed=10 + L)
+    for mode in MODES:
+        _check(eng, m, mode, 3)
+
+
+def test_potts_ties_and_negative_coupling(eng):
+    # equal minima in the message vectors exercise the two-min tie rule; negative diff flips the branch
+    H, W, L = 9, 9, 8
+    n = H * W
+    E_ = len(S.grid_edges(H, W)[0])
+    un = np.round(S.u01(n * L, 3) * 3.0) / 3.0               # many exact ties
+    diffs = np.where(S.u01(E_, 4) < 0.5, -0.5, 0.75)
+    m = S.grid_model(H, W, L, pairwise="potts", unaries=un, potts=diffs)
+    _check(eng, m, M.REPAM_ANISOTROPIC, 4)
+    _check(eng, m, M.REPAM_UNIFORM, 4)
+
+
+@pytest.mark.parametrize("L", [2, 3, 5, 7, 12, 33, 64])
+def test_generic_kernel_odd_sizes(eng, L):
+    _check(eng, S.grid_model(6, 7, L, seed=L), M.REPAM_ANISOTROPIC, 2)
+    _check(eng, S.grid_model(6, 7, L, pairwise="potts", seed=L), M.REPAM_DAMPED_UNIFORM, 2)
+
+
+def test_rectangular_tables(eng):
+    # pairwise factors between variables of different label counts (generic kernel)
+    b = M.ModelBuilder(2, S.mrf_mtypes())
+    rng = np.random.default_rng(5)
+    dims = [3, 6, 4, 9, 2]
+    u = [b.add_vector_factors(0, rng.uniform(0, 1, (1, d)))[0] for d in dims]
+    for i in range(4):
+        p = b.add_dense_pairwise(1, rng.uniform(0, 1, (dims[i], dims[i + 1])))[0]
+        b.add_messages(0, u[i], p)
+        b.add_messages(1, u[i + 1], p)
+        b.add_relations(u[i], p)
+        b.add_relations(p, u[i + 1])
+    m = b.finish()
+    for mode in MODES:
+        _check(eng, m, mode, 3)
+
+
+def test_mixed_dense_and_potts_edges(eng):
+    H, W, L = 7, 8, 8
+    var = S.grid_variable_order(H, W, "row_major").reshape(-1)
+    a, bb = S.grid_edges(H, W)
+    b = M.ModelBuilder(2, S.mrf_mtypes())
+    u = b.add_vector_factors(0, S.u01(H * W * L, 1).reshape(-1, L))
+    rng = np.random.default_rng(2)
+    for k in range(len(a)):
+        if k % 2 == 0:
+            p = b.add_dense_pairwise(1, rng.uniform(0, 1, (L, L)))[0]
+        else:
+            p = b.add_potts_pairwise(1, L, [rng.uniform(0, 1)])[0]
+        b.add_messages(0, u[var[a[k]]], p)
+        b.add_messages(1, u[var[bb[k]]], p)
+        b.add_relations(u[var[a[k]]], p)
+        b.add_relations(p, u[var[bb[k]]])
+    _check(eng, b.finish(), M.REPAM_ANISOTROPIC, 3)
+
+
+def test_chain_c1(eng):
+    """BASELINE.json configs[0]: 4-label Potts chain, 100 variables."""
+    m = S.chain_model(100, 4)
+    lb = _check(eng, m, M.REPAM_ANISOTROPIC, 10)
+    # a chain is a tree: the LP bound is tight after one forward + backward sweep
+    o = Oracle(m)
+    o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    o.ComputePass(10)
+    assert abs(lb - o.LowerBound()) <= 1e-9
+
+
+def test_random_sparse_graph(eng):
+    for mode in (M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM):
+        _check(eng, S.random_graph_model(300, 1200, 16, seed=8), mode, 3)
+
+
+def test_labeling_list_model(eng):
+    m = S.multicut_triangle_model(40, 60, seed=9)
+    for mode in MODES:
+        _check(eng, m, mode, 4)
+
+
+def test_all_schedules_and_roles(eng):
+    from tests.test_plan_host import _full_schedule_model, _toy
+    for mode in MODES:
+        _check(eng, _full_schedule_model(), mode, 3)
+    eng.upload(_toy())
+    eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.compute_pass(1000)                                  # reference test/test_model.cpp:43-45
+    assert abs(eng.lower_bound() - 1.0) <= 1e-8
+
+
+def test_reference_known_answers_on_device(eng, golden_dir):
+    """the reference's recorded lower bounds reproduced by the HIP path"""
+    g = np.load(golden_dir + "/survey_grids.npz")
+    c = g["costs_8x8_L4"]
+    eng.upload(S.grid_model(8, 8, 4, unaries=c[:256], tables=c[256:]))
+    eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    exp = g["lb_8x8_L4_pass0_1_4"]
+    assert eng.lower_bound() == pytest.approx(exp[0], abs=1e-9)
+    eng.compute_pass(1)
+    assert eng.lower_bound() == pytest.approx(exp[1], abs=1e-9)
+    eng.compute_pass(3)
+    assert eng.lower_bound() == pytest.approx(exp[2], abs=1e-9)
+    c = g["costs_16x16_L4"]
+    for k, mode in enumerate((M.REPAM_ANISOTROPIC, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM)):
+        eng.upload(S.grid_model(16, 16, 4, unaries=c[:1024], tables=c[1024:]))
+        eng.set_reparametrization(mode)
+        eng.compute_pass(1)
+        assert eng.lower_bound() == pytest.approx(g["lb_16x16_L4_pass1_aniso_uniform_damped"][k], abs=1e-9)
+    # test/graphical_model.cpp:90-137: chain and frustrated cycle, LB 0
+    from tests.test_oracle_kat import _binary_mrf, NEG, POS
+    for m in (_binary_mrf(5, [(0, 1, NEG), (1, 2, POS), (2, 3, POS), (3, 4, POS)]),
+              _binary_mrf(4, [(0, 1, NEG), (1, 2, POS), (2, 3, POS), (0, 3, POS)])):
+        eng.upload(m)
+        eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+        eng.compute_pass(100)
+        assert abs(eng.lower_bound()) <= 1e-8
+
+
+def test_custom_pass_and_single_directions(eng):
+    m = S.grid_model(9, 8, 8, seed=12)
+    o = Oracle(m)
+    eng.upload(m)
+    o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    o.ComputeForwardPass(); eng.forward_pass()
+    assert np.array_equal(eng.download_duals(), o.duals())
+    o.ComputeBackwardPass(); eng.backward_pass()
+    assert np.array_equal(eng.download_duals(), o.duals())
+    # iterator-range ComputePass with a partition-style sub-list and its own weights
+    order = o.order(M.FORWARD)
+    sub = order[: order.shape[0] // 2]
+    om_off, om, mk_off, mk = o.anisotropic_weights_sublist(sub)
+    upd = np.array([f for f in sub if f in set(o.update_order(M.FORWARD))], np.int32)
+    o.compute_pass_custom(upd, om_off, om, mk_off, mk)
+    eng.compute_pass_custom(upd, om_off, om, mk_off, mk)
+    assert np.array_equal(eng.download_duals(), o.duals())
+    # dual upload round trip
+    d = o.duals() * 0.5
+    eng.upload_duals(d)
+    assert np.array_equal(eng.download_duals(), d)
+
+
+def test_many_levels_graph_replay(eng):
+    # 40x30 row-major: 69 dependent levels per direction -> captured into a hipGraph and replayed
+    m = S.grid_model(40, 30, 8, seed=13)
+    _check(eng, m, M.REPAM_ANISOTROPIC, 4)
+
+
+def test_error_paths(eng):
+    e2 = E.Engine(0)
+    with pytest.raises(E.EngineError):
+        e2.compute_pass(1)                      # no model
+    e2.upload(S.grid_model(3, 3, 2))
+    with pytest.raises(E.EngineError):
+        e2.compute_pass(1)                      # no reparametrization mode set (reference LP_MP.h:458)
+    with pytest.raises(E.EngineError):
+        e2.set_reparametrization(M.REPAM_MIXED)
+    e2.close()
+
+
+# ---- device-resident inputs and full-size properties -----------------------------------------
+def _energy(torch, theta, pw, T, ei, ej, x):
+    """E(x) = sum_i theta_i(x_i) + sum_ij T_ij(x_i,x_j) + m1_ij(x_i) + m2_ij(x_j): invariant under any
+    reparametrisation (messages only move cost between factors)."""
+    n, L = theta.shape
+    ar_n = torch.arange(n, device=theta.device)
+    ar_e = torch.arange(ei.shape[0], device=theta.device)
+    xi, xj = x[ei], x[ej]
+    return (theta[ar_n, x].sum() + T[ar_e, xi, xj].sum() + pw[ar_e, xi].sum() + pw[ar_e, L + xj].sum()).item()
+
+
+def _device_grid(torch, H, W, L, order, seed):
+    m = S.grid_model(H, W, L, order=order, seed=seed, device_const=True)
+    n = H * W
+    n_e = len(S.grid_edges(H, W)[0])
+    dev = torch.device("cuda:0")
+    const = torch.empty(n_e * L * L, dtype=torch.float64, device=dev)
+    E.synth_fill(const.data_ptr(), const.numel(), seed, n * L, torch.cuda.current_stream().cuda_stream)
+    dual = torch.zeros(n * L + n_e * 2 * L, dtype=torch.float64, device=dev)
+    dual[: n * L] = torch.from_numpy(m.dual_data[: n * L]).to(dev)
+    torch.cuda.synchronize()
+    return m, const, dual, n, n_e
+
+
+def test_device_buffers_and_synth_fill_match_host(eng):
+    import torch
+    H, W, L = 20, 24, 16
+    m, const, dual, n, n_e = _device_grid(torch, H, W, L, "colour_major", 21)
+    host = S.grid_model(H, W, L, order="colour_major", seed=21)
+    assert np.array_equal(const.cpu().numpy(), host.const_data)           # device generator == numpy generator
+    e2 = E.Engine(0)
+    e2.upload(m, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual))
+    e2.set_reparametrization(M.REPAM_ANISOTROPIC)
+    e2.compute_pass(3)
+    e2.synchronize()
+    o = Oracle(host)
+    o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    o.ComputePass(3)
+    assert np.array_equal(dual.cpu().numpy(), o.duals())                  # updated in place, zero copy
+    e2.close()
+
+
+@pytest.mark.parametrize("cfg", ["C2_512x512_L8_potts", "C3_1024x1024_L32_dense"])
+def test_full_size_properties(cfg):
+    """BASELINE.json configs[1] and [2] at full size: dual ascent (LB non-decreasing), energy of fixed
+    labelings invariant under the sweep, LB <= energy of any labeling, and the oracle where it is cheap."""
+    import torch
+    e2 = E.Engine(0)
+    dev = torch.device("cuda:0")
+    if cfg.startswith("C2"):
+        H = W = 512; L = 8
+        m = S.grid_model(H, W, L, pairwise="potts", order="colour_major", seed=2)
+        e2.upload(m)
+        e2.set_reparametrization(M.REPAM_ANISOTROPIC)
+        o = Oracle(m)
+        o.set_reparametrization(M.REPAM_ANISOTROPIC)
+        lbs = [e2.lower_bound()]
+        for _ in range(3):
+            e2.compute_pass(1); o.ComputePass(1)
+            lbs.append(e2.lower_bound())
+            assert abs(lbs[-1] - o.LowerBound()) <= LB_RTOL * abs(o.LowerBound())
+        assert np.array_equal(e2.download_duals(), o.duals())
+        assert all(b >= a - 1e-7 for a, b in zip(lbs, lbs[1:]))
+    else:
+        H = W = 1024; L = 32
+        m, const, dual, n, n_e = _device_grid(torch, H, W, L, "colour_major", 3)
+        e2.upload(m, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual))
+        e2.set_reparametrization(M.REPAM_ANISOTROPIC)
+        var = S.grid_variable_order(H, W, "colour_major").reshape(-1)
+        a, b = S.grid_edges(H, W)
+        ei = torch.from_numpy(np.minimum(var[a], var[b])).to(dev)
+        ej = torch.from_numpy(np.maximum(var[a], var[b])).to(dev)
+        T = const.view(n_e, L, L)
+        gen = torch.Generator(device="cpu").manual_seed(0)
+        xs = [torch.randint(0, L, (n,), generator=gen).to(dev) for _ in range(2)]
+        xs.append(dual[: n * L].view(n, L).argmin(1))          # unary-greedy labeling
+        def energies():
+            th = dual[: n * L].view(n, L)
+            pw = dual[n * L:].view(n_e, 2 * L)
+            return [_energy(torch, th, pw, T, ei, ej, x) for x in xs]
+        e0 = energies()
+        lbs = [e2.lower_bound()]
+        for _ in range(3):
+            e2.compute_pass(1)
+            lbs.append(e2.lower_bound())
+        e2.synchronize()
+        e1 = energies()
+        for x0, x1 in zip(e0, e1):
+            assert abs(x0 - x1) <= 1e-9 * abs(x0)                # reparametrisation invariance
+        assert all(b >= a - 1e-7 * abs(a) for a, b in zip(lbs, lbs[1:]))
+        assert lbs[-1] <= min(e1) + 1e-6                          # weak duality
+        assert lbs[-1] > lbs[0]
+    e2.close()

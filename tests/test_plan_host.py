@@ -1,0 +1,139 @@
+"""Host logic of the product (lp_mp_amd/csrc/plan.cpp, reached through the C ABI) against the oracle:
+orderings, per-factor message lists, weights and receive masks for every mode.  No GPU needed."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from lp_mp_amd import model as M
+from lp_mp_amd import synthetic as S
+from lp_mp_amd import engine as E
+from oracle.binding import Oracle
+
+MODES = (M.REPAM_ANISOTROPIC, M.REPAM_ANISOTROPIC2, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM)
+
+
+def _toy():
+    b = M.ModelBuilder(1, [M.MsgType(0, 0, M.SCHED_LEFT, 0, 0, M.M_MINNORM, 0)])
+    f = b.add_vector_factors(0, [[0, 1], [1, 0], [0, 0]])
+    b.add_messages(0, f[0], f[1])
+    b.add_messages(0, f[0], f[2])
+    return b.finish()
+
+
+def _full_schedule_model():
+    """vector-vector messages in every schedule, plus unary/pairwise with schedule full and right."""
+    mt = [M.MsgType(0, 0, M.SCHED_FULL, 0, 0, M.M_MINNORM, 0),
+          M.MsgType(0, 0, M.SCHED_RIGHT, 0, 0, M.M_MINNORM, 0),
+          M.MsgType(0, 0, M.SCHED_ONLY_SEND, 0, 0, M.M_MINNORM, 0),
+          M.MsgType(0, 1, M.SCHED_FULL, 0, 1, M.M_UNARY_PAIRWISE, 0),
+          M.MsgType(0, 1, M.SCHED_RIGHT, 0, 1, M.M_UNARY_PAIRWISE, 1)]
+    b = M.ModelBuilder(2, mt)
+    rng = np.random.default_rng(0)
+    v = b.add_vector_factors(0, rng.uniform(-1, 1, (12, 3)))
+    p = b.add_dense_pairwise(1, rng.uniform(-1, 1, (5, 3, 3)))
+    for k in range(11):
+        b.add_messages(k % 3, v[k], v[k + 1])
+    for k in range(5):
+        b.add_messages(3, v[2 * k], p[k])
+        b.add_messages(4, v[2 * k + 1], p[k])
+        b.add_relations(v[2 * k], p[k])
+        b.add_relations(p[k], v[2 * k + 1])
+    return b.finish()
+
+
+MODELS = {
+    "toy": _toy,
+    "grid_row": lambda: S.grid_model(9, 7, 4, seed=1),
+    "grid_colour": lambda: S.grid_model(8, 8, 3, order="colour_major", seed=2),
+    "potts_grid": lambda: S.grid_model(6, 11, 5, pairwise="potts", seed=3),
+    "chain": lambda: S.chain_model(100, 4),
+    "random_graph": lambda: S.random_graph_model(200, 700, 16, seed=4, pairwise="potts"),
+    "multicut": lambda: S.multicut_triangle_model(30, 40, seed=5),
+    "all_schedules": _full_schedule_model,
+}
+
+
+@pytest.mark.parametrize("name", sorted(MODELS))
+def test_plan_matches_oracle(name):
+    m = MODELS[name]()
+    o, p = Oracle(m), E.Plan(m)
+    o_off, o_ent = o.msg_lists()
+    p_off, p_ent = p.msg_lists(m.n_messages)
+    assert np.array_equal(o_off, p_off) and np.array_equal(o_ent, p_ent)
+    for d in (M.FORWARD, M.BACKWARD):
+        assert np.array_equal(o.order(d), p.order(d))
+        assert np.array_equal(o.update_order(d), p.update_order(d))
+        for mode in MODES:
+            a, b = o.omega(d, mode), p.omega(d, mode)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            a, b = o.mask(d, mode), p.mask(d, mode)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_sublist_weights_match_oracle():
+    """strict-subset rules of ComputeAnisotropicWeights (reference LP_MP.h:1263-1346)"""
+    m = S.grid_model(8, 8, 3, seed=6)
+    o, p = Oracle(m), E.Plan(m)
+    order = o.order(M.FORWARD)
+    rng = np.random.default_rng(1)
+    for trial in range(6):
+        keep = rng.uniform(size=order.shape[0]) < (0.3 + 0.1 * trial)
+        sub = order[keep]
+        a = o.anisotropic_weights_sublist(sub)
+        b = p.anisotropic_weights(sub)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_level_schedule_shapes():
+    # row-major grid: one level per anti-diagonal; colour-major: two levels
+    H, W = 10, 14
+    p = E.Plan(S.grid_model(H, W, 4, order="row_major"))
+    info = p.schedule_info(M.FORWARD, M.REPAM_ANISOTROPIC)
+    n_msgs = 2 * (H * (W - 1) + W * (H - 1))
+    assert info["n_levels"] == H + W - 1
+    assert info["n_receives"] + info["n_sends"] == n_msgs      # each message once per direction
+    p = E.Plan(S.grid_model(H, W, 4, order="colour_major"))
+    for d in (M.FORWARD, M.BACKWARD):
+        info = p.schedule_info(d, M.REPAM_ANISOTROPIC)
+        assert info["n_levels"] == 2 and info["n_launches"] == 2
+        assert info["n_receives"] + info["n_sends"] == n_msgs
+    # algorithmic bytes of a pass follow SURVEY 8(d): 8L^2 + 40L per message + 32L per unary
+    L = 4
+    tot = sum(p.schedule_info(d, M.REPAM_ANISOTROPIC)["algorithmic_bytes"] for d in (0, 1))
+    assert tot == n_msgs * (8 * L * L + 40 * L) + 32 * L * H * W
+
+
+def test_invalid_models_are_rejected():
+    m = S.grid_model(3, 3, 2)
+    bad = S.grid_model(3, 3, 2)
+    bad.m_left[0] = 10 ** 6
+    with pytest.raises(E.EngineError):
+        E.Plan(bad)
+    bad = S.grid_model(3, 3, 2)
+    bad.f_kind[0] = 7
+    with pytest.raises(E.EngineError):
+        E.Plan(bad)
+    p = E.Plan(m)
+    with pytest.raises(E.EngineError):
+        p.omega(0, M.REPAM_MIXED)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import re, os
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "lpmp_engine.h")).read()
+    declared = set(re.findall(r"\b(lpmp_[a-z_0-9]+)\s*\(", hdr))
+    L = E.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(E.EXPORTS)
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(E.EngineError) as ei:
+        E.Engine(0)
+    assert "no CPU path" in str(ei.value) or ei.value.code == -3
