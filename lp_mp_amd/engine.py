@@ -43,6 +43,12 @@ def lib():
     """Loads the HIP extension; raises (never falls back) if it is not built."""
     global _LIB
     if _LIB is None:
+        # torch ships its own HIP runtime; it must be the one the process loads first, otherwise torch
+        # finds no GPU once another libamdhip64 has initialised the device
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         so = library_path()
         if not os.path.exists(so):
             raise RuntimeError(f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
