@@ -108,8 +108,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        # "nccl" is RCCL on ROCm; LPMP_DIST_BACKEND=gloo only for smoke runs of this script on a 1-GPU box
+        dist.init_process_group(os.environ.get("LPMP_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and world > 1:
@@ -144,7 +145,7 @@ def main():
     lb0 = runner.lower_bound()
     dt = time_passes(torch, dist, runner, args.steps, args.warmup, world)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     lb1 = runner.lower_bound()

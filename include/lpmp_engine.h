@@ -90,6 +90,16 @@ int lpmp_compute_backward_pass(lpmp_engine* e);             /* LP::ComputeBackwa
  * any weights / masks (one row per listed factor). */
 int lpmp_compute_pass_custom(lpmp_engine* e, int64_t n, const int32_t* factors, const int64_t* om_off,
                              const double* om, const int64_t* mk_off, const uint8_t* mk);
+/* The same, prepared once and replayed: the partition sweeps of the multi-GPU driver are iterator-range
+ * passes (main sweep without ghost factors, boundary receive, boundary send) that run every iteration.
+ * Precedent in the reference: compute_partition_pass keeps per-partition omega / mask arrays
+ * (include/LP_MP.h:1846-1963). */
+int lpmp_schedule_create(lpmp_engine* e, int64_t n, const int32_t* factors, const int64_t* om_off, const double* om,
+                         const int64_t* mk_off, const uint8_t* mk, int* id_out);
+int lpmp_schedule_run(lpmp_engine* e, int id);
+int lpmp_schedule_info(lpmp_engine* e, int id, int64_t* n_levels, int64_t* n_launches, int64_t* n_receives,
+                       int64_t* n_sends, int64_t* algorithmic_bytes);
+int lpmp_schedule_destroy(lpmp_engine* e, int id);
 int lpmp_lower_bound(lpmp_engine* e, double* out);          /* LP::LowerBound, LP_MP.h:1507-1518 */
 int lpmp_factor_lower_bounds(lpmp_engine* e, double* out /*[n_factors], host*/); /* FactorTypeAdapter::LowerBound */
 int lpmp_synchronize(lpmp_engine* e);

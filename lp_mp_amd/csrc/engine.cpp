@@ -93,6 +93,7 @@ struct lpmp_engine {
   std::vector<LbRun> lb_runs;
   DevSchedule sched[2][LPMP_REPAM_COUNT];
   bool have_sched[LPMP_REPAM_COUNT] = {false, false, false, false};
+  std::vector<std::unique_ptr<DevSchedule>> custom;   // prepared iterator-range passes
   int mode = -1;
   bool use_graph = true;
   bool timing = false;
@@ -104,6 +105,8 @@ struct lpmp_engine {
   void release_model() {
     for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m) sched[d][m].release();
     for (int m = 0; m < LPMP_REPAM_COUNT; ++m) have_sched[m] = false;
+    for (auto& c : custom) if (c) c->release();
+    custom.clear();
     if (own_dual && d_dual) (void)hipFree(d_dual);
     if (own_const && d_const) (void)hipFree(d_const);
     d_dual = nullptr; d_const = nullptr; own_dual = own_const = false;
@@ -441,6 +444,51 @@ int lpmp_compute_pass_custom(lpmp_engine* e, int64_t n, const int32_t* factors, 
       HIP_CHECK(hipStreamSynchronize(e->stream));
     } catch (...) { d.release(); throw; }
     d.release();
+  });
+}
+
+int lpmp_schedule_create(lpmp_engine* e, int64_t n, const int32_t* factors, const int64_t* om_off, const double* om,
+                         const int64_t* mk_off, const uint8_t* mk, int* id_out) {
+  return guarded([&] {
+    require_model(e);
+    if (!id_out || n < 0 || (n > 0 && (!factors || !om_off || !mk_off))) throw std::runtime_error("bad argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    Schedule s;
+    static const double dz = 0; static const uint8_t uz = 0;
+    static const int64_t zero_off[1] = {0};
+    e->plan->p.make_schedule(factors, n, n > 0 ? om_off : zero_off, om ? om : &dz, n > 0 ? mk_off : zero_off, mk ? mk : &uz, s);
+    check_generic_limits(e->plan->p, s);
+    auto d = std::make_unique<DevSchedule>();
+    try { upload_schedule(s, *d); } catch (...) { d->release(); throw; }
+    e->custom.push_back(std::move(d));
+    *id_out = (int)e->custom.size() - 1;
+  });
+}
+static DevSchedule& custom_schedule(lpmp_engine* e, int id) {
+  require_model(e);
+  if (id < 0 || id >= (int)e->custom.size() || !e->custom[id]) throw std::runtime_error("unknown schedule id");
+  return *e->custom[id];
+}
+int lpmp_schedule_run(lpmp_engine* e, int id) {
+  return guarded([&] { DevSchedule& d = custom_schedule(e, id); HIP_CHECK(hipSetDevice(e->device)); run_schedule(e, d); });
+}
+int lpmp_schedule_info(lpmp_engine* e, int id, int64_t* n_levels, int64_t* n_launches, int64_t* n_recv, int64_t* n_send,
+                       int64_t* alg_bytes) {
+  return guarded([&] {
+    DevSchedule& d = custom_schedule(e, id);
+    if (n_levels) *n_levels = d.n_levels;
+    if (n_launches) *n_launches = (int64_t)d.launches.size();
+    if (n_recv) *n_recv = d.n_recv;
+    if (n_send) *n_send = d.n_send;
+    if (alg_bytes) *alg_bytes = d.alg_bytes;
+  });
+}
+int lpmp_schedule_destroy(lpmp_engine* e, int id) {
+  return guarded([&] {
+    DevSchedule& d = custom_schedule(e, id);
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    d.release();
+    e->custom[id].reset();
   });
 }
 

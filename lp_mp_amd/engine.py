@@ -28,7 +28,8 @@ EXPORTS = [
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
     "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
     "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_compute_pass", "lpmp_compute_forward_pass",
-    "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
+    "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_run",
+    "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
     "lpmp_synchronize", "lpmp_dual_size", "lpmp_download_duals", "lpmp_upload_duals", "lpmp_device_duals",
     "lpmp_engine_plan", "lpmp_engine_plan_mut", "lpmp_enable_kernel_timing", "lpmp_get_kernel_timing",
     "lpmp_reset_kernel_timing", "lpmp_synth_fill",
@@ -80,6 +81,10 @@ def lib():
         L.lpmp_compute_forward_pass.argtypes = [C.c_void_p]
         L.lpmp_compute_backward_pass.argtypes = [C.c_void_p]
         L.lpmp_compute_pass_custom.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+        L.lpmp_schedule_create.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 6
+        L.lpmp_schedule_run.argtypes = [C.c_void_p, C.c_int]
+        L.lpmp_schedule_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.lpmp_schedule_destroy.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_lower_bound.argtypes = [C.c_void_p, C.c_void_p]
         L.lpmp_factor_lower_bounds.argtypes = [C.c_void_p, C.c_void_p]
         L.lpmp_synchronize.argtypes = [C.c_void_p]
@@ -239,6 +244,29 @@ class Engine:
         mk = np.ascontiguousarray(mk, np.uint8)
         _chk(self.L.lpmp_compute_pass_custom(self.h, factors.shape[0], factors.ctypes.data, om_off.ctypes.data,
                                              om.ctypes.data, mk_off.ctypes.data, mk.ctypes.data))
+
+    def schedule_create(self, factors, om_off, om, mk_off, mk) -> int:
+        """Prepare an iterator-range pass (reference LP_MP.h:981-1005) for repeated replay."""
+        factors = np.ascontiguousarray(factors, np.int32)
+        om_off = np.ascontiguousarray(om_off, np.int64)
+        om = np.ascontiguousarray(om, np.float64)
+        mk_off = np.ascontiguousarray(mk_off, np.int64)
+        mk = np.ascontiguousarray(mk, np.uint8)
+        sid = C.c_int()
+        _chk(self.L.lpmp_schedule_create(self.h, factors.shape[0], factors.ctypes.data, om_off.ctypes.data,
+                                         om.ctypes.data, mk_off.ctypes.data, mk.ctypes.data, C.addressof(sid)))
+        return sid.value
+
+    def schedule_run(self, sid: int):
+        _chk(self.L.lpmp_schedule_run(self.h, int(sid)))
+
+    def schedule_info(self, sid: int) -> dict:
+        v = [C.c_int64() for _ in range(5)]
+        _chk(self.L.lpmp_schedule_info(self.h, int(sid), *[C.addressof(x) for x in v]))
+        return dict(zip(("n_levels", "n_launches", "n_receives", "n_sends", "algorithmic_bytes"), [x.value for x in v]))
+
+    def schedule_destroy(self, sid: int):
+        _chk(self.L.lpmp_schedule_destroy(self.h, int(sid)))
 
     def lower_bound(self) -> float:
         out = C.c_double()

@@ -1,0 +1,419 @@
+"""Partitioned sweep: one process per GPU, cut-edge messages exchanged once per directional sweep.
+
+The factor graph (unary / pairwise MRF) is split by variables.  Each pairwise factor is owned by the
+part of its earlier endpoint; for a cut edge the owner keeps a zero-cost GHOST unary in place of the
+remote endpoint.  One directional sweep is, in the reference's own terms (the public iterator-range
+``LP::ComputePass(factorIt, factorItEnd, omegaIt, receive_it)``, reference include/LP_MP.h:981-1005, the
+same mechanism compute_partition_pass uses, :1932-1963):
+
+  1. main sweep   — every part runs its level-scheduled update list with its own anisotropic weights
+                    (``ComputeAnisotropicWeights`` on the part's sub-graph, :1232-1415); ghost factors are
+                    not updated, so parts touch disjoint memory and may run concurrently;
+  2. boundary step — ``UpdateFactor`` of every non-owner endpoint u_j restricted to its cut messages:
+                    receive the owner's min-marginal (weight 1), then send back omega_b * theta_j.
+     On the device the two halves of that update live on different GPUs, so the ghost carries the
+     message: owner  ghost <- min-marginal (receive-only pass on the ghosts), ship ghost -> remote,
+              remote theta_j += delta; delta' = omega_b * theta_j; theta_j -= delta'; ship delta' back,
+              owner  ghost <- delta'; send-only pass (omega 1) folds it into the pairwise factor.
+     Two RCCL all-to-all exchanges of (cut edges x L) doubles per directional sweep.
+
+Because every step is an iterator-range pass of the reference, the whole schedule can be replayed by
+the oracle on the unpartitioned model (tests/test_multi_gpu.py does exactly that).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import model as M
+from . import synthetic as S
+
+
+@dataclass
+class LocalPart:
+    rank: int
+    world: int
+    L: int
+    model: M.FlatModel                  # local unaries, ghosts, owned pairwise (mrf_model layout)
+    n_local: int                        # local unaries = factors [0, n_local)
+    n_ghost: int                        # ghosts = factors [n_local, n_local + n_ghost)
+    local_to_global: np.ndarray         # local factor id -> global factor id (ghost -> remote unary)
+    local_msg_to_global: np.ndarray     # local message id -> global message id
+    out_peer: np.ndarray                # owned cut edges, sorted by (peer, key): remote rank
+    out_ghost: np.ndarray               #   local ghost factor id
+    out_key: np.ndarray                 #   global edge id
+    in_peer: np.ndarray                 # cut edges owned elsewhere, sorted by (peer, key): owner rank
+    in_unary: np.ndarray                #   local unary factor id of the remote endpoint
+    in_key: np.ndarray                  #   global edge id
+    const_fill: Optional[list] = None   # [(offset, count, seed, first)] when tables are generated in HBM
+    dual_fill: Optional[list] = None
+
+
+def _sorted_by_peer_key(peer, *cols, key):
+    order = np.lexsort((key, peer))
+    return [np.ascontiguousarray(peer[order])] + [np.ascontiguousarray(c[order]) for c in cols] + [np.ascontiguousarray(key[order])]
+
+
+def partition_mrf(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, part: np.ndarray, world: int,
+                  unaries: np.ndarray, tables: Optional[np.ndarray] = None, potts: Optional[np.ndarray] = None
+                  ) -> List[LocalPart]:
+    """General partitioner for an MRF given as in synthetic.mrf_model (edge e between variables
+    edge_i[e] < edge_j[e]); ``part[v]`` = owning rank of variable v."""
+    edge_i = np.asarray(edge_i, np.int64)
+    edge_j = np.asarray(edge_j, np.int64)
+    part = np.asarray(part, np.int64)
+    unaries = np.asarray(unaries, np.float64).reshape(n_vars, L)
+    n_edges = edge_i.shape[0]
+    owner = part[edge_i]
+    parts = []
+    for k in range(world):
+        lv = np.nonzero(part == k)[0]
+        gmap = np.full(n_vars, -1, np.int64)
+        gmap[lv] = np.arange(lv.shape[0])
+        le = np.nonzero(owner == k)[0]                      # owned edges, global order
+        cut = part[edge_j[le]] != k
+        n_ghost = int(cut.sum())
+        li = gmap[edge_i[le]]
+        lj = gmap[edge_j[le]].copy()
+        lj[cut] = lv.shape[0] + np.arange(n_ghost)
+        un = np.concatenate([unaries[lv], np.zeros((n_ghost, L))])
+        kw = {}
+        if potts is not None:
+            kw["potts"] = np.asarray(potts, np.float64)[le]
+        else:
+            kw["tables"] = np.asarray(tables, np.float64).reshape(n_edges, L, L)[le]
+        m = S.mrf_model(lv.shape[0] + n_ghost, L, li, lj, un, **kw)
+        n_vec = lv.shape[0] + n_ghost
+        l2g = np.concatenate([lv, edge_j[le][cut], n_vars + le]).astype(np.int64)
+        lm2g = np.stack([2 * le, 2 * le + 1], 1).reshape(-1).astype(np.int64)
+        out_peer, out_ghost, out_key = _sorted_by_peer_key(part[edge_j[le][cut]], (lv.shape[0] + np.arange(n_ghost)).astype(np.int32), key=le[cut])
+        ine = np.nonzero((part[edge_j] == k) & (owner != k))[0]
+        in_peer, in_unary, in_key = _sorted_by_peer_key(owner[ine], gmap[edge_j[ine]].astype(np.int32), key=ine)
+        assert n_vec + le.shape[0] == m.n_factors
+        parts.append(LocalPart(k, world, L, m, lv.shape[0], n_ghost, l2g, lm2g, out_peer, out_ghost, out_key,
+                               in_peer, in_unary, in_key))
+    return parts
+
+
+# ---- row-strip grids: closed-form local parts (no global model is ever materialised) ------------
+def strip_sizes(H: int, W: int):
+    return H * W, H * (W - 1) + W * (H - 1)
+
+
+def strip_global_edges(H: int, W: int, world: int, order: str):
+    """Global enumeration: strip-major variables (local order inside a strip); per strip its internal
+    edges (synthetic.grid_edges order) then the W cut edges to the next strip (column order)."""
+    n_loc, e_int = strip_sizes(H, W)
+    var = S.grid_variable_order(H, W, order).reshape(-1)
+    a, b = S.grid_edges(H, W)
+    ei, ej, seg = [], [], []
+    for k in range(world):
+        va, vb = var[a] + k * n_loc, var[b] + k * n_loc
+        ei.append(np.minimum(va, vb)); ej.append(np.maximum(va, vb))
+        if k < world - 1:
+            cols = np.arange(W)
+            ei.append(k * n_loc + var[(H - 1) * W + cols]); ej.append((k + 1) * n_loc + var[cols])
+    return np.concatenate(ei), np.concatenate(ej)
+
+
+def strip_costs(H, W, L, world, pairwise, seed):
+    """Host arrays of the global cost streams (tests only; sizes grow with world)."""
+    n_loc, e_int = strip_sizes(H, W)
+    n_vars = world * n_loc
+    n_edges = world * e_int + (world - 1) * W
+    un = S.u01(n_vars * L, seed, 0)
+    if pairwise == "dense":
+        return un, S.u01(n_edges * L * L, seed, n_vars * L), None
+    return un, None, S.u01(n_edges, seed, n_vars * L)
+
+
+def strip_local_part(H: int, W: int, L: int, pairwise: str, order: str, rank: int, world: int, seed: int,
+                     device_const: bool = False) -> LocalPart:
+    """The same LocalPart that partition_mrf gives for the strip partition of the global grid, built
+    from closed-form index arithmetic on this rank's strip only."""
+    n_loc, e_int = strip_sizes(H, W)
+    n_vars = world * n_loc
+    var = S.grid_variable_order(H, W, order).reshape(-1)
+    a, b = S.grid_edges(H, W)
+    va, vb = var[a], var[b]
+    li, lj = np.minimum(va, vb), np.maximum(va, vb)
+    has_down = rank < world - 1
+    has_up = rank > 0
+    n_ghost = W if has_down else 0
+    cols = np.arange(W)
+    if has_down:
+        li = np.concatenate([li, var[(H - 1) * W + cols]])
+        lj = np.concatenate([lj, n_loc + cols])
+    n_own = li.shape[0]
+    e_first = rank * (e_int + W)                               # global id of this strip's first edge
+    esz = L * L if pairwise == "dense" else 1
+    un_first = rank * n_loc * L
+    pw_first = n_vars * L + e_first * esz
+    unaries = None if device_const else np.concatenate([S.u01(n_loc * L, seed, un_first).reshape(n_loc, L), np.zeros((n_ghost, L))])
+    if device_const:
+        un_host = np.zeros((n_loc + n_ghost) * L)
+        if pairwise == "dense":
+            m = S.mrf_model(n_loc + n_ghost, L, li, lj, un_host, device_const=True)
+        else:
+            m = S.mrf_model(n_loc + n_ghost, L, li, lj, un_host, potts=np.zeros(n_own))
+        const_fill = [(0, n_own * esz, seed, pw_first)]
+        dual_fill = [(0, n_loc * L, seed, un_first)]
+    else:
+        const_fill = dual_fill = None
+        if pairwise == "dense":
+            m = S.mrf_model(n_loc + n_ghost, L, li, lj, unaries, tables=S.u01(n_own * esz, seed, pw_first))
+        else:
+            m = S.mrf_model(n_loc + n_ghost, L, li, lj, unaries, potts=S.u01(n_own, seed, pw_first))
+    ge = e_first + np.arange(n_own)
+    l2g = np.concatenate([rank * n_loc + np.arange(n_loc), (rank + 1) * n_loc + var[cols] if has_down else np.zeros(0, np.int64),
+                          n_vars + ge]).astype(np.int64)
+    lm2g = np.stack([2 * ge, 2 * ge + 1], 1).reshape(-1).astype(np.int64)
+    out_peer = np.full(n_ghost, rank + 1, np.int64)
+    out_ghost = (n_loc + cols[:n_ghost]).astype(np.int32)
+    out_key = e_first + e_int + cols[:n_ghost]
+    if has_up:
+        in_peer = np.full(W, rank - 1, np.int64)
+        in_unary = var[cols].astype(np.int32)
+        in_key = (rank - 1) * (e_int + W) + e_int + cols
+    else:
+        in_peer = np.zeros(0, np.int64); in_unary = np.zeros(0, np.int32); in_key = np.zeros(0, np.int64)
+    return LocalPart(rank, world, L, m, n_loc, n_ghost, l2g, lm2g, out_peer, out_ghost, out_key, in_peer, in_unary,
+                     in_key, const_fill, dual_fill)
+
+
+# ---- communication ---------------------------------------------------------------------------------
+class DistComm:
+    """torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests)."""
+
+    def __init__(self, dist, torch):
+        self.dist, self.torch = dist, torch
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.stage_cpu = dist.get_backend() == "gloo"     # CPU tests, and GPU smoke runs without RCCL
+
+    def exchange(self, send, send_counts, recv_counts):
+        """rows of ``send`` are grouped by destination rank (send_counts[r] rows each); returns the rows
+        received, grouped by source rank.  One all-to-all-v."""
+        if self.stage_cpu and send.is_cuda:
+            dev = send.device
+            return self.exchange(send.cpu(), send_counts, recv_counts).to(dev)
+        out = send.new_empty((int(sum(recv_counts)), send.shape[1]))
+        self.dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(map(int, recv_counts)),
+                                    input_split_sizes=list(map(int, send_counts)))
+        return out
+
+    def all_reduce_sum(self, x: float) -> float:
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.stage_cpu else self._dev)
+        self.dist.all_reduce(t)
+        return float(t.item())
+
+    _dev = "cpu"
+
+
+class LocalComm:
+    """In-process stand-in used to run several parts on ONE device (tests on the 1-GPU box): the parts'
+    sweeps are stepped in lockstep by ``run_lockstep`` and exchange through this mailbox."""
+
+    def __init__(self, world):
+        self.world = world
+        self.box = {}
+
+
+# ---- the sweep ---------------------------------------------------------------------------------------
+class PartitionedSweep:
+    """One part of the partitioned sweep.  ``engine`` is an lp_mp_amd.engine.Engine (or, in CPU tests, an
+    object with the same methods backed by the oracle); ``theta_all`` is a torch view of the engine's dual
+    buffer, so the boundary arithmetic is done in place with torch ops on the engine's stream."""
+
+    def __init__(self, torch, part: LocalPart, engine, dual_tensor, mode: int = M.REPAM_ANISOTROPIC,
+                 omega_b: float = 0.5):
+        self.torch, self.part, self.engine, self.mode, self.omega_b = torch, part, engine, mode, float(omega_b)
+        p = part
+        L = p.L
+        n_vec = p.n_local + p.n_ghost
+        self.dual = dual_tensor
+        self.theta = dual_tensor[: n_vec * L].view(n_vec, L)
+        dev = dual_tensor.device
+        plan = engine.plan
+        ghost = np.zeros(p.model.n_factors, bool)
+        ghost[p.n_local: n_vec] = True
+        # 1. main sweeps: the part's own update lists and anisotropic rows, ghost factors dropped
+        self.main = []
+        self.main_rows = []
+        for d in (M.FORWARD, M.BACKWARD):
+            upd = plan.update_order(d)
+            om_off, om = plan.omega(d, mode)
+            mk_off, mk = plan.mask(d, mode)
+            keep = ~ghost[upd]
+            rows = _select_rows(upd, om_off, om, mk_off, mk, keep)
+            self.main_rows.append(rows)
+            self.main.append(engine.schedule_create(*rows))
+        # 2. boundary passes on the ghosts: every ghost has exactly one message (side 1 of its cut edge)
+        g = np.arange(p.n_local, n_vec, dtype=np.int32)
+        ones_off = np.arange(g.shape[0] + 1, dtype=np.int64)
+        self.ghost_rows_recv = (g, ones_off, np.zeros(g.shape[0]), ones_off, np.ones(g.shape[0], np.uint8))
+        self.ghost_rows_send = (g, ones_off, np.ones(g.shape[0]), ones_off, np.zeros(g.shape[0], np.uint8))
+        self.ghost_recv = engine.schedule_create(*self.ghost_rows_recv)
+        self.ghost_send = engine.schedule_create(*self.ghost_rows_send)
+        # 3. exchange plan
+        self.out_counts = np.bincount(p.out_peer, minlength=p.world).astype(np.int64)
+        self.in_counts = np.bincount(p.in_peer, minlength=p.world).astype(np.int64)
+        self.out_ghost_t = torch.from_numpy(p.out_ghost.astype(np.int64)).to(dev)
+        # rounds: a non-owner unary with several cut edges receives / sends them in its message-list order
+        # (side-1 messages, LIFO storage => descending global edge id; reference factors_messages.hxx:2030-2041)
+        self.rounds = []
+        if p.in_unary.shape[0]:
+            order = np.lexsort((-p.in_key, p.in_unary))
+            u_sorted = p.in_unary[order]
+            first = np.r_[True, u_sorted[1:] != u_sorted[:-1]]
+            start = np.maximum.accumulate(np.where(first, np.arange(order.shape[0]), 0))
+            rnd = np.arange(order.shape[0]) - start
+            for r in range(int(rnd.max()) + 1):
+                sel = order[rnd == r]
+                self.rounds.append((torch.from_numpy(p.in_unary[sel].astype(np.int64)).to(dev),
+                                    torch.from_numpy(sel.astype(np.int64)).to(dev)))
+            self.in_unary_t = torch.from_numpy(p.in_unary.astype(np.int64)).to(dev)
+        self.info = [engine.schedule_info(s) for s in self.main]
+        self.info_ghost = [engine.schedule_info(self.ghost_recv), engine.schedule_info(self.ghost_send)]
+
+    # -- pieces of one directional sweep, split so that LocalComm can interleave several parts --------
+    def main_sweep(self, d):
+        self.engine.schedule_run(self.main[d])
+
+    def boundary_pack(self):
+        """owner: ghost <- min-marginal toward the remote variable; returns rows to ship (by peer, key)."""
+        if self.part.n_ghost == 0:
+            return self.theta.new_zeros((0, self.part.L))
+        self.engine.schedule_run(self.ghost_recv)
+        send = self.theta[self.out_ghost_t]
+        self.theta[self.out_ghost_t] = 0.0
+        return send
+
+    def boundary_reply(self, recv):
+        """non-owner: theta_j += delta (message-list order), delta' = omega_b * theta_j, theta_j -= delta'."""
+        if not self.rounds:
+            return recv.new_zeros((0, self.part.L))
+        for idx, sel in self.rounds:
+            self.theta[idx] += recv[sel]
+        reply = self.omega_b * self.theta[self.in_unary_t]
+        for idx, sel in self.rounds:
+            self.theta[idx] -= reply[sel]
+        return reply
+
+    def boundary_fold(self, recv):
+        """owner: ghost <- delta'; a weight-1 send folds it into the cut edge's pairwise factor."""
+        if self.part.n_ghost == 0:
+            return
+        self.theta[self.out_ghost_t] = recv
+        self.engine.schedule_run(self.ghost_send)
+
+    # -- stand-alone driver over a DistComm -------------------------------------------------------------
+    def sweep(self, comm, d):
+        self.main_sweep(d)
+        send = self.boundary_pack()
+        recv = comm.exchange(send, self.out_counts, self.in_counts)
+        reply = self.boundary_reply(recv)
+        back = comm.exchange(reply, self.in_counts, self.out_counts)
+        self.boundary_fold(back)
+
+    def compute_pass(self, comm, n=1):
+        for _ in range(n):
+            self.sweep(comm, M.FORWARD)
+            self.sweep(comm, M.BACKWARD)
+
+    def local_lower_bound(self):
+        return self.engine.lower_bound()
+
+    def updates_per_pass(self):
+        """executed receives + sends per pass on this part: main sweeps + 2 boundary steps (1 receive and
+        1 send per cut edge each, counted on the non-owner side where the reference would execute them)."""
+        n = sum(i["n_receives"] + i["n_sends"] for i in self.info)
+        return n + 2 * 2 * int(self.part.in_unary.shape[0])
+
+    def bytes_per_pass(self):
+        return sum(i["algorithmic_bytes"] for i in self.info) + 2 * sum(i["algorithmic_bytes"] for i in self.info_ghost)
+
+
+def _select_rows(upd, om_off, om, mk_off, mk, keep):
+    """CSR rows of the kept factors."""
+    idx = np.nonzero(keep)[0]
+    f = upd[idx].astype(np.int32)
+    ol = (om_off[1:] - om_off[:-1])[idx]
+    ml = (mk_off[1:] - mk_off[:-1])[idx]
+    n_off = np.concatenate([[0], np.cumsum(ol)]).astype(np.int64)
+    k_off = np.concatenate([[0], np.cumsum(ml)]).astype(np.int64)
+    def gather(data, off, lens, new_off):
+        out = np.empty(int(new_off[-1]), data.dtype)
+        if out.shape[0]:
+            src = np.repeat(off[:-1][idx], lens) + (np.arange(int(new_off[-1])) - np.repeat(new_off[:-1], lens))
+            out[:] = data[src]
+        return out
+    return f, n_off, gather(om, om_off, ol, n_off), k_off, gather(mk, mk_off, ml, k_off)
+
+
+def run_lockstep(sweeps: List[PartitionedSweep], n_passes: int):
+    """Drive all parts inside one process (LocalComm): same steps as PartitionedSweep.sweep, with the
+    all-to-all replaced by in-process row shuffles.  Used to test the partition schedule on one GPU."""
+    torch = sweeps[0].torch
+    world = len(sweeps)
+
+    def shuffle(rows, counts_out, counts_in):
+        # rows[r] grouped by destination; deliver grouped by source
+        offs = [np.concatenate([[0], np.cumsum(c)]) for c in counts_out]
+        got = []
+        for dst in range(world):
+            pieces = [rows[src][offs[src][dst]: offs[src][dst + 1]] for src in range(world)]
+            got.append(torch.cat(pieces) if pieces else rows[dst].new_zeros((0, rows[dst].shape[1])))
+            assert got[-1].shape[0] == int(sum(counts_in[dst]))
+        return got
+
+    for _ in range(n_passes):
+        for d in (M.FORWARD, M.BACKWARD):
+            for s in sweeps:
+                s.main_sweep(d)
+            sent = [s.boundary_pack() for s in sweeps]
+            recv = shuffle(sent, [s.out_counts for s in sweeps], [s.in_counts for s in sweeps])
+            rep = [s.boundary_reply(r) for s, r in zip(sweeps, recv)]
+            back = shuffle(rep, [s.in_counts for s in sweeps], [s.out_counts for s in sweeps])
+            for s, b in zip(sweeps, back):
+                s.boundary_fold(b)
+
+
+class StripSweep:
+    """bench.py driver: this rank's H x W strip of a (world*H) x W grid on its own GPU."""
+
+    def __init__(self, torch, dist, H, W, L, pairwise, order, mode, seed=1, omega_b=0.5):
+        from . import engine as E
+        self.torch, self.dist = torch, dist
+        self.comm = DistComm(dist, torch)
+        rank, world = self.comm.rank, self.comm.world
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.comm._dev = dev
+        part = strip_local_part(H, W, L, pairwise, order, rank, world, seed, device_const=True)
+        m = part.model
+        stream = torch.cuda.current_stream().cuda_stream
+        n_const = int(m.const_sizes().sum())
+        self.const = torch.empty(max(n_const, 2), dtype=torch.float64, device=dev)
+        self.dualt = torch.zeros(int(m.dual_sizes().sum()), dtype=torch.float64, device=dev)
+        for (off, cnt, sd, first) in part.const_fill:
+            E.synth_fill(self.const.data_ptr() + 8 * off, cnt, sd, first, stream)
+        for (off, cnt, sd, first) in part.dual_fill:
+            E.synth_fill(self.dualt.data_ptr() + 8 * off, cnt, sd, first, stream)
+        torch.cuda.synchronize()
+        self.engine = E.Engine(torch.cuda.current_device())
+        self.engine.set_stream(stream)
+        self.engine.upload(m, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt))
+        self.sweep = PartitionedSweep(torch, part, self.engine, self.dualt, mode, omega_b)
+        t = torch.tensor([self.sweep.updates_per_pass(), self.sweep.bytes_per_pass()], dtype=torch.float64,
+                         device="cpu" if self.comm.stage_cpu else dev)
+        dist.all_reduce(t)
+        self.global_updates_per_pass = int(t[0].item())
+        self.global_bytes_per_pass = int(t[1].item())
+        self.levels = [i["n_levels"] for i in self.sweep.info]
+
+    def compute_pass(self, n=1):
+        self.sweep.compute_pass(self.comm, n)
+
+    def lower_bound(self):
+        return self.comm.all_reduce_sum(self.sweep.local_lower_bound())

@@ -1,0 +1,105 @@
+"""Test-only helpers for the partitioned sweep: an oracle-backed stand-in for the device engine (so the
+partition / exchange logic can run on CPU, incl. 2-process gloo runs) and the replay of the partition
+schedule on the UNPARTITIONED model with the oracle's iterator-range ComputePass."""
+import numpy as np
+
+from lp_mp_amd import engine as E
+from lp_mp_amd import model as M
+from oracle.binding import Oracle
+
+
+class OracleEngine:
+    """Same methods as lp_mp_amd.engine.Engine, computed by the oracle on a shared numpy dual buffer.
+    Lives in tests/ only: the product never routes through the oracle."""
+
+    def __init__(self, model, dual_np):
+        self.o = Oracle(model)
+        self.dual = dual_np
+        self.model = model
+        self.plan = E.Plan(model)
+        self.rows = []
+
+    def schedule_create(self, factors, om_off, om, mk_off, mk):
+        self.rows.append((np.array(factors), np.array(om_off), np.array(om), np.array(mk_off), np.array(mk)))
+        return len(self.rows) - 1
+
+    def schedule_run(self, sid):
+        self.o.set_duals(self.dual)
+        self.o.compute_pass_custom(*self.rows[sid])
+        self.dual[:] = self.o.duals()
+
+    def schedule_info(self, sid):
+        f, oo, om, mo, mk = self.rows[sid]
+        return dict(n_levels=0, n_launches=0, n_receives=int(mk.sum()), n_sends=int((om != 0).sum()), algorithmic_bytes=0)
+
+    def lower_bound(self):
+        self.o.set_duals(self.dual)
+        return self.o.LowerBound()
+
+
+def global_replay(global_model, parts, main_rows, n_passes, omega_b):
+    """Runs the partition schedule on the global model with the oracle:
+    per direction  ComputePass(concatenated part lists, expanded rows)  then
+                   ComputePass(non-owner boundary unaries, cut slots only)."""
+    o = Oracle(global_model)
+    g_off, g_ent = o.msg_lists()
+    n_f = global_model.n_factors
+
+    def glist(f):
+        return g_ent[g_off[f]:g_off[f + 1]] // 2          # message ids in list order (MRF: every entry sends+receives)
+
+    for _ in range(n_passes):
+        for d in (M.FORWARD, M.BACKWARD):
+            F, OM, MK, off = [], [], [], [0]
+            for p, rows_d in zip(parts, main_rows):
+                f_loc, om_off, om, mk_off, mk = rows_d[d]
+                l_off, l_ent = p._local_lists
+                for r, fl in enumerate(f_loc):
+                    g = int(p.local_to_global[fl])
+                    lm = p.local_msg_to_global[l_ent[l_off[fl]:l_off[fl + 1]] // 2]
+                    gm = glist(g)
+                    o_row = np.zeros(gm.shape[0]); m_row = np.zeros(gm.shape[0], np.uint8)
+                    pos = {int(x): i for i, x in enumerate(gm)}
+                    lo = om[om_off[r]:om_off[r + 1]]; lk = mk[mk_off[r]:mk_off[r + 1]]
+                    for j, x in enumerate(lm):
+                        o_row[pos[int(x)]] = lo[j]; m_row[pos[int(x)]] = lk[j]
+                    F.append(g); OM.append(o_row); MK.append(m_row); off.append(off[-1] + gm.shape[0])
+            o.compute_pass_custom(np.array(F, np.int32), off, np.concatenate(OM), off, np.concatenate(MK))
+            # boundary step
+            cut = {}
+            for p in parts:
+                for u, key in zip(p.in_unary, p.in_key):
+                    cut.setdefault(int(p.local_to_global[u]), []).append(2 * int(key) + 1)
+            F, OM, MK, off = [], [], [], [0]
+            for g in sorted(cut):
+                gm = glist(g)
+                o_row = np.zeros(gm.shape[0]); m_row = np.zeros(gm.shape[0], np.uint8)
+                for i, x in enumerate(gm):
+                    if int(x) in cut[g]:
+                        o_row[i] = omega_b; m_row[i] = 1
+                F.append(g); OM.append(o_row); MK.append(m_row); off.append(off[-1] + gm.shape[0])
+            if F:
+                o.compute_pass_custom(np.array(F, np.int32), off, np.concatenate(OM), off, np.concatenate(MK))
+    assert n_f == global_model.n_factors
+    return o
+
+
+def gather_global_duals(global_model, parts, local_duals):
+    """Scatter every part's local duals (ghosts excluded) into the global packed layout."""
+    g_off = global_model.dual_offsets()
+    out = np.full(int(g_off[-1]), np.nan)
+    for p, d in zip(parts, local_duals):
+        l_off = p.model.dual_offsets()
+        for fl in range(p.model.n_factors):
+            if p.n_local <= fl < p.n_local + p.n_ghost:
+                assert np.all(d[l_off[fl]:l_off[fl + 1]] == 0.0)      # ghosts are empty between sweeps
+                continue
+            g = int(p.local_to_global[fl])
+            out[g_off[g]:g_off[g + 1]] = d[l_off[fl]:l_off[fl + 1]]
+    assert not np.isnan(out).any()
+    return out
+
+
+def attach_local_lists(parts):
+    for p in parts:
+        p._local_lists = E.Plan(p.model).msg_lists(p.model.n_messages)

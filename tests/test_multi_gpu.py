@@ -1,0 +1,161 @@
+"""Partitioned (multi-GPU) sweep.  CPU tests: partition + exchange logic with an oracle-backed engine
+stand-in, incl. a world_size-2 gloo run; GPU test: the same schedule on real HIP engines, several parts
+on one device.  Everything is checked against the oracle replaying the partition schedule on the
+UNPARTITIONED model through the reference's iterator-range ComputePass."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from lp_mp_amd import model as M
+from lp_mp_amd import multi_gpu as MG
+from lp_mp_amd import synthetic as S
+from oracle.binding import Oracle
+from tests.mgpu_helpers import OracleEngine, attach_local_lists, gather_global_duals, global_replay
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _strip_setup(H, W, L, world, pairwise, order, seed):
+    ei, ej = MG.strip_global_edges(H, W, world, order)
+    un, tables, potts = MG.strip_costs(H, W, L, world, pairwise, seed)
+    n_vars = world * H * W
+    gm = S.mrf_model(n_vars, L, ei, ej, un, tables=tables, potts=potts)
+    part_of = np.repeat(np.arange(world), H * W)
+    parts = MG.partition_mrf(n_vars, L, ei, ej, part_of, world, un, tables=tables, potts=potts)
+    return gm, parts
+
+
+def _cpu_sweeps(parts, omega_b):
+    sweeps, duals = [], []
+    for p in parts:
+        d = p.model.dual_data.copy()
+        eng = OracleEngine(p.model, d)
+        sweeps.append(MG.PartitionedSweep(torch, p, eng, torch.from_numpy(d), M.REPAM_ANISOTROPIC, omega_b))
+        duals.append(d)
+    return sweeps, duals
+
+
+@pytest.mark.parametrize("pairwise,order,world", [("dense", "colour_major", 2), ("potts", "row_major", 3),
+                                                   ("dense", "row_major", 4)])
+def test_strip_generator_equals_general_partitioner(pairwise, order, world):
+    H, W, L = 4, 5, 3
+    gm, parts = _strip_setup(H, W, L, world, pairwise, order, 7)
+    for k in range(world):
+        q = MG.strip_local_part(H, W, L, pairwise, order, k, world, 7)
+        p = parts[k]
+        for name in ("f_type", "f_kind", "f_dim0", "m_type", "m_left", "m_right", "rel_fwd", "rel_bwd", "const_data", "dual_data"):
+            assert np.array_equal(getattr(p.model, name), getattr(q.model, name)), name
+        for name in ("local_to_global", "local_msg_to_global", "out_peer", "out_ghost", "out_key", "in_peer", "in_unary", "in_key"):
+            assert np.array_equal(getattr(p, name), getattr(q, name)), name
+        assert (p.n_local, p.n_ghost) == (q.n_local, q.n_ghost)
+
+
+@pytest.mark.parametrize("pairwise,order,world", [("dense", "colour_major", 2), ("potts", "row_major", 3)])
+def test_lockstep_parts_equal_oracle_replay_on_global_model(pairwise, order, world):
+    H, W, L = 5, 6, 4
+    gm, parts = _strip_setup(H, W, L, world, pairwise, order, 3)
+    attach_local_lists(parts)
+    sweeps, duals = _cpu_sweeps(parts, 0.5)
+    MG.run_lockstep(sweeps, 3)
+    o = global_replay(gm, parts, [s.main_rows for s in sweeps], 3, 0.5)
+    got = gather_global_duals(gm, parts, duals)
+    assert np.array_equal(got, o.duals())
+    lb = sum(s.local_lower_bound() for s in sweeps)
+    assert abs(lb - o.LowerBound()) <= 1e-9 * max(1.0, abs(lb))
+    # dual-bound gap to the unpartitioned sweep after the same number of passes: reported, and bounded
+    ref = Oracle(gm)
+    ref.set_reparametrization(M.REPAM_ANISOTROPIC)
+    lb0 = ref.LowerBound()
+    ref.ComputePass(3)
+    assert lb > lb0 and lb <= ref.LowerBound() + 0.2 * abs(ref.LowerBound())
+
+
+def test_random_graph_general_partition_with_multi_cut_unaries():
+    # random sparse graph, random 3-way split: unaries with several cut edges exercise the rounds
+    n, m_edges, L, world = 40, 120, 3, 3
+    g = S.random_graph_model(n, m_edges, L, seed=11)
+    ei = g.m_left[0::2].astype(np.int64)
+    ej = g.m_left[1::2].astype(np.int64)
+    un = g.dual_data[: n * L]
+    tables = g.const_data
+    rng = np.random.default_rng(0)
+    part_of = rng.integers(0, world, n)
+    parts = MG.partition_mrf(n, L, ei, ej, part_of, world, un, tables=tables)
+    assert max(np.bincount(p.in_unary).max() if p.in_unary.size else 0 for p in parts) >= 2
+    attach_local_lists(parts)
+    sweeps, duals = _cpu_sweeps(parts, 0.25)
+    MG.run_lockstep(sweeps, 2)
+    o = global_replay(g, parts, [s.main_rows for s in sweeps], 2, 0.25)
+    assert np.array_equal(gather_global_duals(g, parts, duals), o.duals())
+
+
+WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from lp_mp_amd import model as M, multi_gpu as MG
+from tests.mgpu_helpers import OracleEngine
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+H, W, L = 5, 6, 4
+part = MG.strip_local_part(H, W, L, "dense", "colour_major", rank, world, 3)
+d = part.model.dual_data.copy()
+sw = MG.PartitionedSweep(torch, part, OracleEngine(part.model, d), torch.from_numpy(d), M.REPAM_ANISOTROPIC, 0.5)
+comm = MG.DistComm(dist, torch)
+sw.compute_pass(comm, 3)
+lb = comm.all_reduce_sum(sw.local_lower_bound())
+np.save(os.path.join({out!r}, f"duals_{{rank}}.npy"), d)
+if rank == 0:
+    np.save(os.path.join({out!r}, "lb.npy"), np.array([lb]))
+dist.destroy_process_group()
+"""
+
+
+def test_two_process_gloo_run_equals_lockstep(tmp_path):
+    """world_size 2 over torch.distributed (gloo): all_to_all_single exchange of the cut-edge messages."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)], env=env, cwd=ROOT,
+                          timeout=300)
+    gm, parts = _strip_setup(5, 6, 4, 2, "dense", "colour_major", 3)
+    attach_local_lists(parts)
+    sweeps, duals = _cpu_sweeps(parts, 0.5)
+    MG.run_lockstep(sweeps, 3)
+    for k in range(2):
+        assert np.array_equal(np.load(tmp_path / f"duals_{k}.npy"), duals[k])
+    o = global_replay(gm, parts, [s.main_rows for s in sweeps], 3, 0.5)
+    assert abs(np.load(tmp_path / "lb.npy")[0] - o.LowerBound()) <= 1e-9 * abs(o.LowerBound())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pairwise,L,order,world", [("dense", 32, "colour_major", 2), ("potts", 8, "colour_major", 4),
+                                                     ("dense", 16, "row_major", 3)])
+def test_partitioned_sweep_on_device_equals_oracle_replay(pairwise, L, order, world):
+    """real HIP engines, all parts on the one GPU of the test box, lock-stepped in process"""
+    from lp_mp_amd import engine as E
+    H, W = 10, 12
+    gm, parts = _strip_setup(H, W, L, world, pairwise, order, 5)
+    attach_local_lists(parts)
+    dev = torch.device("cuda:0")
+    sweeps, tensors, engines = [], [], []
+    for p in parts:
+        dual = torch.from_numpy(p.model.dual_data.copy()).to(dev)
+        eng = E.Engine(0)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual)
+        sweeps.append(MG.PartitionedSweep(torch, p, eng, dual, M.REPAM_ANISOTROPIC, 0.5))
+        tensors.append(dual); engines.append(eng)
+    MG.run_lockstep(sweeps, 3)
+    torch.cuda.synchronize()
+    o = global_replay(gm, parts, [s.main_rows for s in sweeps], 3, 0.5)
+    got = gather_global_duals(gm, parts, [t.cpu().numpy() for t in tensors])
+    assert np.array_equal(got, o.duals())
+    lb = sum(s.local_lower_bound() for s in sweeps)
+    assert abs(lb - o.LowerBound()) <= 1e-5 * max(1.0, abs(lb))
+    for e in engines:
+        e.close()
