@@ -73,6 +73,22 @@ def time_passes(torch, dist, eng, steps, warmup, world):
     return time.perf_counter() - t0
 
 
+def pmc_traffic(kernel_name, args):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes; summarised
+    by tools/pmc_traffic.py into profiles/).  None when no summary for this workload is committed."""
+    import glob
+    if not (args.grid == 1024 and args.labels == 32 and args.pairwise == "dense" and args.order == "colour_major"):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_c3_dense32.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    if d.get("kernel") not in kernel_name:
+        return None, None
+    return d["hbm_bytes_per_launch_avg"], os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(args, synthetic, M):
     """The oracle (single-threaded C restatement of the reference sweep; the reference sweep is
     single-threaded too) on a bounded sample of the same workload."""
@@ -167,8 +183,9 @@ def main():
             k = dom[1]
             avg_ms = k["ms"] / k["launches"]
             achieved = (k["bytes"] / k["launches"]) / (avg_ms * 1e-3) / 1e9
+            traffic, src = pmc_traffic(k["kernel"], args) if world == 1 else (None, None)
             roof = {"bound": "hbm", "kernel": k["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_launch_ms": avg_ms,
                     "launches": k["launches"], "algorithmic_bytes_per_launch": k["bytes"] / k["launches"]}
         out = {
             "metric": "message updates/sec, 32-label grid MRF sweep (LP::ComputePass)" if L == 32 else "message updates/sec, grid MRF sweep (LP::ComputePass)",

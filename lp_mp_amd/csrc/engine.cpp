@@ -83,6 +83,7 @@ struct lpmp_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t capture_stream = nullptr;   // graphs are captured here (the caller's stream may be the legacy default stream, which cannot capture) and replayed on `stream`
   std::unique_ptr<lpmp_plan> plan;
   double* d_dual = nullptr; bool own_dual = false;
   double* d_const = nullptr; bool own_const = false;
@@ -175,13 +176,13 @@ void ensure_device_schedules(lpmp_engine* e, int mode) {
   e->have_sched[mode] = true;
 }
 
-void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed) {
+void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_t stream) {
   for (const auto& lr : s.launches) {
     hipEvent_t a = nullptr, b = nullptr;
-    if (timed) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, e->stream)); }
-    launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, lr.begin, lr.end - lr.begin, e->stream);
+    if (timed) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, stream)); }
+    launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, lr.begin, lr.end - lr.begin, stream);
     if (timed) {
-      HIP_CHECK(hipEventRecord(b, e->stream));
+      HIP_CHECK(hipEventRecord(b, stream));
       e->pending.push_back({a, b, lr.kclass, lr.end - lr.begin, lr.n_recv, lr.bytes});
     }
   }
@@ -192,21 +193,22 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed) {
 // are captured once into a hipGraph and replayed
 void run_schedule(lpmp_engine* e, DevSchedule& s) {
   if (s.launches.empty()) return;
-  if (e->timing) { issue_launches(e, s, true); if (e->pending.size() > 4096) e->drain_timing(); return; }
+  if (e->timing) { issue_launches(e, s, true, e->stream); if (e->pending.size() > 4096) e->drain_timing(); return; }
   if (e->use_graph && s.launches.size() > 8) {
     if (!s.graph) {
       hipGraph_t g = nullptr;
-      HIP_CHECK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-      try { issue_launches(e, s, false); }
-      catch (...) { (void)hipStreamEndCapture(e->stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
-      HIP_CHECK(hipStreamEndCapture(e->stream, &g));
+      if (!e->capture_stream) HIP_CHECK(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
+      HIP_CHECK(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
+      try { issue_launches(e, s, false, e->capture_stream); }
+      catch (...) { (void)hipStreamEndCapture(e->capture_stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
+      HIP_CHECK(hipStreamEndCapture(e->capture_stream, &g));
       HIP_CHECK(hipGraphInstantiate(&s.graph, g, nullptr, nullptr, 0));
       HIP_CHECK(hipGraphDestroy(g));
     }
     HIP_CHECK(hipGraphLaunch(s.graph, e->stream));
     return;
   }
-  issue_launches(e, s, false);
+  issue_launches(e, s, false, e->stream);
 }
 
 void require_model(const lpmp_engine* e) { if (!e || !e->plan) throw StateError("no model uploaded"); }
@@ -335,6 +337,7 @@ void lpmp_destroy(lpmp_engine* e) {
   for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
   e->release_model();
   if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
   delete e;
 }
 

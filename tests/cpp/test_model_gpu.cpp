@@ -1,0 +1,163 @@
+// C++ drop-in test: reads like the reference's own tests
+//   test/test_model.cpp:18-48   (3 toy factors, 2 messages, Solver default 1000 iterations, LB = 1.0)
+//   test/graphical_model.cpp:90-137 (binary chain / frustrated cycle, LB = 0)
+//   test/multicut.cpp:8-32      (labeling_factor lower bounds)
+// but is built against lp_mp_amd/include/LP_gpu.hxx and runs the sweep on the MI355X.
+// usage: test_model_gpu [--host-only]   (host-only: construction + counts, no device call)
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+
+#include "LP_gpu.hxx"
+
+using namespace LP_MP;
+
+static void test(const bool pred) { if (!pred) throw std::runtime_error("Test failed."); }   // reference test/test.h:7-11
+
+struct test_FMC {   // reference test/test_model.hxx:130-137, verbatim surface
+  constexpr static const char* name = "test model";
+  using factor = FactorContainer<test_factor, test_FMC, 0>;
+  using message = MessageContainer<test_message, 0, 0, message_passing_schedule::left, variableMessageNumber, variableMessageNumber, test_FMC, 0>;
+  using FactorList = meta::list<factor>;
+  using MessageList = meta::list<message>;
+  using ProblemDecompositionList = meta::list<>;
+};
+
+struct FMC_SRMP {   // unary / pairwise MRF as LP_MP-MRF declares it
+  constexpr static const char* name = "SRMP";
+  using UnaryFactor = FactorContainer<UnarySimplexFactor, FMC_SRMP, 0>;
+  using PairwiseFactor = FactorContainer<PairwiseSimplexFactor, FMC_SRMP, 1>;
+  using UnaryPairwiseMessageLeftContainer = MessageContainer<UnaryPairwiseMessage<Chirality::left>, 0, 1, message_passing_schedule::left, variableMessageNumber, 1, FMC_SRMP, 0>;
+  using UnaryPairwiseMessageRightContainer = MessageContainer<UnaryPairwiseMessage<Chirality::right>, 0, 1, message_passing_schedule::left, variableMessageNumber, 1, FMC_SRMP, 1>;
+  using FactorList = meta::list<UnaryFactor, PairwiseFactor>;
+  using MessageList = meta::list<UnaryPairwiseMessageLeftContainer, UnaryPairwiseMessageRightContainer>;
+  using ProblemDecompositionList = meta::list<>;
+};
+
+using edge_labelings = labelings<labeling<1>>;
+using triplet_labelings = labelings<labeling<0, 1, 1>, labeling<1, 0, 1>, labeling<1, 1, 0>, labeling<1, 1, 1>>;
+using multicut_edge_factor = labeling_factor<edge_labelings, true>;
+using multicut_triplet_factor = labeling_factor<triplet_labelings, true>;
+struct FMC_MULTICUT {
+  constexpr static const char* name = "multicut";
+  using edge_factor_container = FactorContainer<multicut_edge_factor, FMC_MULTICUT, 0>;
+  using triplet_factor_container = FactorContainer<multicut_triplet_factor, FMC_MULTICUT, 1>;
+  using m0 = MessageContainer<labeling_message<edge_labelings, triplet_labelings, 0>, 0, 1, message_passing_schedule::left, variableMessageNumber, 1, FMC_MULTICUT, 0>;
+  using m1 = MessageContainer<labeling_message<edge_labelings, triplet_labelings, 1>, 0, 1, message_passing_schedule::left, variableMessageNumber, 1, FMC_MULTICUT, 1>;
+  using m2 = MessageContainer<labeling_message<edge_labelings, triplet_labelings, 2>, 0, 1, message_passing_schedule::left, variableMessageNumber, 1, FMC_MULTICUT, 2>;
+  using FactorList = meta::list<edge_factor_container, triplet_factor_container>;
+  using MessageList = meta::list<m0, m1, m2>;
+  using ProblemDecompositionList = meta::list<>;
+};
+
+template <class MRF>
+static void add_pairwise(MRF& lp, typename FMC_SRMP::UnaryFactor* u1, typename FMC_SRMP::UnaryFactor* u2, const double c[2][2]) {
+  auto* p = lp.template add_factor<typename FMC_SRMP::PairwiseFactor>(2, 2);
+  for (INDEX a = 0; a < 2; ++a) for (INDEX b = 0; b < 2; ++b) p->GetFactor()->cost(a, b) = c[a][b];
+  lp.template add_message<typename FMC_SRMP::UnaryPairwiseMessageLeftContainer>(u1, p);
+  lp.template add_message<typename FMC_SRMP::UnaryPairwiseMessageRightContainer>(u2, p);
+  lp.AddFactorRelation(u1, p);
+  lp.AddFactorRelation(p, u2);
+}
+
+int main(int argc, char** argv) {
+  const bool host_only = argc > 1 && std::strcmp(argv[1], "--host-only") == 0;
+  {   // ---- test/test_model.cpp ----
+    Solver<LP<test_FMC>, StandardVisitor> s;
+    auto& lp = s.GetLP();
+    auto* f1 = lp.template add_factor<typename test_FMC::factor>(0, 1);
+    auto* f2 = lp.template add_factor<typename test_FMC::factor>(1, 0);
+    auto* f3 = lp.template add_factor<typename test_FMC::factor>(0, 0);
+    lp.template add_message<typename test_FMC::message>(f1, f2);
+    lp.template add_message<typename test_FMC::message>(f1, f3);
+    test(lp.GetNumberOfFactors() == 3);
+    test(lp.GetNumberOfMessages() == 2);
+    test(lp.GetFactor(0) == f1);
+    test(lp.GetFactor(1) == f2);
+    test(lp.GetFactor(2) == f3);
+    test(f1->no_messages() == 2);
+    test(f1->no_send_messages() == 2);
+    test(f2->no_messages() == 1);
+    test(f2->no_send_messages() == 0);
+    test(f3->no_messages() == 1);
+    test(f3->no_send_messages() == 0);
+    if (!host_only) {
+      std::cout << "lower bound before optimization = " << s.GetLP().LowerBound() << "\n";
+      s.Solve();
+      std::cout << "lower bound after optimization = " << s.GetLP().LowerBound() << "\n";
+      test(std::abs(s.GetLP().LowerBound() - 1.0) <= eps);
+      test(s.iter == 1000);
+      // the factor ops hold the reparametrised costs after End(), as in the reference
+      test(std::abs((*f1->GetFactor())[0] - 1.0) <= eps && std::abs((*f1->GetFactor())[1] - 1.0) <= eps);
+      // call-order error of the reference (LP_MP.h:458)
+      bool threw = false;
+      lp.Begin();
+      try { lp.ComputePass(0); } catch (const std::runtime_error&) { threw = true; }
+      test(threw);
+    }
+  }
+  {   // ---- test/simplex.cpp, test/potts_factor.cpp, test/multicut.cpp: factor op known answers (host) ----
+    UnarySimplexFactor simplex(std::vector<double>{0.1, 0.2, 0.05, 1});
+    test(simplex.LowerBound() == 0.05);
+    PairwiseSimplexFactor pw(3, 3);
+    for (INDEX x1 = 0; x1 < 3; ++x1) for (INDEX x2 = 0; x2 < 3; ++x2) pw.cost(x1, x2) = x1 != x2 ? 0 : -REAL(x1) - 1.0;
+    test(pw.LowerBound() == -3.0);
+    pairwise_potts_factor potts(3, 1.0);
+    PairwiseSimplexFactor potts2(3, 3);
+    for (INDEX a = 0; a < 3; ++a) for (INDEX b = 0; b < 3; ++b) potts2.cost(a, b) = a == b ? 0.0 : 1.0;
+    potts.msg1(0) = -0.1; potts2.msg1(0) = -0.1; potts.msg1(1) = 0.5; potts2.msg1(1) = 0.5; potts.msg1(2) = 0.8; potts2.msg1(2) = 0.8;
+    potts.msg2(0) = 1.5; potts2.msg2(0) = 1.5; potts.msg2(1) = 1.0; potts2.msg2(1) = 1.0;
+    test(potts.LowerBound() == potts2.LowerBound());
+    multicut_edge_factor unary;
+    unary[0] = 1.0; test(unary.size() == 1); test(unary.LowerBound() == 0);
+    unary[0] = -1.0; test(unary.LowerBound() == -1);
+    multicut_triplet_factor triangle;
+    test(triangle.size() == 4);
+    triangle[0] = 1.0; triangle[1] = 2.0; triangle[2] = 3.3; triangle[3] = 1.5; test(triangle.LowerBound() == 0.0);
+    triangle[1] = -0.5; triangle[2] = -0.3; test(triangle.LowerBound() == -0.5);
+    using msg0 = labeling_message<edge_labelings, triplet_labelings, 0>;
+    const auto tab = msg0::match_table();
+    test(tab.size() == 4 && tab[0] == 1 && tab[1] == 0 && tab[2] == 0 && tab[3] == 0);
+  }
+  const double negPotts[2][2] = {{1.0, 0.0}, {0.0, 1.0}};
+  const double posPotts[2][2] = {{0.0, 1.0}, {1.0, 0.0}};
+  for (int cycle = 0; cycle < 2; ++cycle) {   // ---- test/graphical_model.cpp:90-137 ----
+    Solver<LP<FMC_SRMP>, StandardVisitor> s(std::vector<std::string>{"--maxIter", "100", "--standardReparametrization", "anisotropic"});
+    auto& lp = s.GetLP();
+    std::vector<typename FMC_SRMP::UnaryFactor*> u;
+    for (int i = 0; i < (cycle ? 4 : 5); ++i) u.push_back(lp.template add_factor<typename FMC_SRMP::UnaryFactor>(std::vector<REAL>(2, 0.0)));
+    add_pairwise(lp, u[0], u[1], negPotts);
+    add_pairwise(lp, u[1], u[2], posPotts);
+    add_pairwise(lp, u[2], u[3], posPotts);
+    if (cycle) add_pairwise(lp, u[0], u[3], posPotts); else add_pairwise(lp, u[3], u[4], posPotts);
+    test(lp.GetNumberOfFactors() == (cycle ? 8u : 9u));
+    if (!host_only) {
+      s.Solve();
+      test(std::abs(s.lower_bound() - 0.0) <= eps);
+      auto om = lp.get_omega();
+      test(om.forward.size() == u.size());
+    }
+  }
+  if (!host_only) {   // ---- multicut-style triangle through the labeling-list family ----
+    LP<FMC_MULTICUT> lp;
+    const double ec[3] = {-1.0, 2.0, 2.0};
+    typename FMC_MULTICUT::edge_factor_container* e[3];
+    for (int k = 0; k < 3; ++k) { e[k] = lp.template add_factor<typename FMC_MULTICUT::edge_factor_container>(); (*e[k]->GetFactor())[0] = ec[k]; }
+    auto* t = lp.template add_factor<typename FMC_MULTICUT::triplet_factor_container>();
+    lp.template add_message<typename FMC_MULTICUT::m0>(e[0], t);
+    lp.template add_message<typename FMC_MULTICUT::m1>(e[1], t);
+    lp.template add_message<typename FMC_MULTICUT::m2>(e[2], t);
+    for (int k = 0; k < 3; ++k) lp.AddFactorRelation(e[k], t);
+    lp.Begin();
+    lp.set_reparametrization(LPReparametrizationMode::Anisotropic);
+    const double lb0 = lp.LowerBound();
+    test(lb0 == -1.0);
+    for (int it = 0; it < 50; ++it) lp.ComputePass(it);
+    // cutting only edge 0 (relaxed optimum -1) is not a multicut of a triangle: the best labeling is the all-zero one
+    test(lp.LowerBound() >= lb0 - eps && lp.LowerBound() <= 0.0 + eps);
+    test(std::abs(lp.LowerBound() - 0.0) <= 1e-6);
+  }
+  std::cout << "all tests passed\n";
+  return 0;
+}

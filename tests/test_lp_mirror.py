@@ -1,0 +1,140 @@
+"""The Python mirror of the reference's LP<FMC> / Solver surface (lp_mp_amd/lp.py).  The GPU tests read like
+the reference's own tests (test/test_model.cpp, test/graphical_model.cpp)."""
+import numpy as np
+import pytest
+
+from lp_mp_amd import lp as LPM
+from lp_mp_amd import model as M
+from lp_mp_amd import synthetic as S
+
+
+def make_test_fmc():
+    factor = LPM.FactorContainer(LPM.test_factor, 0)
+    message = LPM.MessageContainer(LPM.test_message(), 0, 0, M.SCHED_LEFT, M.variableMessageNumber,
+                                   M.variableMessageNumber, 0)
+    return LPM.FMC("test model", [factor], [message]), factor, message
+
+
+def FMC_SRMP():
+    U = LPM.FactorContainer(LPM.UnarySimplexFactor, 0)
+    P = LPM.FactorContainer(LPM.PairwiseSimplexFactor, 1)
+    ML = LPM.MessageContainer(LPM.UnaryPairwiseMessage(0), 0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, 0)
+    MR = LPM.MessageContainer(LPM.UnaryPairwiseMessage(1), 0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, 1)
+    return LPM.FMC("SRMP", [U, P], [ML, MR]), U, P, ML, MR
+
+
+def _grid_through_lp(H, W, L, seed):
+    """the synthetic grid built call by call through add_factor / add_message / AddFactorRelation"""
+    fmc, U, P, ML, MR = FMC_SRMP()
+    lp = LPM.LP(fmc)
+    ref = S.grid_model(H, W, L, seed=seed)
+    n = H * W
+    un = ref.dual_data[: n * L].reshape(n, L)
+    u = [lp.add_factor(U, un[i]) for i in range(n)]
+    a, b = S.grid_edges(H, W)
+    tabs = ref.const_data.reshape(-1, L, L)
+    for k in range(len(a)):
+        p = lp.add_factor(P, L, L, tabs[k])
+        lp.add_message(ML, u[a[k]], p)
+        lp.add_message(MR, u[b[k]], p)
+        lp.AddFactorRelation(u[a[k]], p)
+        lp.AddFactorRelation(p, u[b[k]])
+    return lp, ref
+
+
+def test_flattening_matches_bulk_builder_up_to_insertion_order():
+    lp, ref = _grid_through_lp(4, 5, 3, 2)
+    m = lp.flat_model()
+    assert m.n_factors == ref.n_factors and m.n_messages == ref.n_messages
+    # same factors, but pairwise factors are interleaved with nothing here: unaries first, then edges
+    assert np.array_equal(np.sort(m.const_data), np.sort(ref.const_data))
+    assert lp.GetNumberOfFactors() == ref.n_factors and lp.GetNumberOfMessages() == ref.n_messages
+
+
+def test_error_behaviour_mirrors_reference():
+    fmc, factor, message = make_test_fmc()
+    with pytest.raises(RuntimeError):
+        LPM.LPReparametrizationModeConvert("bogus")                # config.hxx:88 throws runtime_error
+    class UserFactor:                                              # an op without a device kind is rejected
+        pass
+    with pytest.raises(RuntimeError):
+        LPM.FMC("x", [LPM.FactorContainer(UserFactor, 0)], [])
+    lp = LPM.LP(fmc)
+    f1 = lp.add_factor(factor, 0, 1)
+    fmc2, U, P, ML, MR = FMC_SRMP()
+    lp2 = LPM.LP(fmc2)
+    a = lp2.add_factor(U, [0, 1]); b = lp2.add_factor(U, [0, 1])
+    with pytest.raises(RuntimeError):
+        lp2.add_message(ML, a, b)                                   # right factor is not a pairwise factor
+
+
+@pytest.mark.gpu
+def test_test_model_like_reference():
+    """reference test/test_model.cpp:18-48"""
+    fmc, factor, message = make_test_fmc()
+    s = LPM.Solver(LPM.LP(fmc), LPM.StandardVisitor())
+    lp = s.GetLP()
+    f1 = lp.add_factor(factor, 0, 1)
+    f2 = lp.add_factor(factor, 1, 0)
+    f3 = lp.add_factor(factor, 0, 0)
+    lp.add_message(message, f1, f2)
+    lp.add_message(message, f1, f3)
+    assert lp.GetNumberOfFactors() == 3
+    assert lp.GetNumberOfMessages() == 2
+    with pytest.raises(RuntimeError):
+        lp.ComputePass(0)                                           # no reparametrization mode set (LP_MP.h:458)
+    s.Solve()
+    assert abs(s.GetLP().LowerBound() - 1.0) <= 1e-8
+    assert s.iter == 1000                                           # default --maxIter
+
+
+@pytest.mark.gpu
+def test_solver_on_grid_matches_oracle_with_mode_switches():
+    """the visitor switches to the rounding reparametrisation every 5th iteration (standard_visitor.hxx:172-185):
+    both weight sets are resident and the device follows the same sequence as the oracle."""
+    from oracle.binding import Oracle
+    lp, ref = _grid_through_lp(6, 7, 4, 3)
+    vis = LPM.StandardVisitor(maxIter=12)
+    s = LPM.Solver(lp, vis)
+    s.Solve()
+    o = Oracle(lp.flat_model())
+    v2 = LPM.StandardVisitor(maxIter=12)
+    c = v2.begin(None)
+    lbs = []
+    while not c.end:
+        o.set_reparametrization(c.repam)
+        o.ComputePass(1)
+        lbs.append(o.LowerBound())
+        c = v2.visit(c, lbs[-1], np.inf)
+    assert len(vis.lowerBound_) == len(lbs) == 12
+    assert np.allclose(vis.lowerBound_, lbs, rtol=1e-9)
+    assert np.array_equal(lp.duals(), o.duals())
+    om = lp.get_omega()
+    assert set(om) == {"forward", "backward", "receive_mask_forward", "receive_mask_backward"}
+
+
+@pytest.mark.gpu
+def test_multicut_style_labeling_model_through_lp():
+    from oracle.binding import Oracle
+    edge = LPM.labeling_factor([(1,)], True)
+    trip = LPM.labeling_factor(S.TRIPLET_LABELINGS, True)
+    E_ = LPM.FactorContainer(edge, 0)
+    T_ = LPM.FactorContainer(trip, 1)
+    msgs = [LPM.MessageContainer(LPM.labeling_message(((1,),), tuple(S.TRIPLET_LABELINGS), (k,)), 0, 1, M.SCHED_LEFT,
+                                 M.variableMessageNumber, 1, k) for k in range(3)]
+    lp = LPM.LP(LPM.FMC("multicut", [E_, T_], msgs))
+    e = [lp.add_factor(E_, [c]) for c in (0.7, -0.4, -0.9, 0.2, -0.3)]
+    for tri in ((0, 1, 2), (1, 2, 3), (2, 3, 4)):
+        t = lp.add_factor(T_)
+        for k, ei in enumerate(tri):
+            lp.add_message(msgs[k], e[ei], t)
+            lp.AddFactorRelation(e[ei], t)
+    lp.Begin()
+    lp.set_reparametrization("anisotropic")
+    o = Oracle(lp.flat_model())
+    o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    for _ in range(5):
+        lp.ComputePass(0)
+        o.ComputePass(1)
+    assert np.array_equal(lp.duals(), o.duals())
+    assert abs(lp.LowerBound() - o.LowerBound()) <= 1e-12

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs with
+--kernel-trace only) into per-launch HBM traffic of one kernel.
+
+Units and gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section) and
+cdna_hip_programming.md section 7: counters are in KiB; FETCH_SIZE reports exactly half the bytes of a
+wide coalesced streaming read on gfx950, WRITE_SIZE is exact:  bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring> <out.json>
+"""
+import csv
+import json
+import sys
+
+
+def per_launch(path, counter, kernel):
+    vals = []
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and kernel in r["Kernel_Name"]:
+            vals.append(float(r["Counter_Value"]))
+    return vals
+
+
+def main():
+    fetch_csv, write_csv, kernel, out = sys.argv[1:5]
+    f = per_launch(fetch_csv, "FETCH_SIZE", kernel)
+    w = per_launch(write_csv, "WRITE_SIZE", kernel)
+    assert f and w and len(f) == len(w), (len(f), len(w))
+    by = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w)]
+    res = {"kernel": kernel, "launches": len(by), "fetch_size_kib_avg": sum(f) / len(f), "write_size_kib_avg": sum(w) / len(w),
+           "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
+           "hbm_bytes_per_launch_avg": sum(by) / len(by), "hbm_bytes_per_launch_min": min(by), "hbm_bytes_per_launch_max": max(by)}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
