@@ -70,6 +70,11 @@ int lpmp_plan_anisotropic_weights(const lpmp_plan* p, int64_t n, const int32_t* 
 int lpmp_plan_schedule_info(lpmp_plan* p, int direction, int mode, int64_t* n_levels, int64_t* n_launches,
                             int64_t* n_receives, int64_t* n_sends, int64_t* algorithmic_bytes);
 
+/* the same for a whole pass (forward then backward sweep scheduled as one sequence; back-to-back updates
+ * of one factor across the two sweeps are folded into one record) */
+int lpmp_plan_pass_schedule_info(lpmp_plan* p, int mode, int64_t* n_levels, int64_t* n_launches,
+                                 int64_t* n_receives, int64_t* n_sends, int64_t* algorithmic_bytes);
+
 /* ---- device engine --------------------------------------------------------------------------- */
 /* LP<FMC>::LP(cmd) (include/LP_MP.h:589-593).  device = HIP device ordinal. */
 int lpmp_create(int device, lpmp_engine** out);

@@ -10,7 +10,7 @@ SO = os.path.join(CSRC, "liblpmp_engine.so")
 SOURCES = ["kernels.hip", "engine.cpp", "plan.cpp"]
 HEADERS = ["plan.hpp", os.path.join("..", "..", "include", "lpmp_engine.h"), os.path.join("..", "..", "include", "lpmp_model.h")]
 # -ffp-contract=off: the sweep's duals must equal the sequential CPU semantics bit for bit
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-strict-aliasing", "-Wall",
          "-Wno-unused-function"]
 
 

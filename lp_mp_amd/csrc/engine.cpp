@@ -17,6 +17,7 @@
 namespace lpmp {
 void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
                   int64_t first, int64_t count, hipStream_t s);
+bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, int64_t count, hipStream_t s);
 void launch_factor_lb(const void* recs, const double* dual, const double* cdata, double* out, int64_t count, hipStream_t s);
 bool launch_dense_lb(int L, const void* recs, const double* dual, const double* cdata, double* out, int64_t first, int64_t count, hipStream_t s);
 void launch_sum_stage(const double* in, double* out, int64_t n, int64_t per_block, int64_t n_blocks, hipStream_t s);
@@ -52,6 +53,7 @@ int guarded(F&& f) {
 struct DevSchedule {
   UpdRec* recs = nullptr;
   Op* ops = nullptr;
+  Op* packets = nullptr;
   std::vector<LevelRange> launches;
   int64_t n_levels = 0, n_recv = 0, n_send = 0, alg_bytes = 0;
   hipGraphExec_t graph = nullptr;
@@ -59,6 +61,7 @@ struct DevSchedule {
     if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
     if (recs) { (void)hipFree(recs); recs = nullptr; }
     if (ops) { (void)hipFree(ops); ops = nullptr; }
+    if (packets) { (void)hipFree(packets); packets = nullptr; }
     launches.clear();
   }
 };
@@ -67,7 +70,24 @@ struct ClassTiming { double ms = 0; int64_t launches = 0, factors = 0, receives 
 
 }  // namespace
 
-struct lpmp_plan { Plan p; Schedule sched_cache[2][LPMP_REPAM_COUNT]; bool have_sched[2][LPMP_REPAM_COUNT] = {{false}}; };
+struct lpmp_plan {
+  Plan p;
+  Schedule sched_cache[2][LPMP_REPAM_COUNT]; bool have_sched[2][LPMP_REPAM_COUNT] = {{false}};
+  Schedule pass_cache[LPMP_REPAM_COUNT]; bool have_pass[LPMP_REPAM_COUNT] = {false};   // forward+backward as one fused sequence
+};
+
+static void plan_pass_schedule(lpmp_plan* pl, int mode) {
+  if (pl->have_pass[mode]) return;
+  pl->p.ensure_weights(mode);
+  std::vector<Plan::Segment> segs;
+  for (int d = 0; d < 2; ++d) {
+    const auto& om = pl->p.omega[d][mode];
+    const auto& mk = pl->p.mask[d][mode];
+    segs.push_back({pl->p.upd[d].data(), (int64_t)pl->p.upd[d].size(), om.off.data(), om.data.data(), mk.off.data(), mk.data.data()});
+  }
+  pl->p.make_schedule(segs, true, pl->pass_cache[mode]);
+  pl->have_pass[mode] = true;
+}
 
 static void plan_schedule(lpmp_plan* pl, int d, int mode) {
   if (pl->have_sched[d][mode]) return;
@@ -94,9 +114,13 @@ struct lpmp_engine {
   std::vector<LbRun> lb_runs;
   DevSchedule sched[2][LPMP_REPAM_COUNT];
   bool have_sched[LPMP_REPAM_COUNT] = {false, false, false, false};
+  DevSchedule sched_pass[LPMP_REPAM_COUNT];            // fused forward+backward (ComputePass)
+  bool have_pass[LPMP_REPAM_COUNT] = {false, false, false, false};
+  bool use_fused = true;
   std::vector<std::unique_ptr<DevSchedule>> custom;   // prepared iterator-range passes
   int mode = -1;
   bool use_graph = true;
+  bool use_packed = true;
   bool timing = false;
   ClassTiming ct[KC_COUNT];
   struct Pending { hipEvent_t a, b; int cls; int64_t factors, receives, bytes; };
@@ -105,7 +129,7 @@ struct lpmp_engine {
 
   void release_model() {
     for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m) sched[d][m].release();
-    for (int m = 0; m < LPMP_REPAM_COUNT; ++m) have_sched[m] = false;
+    for (int m = 0; m < LPMP_REPAM_COUNT; ++m) { have_sched[m] = false; sched_pass[m].release(); have_pass[m] = false; }
     for (auto& c : custom) if (c) c->release();
     custom.clear();
     if (own_dual && d_dual) (void)hipFree(d_dual);
@@ -149,6 +173,10 @@ void upload_schedule(const Schedule& s, DevSchedule& d) {
     HIP_CHECK(hipMalloc((void**)&d.ops, s.ops.size() * sizeof(Op)));
     HIP_CHECK(hipMemcpy(d.ops, s.ops.data(), s.ops.size() * sizeof(Op), hipMemcpyHostToDevice));
   }
+  if (!s.packets.empty()) {
+    HIP_CHECK(hipMalloc((void**)&d.packets, s.packets.size() * sizeof(Op)));
+    HIP_CHECK(hipMemcpy(d.packets, s.packets.data(), s.packets.size() * sizeof(Op), hipMemcpyHostToDevice));
+  }
 }
 
 void check_generic_limits(const Plan& p, const Schedule& s) {
@@ -176,11 +204,24 @@ void ensure_device_schedules(lpmp_engine* e, int mode) {
   e->have_sched[mode] = true;
 }
 
+void ensure_pass_schedule(lpmp_engine* e, int mode) {
+  if (e->have_pass[mode]) return;
+  plan_pass_schedule(e->plan.get(), mode);
+  check_generic_limits(e->plan->p, e->plan->pass_cache[mode]);
+  upload_schedule(e->plan->pass_cache[mode], e->sched_pass[mode]);
+  // the host copy is only needed for its summary
+  Schedule& h = e->plan->pass_cache[mode];
+  h.recs.clear(); h.recs.shrink_to_fit(); h.ops.clear(); h.ops.shrink_to_fit(); h.packets.clear(); h.packets.shrink_to_fit();
+  e->have_pass[mode] = true;
+}
+
 void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_t stream) {
   for (const auto& lr : s.launches) {
     hipEvent_t a = nullptr, b = nullptr;
     if (timed) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, stream)); }
-    launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, lr.begin, lr.end - lr.begin, stream);
+    if (!(e->use_packed && lr.stride > 0 &&
+          launch_sweep_packed(lr.kclass, s.packets + lr.pk_begin, lr.stride, e->d_dual, e->d_const, lr.end - lr.begin, stream)))
+      launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, lr.begin, lr.end - lr.begin, stream);
     if (timed) {
       HIP_CHECK(hipEventRecord(b, stream));
       e->pending.push_back({a, b, lr.kclass, lr.end - lr.begin, lr.n_recv, lr.bytes});
@@ -311,6 +352,20 @@ int lpmp_plan_schedule_info(lpmp_plan* p, int d, int mode, int64_t* n_levels, in
   });
 }
 
+int lpmp_plan_pass_schedule_info(lpmp_plan* p, int mode, int64_t* n_levels, int64_t* n_launches, int64_t* n_recv,
+                                 int64_t* n_send, int64_t* alg_bytes) {
+  return guarded([&] {
+    if (!p || mode < 0 || mode >= LPMP_REPAM_COUNT) throw std::runtime_error("bad argument");
+    plan_pass_schedule(p, mode);
+    const Schedule& s = p->pass_cache[mode];
+    if (n_levels) *n_levels = s.n_levels;
+    if (n_launches) *n_launches = (int64_t)s.launches.size();
+    if (n_recv) *n_recv = s.n_recv;
+    if (n_send) *n_send = s.n_send;
+    if (alg_bytes) *alg_bytes = s.alg_bytes;
+  });
+}
+
 // ---- engine ---------------------------------------------------------------------------------------
 int lpmp_create(int device, lpmp_engine** out) {
   return guarded([&] {
@@ -325,6 +380,10 @@ int lpmp_create(int device, lpmp_engine** out) {
     e->own_stream = true;
     const char* ng = std::getenv("LPMP_NO_GRAPH");
     e->use_graph = !(ng && ng[0] == '1');
+    const char* nf = std::getenv("LPMP_NO_FUSE");
+    e->use_fused = !(nf && nf[0] == '1');
+    const char* np = std::getenv("LPMP_NO_PACKED");
+    e->use_packed = !(np && np[0] == '1');
     *out = e.release();
   });
 }
@@ -347,6 +406,8 @@ int lpmp_set_stream(lpmp_engine* e, void* s) {
     HIP_CHECK(hipStreamSynchronize(e->stream));
     for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m)
       if (e->sched[d][m].graph) { (void)hipGraphExecDestroy(e->sched[d][m].graph); e->sched[d][m].graph = nullptr; }
+    for (int m = 0; m < LPMP_REPAM_COUNT; ++m)
+      if (e->sched_pass[m].graph) { (void)hipGraphExecDestroy(e->sched_pass[m].graph); e->sched_pass[m].graph = nullptr; }
     if (e->own_stream && e->stream) { HIP_CHECK(hipStreamDestroy(e->stream)); }
     e->stream = (hipStream_t)s; e->own_stream = false;
   });
@@ -424,7 +485,12 @@ int lpmp_compute_pass(lpmp_engine* e, int n) {
   return guarded([&] {
     require_mode(e);
     HIP_CHECK(hipSetDevice(e->device));
-    for (int i = 0; i < n; ++i) { run_schedule(e, e->sched[0][e->mode]); run_schedule(e, e->sched[1][e->mode]); }
+    if (e->use_fused) {
+      ensure_pass_schedule(e, e->mode);
+      for (int i = 0; i < n; ++i) run_schedule(e, e->sched_pass[e->mode]);
+    } else {
+      for (int i = 0; i < n; ++i) { run_schedule(e, e->sched[0][e->mode]); run_schedule(e, e->sched[1][e->mode]); }
+    }
   });
 }
 

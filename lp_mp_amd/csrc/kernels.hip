@@ -15,6 +15,8 @@
 // bit-identical to the sequential CPU semantics (min and + are exact; evaluation order is copied).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 
 #include "plan.hpp"
 
@@ -51,6 +53,27 @@ template <int G>
 __device__ __forceinline__ double group_min(double v) {
 #pragma unroll
   for (int m = G / 2; m >= 1; m >>= 1) v = fmin(v, shfl_xor_f64(v, m));
+  return v;
+}
+
+
+// min all-reduce over aligned groups of CL lanes (CL <= 16) with DPP moves: no LDS-crossbar round trip.
+// quad_perm [1,0,3,2] and [2,3,0,1] pair lanes inside a quad, row_half_mirror / row_mirror pair quads and
+// half rows; for a min it only matters that every step pairs the two halves that are still missing.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CL>
+__device__ __forceinline__ double row_allreduce_min(double v) {
+  static_assert(CL == 2 || CL == 4 || CL == 8 || CL == 16, "row width");
+  v = fmin(v, dpp_mov_f64<0xB1>(v));                       // lane ^ 1
+  if constexpr (CL >= 4) v = fmin(v, dpp_mov_f64<0x4E>(v));   // lane ^ 2
+  if constexpr (CL >= 8) v = fmin(v, dpp_mov_f64<0x141>(v));  // row_half_mirror: other quad of the 8
+  if constexpr (CL >= 16) v = fmin(v, dpp_mov_f64<0x140>(v)); // row_mirror: other half of the 16
   return v;
 }
 
@@ -267,8 +290,7 @@ sweep_dense_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         double v = fmin(t[i].x + mv.x, t[i].y + mv.y);
-#pragma unroll
-        for (int m = CL / 2; m >= 1; m >>= 1) v = fmin(v, shfl_xor_f64(v, m));
+        v = row_allreduce_min<CL>(v);
         if (c2 == 0) lds_q[grp][i * RPL + rl] = v;
       }
     } else {
@@ -299,6 +321,184 @@ sweep_dense_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
       const int side = (op.info >> 5) & 1;
       double* ms = dual + op.peer_dual + (side == 0 ? 0 : L);
       const double delta = op.omega * snap;
+      ms[g] += delta;
+      theta -= delta;
+    }
+    own_g[g] = theta;
+  }
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// Dense fast path, packed form (v2).  Same arithmetic as sweep_dense_kernel, restructured for latency:
+//   * the factor's record and all its ops arrive as ONE coalesced packet (no rec -> ops dependent hop);
+//   * the tables of up to KMAX receives and the target vectors of up to 4 sends are requested before
+//     anything is reduced, so a factor's HBM round trips overlap instead of chaining
+//     (what bounds the row-major order, where a level holds only <= min(H,W) factors).
+// -------------------------------------------------------------------------------------------------
+template <int G, class T> __device__ __forceinline__ T uni(T v) {
+  if constexpr (G == 64 && sizeof(T) == 4) return (T)__builtin_amdgcn_readfirstlane((int)v);
+  else return v;
+}
+template <int G> __device__ __forceinline__ int64_t uni64(int64_t v) {
+  if constexpr (G == 64) {
+    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((int64_t)hi << 32) | (unsigned int)lo;
+  } else return v;
+}
+
+template <int L, int KMAX>
+__global__ void __launch_bounds__(256)
+sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual, const double* __restrict__ cdata,
+                      int64_t count, int stride) {
+  constexpr int G = DenseCfg<L>::G;
+  constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
+  constexpr int KS = 4;                          // sends whose target vectors are prefetched / forwarded
+  constexpr int NFW = 4;                         // receives whose result can be forwarded in registers
+  constexpr int PIECES = 3 * (1 + PK_MAX_OPS);   // 16-B pieces of the largest packet
+  __shared__ double2_t lds_pk[GPB][PIECES];
+  __shared__ double lds_mo[GPB][L];
+  __shared__ double lds_q[GPB][L];
+  const int grp = threadIdx.x / G, g = threadIdx.x % G;
+  const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
+  const bool live = idx < count;
+  const int c2 = g % CL, rl = g / CL;
+  const int pieces = 3 * stride;
+  if (live) {
+    const double2_t* src = reinterpret_cast<const double2_t*>(packets + idx * stride);
+    for (int p = g; p < pieces; p += G) lds_pk[grp][p] = src[p];
+  }
+  wave_sync();
+  const UpdRec* hdr = reinterpret_cast<const UpdRec*>(&lds_pk[grp][0]);
+  const Op* lop = reinterpret_cast<const Op*>(&lds_pk[grp][3]);
+  const int n_recv = live ? uni<G>((int)hdr->n_recv) : 0;
+  const int n_send = live ? uni<G>((int)hdr->n_send) : 0;
+  const bool preload_ok = live && (uni<G>(hdr->kind_flags) & UPD_PRELOAD_OK) != 0;
+  double* own_g = dual + (live ? uni64<G>(hdr->dual_off) : 0);
+  const bool vl = live && g < L;
+  double theta = vl ? own_g[g] : 0.0;
+  // target vectors of the first KS sends
+  double sm[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    sm[k] = 0.0;
+    if (preload_ok && k < n_send && g < L) {
+      const Op& o = lop[n_recv + k];
+      sm[k] = dual[uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? L : 0) + g];
+    }
+  }
+  double mnew[NFW];                              // results of receives whose store is deferred to a send
+#pragma unroll
+  for (int k = 0; k < NFW; ++k) mnew[k] = 0.0;
+  int max_recv = n_recv;
+  if (G < 64) {
+#pragma unroll
+    for (int m = 32; m >= G; m >>= 1) max_recv = max(max_recv, __shfl_xor(max_recv, m, 64));
+  }
+
+  // one chunk of up to KMAX receives starting at c; FW: c is a compile-time constant and results may be forwarded
+  auto chunk = [&](const int c, auto fw_tag) {
+    constexpr bool FW = decltype(fw_tag)::value;
+    double2_t t[KMAX][NL];
+    double msv[KMAX], mov[KMAX];
+    int64_t pdual[KMAX];
+    int side[KMAX], defer[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {             // request everything first
+      const bool act = c + j < n_recv;
+      pdual[j] = 0; side[j] = 0; defer[j] = 0; msv[j] = 0.0; mov[j] = 0.0;
+      if (act) {
+        const Op& o = lop[c + j];
+        pdual[j] = uni64<G>(o.peer_dual);
+        side[j] = (uni<G>(o.info) >> 5) & 1;
+        defer[j] = FW ? uni<G>(o.pad) : 0;
+        const double* T = cdata + uni64<G>(o.peer_const);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) t[j][i] = *reinterpret_cast<const double2_t*>(T + (int64_t)i * 2 * G + 2 * g);
+        if (g < L) {
+          msv[j] = dual[pdual[j] + (side[j] == 0 ? 0 : L) + g];
+          mov[j] = dual[pdual[j] + (side[j] == 0 ? L : 0) + g];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) t[j][i] = double2_t{0.0, 0.0};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {             // then reduce, in message order
+      if (c + j >= max_recv) break;
+      const bool act = c + j < n_recv;
+      if (g < L) lds_mo[grp][g] = mov[j];
+      wave_sync();
+      if (side[j] == 0) {
+        const double2_t mv = *reinterpret_cast<const double2_t*>(&lds_mo[grp][2 * c2]);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          double v = fmin(t[j][i].x + mv.x, t[j][i].y + mv.y);
+#ifndef LPMP_ABLATE_REDUCE
+          v = row_allreduce_min<CL>(v);
+#endif
+          if (c2 == 0) lds_q[grp][i * RPL + rl] = v;
+        }
+      } else {
+        double vx = LPMP_INF, vy = LPMP_INF;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          const double m1v = lds_mo[grp][i * RPL + rl];
+          vx = fmin(vx, t[j][i].x + m1v);
+          vy = fmin(vy, t[j][i].y + m1v);
+        }
+#ifndef LPMP_ABLATE_REDUCE
+#pragma unroll
+        for (int m = G / 2; m >= CL; m >>= 1) { vx = fmin(vx, shfl_xor_f64(vx, m)); vy = fmin(vy, shfl_xor_f64(vy, m)); }
+#endif
+        if (rl == 0) { lds_q[grp][2 * c2] = vx; lds_q[grp][2 * c2 + 1] = vy; }
+      }
+      wave_sync();
+      if (act && g < L) {
+        const double delta = msv[j] + lds_q[grp][g];
+        theta += delta;
+        const double mn = msv[j] - delta;
+        bool stored = false;
+        if constexpr (FW) {
+          if (defer[j]) {                        // c + j < NFW by construction on the host
+#pragma unroll
+            for (int q = 0; q < NFW; ++q) if (q == c + j) mnew[q] = mn;
+            stored = true;
+          }
+        }
+        if (!stored) dual[pdual[j] + (side[j] == 0 ? 0 : L) + g] = mn;
+      }
+      wave_sync();
+    }
+  };
+  // the first chunks are unrolled with constant indices so that forwarded results stay in registers
+  if (max_recv > 0) chunk(0, std::true_type{});
+  if constexpr (KMAX < NFW) { if (max_recv > KMAX) chunk(KMAX, std::true_type{}); }
+  if constexpr (2 * KMAX < NFW) { if (max_recv > 2 * KMAX) chunk(2 * KMAX, std::true_type{}); if (max_recv > 3 * KMAX) chunk(3 * KMAX, std::true_type{}); }
+  for (int c = (KMAX >= NFW ? KMAX : NFW); c < max_recv; c += KMAX) chunk(c, std::false_type{});
+
+  if (vl) {
+    const double snap = theta;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (k < n_send) {
+        const Op& o = lop[n_recv + k];
+        double* ms = dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? L : 0);
+        const int fw = uni<G>(o.pad);
+        double cur;
+        if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
+        else cur = preload_ok ? sm[k] : ms[g];
+        const double delta = o.omega * snap;
+        ms[g] = cur + delta;
+        theta -= delta;
+      }
+    }
+    for (int k = KS; k < n_send; ++k) {
+      const Op& o = lop[n_recv + k];
+      double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? L : 0);
+      const double delta = o.omega * snap;
       ms[g] += delta;
       theta -= delta;
     }
@@ -445,8 +645,7 @@ dense_lb_kernel(const LbRec* __restrict__ recs, const double* __restrict__ dual,
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     double v = fmin(t[i].x + m2.x, t[i].y + m2.y);
-#pragma unroll
-    for (int m = CL / 2; m >= 1; m >>= 1) v = fmin(v, shfl_xor_f64(v, m));
+    v = row_allreduce_min<CL>(v);
     best = fmin(best, lds_m[grp][i * RPL + rl] + v);
   }
 #pragma unroll
@@ -499,6 +698,27 @@ void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, c
     case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
     default: hipLaunchKernelGGL(sweep_generic_kernel, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, first, count); break;
   }
+}
+
+static int dense_kmax() {
+  static int k = [] { const char* e = getenv("LPMP_DENSE_KMAX"); return e ? atoi(e) : 2; }();
+  return k;
+}
+
+bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, int64_t count, hipStream_t s) {
+  if (count <= 0) return true;
+  if (stride > 1 + PK_MAX_OPS) return false;
+  auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
+  const int km = dense_kmax();
+#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, dual, cdata, count, stride)
+  switch (kclass) {
+    case KC_DENSE_32: if (km >= 4) PK_LAUNCH(32, 4); else if (km == 1) PK_LAUNCH(32, 1); else PK_LAUNCH(32, 2); return true;
+    case KC_DENSE_16: if (km >= 4) PK_LAUNCH(16, 4); else PK_LAUNCH(16, 2); return true;
+    case KC_DENSE_8: PK_LAUNCH(8, 4); return true;
+    case KC_DENSE_4: PK_LAUNCH(4, 4); return true;
+    default: return false;
+  }
+#undef PK_LAUNCH
 }
 
 void launch_factor_lb(const void* recs, const double* dual, const double* cdata, double* out, int64_t count, hipStream_t s) {

@@ -3,6 +3,7 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <limits>
 #include <numeric>
 #include <stdexcept>
@@ -325,67 +326,89 @@ void Plan::ensure_weights(int mode) {
 // commute exactly when they touch disjoint factors, so update u gets
 //   level(u) = 1 + max(level of the latest earlier update that touched u or one of the factors u touches)
 // and all updates of one level run concurrently with a result identical to the sequential sweep.
-void Plan::make_schedule(const int32_t* factors, int64_t n, const int64_t* om_off, const double* om,
-                         const int64_t* mk_off, const uint8_t* mk, Schedule& out) const {
+//
+// Several sweeps can be scheduled as ONE sequence (forward then backward of a pass).  With `fuse`, an
+// update u2 that directly follows an update u1 of the SAME factor — nothing else touched anything u2
+// touches in between — is folded into u1's record when u1 has no sends: "receive R1; receive R2; send S2
+// from the state after the receives" is exactly what running u1 then u2 computes, and the factor's dual
+// makes one round trip instead of two (2-colour grids: the receive level of the forward sweep and the
+// send level of the backward sweep are the same factors).
+void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out) const {
   out = Schedule();
-  std::vector<int32_t> level(n, 0), kclass(n, KC_GENERIC);
-  std::vector<int32_t> last_touch(nf, 0);
-  std::vector<int64_t> n_ops(n, 0);
+  int64_t N = 0;
+  for (const auto& sg : segs) N += sg.n;
+  struct Upd { int32_t f; int32_t owner; int64_t om, mk; };   // om / mk: absolute pointers are per segment
+  std::vector<int32_t> uf(N), owner(N), level(N, 0);
+  std::vector<const double*> uom(N);
+  std::vector<const uint8_t*> umk(N);
+  std::vector<int32_t> n_recv_of(N, 0), n_send_of(N, 0);       // active ops accumulated on the owner record
+  {
+    int64_t u = 0;
+    for (const auto& sg : segs)
+      for (int64_t i = 0; i < sg.n; ++i, ++u) {
+        const int32_t f = sg.factors[i];
+        if (f < 0 || f >= nf) fail("factor index out of range");
+        if (sg.om_off[i + 1] - sg.om_off[i] != row_sends(f) || sg.mk_off[i + 1] - sg.mk_off[i] != row_receives(f))
+          fail("row " + std::to_string(i) + ": omega / receive mask length does not match the factor's messages");
+        uf[u] = f; uom[u] = sg.om + sg.om_off[i]; umk[u] = sg.mk + sg.mk_off[i];
+      }
+  }
+  if (N > std::numeric_limits<int32_t>::max()) fail("too many updates for one schedule");
+  std::vector<int32_t> last_level(nf, 0), last_toucher(nf, -1), last_update_of(nf, -1);
   int32_t max_level = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    const int32_t f = factors[i];
-    if (f < 0 || f >= nf) fail("factor index out of range");
-    if (om_off[i + 1] - om_off[i] != row_sends(f) || mk_off[i + 1] - mk_off[i] != row_receives(f))
-      fail("row " + std::to_string(i) + ": omega / receive mask length does not match the factor's messages");
-    int32_t lv = last_touch[f];
-    int64_t ks = om_off[i], kr = mk_off[i], cnt = 0;
-    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
-      const MsgEntry& e = fm[j];
-      bool active = false;
-      if (e.receives) active = mk[kr++] != 0;
-      if (e.sends) { const double w = om[ks++]; if (w < 0) fail("negative send weight"); active = active || w != 0.0; }
-      if (active) lv = std::max(lv, last_touch[e.adjacent]);
+  std::vector<int32_t> touched;
+  for (int64_t u = 0; u < N; ++u) {
+    const int32_t f = uf[u];
+    touched.clear();
+    touched.push_back(f);
+    int32_t nr = 0, ns = 0;
+    {
+      int64_t ks = 0, kr = 0;
+      for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
+        const MsgEntry& e = fm[j];
+        bool active = false;
+        if (e.receives && umk[u][kr++]) { active = true; ++nr; }
+        if (e.sends) { const double w = uom[u][ks++]; if (w < 0) fail("negative send weight"); if (w != 0.0) { active = true; ++ns; } }
+        if (active) touched.push_back(e.adjacent);
+      }
     }
-    // count ops
-    ks = om_off[i]; kr = mk_off[i];
-    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
-      const MsgEntry& e = fm[j];
-      if (e.receives && mk[kr++]) ++cnt;
-      if (e.sends && om[ks++] != 0.0) ++cnt;
-    }
-    n_ops[i] = cnt;
-    level[i] = lv + 1;
-    max_level = std::max(max_level, level[i]);
-    last_touch[f] = level[i];
-    ks = om_off[i]; kr = mk_off[i];
-    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
-      const MsgEntry& e = fm[j];
-      bool active = false;
-      if (e.receives) active = mk[kr++] != 0;
-      if (e.sends) active = (om[ks++] != 0.0) || active;
-      if (active) last_touch[e.adjacent] = level[i];
+    int32_t lv = 0;
+    for (int32_t g : touched) lv = std::max(lv, last_level[g]);
+    const int32_t prev = last_update_of[f];
+    bool merge = fuse && prev >= 0 && nr + ns > 0 && n_send_of[prev] == 0 && level[prev] == lv &&
+                 n_recv_of[prev] + nr + ns <= 32000;
+    if (merge)
+      for (int32_t g : touched)
+        if (last_level[g] == lv && last_toucher[g] != prev) { merge = false; break; }
+    if (merge) {
+      owner[u] = prev; level[u] = lv;
+      n_recv_of[prev] += nr; n_send_of[prev] += ns;
+      for (int32_t g : touched) { last_level[g] = lv; last_toucher[g] = prev; }
+    } else {
+      owner[u] = (int32_t)u; level[u] = lv + 1;
+      n_recv_of[u] = nr; n_send_of[u] = ns;
+      max_level = std::max(max_level, level[u]);
+      if (nr + ns > 0) {   // an update without active ops touches nothing
+        for (int32_t g : touched) { last_level[g] = level[u]; last_toucher[g] = (int32_t)u; }
+        last_update_of[f] = (int32_t)u;
+      }
     }
   }
   out.n_levels = max_level;
 
-  // build records + ops in list order first, then bucket by (level, class)
-  std::vector<UpdRec> recs(n);
-  std::vector<int64_t> rec_bytes(n, 0);
-  std::vector<int64_t> op_start(n + 1, 0);
-  for (int64_t i = 0; i < n; ++i) op_start[i + 1] = op_start[i] + n_ops[i];
-  if (op_start[n] > std::numeric_limits<int32_t>::max()) fail("too many active message operations for one schedule");
-  std::vector<Op> ops(op_start[n]);
-  for (int64_t i = 0; i < n; ++i) {
-    const int32_t f = factors[i];
-    UpdRec& r = recs[i];
-    r.dual_off = f_doff[f];
-    r.const_off = f_kind[f] == LPMP_F_VECTOR ? -1 : f_coff[f];
-    r.d0 = f_dim0[f]; r.d1 = f_dim1[f];
-    r.factor = f;
-    r.kind_flags = f_kind[f] | (f_flags[f] << 4);
-    Op* o = ops.data() + op_start[i];
-    int64_t nrecv = 0, nsend = 0;
-    bool all_dense = f_kind[f] == LPMP_F_VECTOR, all_potts = all_dense;
+  // records of the owners, ops = all receives of the members (sequence order), then all sends
+  std::vector<int64_t> op_start(N + 1, 0);
+  for (int64_t u = 0; u < N; ++u) op_start[u + 1] = op_start[u] + (owner[u] == u ? n_recv_of[u] + n_send_of[u] : 0);
+  if (op_start[N] > std::numeric_limits<int32_t>::max()) fail("too many active message operations for one schedule");
+  std::vector<Op> ops(op_start[N]);
+  std::vector<int32_t> cur_r(N, 0), cur_s(N, 0);
+  std::vector<int64_t> rec_bytes(N, 0);
+  std::vector<uint8_t> all_dense(N, 1), all_potts(N, 1);
+  for (int64_t u = 0; u < N; ++u) {
+    const int32_t f = uf[u];
+    const int32_t o = owner[u];
+    const int32_t own_d0 = f_dim0[f];
+    Op* base = ops.data() + op_start[o];
     auto fill = [&](const MsgEntry& e, double w) {
       const auto& mt = mtypes[m_type[e.msg]];
       const int32_t peer = e.adjacent;
@@ -400,10 +423,10 @@ void Plan::make_schedule(const int32_t* factors, int64_t n, const int64_t* om_of
       if (mt.kind == LPMP_M_UNARY_PAIRWISE) {
         side = mt.param;
         op.peer_const = e.role == 0 ? f_coff[peer] : -1;
-        if (!(e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && f_dim0[peer] == r.d0 && f_dim1[peer] == r.d0 && (f_coff[peer] % 2) == 0)) all_dense = false;
-        if (!(e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == r.d0)) all_potts = false;
+        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && f_dim0[peer] == own_d0 && f_dim1[peer] == own_d0 && (f_coff[peer] % 2) == 0)) all_dense[o] = 0;
+        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == own_d0)) all_potts[o] = 0;
       } else {
-        all_dense = all_potts = false;
+        all_dense[o] = all_potts[o] = 0;
         if (mt.kind == LPMP_M_LABELING) {
           op.peer_const = tab_off[mt.param];
           op.pd1 = tab_nleft[mt.param];
@@ -413,62 +436,70 @@ void Plan::make_schedule(const int32_t* factors, int64_t n, const int64_t* om_of
       op.info = mt.kind | (e.role << 4) | (side << 5) | (imp << 6) | (f_kind[peer] << 8);
       return op;
     };
-    int64_t ks = om_off[i], kr = mk_off[i];
-    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {   // receives first, list order
-      const MsgEntry& e = fm[j];
-      if (e.receives && mk[kr++]) { *o++ = fill(e, 1.0); ++nrecv; }
-    }
-    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {   // then sends, list order
-      const MsgEntry& e = fm[j];
-      if (e.sends) { const double w = om[ks++]; if (w != 0.0) { *o++ = fill(e, w); ++nsend; } }
-    }
-    if (nrecv > 32767 || nsend > 32767) fail("factor has too many messages");
-    r.op_begin = (int32_t)op_start[i];
-    r.n_recv = (int16_t)nrecv; r.n_send = (int16_t)nsend;
-    // the reference snapshots the factor only when it has more than one send CALL (all sending messages,
-    // active or not, factors_messages.hxx:2544-2558,2799-2805); with a single one it sends from the live
-    // factor, which gives the same numbers, so the kernels always send from the post-receive state.
-    out.n_recv += nrecv; out.n_send += nsend;
-    // algorithmic bytes: own dual read + written once, per receive the peer's table and both
-    // message vectors read and one written, per send one peer vector read and written
-    const int64_t own = f_doff[f + 1] - f_doff[f];
-    const int64_t bytes_before = out.alg_bytes;
-    out.alg_bytes += 16 * own;
-    for (int64_t k = 0; k < nrecv + nsend; ++k) {
-      const Op& op = ops[op_start[i] + k];
-      const int code = op.info & 15;
-      const int pk = (op.info >> 8) & 15;
-      const bool recv = k < nrecv;
+    // algorithmic bytes, counted per update as the reference executes it: own dual read + written
+    // once, per receive the peer's table and both message vectors read and one written, per send one peer
+    // vector read and written
+    auto op_bytes = [&](const Op& op, bool recv) -> int64_t {
+      const int code = op.info & 15, pk = (op.info >> 8) & 15;
       if (code == LPMP_M_UNARY_PAIRWISE) {
         const int64_t L = op.len;
-        if (recv) out.alg_bytes += 24 * L + (pk == LPMP_F_PAIRWISE_DENSE ? 8 * (int64_t)op.pd0 * op.pd1 : (pk == LPMP_F_PAIRWISE_POTTS ? 8 : 0));
-        else out.alg_bytes += 16 * L;
-      } else {
-        out.alg_bytes += 16 * (int64_t)op.pd0;
+        if (recv) return 24 * L + (pk == LPMP_F_PAIRWISE_DENSE ? 8 * (int64_t)op.pd0 * op.pd1 : (pk == LPMP_F_PAIRWISE_POTTS ? 8 : 0));
+        return 16 * L;
       }
+      return 16 * (int64_t)op.pd0;
+    };
+    int64_t ks = 0, kr = 0, bytes = 0, n_act = 0;
+    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
+      const MsgEntry& e = fm[j];
+      if (e.receives && umk[u][kr++]) { Op op = fill(e, 1.0); bytes += op_bytes(op, true); base[cur_r[o]++] = op; ++n_act; }
     }
-    rec_bytes[i] = out.alg_bytes - bytes_before;
-    const int n_all = (int)(nrecv + nsend);
-    if (n_all == 0) { out.alg_bytes = bytes_before; rec_bytes[i] = 0; }
-    if (n_all > 0 && all_dense && (r.d0 == 4 || r.d0 == 8 || r.d0 == 16 || r.d0 == 32))
-      kclass[i] = r.d0 == 4 ? KC_DENSE_4 : r.d0 == 8 ? KC_DENSE_8 : r.d0 == 16 ? KC_DENSE_16 : KC_DENSE_32;
-    else if (n_all > 0 && all_potts && (r.d0 == 4 || r.d0 == 8 || r.d0 == 16 || r.d0 == 32))
-      kclass[i] = r.d0 == 4 ? KC_POTTS_4 : r.d0 == 8 ? KC_POTTS_8 : r.d0 == 16 ? KC_POTTS_16 : KC_POTTS_32;
+    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
+      const MsgEntry& e = fm[j];
+      if (e.sends) { const double w = uom[u][ks++]; if (w != 0.0) { Op op = fill(e, w); bytes += op_bytes(op, false); base[n_recv_of[o] + cur_s[o]++] = op; ++n_act; } }
+    }
+    if (n_act > 0) bytes += 16 * (f_doff[f + 1] - f_doff[f]);
+    rec_bytes[o] += bytes;
+    out.alg_bytes += bytes;
   }
-  // bucket sort by (level, class); factors without any active op touch nothing and are dropped
+  // bucket the owner records by (level, class); updates without any active op are dropped
   const int64_t n_keys = (int64_t)max_level * KC_COUNT;
   std::vector<int64_t> key_count(n_keys + 1, 0), key_recv(n_keys, 0), key_send(n_keys, 0), key_bytes(n_keys, 0);
-  auto key = [&](int64_t i) { return (int64_t)(level[i] - 1) * KC_COUNT + kclass[i]; };
-  for (int64_t i = 0; i < n; ++i) {
-    if (n_ops[i] == 0) continue;
-    ++key_count[key(i) + 1];
-    key_recv[key(i)] += recs[i].n_recv; key_send[key(i)] += recs[i].n_send; key_bytes[key(i)] += rec_bytes[i];
+  std::vector<int32_t> kclass(N, KC_GENERIC);
+  auto cls_of = [&](int64_t u) -> int32_t {
+    const int d0 = f_dim0[uf[u]];
+    const bool pow = d0 == 4 || d0 == 8 || d0 == 16 || d0 == 32;
+    if (f_kind[uf[u]] != LPMP_F_VECTOR || !pow) return KC_GENERIC;
+    if (all_dense[u]) return d0 == 4 ? KC_DENSE_4 : d0 == 8 ? KC_DENSE_8 : d0 == 16 ? KC_DENSE_16 : KC_DENSE_32;
+    if (all_potts[u]) return d0 == 4 ? KC_POTTS_4 : d0 == 8 ? KC_POTTS_8 : d0 == 16 ? KC_POTTS_16 : KC_POTTS_32;
+    return KC_GENERIC;
+  };
+  auto key = [&](int64_t u) { return (int64_t)(level[u] - 1) * KC_COUNT + kclass[u]; };
+  auto is_rec = [&](int64_t u) { return owner[u] == u && n_recv_of[u] + n_send_of[u] > 0; };
+  for (int64_t u = 0; u < N; ++u) {
+    if (!is_rec(u)) continue;
+    if (n_recv_of[u] > 32767 || n_send_of[u] > 32767) fail("factor has too many messages");
+    kclass[u] = cls_of(u);
+    ++key_count[key(u) + 1];
+    key_recv[key(u)] += n_recv_of[u]; key_send[key(u)] += n_send_of[u]; key_bytes[key(u)] += rec_bytes[u];
+    out.n_recv += n_recv_of[u]; out.n_send += n_send_of[u];
   }
   std::partial_sum(key_count.begin(), key_count.end(), key_count.begin());
   out.recs.resize(key_count[n_keys]);
   {
     std::vector<int64_t> cur(key_count.begin(), key_count.end() - 1);
-    for (int64_t i = 0; i < n; ++i) if (n_ops[i] > 0) out.recs[cur[key(i)]++] = recs[i];
+    for (int64_t u = 0; u < N; ++u) {
+      if (!is_rec(u)) continue;
+      const int32_t f = uf[u];
+      UpdRec r{};
+      r.dual_off = f_doff[f];
+      r.const_off = f_kind[f] == LPMP_F_VECTOR ? -1 : f_coff[f];
+      r.d0 = f_dim0[f]; r.d1 = f_dim1[f];
+      r.op_begin = (int32_t)op_start[u];
+      r.n_recv = (int16_t)n_recv_of[u]; r.n_send = (int16_t)n_send_of[u];
+      r.factor = f;
+      r.kind_flags = f_kind[f] | (f_flags[f] << 4);
+      out.recs[cur[key(u)]++] = r;
+    }
   }
   for (int64_t k = 0; k < n_keys; ++k)
     if (key_count[k + 1] > key_count[k]) {
@@ -478,6 +509,46 @@ void Plan::make_schedule(const int32_t* factors, int64_t n, const int64_t* om_of
       out.launches.push_back(lr);
     }
   out.ops = std::move(ops);
+  // packed form for the dense fast classes
+  static_assert(sizeof(UpdRec) == sizeof(Op), "a packet slot holds either record");
+  for (auto& lr : out.launches) {
+    if (lr.kclass < KC_DENSE_4 || lr.kclass > KC_DENSE_32) continue;
+    int kmax = 0;
+    for (int64_t i = lr.begin; i < lr.end; ++i) kmax = std::max<int>(kmax, out.recs[i].n_recv + out.recs[i].n_send);
+    if (kmax > PK_MAX_OPS) continue;
+    lr.stride = 1 + kmax;
+    lr.pk_begin = (int64_t)out.packets.size();
+    out.packets.resize(out.packets.size() + (size_t)(lr.end - lr.begin) * lr.stride);
+    for (int64_t i = lr.begin; i < lr.end; ++i) {
+      Op* slot = out.packets.data() + lr.pk_begin + (i - lr.begin) * lr.stride;
+      UpdRec r = out.recs[i];
+      const Op* o = out.ops.data() + r.op_begin;
+      bool preload_ok = true;   // a send may be prefetched unless a receive of this update writes the same vector
+      for (int a = 0; a < r.n_recv; ++a)
+        for (int b = r.n_recv; b < r.n_recv + r.n_send; ++b)
+          if (o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1)) preload_ok = false;
+      if (preload_ok) r.kind_flags |= UPD_PRELOAD_OK;
+      std::memcpy(slot, &r, sizeof(Op));
+      for (int k = 0; k < r.n_recv + r.n_send; ++k) { slot[1 + k] = o[k]; slot[1 + k].pad = 0; }
+      // register forwarding: send b targets the vector receive a (one of the first 4) has just rewritten ->
+      // the receive keeps its result in a register (pad = 1: no store) and the send reads it from there
+      // (pad = a + 1); at most one send per receive, and only if no later receive/send touches that vector
+      for (int b = r.n_recv; b < r.n_recv + r.n_send && b - r.n_recv < 4; ++b) {
+        int hit = -1, n_hit = 0;
+        for (int a = 0; a < r.n_recv; ++a)
+          if (o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1)) { hit = a; ++n_hit; }
+        int n_send_same = 0;
+        for (int b2 = r.n_recv; b2 < r.n_recv + r.n_send; ++b2)
+          if (o[b2].peer_dual == o[b].peer_dual && ((o[b2].info >> 5) & 1) == ((o[b].info >> 5) & 1)) ++n_send_same;
+        if (n_hit == 1 && n_send_same == 1 && hit < 4) { slot[1 + hit].pad = 1; slot[1 + b].pad = hit + 1; }
+      }
+    }
+  }
+}
+
+void Plan::make_schedule(const int32_t* factors, int64_t n, const int64_t* om_off, const double* om,
+                         const int64_t* mk_off, const uint8_t* mk, Schedule& out) const {
+  make_schedule(std::vector<Segment>{Segment{factors, n, om_off, om, mk_off, mk}}, false, out);
 }
 
 }  // namespace lpmp

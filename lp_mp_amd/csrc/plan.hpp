@@ -69,11 +69,18 @@ enum KClass : int32_t {
 struct LevelRange {            // one kernel launch: a range of UpdRec indices of one level and class
   int32_t kclass; int64_t begin, end;
   int64_t n_recv = 0, n_send = 0, bytes = 0;   // active receives / sends / algorithmic bytes of the range
+  // packed form (fast classes with few ops per factor): factor i of the range has its UpdRec in slot
+  // pk_begin + i*stride of Schedule::packets and its ops in the following slots -> one coalesced load, no
+  // dependent rec -> ops hop.  stride 0: not packed.
+  int32_t stride = 0; int64_t pk_begin = 0;
 };
+constexpr int PK_MAX_OPS = 8;                 // packets hold at most this many ops per factor
+constexpr int32_t UPD_PRELOAD_OK = 1 << 16;   // UpdRec::kind_flags: no send targets a vector a receive writes
 
 struct Schedule {             // executable form of one (factor list, omega, mask) sweep
   std::vector<UpdRec> recs;   // sorted by (level, kclass)
   std::vector<Op> ops;
+  std::vector<Op> packets;            // packed launches: [UpdRec | Op x (stride-1)] per factor
   std::vector<LevelRange> launches;   // in execution order
   int64_t n_levels = 0;
   int64_t n_recv = 0, n_send = 0;     // active receives / sends = message updates per sweep
@@ -107,7 +114,10 @@ struct Plan {
   void build(const lpmp_model& m);
   void ensure_weights(int mode);
   void anisotropic_weights(const int32_t* list, int64_t n, Csr<double>& om, Csr<uint8_t>& mk) const;
-  // turn a factor list + rows into levels/records/ops; rows are indexed like the list's updated factors
+  // one sweep: a factor list with one omega row and one receive-mask row per listed factor
+  struct Segment { const int32_t* factors; int64_t n; const int64_t* om_off; const double* om; const int64_t* mk_off; const uint8_t* mk; };
+  // turn a sequence of sweeps into levels/records/ops; fuse: fold back-to-back updates of one factor (plan.cpp)
+  void make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out) const;
   void make_schedule(const int32_t* factors, int64_t n, const int64_t* om_off, const double* om,
                      const int64_t* mk_off, const uint8_t* mk, Schedule& out) const;
   int64_t row_sends(int32_t f) const;

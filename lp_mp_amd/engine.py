@@ -26,7 +26,7 @@ EXPORTS = [
     "lpmp_last_error", "lpmp_version", "lpmp_plan_create", "lpmp_plan_destroy", "lpmp_plan_n_factors",
     "lpmp_plan_n_updated", "lpmp_plan_get_order", "lpmp_plan_get_update_order", "lpmp_plan_omega_nnz",
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
-    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
+    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_pass_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
     "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_compute_pass", "lpmp_compute_forward_pass",
     "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_run",
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
@@ -37,7 +37,8 @@ EXPORTS = [
 
 
 def library_path() -> str:
-    return _build.SO
+    # LPMP_ENGINE_SO: load an experimental build of the same sources (kernel ablations); never a CPU path
+    return os.environ.get("LPMP_ENGINE_SO", _build.SO)
 
 
 def lib():
@@ -72,6 +73,7 @@ def lib():
         L.lpmp_plan_get_msg_lists.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.lpmp_plan_anisotropic_weights.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
         L.lpmp_plan_schedule_info.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.lpmp_plan_pass_schedule_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.lpmp_create.argtypes = [C.c_int, C.c_void_p]
         L.lpmp_destroy.argtypes = [C.c_void_p]
         L.lpmp_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -185,6 +187,15 @@ class Plan:
         v = [C.c_int64() for _ in range(5)]
         _chk(self.L.lpmp_plan_schedule_info(self.h, d, mode, *[C.addressof(x) for x in v]))
         return dict(zip(("n_levels", "n_launches", "n_receives", "n_sends", "algorithmic_bytes"), [x.value for x in v]))
+
+
+def _pass_info(self, mode: int) -> dict:
+    v = [C.c_int64() for _ in range(5)]
+    _chk(self.L.lpmp_plan_pass_schedule_info(self.h, mode, *[C.addressof(x) for x in v]))
+    return dict(zip(("n_levels", "n_launches", "n_receives", "n_sends", "algorithmic_bytes"), [x.value for x in v]))
+
+
+Plan.pass_schedule_info = _pass_info
 
 
 class Engine:
