@@ -3,6 +3,7 @@
 // entry point needs a HIP device and fails with LPMP_ERR_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -74,6 +75,8 @@ struct lpmp_plan {
   Plan p;
   Schedule sched_cache[2][LPMP_REPAM_COUNT]; bool have_sched[2][LPMP_REPAM_COUNT] = {{false}};
   Schedule pass_cache[LPMP_REPAM_COUNT]; bool have_pass[LPMP_REPAM_COUNT] = {false};   // forward+backward as one fused sequence
+  Schedule bf_cache[LPMP_REPAM_COUNT]; bool have_bf[LPMP_REPAM_COUNT] = {false};       // backward+forward (the seam between two passes)
+  bool rotation_ok[LPMP_REPAM_COUNT] = {false};
 };
 
 static void plan_pass_schedule(lpmp_plan* pl, int mode) {
@@ -99,6 +102,54 @@ static void plan_schedule(lpmp_plan* pl, int d, int mode) {
   pl->have_sched[d][mode] = true;
 }
 
+// Seam between two consecutive passes.  If forward+backward fuses into exactly three steps
+//   [H: head of the forward sweep] [W] [T: tail of the backward sweep]
+// and backward+forward fuses into [H'] [K] [T'] where K updates exactly the factors of T and H (their
+// receives, then their sends) and H', T' together are W's factors, then n passes are
+//   H, W, (K, W) x (n-1), T
+// — every record is the same sequence of receives and sends the unfused sweeps execute (plan.cpp, fusion).
+// 2-colour orders of bipartite graphs (checkerboard grids) have this shape.
+static std::vector<int32_t> level_factors(const Schedule& s, int level) {
+  std::vector<int32_t> f;
+  for (const auto& lr : s.launches) if (lr.level == level) for (int64_t i = lr.begin; i < lr.end; ++i) f.push_back(s.recs[i].factor);
+  std::sort(f.begin(), f.end());
+  return f;
+}
+static int64_t level_ops(const Schedule& s, int level, bool recv) {
+  int64_t n = 0;
+  for (const auto& lr : s.launches) if (lr.level == level) n += recv ? lr.n_recv : lr.n_send;
+  return n;
+}
+static void plan_rotation(lpmp_plan* pl, int mode) {
+  if (pl->have_bf[mode]) return;
+  pl->have_bf[mode] = true;
+  pl->rotation_ok[mode] = false;
+  const Schedule& fb = pl->pass_cache[mode];
+  if (fb.n_levels != 3 || fb.recs.empty()) return;
+  std::vector<Plan::Segment> segs;
+  for (int d = 1; d >= 0; --d) {
+    const auto& om = pl->p.omega[d][mode];
+    const auto& mk = pl->p.mask[d][mode];
+    segs.push_back({pl->p.upd[d].data(), (int64_t)pl->p.upd[d].size(), om.off.data(), om.data.data(), mk.off.data(), mk.data.data()});
+  }
+  Schedule& bf = pl->bf_cache[mode];
+  pl->p.make_schedule(segs, true, bf);
+  bool ok = bf.n_levels == 3;
+  if (ok) {
+    const auto h = level_factors(fb, 1), w = level_factors(fb, 2), t = level_factors(fb, 3);
+    const auto h2 = level_factors(bf, 1), k = level_factors(bf, 2), t2 = level_factors(bf, 3);
+    ok = h == t && k == h && h2 == t2 && h2 == w;
+    // K = receives of T then sends of H; W = receives of T' then sends of H'
+    ok = ok && level_ops(bf, 2, true) == level_ops(fb, 3, true) && level_ops(bf, 2, false) == level_ops(fb, 1, false) &&
+         level_ops(fb, 1, true) == 0 && level_ops(fb, 3, false) == 0 &&
+         level_ops(fb, 2, true) == level_ops(bf, 3, true) && level_ops(fb, 2, false) == level_ops(bf, 1, false) &&
+         level_ops(bf, 1, true) == 0 && level_ops(bf, 3, false) == 0;
+  }
+  pl->rotation_ok[mode] = ok;
+  if (!ok) bf = Schedule();
+}
+
+
 struct lpmp_engine {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -115,8 +166,11 @@ struct lpmp_engine {
   DevSchedule sched[2][LPMP_REPAM_COUNT];
   bool have_sched[LPMP_REPAM_COUNT] = {false, false, false, false};
   DevSchedule sched_pass[LPMP_REPAM_COUNT];            // fused forward+backward (ComputePass)
+  DevSchedule sched_bf[LPMP_REPAM_COUNT];              // fused backward+forward: its middle step joins two passes
+  bool rotation_ok[LPMP_REPAM_COUNT] = {false, false, false, false};
   bool have_pass[LPMP_REPAM_COUNT] = {false, false, false, false};
   bool use_fused = true;
+  bool use_rotation = true;
   std::vector<std::unique_ptr<DevSchedule>> custom;   // prepared iterator-range passes
   int mode = -1;
   bool use_graph = true;
@@ -129,7 +183,7 @@ struct lpmp_engine {
 
   void release_model() {
     for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m) sched[d][m].release();
-    for (int m = 0; m < LPMP_REPAM_COUNT; ++m) { have_sched[m] = false; sched_pass[m].release(); have_pass[m] = false; }
+    for (int m = 0; m < LPMP_REPAM_COUNT; ++m) { have_sched[m] = false; sched_pass[m].release(); sched_bf[m].release(); have_pass[m] = false; rotation_ok[m] = false; }
     for (auto& c : custom) if (c) c->release();
     custom.clear();
     if (own_dual && d_dual) (void)hipFree(d_dual);
@@ -209,14 +263,21 @@ void ensure_pass_schedule(lpmp_engine* e, int mode) {
   plan_pass_schedule(e->plan.get(), mode);
   check_generic_limits(e->plan->p, e->plan->pass_cache[mode]);
   upload_schedule(e->plan->pass_cache[mode], e->sched_pass[mode]);
+  plan_rotation(e->plan.get(), mode);
+  e->rotation_ok[mode] = e->plan->rotation_ok[mode];
+  if (e->rotation_ok[mode]) {
+    upload_schedule(e->plan->bf_cache[mode], e->sched_bf[mode]);
+    e->plan->bf_cache[mode] = Schedule();
+  }
   // the host copy is only needed for its summary
   Schedule& h = e->plan->pass_cache[mode];
   h.recs.clear(); h.recs.shrink_to_fit(); h.ops.clear(); h.ops.shrink_to_fit(); h.packets.clear(); h.packets.shrink_to_fit();
   e->have_pass[mode] = true;
 }
 
-void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_t stream) {
+void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_t stream, int only_level = 0) {
   for (const auto& lr : s.launches) {
+    if (only_level > 0 && lr.level != only_level) continue;
     hipEvent_t a = nullptr, b = nullptr;
     if (timed) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, stream)); }
     if (!(e->use_packed && lr.stride > 0 &&
@@ -382,6 +443,8 @@ int lpmp_create(int device, lpmp_engine** out) {
     e->use_graph = !(ng && ng[0] == '1');
     const char* nf = std::getenv("LPMP_NO_FUSE");
     e->use_fused = !(nf && nf[0] == '1');
+    const char* nr = std::getenv("LPMP_NO_ROTATION");
+    e->use_rotation = !(nr && nr[0] == '1');
     const char* np = std::getenv("LPMP_NO_PACKED");
     e->use_packed = !(np && np[0] == '1');
     *out = e.release();
@@ -487,7 +550,18 @@ int lpmp_compute_pass(lpmp_engine* e, int n) {
     HIP_CHECK(hipSetDevice(e->device));
     if (e->use_fused) {
       ensure_pass_schedule(e, e->mode);
-      for (int i = 0; i < n; ++i) run_schedule(e, e->sched_pass[e->mode]);
+      if (n >= 2 && e->rotation_ok[e->mode] && e->use_rotation) {
+        const DevSchedule& fb = e->sched_pass[e->mode];
+        const DevSchedule& bf = e->sched_bf[e->mode];
+        const bool timed = e->timing;
+        issue_launches(e, fb, timed, e->stream, 1);
+        issue_launches(e, fb, timed, e->stream, 2);
+        for (int i = 1; i < n; ++i) { issue_launches(e, bf, timed, e->stream, 2); issue_launches(e, fb, timed, e->stream, 2); }
+        issue_launches(e, fb, timed, e->stream, 3);
+        if (timed && e->pending.size() > 4096) e->drain_timing();
+      } else {
+        for (int i = 0; i < n; ++i) run_schedule(e, e->sched_pass[e->mode]);
+      }
     } else {
       for (int i = 0; i < n; ++i) { run_schedule(e, e->sched[0][e->mode]); run_schedule(e, e->sched[1][e->mode]); }
     }

@@ -505,6 +505,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     if (key_count[k + 1] > key_count[k]) {
       LevelRange lr;
       lr.kclass = (int32_t)(k % KC_COUNT); lr.begin = key_count[k]; lr.end = key_count[k + 1];
+      lr.level = (int32_t)(k / KC_COUNT) + 1;
       lr.n_recv = key_recv[k]; lr.n_send = key_send[k]; lr.bytes = key_bytes[k];
       out.launches.push_back(lr);
     }

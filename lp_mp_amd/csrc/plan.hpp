@@ -68,6 +68,7 @@ enum KClass : int32_t {
 
 struct LevelRange {            // one kernel launch: a range of UpdRec indices of one level and class
   int32_t kclass; int64_t begin, end;
+  int32_t level = 0;                            // 1-based dependent step this launch belongs to
   int64_t n_recv = 0, n_send = 0, bytes = 0;   // active receives / sends / algorithmic bytes of the range
   // packed form (fast classes with few ops per factor): factor i of the range has its UpdRec in slot
   // pk_begin + i*stride of Schedule::packets and its ops in the following slots -> one coalesced load, no

@@ -318,3 +318,23 @@ def test_full_size_properties(cfg):
         assert lbs[-1] <= min(e1) + 1e-6                          # weak duality
         assert lbs[-1] > lbs[0]
     e2.close()
+
+
+@pytest.mark.parametrize("pairwise,L", [("dense", 32), ("dense", 8), ("potts", 16)])
+@pytest.mark.parametrize("order", ["colour_major", "row_major"])
+def test_multi_pass_call_fused_and_rotated_schedules(eng, pairwise, L, order):
+    """lpmp_compute_pass(n >= 2): forward+backward fused into one sequence, and on 2-colour orders the tail of
+    a pass joined with the head of the next one; must equal n sequential reference passes exactly."""
+    m = S.grid_model(14, 10, L, pairwise=pairwise, order=order, seed=31)
+    for mode in MODES:
+        o = Oracle(m)
+        o.set_reparametrization(mode)
+        eng.upload(m)
+        eng.set_reparametrization(mode)
+        eng.compute_pass(5); o.ComputePass(5)
+        assert np.array_equal(eng.download_duals(), o.duals())
+        eng.compute_pass(2); o.ComputePass(2)
+        eng.compute_pass(1); o.ComputePass(1)
+        assert np.array_equal(eng.download_duals(), o.duals())
+    info = eng.plan.pass_schedule_info(M.REPAM_ANISOTROPIC)
+    assert info["n_levels"] == (3 if order == "colour_major" else 2 * (14 + 10 - 1) - 1)
