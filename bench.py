@@ -156,7 +156,7 @@ def main():
         bytes_per_pass = runner.global_bytes_per_pass
         levels = runner.levels
         eng = runner.engine
-        parallelism = f"{world} row strips of {H}x{W}, cut-edge exchange once per sweep"
+        parallelism = f"{world} row strips of {H}x{W}, cut-edge exchange once per pass"
 
     lb0 = runner.lower_bound()
     dt = time_passes(torch, dist, runner, args.steps, args.warmup, world)

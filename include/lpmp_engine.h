@@ -101,6 +101,10 @@ int lpmp_compute_pass_custom(lpmp_engine* e, int64_t n, const int32_t* factors, 
  * (include/LP_MP.h:1846-1963). */
 int lpmp_schedule_create(lpmp_engine* e, int64_t n, const int32_t* factors, const int64_t* om_off, const double* om,
                          const int64_t* mk_off, const uint8_t* mk, int* id_out);
+/* as lpmp_schedule_create for a list that concatenates several sweeps (e.g. forward then backward update lists):
+ * with fuse != 0 back-to-back updates of one factor are folded into one record (same results) */
+int lpmp_schedule_create_fused(lpmp_engine* e, int64_t n, const int32_t* factors, const int64_t* om_off,
+                               const double* om, const int64_t* mk_off, const uint8_t* mk, int fuse, int* id_out);
 int lpmp_schedule_run(lpmp_engine* e, int id);
 int lpmp_schedule_info(lpmp_engine* e, int id, int64_t* n_levels, int64_t* n_launches, int64_t* n_receives,
                        int64_t* n_sends, int64_t* algorithmic_bytes);

@@ -592,6 +592,10 @@ int lpmp_compute_pass_custom(lpmp_engine* e, int64_t n, const int32_t* factors, 
 
 int lpmp_schedule_create(lpmp_engine* e, int64_t n, const int32_t* factors, const int64_t* om_off, const double* om,
                          const int64_t* mk_off, const uint8_t* mk, int* id_out) {
+  return lpmp_schedule_create_fused(e, n, factors, om_off, om, mk_off, mk, 0, id_out);
+}
+int lpmp_schedule_create_fused(lpmp_engine* e, int64_t n, const int32_t* factors, const int64_t* om_off, const double* om,
+                               const int64_t* mk_off, const uint8_t* mk, int fuse, int* id_out) {
   return guarded([&] {
     require_model(e);
     if (!id_out || n < 0 || (n > 0 && (!factors || !om_off || !mk_off))) throw std::runtime_error("bad argument");
@@ -599,7 +603,9 @@ int lpmp_schedule_create(lpmp_engine* e, int64_t n, const int32_t* factors, cons
     Schedule s;
     static const double dz = 0; static const uint8_t uz = 0;
     static const int64_t zero_off[1] = {0};
-    e->plan->p.make_schedule(factors, n, n > 0 ? om_off : zero_off, om ? om : &dz, n > 0 ? mk_off : zero_off, mk ? mk : &uz, s);
+    e->plan->p.make_schedule(std::vector<Plan::Segment>{Plan::Segment{factors, n, n > 0 ? om_off : zero_off, om ? om : &dz,
+                                                                      n > 0 ? mk_off : zero_off, mk ? mk : &uz}},
+                             fuse != 0 && e->use_fused, s);
     check_generic_limits(e->plan->p, s);
     auto d = std::make_unique<DevSchedule>();
     try { upload_schedule(s, *d); } catch (...) { d->release(); throw; }

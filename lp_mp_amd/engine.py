@@ -30,7 +30,7 @@ EXPORTS = [
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
     "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_pass_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
     "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_compute_pass", "lpmp_compute_forward_pass",
-    "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_run",
+    "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_create_fused", "lpmp_schedule_run",
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
     "lpmp_synchronize", "lpmp_dual_size", "lpmp_download_duals", "lpmp_upload_duals", "lpmp_device_duals",
     "lpmp_engine_plan", "lpmp_engine_plan_mut", "lpmp_enable_kernel_timing", "lpmp_get_kernel_timing",
@@ -86,6 +86,7 @@ def lib():
         L.lpmp_compute_backward_pass.argtypes = [C.c_void_p]
         L.lpmp_compute_pass_custom.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5
         L.lpmp_schedule_create.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 6
+        L.lpmp_schedule_create_fused.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
         L.lpmp_schedule_run.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_schedule_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.lpmp_schedule_destroy.argtypes = [C.c_void_p, C.c_int]
@@ -258,16 +259,18 @@ class Engine:
         _chk(self.L.lpmp_compute_pass_custom(self.h, factors.shape[0], factors.ctypes.data, om_off.ctypes.data,
                                              om.ctypes.data, mk_off.ctypes.data, mk.ctypes.data))
 
-    def schedule_create(self, factors, om_off, om, mk_off, mk) -> int:
-        """Prepare an iterator-range pass (reference LP_MP.h:981-1005) for repeated replay."""
+    def schedule_create(self, factors, om_off, om, mk_off, mk, fuse: bool = False) -> int:
+        """Prepare an iterator-range pass (reference LP_MP.h:981-1005) for repeated replay.  ``fuse``: the list
+        concatenates several sweeps; back-to-back updates of one factor are folded into one record."""
         factors = np.ascontiguousarray(factors, np.int32)
         om_off = np.ascontiguousarray(om_off, np.int64)
         om = np.ascontiguousarray(om, np.float64)
         mk_off = np.ascontiguousarray(mk_off, np.int64)
         mk = np.ascontiguousarray(mk, np.uint8)
         sid = C.c_int()
-        _chk(self.L.lpmp_schedule_create(self.h, factors.shape[0], factors.ctypes.data, om_off.ctypes.data,
-                                         om.ctypes.data, mk_off.ctypes.data, mk.ctypes.data, C.addressof(sid)))
+        _chk(self.L.lpmp_schedule_create_fused(self.h, factors.shape[0], factors.ctypes.data, om_off.ctypes.data,
+                                               om.ctypes.data, mk_off.ctypes.data, mk.ctypes.data, 1 if fuse else 0,
+                                               C.addressof(sid)))
         return sid.value
 
     def schedule_run(self, sid: int):

@@ -227,7 +227,12 @@ class PartitionedSweep:
     buffer, so the boundary arithmetic is done in place with torch ops on the engine's stream."""
 
     def __init__(self, torch, part: LocalPart, engine, dual_tensor, mode: int = M.REPAM_ANISOTROPIC,
-                 omega_b: float = 0.5):
+                 omega_b: float = 0.5, boundary_every: str = "pass"):
+        """boundary_every: "pass" — one boundary step after the forward+backward main sweeps (every cut message is
+        received once and sent once per pass, like every other message under anisotropic weights; the two main
+        sweeps run as one fused schedule); "sweep" — one after each directional sweep."""
+        assert boundary_every in ("pass", "sweep")
+        self.boundary_every = boundary_every
         self.torch, self.part, self.engine, self.mode, self.omega_b = torch, part, engine, mode, float(omega_b)
         p = part
         L = p.L
@@ -249,6 +254,11 @@ class PartitionedSweep:
             rows = _select_rows(upd, om_off, om, mk_off, mk, keep)
             self.main_rows.append(rows)
             self.main.append(engine.schedule_create(*rows))
+        # forward then backward main sweep as one (fused) sequence
+        f0, f1 = self.main_rows
+        cat_rows = (np.concatenate([f0[0], f1[0]]), np.concatenate([f0[1], f0[1][-1] + f1[1][1:]]), np.concatenate([f0[2], f1[2]]),
+                    np.concatenate([f0[3], f0[3][-1] + f1[3][1:]]), np.concatenate([f0[4], f1[4]]))
+        self.main_pass = engine.schedule_create(*cat_rows, fuse=True)
         # 2. boundary passes on the ghosts: every ghost has exactly one message (side 1 of its cut edge)
         g = np.arange(p.n_local, n_vec, dtype=np.int32)
         ones_off = np.arange(g.shape[0] + 1, dtype=np.int64)
@@ -317,10 +327,21 @@ class PartitionedSweep:
         back = comm.exchange(reply, self.in_counts, self.out_counts)
         self.boundary_fold(back)
 
+    def boundary_step(self, comm):
+        send = self.boundary_pack()
+        recv = comm.exchange(send, self.out_counts, self.in_counts)
+        reply = self.boundary_reply(recv)
+        back = comm.exchange(reply, self.in_counts, self.out_counts)
+        self.boundary_fold(back)
+
     def compute_pass(self, comm, n=1):
         for _ in range(n):
-            self.sweep(comm, M.FORWARD)
-            self.sweep(comm, M.BACKWARD)
+            if self.boundary_every == "sweep":
+                self.sweep(comm, M.FORWARD)
+                self.sweep(comm, M.BACKWARD)
+            else:
+                self.engine.schedule_run(self.main_pass)
+                self.boundary_step(comm)
 
     def local_lower_bound(self):
         return self.engine.lower_bound()
@@ -329,10 +350,12 @@ class PartitionedSweep:
         """executed receives + sends per pass on this part: main sweeps + 2 boundary steps (1 receive and
         1 send per cut edge each, counted on the non-owner side where the reference would execute them)."""
         n = sum(i["n_receives"] + i["n_sends"] for i in self.info)
-        return n + 2 * 2 * int(self.part.in_unary.shape[0])
+        steps = 2 if self.boundary_every == "sweep" else 1
+        return n + steps * 2 * int(self.part.in_unary.shape[0])
 
     def bytes_per_pass(self):
-        return sum(i["algorithmic_bytes"] for i in self.info) + 2 * sum(i["algorithmic_bytes"] for i in self.info_ghost)
+        steps = 2 if self.boundary_every == "sweep" else 1
+        return sum(i["algorithmic_bytes"] for i in self.info) + steps * sum(i["algorithmic_bytes"] for i in self.info_ghost)
 
 
 def _select_rows(upd, om_off, om, mk_off, mk, keep):
@@ -368,10 +391,14 @@ def run_lockstep(sweeps: List[PartitionedSweep], n_passes: int):
             assert got[-1].shape[0] == int(sum(counts_in[dst]))
         return got
 
+    per_sweep = sweeps[0].boundary_every == "sweep"
     for _ in range(n_passes):
-        for d in (M.FORWARD, M.BACKWARD):
+        for d in ((M.FORWARD, M.BACKWARD) if per_sweep else (None,)):
             for s in sweeps:
-                s.main_sweep(d)
+                if per_sweep:
+                    s.main_sweep(d)
+                else:
+                    s.engine.schedule_run(s.main_pass)
             sent = [s.boundary_pack() for s in sweeps]
             recv = shuffle(sent, [s.out_counts for s in sweeps], [s.in_counts for s in sweeps])
             rep = [s.boundary_reply(r) for s, r in zip(sweeps, recv)]
@@ -383,7 +410,7 @@ def run_lockstep(sweeps: List[PartitionedSweep], n_passes: int):
 class StripSweep:
     """bench.py driver: this rank's H x W strip of a (world*H) x W grid on its own GPU."""
 
-    def __init__(self, torch, dist, H, W, L, pairwise, order, mode, seed=1, omega_b=0.5):
+    def __init__(self, torch, dist, H, W, L, pairwise, order, mode, seed=1, omega_b=0.5, boundary_every="pass"):
         from . import engine as E
         self.torch, self.dist = torch, dist
         self.comm = DistComm(dist, torch)
@@ -404,7 +431,7 @@ class StripSweep:
         self.engine = E.Engine(torch.cuda.current_device())
         self.engine.set_stream(stream)
         self.engine.upload(m, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt))
-        self.sweep = PartitionedSweep(torch, part, self.engine, self.dualt, mode, omega_b)
+        self.sweep = PartitionedSweep(torch, part, self.engine, self.dualt, mode, omega_b, boundary_every)
         t = torch.tensor([self.sweep.updates_per_pass(), self.sweep.bytes_per_pass()], dtype=torch.float64,
                          device="cpu" if self.comm.stage_cpu else dev)
         dist.all_reduce(t)

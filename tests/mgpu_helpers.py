@@ -19,7 +19,7 @@ class OracleEngine:
         self.plan = E.Plan(model)
         self.rows = []
 
-    def schedule_create(self, factors, om_off, om, mk_off, mk):
+    def schedule_create(self, factors, om_off, om, mk_off, mk, fuse=False):
         self.rows.append((np.array(factors), np.array(om_off), np.array(om), np.array(mk_off), np.array(mk)))
         return len(self.rows) - 1
 
@@ -37,50 +37,55 @@ class OracleEngine:
         return self.o.LowerBound()
 
 
-def global_replay(global_model, parts, main_rows, n_passes, omega_b):
+def global_replay(global_model, parts, main_rows, n_passes, omega_b, boundary_every="pass"):
     """Runs the partition schedule on the global model with the oracle:
-    per direction  ComputePass(concatenated part lists, expanded rows)  then
-                   ComputePass(non-owner boundary unaries, cut slots only)."""
+    ComputePass(concatenated part lists, expanded rows) for the forward and the backward main sweep, and
+    ComputePass(non-owner boundary unaries, cut slots only) after each sweep ("sweep") or after both ("pass")."""
     o = Oracle(global_model)
     g_off, g_ent = o.msg_lists()
-    n_f = global_model.n_factors
 
     def glist(f):
         return g_ent[g_off[f]:g_off[f + 1]] // 2          # message ids in list order (MRF: every entry sends+receives)
 
-    for _ in range(n_passes):
-        for d in (M.FORWARD, M.BACKWARD):
-            F, OM, MK, off = [], [], [], [0]
-            for p, rows_d in zip(parts, main_rows):
-                f_loc, om_off, om, mk_off, mk = rows_d[d]
-                l_off, l_ent = p._local_lists
-                for r, fl in enumerate(f_loc):
-                    g = int(p.local_to_global[fl])
-                    lm = p.local_msg_to_global[l_ent[l_off[fl]:l_off[fl + 1]] // 2]
-                    gm = glist(g)
-                    o_row = np.zeros(gm.shape[0]); m_row = np.zeros(gm.shape[0], np.uint8)
-                    pos = {int(x): i for i, x in enumerate(gm)}
-                    lo = om[om_off[r]:om_off[r + 1]]; lk = mk[mk_off[r]:mk_off[r + 1]]
-                    for j, x in enumerate(lm):
-                        o_row[pos[int(x)]] = lo[j]; m_row[pos[int(x)]] = lk[j]
-                    F.append(g); OM.append(o_row); MK.append(m_row); off.append(off[-1] + gm.shape[0])
-            o.compute_pass_custom(np.array(F, np.int32), off, np.concatenate(OM), off, np.concatenate(MK))
-            # boundary step
-            cut = {}
-            for p in parts:
-                for u, key in zip(p.in_unary, p.in_key):
-                    cut.setdefault(int(p.local_to_global[u]), []).append(2 * int(key) + 1)
-            F, OM, MK, off = [], [], [], [0]
-            for g in sorted(cut):
+    def main_sweep(d):
+        F, OM, MK, off = [], [], [], [0]
+        for p, rows_d in zip(parts, main_rows):
+            f_loc, om_off, om, mk_off, mk = rows_d[d]
+            l_off, l_ent = p._local_lists
+            for r, fl in enumerate(f_loc):
+                g = int(p.local_to_global[fl])
+                lm = p.local_msg_to_global[l_ent[l_off[fl]:l_off[fl + 1]] // 2]
                 gm = glist(g)
                 o_row = np.zeros(gm.shape[0]); m_row = np.zeros(gm.shape[0], np.uint8)
-                for i, x in enumerate(gm):
-                    if int(x) in cut[g]:
-                        o_row[i] = omega_b; m_row[i] = 1
+                pos = {int(x): i for i, x in enumerate(gm)}
+                lo = om[om_off[r]:om_off[r + 1]]; lk = mk[mk_off[r]:mk_off[r + 1]]
+                for j, x in enumerate(lm):
+                    o_row[pos[int(x)]] = lo[j]; m_row[pos[int(x)]] = lk[j]
                 F.append(g); OM.append(o_row); MK.append(m_row); off.append(off[-1] + gm.shape[0])
-            if F:
-                o.compute_pass_custom(np.array(F, np.int32), off, np.concatenate(OM), off, np.concatenate(MK))
-    assert n_f == global_model.n_factors
+        o.compute_pass_custom(np.array(F, np.int32), off, np.concatenate(OM), off, np.concatenate(MK))
+
+    def boundary():
+        cut = {}
+        for p in parts:
+            for u, key in zip(p.in_unary, p.in_key):
+                cut.setdefault(int(p.local_to_global[u]), []).append(2 * int(key) + 1)
+        F, OM, MK, off = [], [], [], [0]
+        for g in sorted(cut):
+            gm = glist(g)
+            o_row = np.zeros(gm.shape[0]); m_row = np.zeros(gm.shape[0], np.uint8)
+            for i, x in enumerate(gm):
+                if int(x) in cut[g]:
+                    o_row[i] = omega_b; m_row[i] = 1
+            F.append(g); OM.append(o_row); MK.append(m_row); off.append(off[-1] + gm.shape[0])
+        if F:
+            o.compute_pass_custom(np.array(F, np.int32), off, np.concatenate(OM), off, np.concatenate(MK))
+
+    for _ in range(n_passes):
+        main_sweep(M.FORWARD)
+        if boundary_every == "sweep":
+            boundary()
+        main_sweep(M.BACKWARD)
+        boundary()
     return o
 
 

@@ -29,12 +29,12 @@ def _strip_setup(H, W, L, world, pairwise, order, seed):
     return gm, parts
 
 
-def _cpu_sweeps(parts, omega_b):
+def _cpu_sweeps(parts, omega_b, every="pass"):
     sweeps, duals = [], []
     for p in parts:
         d = p.model.dual_data.copy()
         eng = OracleEngine(p.model, d)
-        sweeps.append(MG.PartitionedSweep(torch, p, eng, torch.from_numpy(d), M.REPAM_ANISOTROPIC, omega_b))
+        sweeps.append(MG.PartitionedSweep(torch, p, eng, torch.from_numpy(d), M.REPAM_ANISOTROPIC, omega_b, every))
         duals.append(d)
     return sweeps, duals
 
@@ -54,14 +54,15 @@ def test_strip_generator_equals_general_partitioner(pairwise, order, world):
         assert (p.n_local, p.n_ghost) == (q.n_local, q.n_ghost)
 
 
+@pytest.mark.parametrize("every", ["pass", "sweep"])
 @pytest.mark.parametrize("pairwise,order,world", [("dense", "colour_major", 2), ("potts", "row_major", 3)])
-def test_lockstep_parts_equal_oracle_replay_on_global_model(pairwise, order, world):
+def test_lockstep_parts_equal_oracle_replay_on_global_model(pairwise, order, world, every):
     H, W, L = 5, 6, 4
     gm, parts = _strip_setup(H, W, L, world, pairwise, order, 3)
     attach_local_lists(parts)
-    sweeps, duals = _cpu_sweeps(parts, 0.5)
+    sweeps, duals = _cpu_sweeps(parts, 0.5, every)
     MG.run_lockstep(sweeps, 3)
-    o = global_replay(gm, parts, [s.main_rows for s in sweeps], 3, 0.5)
+    o = global_replay(gm, parts, [s.main_rows for s in sweeps], 3, 0.5, every)
     got = gather_global_duals(gm, parts, duals)
     assert np.array_equal(got, o.duals())
     lb = sum(s.local_lower_bound() for s in sweeps)
@@ -133,9 +134,10 @@ def test_two_process_gloo_run_equals_lockstep(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("every", ["pass", "sweep"])
 @pytest.mark.parametrize("pairwise,L,order,world", [("dense", 32, "colour_major", 2), ("potts", 8, "colour_major", 4),
                                                      ("dense", 16, "row_major", 3)])
-def test_partitioned_sweep_on_device_equals_oracle_replay(pairwise, L, order, world):
+def test_partitioned_sweep_on_device_equals_oracle_replay(pairwise, L, order, world, every):
     """real HIP engines, all parts on the one GPU of the test box, lock-stepped in process"""
     from lp_mp_amd import engine as E
     H, W = 10, 12
@@ -148,11 +150,11 @@ def test_partitioned_sweep_on_device_equals_oracle_replay(pairwise, L, order, wo
         eng = E.Engine(0)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual)
-        sweeps.append(MG.PartitionedSweep(torch, p, eng, dual, M.REPAM_ANISOTROPIC, 0.5))
+        sweeps.append(MG.PartitionedSweep(torch, p, eng, dual, M.REPAM_ANISOTROPIC, 0.5, every))
         tensors.append(dual); engines.append(eng)
     MG.run_lockstep(sweeps, 3)
     torch.cuda.synchronize()
-    o = global_replay(gm, parts, [s.main_rows for s in sweeps], 3, 0.5)
+    o = global_replay(gm, parts, [s.main_rows for s in sweeps], 3, 0.5, every)
     got = gather_global_duals(gm, parts, [t.cpu().numpy() for t in tensors])
     assert np.array_equal(got, o.duals())
     lb = sum(s.local_lower_bound() for s in sweeps)
