@@ -88,6 +88,14 @@ int lpmp_set_stream(lpmp_engine* e, void* hip_stream);
 int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int dual_mem);
 
 int lpmp_set_reparametrization(lpmp_engine* e, int mode);   /* LP::set_reparametrization, LP_MP.h:330 */
+/* --reparametrizationType parsed by LP::Begin (LP_MP.h:589-593, :710-722) and switched on in the hot loop
+ * (:988-1004).  shared (default) and residual (update_factor_residual, factors_messages.hxx:2270-2279,
+ * :2960-3007) run on the device; partition / overlapping_partition / adaptive return LPMP_ERR_UNSUPPORTED. */
+enum lpmp_reparametrization_type {
+  LPMP_RTYPE_SHARED = 0, LPMP_RTYPE_RESIDUAL = 1, LPMP_RTYPE_PARTITION = 2, LPMP_RTYPE_OVERLAPPING_PARTITION = 3,
+  LPMP_RTYPE_ADAPTIVE = 4
+};
+int lpmp_set_reparametrization_type(lpmp_engine* e, int rtype);
 int lpmp_compute_pass(lpmp_engine* e, int n_passes);        /* LP::ComputePass, LP_MP.h:869-887 ('shared') */
 int lpmp_compute_forward_pass(lpmp_engine* e);              /* LP::ComputeForwardPass, LP_MP.h:889-900 */
 int lpmp_compute_backward_pass(lpmp_engine* e);             /* LP::ComputeBackwardPass, LP_MP.h:902-911 */

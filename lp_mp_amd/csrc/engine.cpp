@@ -17,8 +17,8 @@
 
 namespace lpmp {
 void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
-                  int64_t first, int64_t count, hipStream_t s);
-bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, int64_t count, hipStream_t s);
+                  int64_t first, int64_t count, int flags, hipStream_t s);
+bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, int64_t count, int flags, hipStream_t s);
 void launch_factor_lb(const void* recs, const double* dual, const double* cdata, double* out, int64_t count, hipStream_t s);
 bool launch_dense_lb(int L, const void* recs, const double* dual, const double* cdata, double* out, int64_t first, int64_t count, hipStream_t s);
 void launch_sum_stage(const double* in, double* out, int64_t n, int64_t per_block, int64_t n_blocks, hipStream_t s);
@@ -173,6 +173,7 @@ struct lpmp_engine {
   bool use_rotation = true;
   std::vector<std::unique_ptr<DevSchedule>> custom;   // prepared iterator-range passes
   int mode = -1;
+  int rtype = 0;   // reparametrization_type: 0 shared, 1 residual (kernel flag SWEEP_RESIDUAL)
   bool use_graph = true;
   bool use_packed = true;
   bool timing = false;
@@ -281,8 +282,8 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
     hipEvent_t a = nullptr, b = nullptr;
     if (timed) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, stream)); }
     if (!(e->use_packed && lr.stride > 0 &&
-          launch_sweep_packed(lr.kclass, s.packets + lr.pk_begin, lr.stride, e->d_dual, e->d_const, lr.end - lr.begin, stream)))
-      launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, lr.begin, lr.end - lr.begin, stream);
+          launch_sweep_packed(lr.kclass, s.packets + lr.pk_begin, lr.stride, e->d_dual, e->d_const, lr.end - lr.begin, e->rtype, stream)))
+      launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, lr.begin, lr.end - lr.begin, e->rtype, stream);
     if (timed) {
       HIP_CHECK(hipEventRecord(b, stream));
       e->pending.push_back({a, b, lr.kclass, lr.end - lr.begin, lr.n_recv, lr.bytes});
@@ -535,6 +536,24 @@ int lpmp_set_reparametrization(lpmp_engine* e, int mode) {
     HIP_CHECK(hipSetDevice(e->device));
     ensure_device_schedules(e, mode);
     e->mode = mode;
+  });
+}
+
+int lpmp_set_reparametrization_type(lpmp_engine* e, int rtype) {
+  return guarded([&] {
+    if (!e) throw std::runtime_error("null engine");
+    if (rtype == LPMP_RTYPE_PARTITION || rtype == LPMP_RTYPE_OVERLAPPING_PARTITION || rtype == LPMP_RTYPE_ADAPTIVE)
+      throw UnsupportedError("reparametrization type not executable on the device (DESIGN.md 2)");
+    if (rtype != LPMP_RTYPE_SHARED && rtype != LPMP_RTYPE_RESIDUAL) throw std::runtime_error("unknown reparametrization type");
+    if (rtype != e->rtype) {   // captured graphs bake the kernel flag in
+      HIP_CHECK(hipStreamSynchronize(e->stream));
+      for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m)
+        if (e->sched[d][m].graph) { (void)hipGraphExecDestroy(e->sched[d][m].graph); e->sched[d][m].graph = nullptr; }
+      for (int m = 0; m < LPMP_REPAM_COUNT; ++m)
+        if (e->sched_pass[m].graph) { (void)hipGraphExecDestroy(e->sched_pass[m].graph); e->sched_pass[m].graph = nullptr; }
+      for (auto& c : e->custom) if (c && c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+    }
+    e->rtype = rtype;
   });
 }
 

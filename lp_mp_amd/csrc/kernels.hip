@@ -25,6 +25,7 @@ namespace lpmp {
 #define LPMP_INF (__builtin_inf())
 constexpr int GEN_MAXD = 512;       // generic kernel: max dual size / message length held in LDS per wave
 constexpr int GEN_WAVES = 4;
+constexpr int SWEEP_RESIDUAL = 1;   // kernel flag: --reparametrizationType residual
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -140,7 +141,7 @@ __device__ void minnorm_delta(GenLds& L, SPtr src, int n, double omega, int lane
 
 __global__ void __launch_bounds__(64 * GEN_WAVES)
 sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
-                     const double* __restrict__ cdata, const int32_t* __restrict__ tabs, int64_t first, int64_t count) {
+                     const double* __restrict__ cdata, const int32_t* __restrict__ tabs, int64_t first, int64_t count, int flags) {
   __shared__ GenLds lds[GEN_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t idx = (int64_t)blockIdx.x * GEN_WAVES + wave;
@@ -155,50 +156,41 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
   wave_sync();
 
   const int n_ops = rec.n_recv + rec.n_send;
-  for (int k = 0; k < n_ops; ++k) {
-    if (k == rec.n_recv) {   // state after the receives: what every send is computed from
-      for (int i = lane; i < on; i += 64) L.snap[i] = L.own[i];
-      wave_sync();
-    }
-    const Op op = ops[rec.op_begin + k];
-    const bool recv = k < rec.n_recv;
+  // one receive or send: compute delta from `src` (peer for a receive; snapshot or live own state for a send),
+  // then +delta to the side that did not compute it and -delta to the side that did
+  auto run_op = [&](const Op& op, const bool recv, const double* own_src, const double omega) {
     const int code = op.info & 15, role = (op.info >> 4) & 1, side = (op.info >> 5) & 1, imp = (op.info >> 6) & 1;
     const int pkind = (op.info >> 8) & 15;
     double* peer = dual + op.peer_dual;
     const int len = op.len;
-    // ---- compute delta (into L.dl) ------------------------------------------------------------
     // the message is computed by the peer for a receive and by the updated factor for a send
     const bool by_right = recv ? (role == 0) : (role == 1);
     if (code == OP_UP) {
       if (by_right) {   // min-marginal of the pairwise (right) factor
-        if (recv) pw_min_marginal(L, cdata, op.peer_const, pkind, op.pd0, op.pd1, (const double*)peer, side, op.omega, lane);
-        else pw_min_marginal(L, cdata, rec.const_off, okind, rec.d0, rec.d1, (const double*)L.snap, side, op.omega, lane);
+        if (recv) pw_min_marginal(L, cdata, op.peer_const, pkind, op.pd0, op.pd1, (const double*)peer, side, omega, lane);
+        else pw_min_marginal(L, cdata, rec.const_off, okind, rec.d0, rec.d1, own_src, side, omega, lane);
       } else {          // omega * theta of the unary (left) factor
-        for (int i = lane; i < len; i += 64) L.dl[i] = op.omega * (recv ? peer[i] : L.snap[i]);
+        for (int i = lane; i < len; i += 64) L.dl[i] = omega * (recv ? peer[i] : own_src[i]);
         wave_sync();
       }
     } else if (code == OP_LABELING) {
       const int32_t* tab = tabs + op.peer_const;
       if (by_right) {
-        if (recv) labeling_to_left(L, (const double*)peer, op.pd0, tab, op.pd1, imp, op.omega, lane);
-        else labeling_to_left(L, (const double*)L.snap, rec.d0, tab, op.pd1, imp, op.omega, lane);
+        if (recv) labeling_to_left(L, (const double*)peer, op.pd0, tab, op.pd1, imp, omega, lane);
+        else labeling_to_left(L, own_src, rec.d0, tab, op.pd1, imp, omega, lane);
       } else {
-        for (int i = lane; i < len; i += 64) L.dl[i] = op.omega * (recv ? peer[i] : L.snap[i]);
+        for (int i = lane; i < len; i += 64) L.dl[i] = omega * (recv ? peer[i] : own_src[i]);
         wave_sync();
       }
     } else {            // OP_MINNORM
-      if (recv) minnorm_delta(L, (const double*)peer, len, op.omega, lane);
-      else minnorm_delta(L, (const double*)L.snap, len, op.omega, lane);
+      if (recv) minnorm_delta(L, (const double*)peer, len, omega, lane);
+      else minnorm_delta(L, own_src, len, omega, lane);
     }
-    // ---- apply: +delta to the side that did not compute it, -delta to the side that did ----------
     // (reference MessageContainerView::operator-=, factors_messages.hxx:495-508)
-    // which of {own, peer} is the left factor?
     const bool own_is_left = role == 0;
     const double s_left = by_right ? +1.0 : -1.0, s_right = -s_left;
-    // left factor is always a vector of length len
     if (own_is_left) { for (int i = lane; i < len; i += 64) L.own[i] += s_left * L.dl[i]; }
     else { for (int i = lane; i < len; i += 64) peer[i] += s_left * L.dl[i]; }
-    // right factor
     if (code == OP_UP) {
       if (own_is_left) { double* m = peer + (side == 0 ? 0 : op.pd0); for (int i = lane; i < len; i += 64) m[i] += s_right * L.dl[i]; }
       else { double* m = L.own + (side == 0 ? 0 : rec.d0); for (int i = lane; i < len; i += 64) m[i] += s_right * L.dl[i]; }
@@ -212,8 +204,24 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
       else { for (int i = lane; i < len; i += 64) L.own[i] += s_right * L.dl[i]; }
     }
     wave_sync();
-    (void)oflags;
+  };
+  for (int k = 0; k < n_ops; ++k) {
+    if (k == rec.n_recv) {   // state after the receives: what every shared send is computed from
+      for (int i = lane; i < on; i += 64) L.snap[i] = L.own[i];
+      wave_sync();
+    }
+    const Op op = ops[rec.op_begin + k];
+    run_op(op, k < rec.n_recv, L.snap, op.omega);
   }
+  if (flags & SWEEP_RESIDUAL) {   // reference send_messages_residual, factors_messages.hxx:2960-3007
+    double residual = 0.0;
+    for (int k = rec.n_recv; k < n_ops; ++k) {
+      const Op op = ops[rec.op_begin + k];
+      residual += op.omega;
+      run_op(op, false, L.own, residual);
+    }
+  }
+  (void)oflags;
   for (int i = lane; i < on; i += 64) own_g[i] = L.own[i];
 }
 
@@ -238,7 +246,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 template <int L>
 __global__ void __launch_bounds__(256)
 sweep_dense_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
-                   const double* __restrict__ cdata, int64_t first, int64_t count) {
+                   const double* __restrict__ cdata, int64_t first, int64_t count, int flags) {
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2;            // lanes per table row
   constexpr int RPL = 2 * G / L;       // rows per load step
@@ -324,6 +332,18 @@ sweep_dense_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
       ms[g] += delta;
       theta -= delta;
     }
+    if (flags & SWEEP_RESIDUAL) {   // second round from the live factor with the running weight sum
+      double residual = 0.0;
+      for (int k = 0; k < rec.n_send; ++k) {
+        const Op op = ops[rec.op_begin + rec.n_recv + k];
+        const int side = (op.info >> 5) & 1;
+        double* ms = dual + op.peer_dual + (side == 0 ? 0 : L);
+        residual += op.omega;
+        const double delta = residual * theta;
+        ms[g] += delta;
+        theta -= delta;
+      }
+    }
     own_g[g] = theta;
   }
 }
@@ -351,7 +371,7 @@ template <int G> __device__ __forceinline__ int64_t uni64(int64_t v) {
 template <int L, int KMAX>
 __global__ void __launch_bounds__(256)
 sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual, const double* __restrict__ cdata,
-                      int64_t count, int stride) {
+                      int64_t count, int stride, int flags) {
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
   constexpr int KS = 4;                          // sends whose target vectors are prefetched / forwarded
@@ -502,6 +522,17 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
       ms[g] += delta;
       theta -= delta;
     }
+    if (flags & SWEEP_RESIDUAL) {
+      double residual = 0.0;
+      for (int k = 0; k < n_send; ++k) {
+        const Op& o = lop[n_recv + k];
+        double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? L : 0);
+        residual += o.omega;
+        const double delta = residual * theta;
+        ms[g] += delta;
+        theta -= delta;
+      }
+    }
     own_g[g] = theta;
   }
 }
@@ -514,7 +545,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
 template <int L>
 __global__ void __launch_bounds__(256)
 sweep_potts_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
-                   const double* __restrict__ cdata, int64_t first, int64_t count) {
+                   const double* __restrict__ cdata, int64_t first, int64_t count, int flags) {
   constexpr int GPB = 256 / L;
   const int grp = threadIdx.x / L, g = threadIdx.x % L;
   const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
@@ -567,6 +598,18 @@ sweep_potts_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
       const double delta = op.omega * snap;
       ms[g] += delta;
       theta -= delta;
+    }
+    if (flags & SWEEP_RESIDUAL) {   // second round from the live factor with the running weight sum
+      double residual = 0.0;
+      for (int k = 0; k < rec.n_send; ++k) {
+        const Op op = ops[rec.op_begin + rec.n_recv + k];
+        const int side = (op.info >> 5) & 1;
+        double* ms = dual + op.peer_dual + (side == 0 ? 0 : L);
+        residual += op.omega;
+        const double delta = residual * theta;
+        ms[g] += delta;
+        theta -= delta;
+      }
     }
     own_g[g] = theta;
   }
@@ -684,19 +727,19 @@ __global__ void synth_fill_kernel(double* __restrict__ out, int64_t n, uint64_t 
 
 // ---- launch wrappers (called from engine.cpp) -----------------------------------------------------
 void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
-                  int64_t first, int64_t count, hipStream_t s) {
+                  int64_t first, int64_t count, int flags, hipStream_t s) {
   if (count <= 0) return;
   auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
   switch (kclass) {
-    case KC_DENSE_32: hipLaunchKernelGGL(sweep_dense_kernel<32>, blocks(256 / DenseCfg<32>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
-    case KC_DENSE_16: hipLaunchKernelGGL(sweep_dense_kernel<16>, blocks(256 / DenseCfg<16>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
-    case KC_DENSE_8: hipLaunchKernelGGL(sweep_dense_kernel<8>, blocks(256 / DenseCfg<8>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
-    case KC_DENSE_4: hipLaunchKernelGGL(sweep_dense_kernel<4>, blocks(256 / DenseCfg<4>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
-    case KC_POTTS_32: hipLaunchKernelGGL(sweep_potts_kernel<32>, blocks(256 / 32), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
-    case KC_POTTS_16: hipLaunchKernelGGL(sweep_potts_kernel<16>, blocks(256 / 16), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
-    case KC_POTTS_8: hipLaunchKernelGGL(sweep_potts_kernel<8>, blocks(256 / 8), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
-    case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, first, count); break;
-    default: hipLaunchKernelGGL(sweep_generic_kernel, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, first, count); break;
+    case KC_DENSE_32: hipLaunchKernelGGL(sweep_dense_kernel<32>, blocks(256 / DenseCfg<32>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
+    case KC_DENSE_16: hipLaunchKernelGGL(sweep_dense_kernel<16>, blocks(256 / DenseCfg<16>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
+    case KC_DENSE_8: hipLaunchKernelGGL(sweep_dense_kernel<8>, blocks(256 / DenseCfg<8>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
+    case KC_DENSE_4: hipLaunchKernelGGL(sweep_dense_kernel<4>, blocks(256 / DenseCfg<4>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
+    case KC_POTTS_32: hipLaunchKernelGGL(sweep_potts_kernel<32>, blocks(256 / 32), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
+    case KC_POTTS_16: hipLaunchKernelGGL(sweep_potts_kernel<16>, blocks(256 / 16), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
+    case KC_POTTS_8: hipLaunchKernelGGL(sweep_potts_kernel<8>, blocks(256 / 8), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
+    case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
+    default: hipLaunchKernelGGL(sweep_generic_kernel, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, first, count, flags); break;
   }
 }
 
@@ -705,12 +748,12 @@ static int dense_kmax() {
   return k;
 }
 
-bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, int64_t count, hipStream_t s) {
+bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, int64_t count, int flags, hipStream_t s) {
   if (count <= 0) return true;
   if (stride > 1 + PK_MAX_OPS) return false;
   auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
   const int km = dense_kmax();
-#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, dual, cdata, count, stride)
+#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, dual, cdata, count, stride, flags)
   switch (kclass) {
     case KC_DENSE_32: if (km >= 4) PK_LAUNCH(32, 4); else if (km == 1) PK_LAUNCH(32, 1); else PK_LAUNCH(32, 2); return true;
     case KC_DENSE_16: if (km >= 4) PK_LAUNCH(16, 4); else PK_LAUNCH(16, 2); return true;

@@ -29,7 +29,7 @@ EXPORTS = [
     "lpmp_plan_n_updated", "lpmp_plan_get_order", "lpmp_plan_get_update_order", "lpmp_plan_omega_nnz",
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
     "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_pass_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
-    "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_compute_pass", "lpmp_compute_forward_pass",
+    "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_set_reparametrization_type", "lpmp_compute_pass", "lpmp_compute_forward_pass",
     "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_create_fused", "lpmp_schedule_run",
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
     "lpmp_synchronize", "lpmp_dual_size", "lpmp_download_duals", "lpmp_upload_duals", "lpmp_device_duals",
@@ -81,6 +81,7 @@ def lib():
         L.lpmp_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.lpmp_upload_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.lpmp_set_reparametrization.argtypes = [C.c_void_p, C.c_int]
+        L.lpmp_set_reparametrization_type.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_compute_pass.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_compute_forward_pass.argtypes = [C.c_void_p]
         L.lpmp_compute_backward_pass.argtypes = [C.c_void_p]
@@ -240,6 +241,10 @@ class Engine:
 
     def set_reparametrization(self, mode: int):
         _chk(self.L.lpmp_set_reparametrization(self.h, int(mode)))
+
+    def set_reparametrization_type(self, rtype: int):
+        """0 shared, 1 residual (reference --reparametrizationType)."""
+        _chk(self.L.lpmp_set_reparametrization_type(self.h, int(rtype)))
 
     def compute_pass(self, n: int = 1):
         _chk(self.L.lpmp_compute_pass(self.h, int(n)))

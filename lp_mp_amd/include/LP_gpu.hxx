@@ -331,6 +331,16 @@ class LP_gpu {
   void BackwardPassFactorRelation(FactorTypeAdapter* f1, FactorTypeAdapter* f2) { rel_bwd_.push_back((int32_t)f1->index_); rel_bwd_.push_back((int32_t)f2->index_); set_flags_dirty(); }
 
   void Begin() { repamMode_ = LPReparametrizationMode::Undefined; }   // reference LP_MP.h:705-708
+  // --reparametrizationType {shared|residual|partition|overlapping_partition|adaptive} (reference LP_MP.h:589-593,
+  // :710-722); shared and residual run on the device, the others throw when the engine is asked for them
+  void set_reparametrization_type(const std::string& t) {
+    if (t == "shared") rtype_ = LPMP_RTYPE_SHARED;
+    else if (t == "residual") rtype_ = LPMP_RTYPE_RESIDUAL;
+    else if (t == "partition") rtype_ = LPMP_RTYPE_PARTITION;
+    else if (t == "overlapping_partition") rtype_ = LPMP_RTYPE_OVERLAPPING_PARTITION;
+    else if (t == "adaptive") rtype_ = LPMP_RTYPE_ADAPTIVE;
+    else throw std::runtime_error("reparametrization type " + t + " unknown");
+  }
   void End() { pull_duals(); }
   void set_reparametrization(const LPReparametrizationMode r) { repamMode_ = r; }
   LPReparametrizationMode GetRepamMode() const { return repamMode_; }
@@ -471,7 +481,7 @@ class LP_gpu {
   void ready() {
     if (f_.size() <= 1) throw std::runtime_error("LP needs more than one factor");   // reference assert LP_MP.h:708
     if (!engine_) check(lpmp_create(device_, &engine_));
-    if (!dirty_) return;
+    if (!dirty_) { check(lpmp_set_reparametrization_type(engine_, rtype_)); return; }
     Flat fl;
     for (INDEX i = 0; i < f_.size(); ++i) (this->*flatteners_[i])(f_[i].get(), fl);
     std::vector<lpmp_msg_type> mt;
@@ -492,6 +502,7 @@ class LP_gpu {
     static const double zero = 0;
     if (!m.const_data) m.const_data = &zero;
     check(lpmp_upload_model(engine_, &m, LPMP_MEM_HOST, LPMP_MEM_HOST));
+    check(lpmp_set_reparametrization_type(engine_, rtype_));
     dirty_ = false;
     duals_on_device_ = false;
   }
@@ -510,6 +521,7 @@ class LP_gpu {
   int device_;
   lpmp_engine* engine_ = nullptr;
   bool dirty_ = true, duals_on_device_ = false;
+  int rtype_ = LPMP_RTYPE_SHARED;
   LPReparametrizationMode repamMode_ = LPReparametrizationMode::Undefined;
   REAL constant_ = 0;
   std::vector<std::unique_ptr<FactorTypeAdapter>> f_;
@@ -588,7 +600,10 @@ class Solver {
  public:
   using FMC = typename LP_TYPE::FMC;
   Solver() : lp_(0) {}
-  explicit Solver(const std::vector<std::string>& options) : lp_(0), visitor_(options) {}
+  explicit Solver(const std::vector<std::string>& options) : lp_(0), visitor_(options) {
+    for (std::size_t i = 0; i + 1 < options.size(); ++i)
+      if (options[i] == "--reparametrizationType") lp_.set_reparametrization_type(options[i + 1]);
+  }
   LP_TYPE& GetLP() { return lp_; }
   int Solve() {
     lp_.Begin();

@@ -153,7 +153,14 @@ class LP:
     uploaded lazily by the first call that needs the device (everything the reference does after
     set_flags_dirty(), LP_MP.h:1623)."""
 
-    def __init__(self, fmc: FMC, device: int = 0):
+    REPARAMETRIZATION_TYPES = {"shared": 0, "residual": 1, "partition": 2, "overlapping_partition": 3, "adaptive": 4}
+
+    def __init__(self, fmc: FMC, device: int = 0, reparametrizationType: str = "shared"):
+        """reparametrizationType: the reference's --reparametrizationType (LP_MP.h:589-593); shared and residual
+        run on the device, the others raise when Begin() hands them to the engine."""
+        if reparametrizationType not in self.REPARAMETRIZATION_TYPES:
+            raise RuntimeError("reparametrization type " + reparametrizationType + " unknown")
+        self._rtype = self.REPARAMETRIZATION_TYPES[reparametrizationType]
         self.FMC = fmc
         self._device = device
         self._factors = []       # (container, op)
@@ -266,6 +273,7 @@ class LP:
             self._model = self.flat_model()
             self._engine.upload(self._model)
             self._dirty = False
+        self._engine.set_reparametrization_type(self._rtype)
         return self._engine
 
     # -- the hot path ---------------------------------------------------------------------------------------

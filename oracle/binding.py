@@ -41,6 +41,7 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_int]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_set_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_reparametrization_type.argtypes = [C.c_void_p, C.c_int]
         L.orc_compute_pass.argtypes = [C.c_void_p, C.c_int]
         L.orc_forward_pass.argtypes = [C.c_void_p]
         L.orc_backward_pass.argtypes = [C.c_void_p]
@@ -83,6 +84,9 @@ class Oracle:
 
     def set_reparametrization(self, mode: int):
         self._chk(self.L.orc_set_mode(self.h, int(mode)))
+
+    def set_reparametrization_type(self, rtype: int):
+        self._chk(self.L.orc_set_reparametrization_type(self.h, int(rtype)))
 
     def ComputePass(self, n: int = 1):
         self._chk(self.L.orc_compute_pass(self.h, int(n)))

@@ -27,6 +27,7 @@ void orc_destroy(orc_t* o);
 const char* orc_last_error(void);
 
 int orc_set_mode(orc_t* o, int repam_mode);             /* LP::set_reparametrization */
+int orc_set_reparametrization_type(orc_t* o, int rtype); /* --reparametrizationType: 0 shared, 1 residual (LP_MP.h:710-722) */
 int orc_compute_pass(orc_t* o, int n_passes);           /* LP::ComputePass, default 'shared' type */
 int orc_forward_pass(orc_t* o);                         /* LP::ComputeForwardPass */
 int orc_backward_pass(orc_t* o);                        /* LP::ComputeBackwardPass */

@@ -338,3 +338,63 @@ def test_multi_pass_call_fused_and_rotated_schedules(eng, pairwise, L, order):
         assert np.array_equal(eng.download_duals(), o.duals())
     info = eng.plan.pass_schedule_info(M.REPAM_ANISOTROPIC)
     assert info["n_levels"] == (3 if order == "colour_major" else 2 * (14 + 10 - 1) - 1)
+
+
+def test_residual_send_rule(eng):
+    """--reparametrizationType residual (reference update_factor_residual, factors_messages.hxx:2270-2279,2960-3007)"""
+    from tests.test_plan_host import _full_schedule_model
+    models = [S.grid_model(9, 7, 32, order="colour_major", seed=41), S.grid_model(8, 9, 8, order="row_major", seed=42),
+              S.grid_model(7, 8, 16, pairwise="potts", seed=43), S.grid_model(5, 6, 5, seed=44),
+              S.multicut_triangle_model(25, 30, seed=45), _full_schedule_model()]
+    try:
+        for m in models:
+            for mode in (M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM):
+                o = Oracle(m)
+                o.set_reparametrization_type(1)
+                o.set_reparametrization(mode)
+                eng.upload(m)
+                eng.set_reparametrization_type(1)
+                eng.set_reparametrization(mode)
+                eng.compute_pass(3); o.ComputePass(3)
+                eng.compute_pass(1); o.ComputePass(1)
+                assert np.array_equal(eng.download_duals(), o.duals())
+                assert abs(eng.lower_bound() - o.LowerBound()) <= LB_RTOL * max(1.0, abs(o.LowerBound()))
+        with pytest.raises(E.EngineError):
+            eng.set_reparametrization_type(4)      # adaptive: needs op-level improvement functions, not on the device
+    finally:
+        eng.set_reparametrization_type(0)
+
+
+def test_c5_style_mixed_model(eng):
+    """BASELINE.json configs[4] in miniature: grid pairwise MRF plus labeling-list higher-order factors of mixed
+    arity (edge factors with 1 labeling, triplets with 4, quadruple-style factors with 7) in ONE factor graph:
+    several kernel classes inside the same level."""
+    H, W, L = 8, 9, 8
+    mt = S.mrf_mtypes() + [M.MsgType(2, 3, M.SCHED_LEFT, 0, 1, M.M_LABELING, k) for k in range(3)] + \
+        [M.MsgType(2, 4, M.SCHED_LEFT, 0, 1, M.M_LABELING, 3 + k) for k in range(4)]
+    b = M.ModelBuilder(5, mt)
+    quad = [(1, 1, 0, 0), (0, 1, 1, 0), (0, 0, 1, 1), (1, 0, 0, 1), (1, 1, 1, 1), (1, 0, 1, 0), (0, 1, 0, 1)]
+    for k in range(3):
+        b.add_labeling_table(S.EDGE_LABELINGS, S.TRIPLET_LABELINGS, (k,))
+    for k in range(4):
+        b.add_labeling_table(S.EDGE_LABELINGS, quad, (k,))
+    var = S.grid_variable_order(H, W, "colour_major").reshape(-1)
+    a, bb = S.grid_edges(H, W)
+    u = b.add_vector_factors(0, S.u01(H * W * L, 5).reshape(-1, L))
+    p = b.add_potts_pairwise(1, L, S.u01(len(a), 6))
+    i, j = np.minimum(var[a], var[bb]), np.maximum(var[a], var[bb])
+    b.add_interleaved_messages(np.tile(np.array([0, 1], np.int32), len(a)), np.stack([u[i], u[j]], 1).reshape(-1), np.repeat(p, 2))
+    b.add_relations(np.stack([u[i], p], 1).reshape(-1), np.stack([p, u[j]], 1).reshape(-1))
+    rng = np.random.default_rng(3)
+    e = b.add_vector_factors(2, (2 * S.u01(40, 7) - 1).reshape(-1, 1), implicit_origin=True)
+    for _ in range(25):
+        t = b.add_vector_factors(3, np.zeros((1, 4)), implicit_origin=True)[0]
+        for k, ei in enumerate(rng.choice(40, 3, replace=False)):
+            b.add_messages(2 + k, e[ei], t); b.add_relations(e[ei], t)
+    for _ in range(10):
+        q = b.add_vector_factors(4, np.zeros((1, 7)), implicit_origin=True)[0]
+        for k, ei in enumerate(rng.choice(40, 4, replace=False)):
+            b.add_messages(5 + k, e[ei], q); b.add_relations(e[ei], q)
+    m = b.finish()
+    for mode in MODES:
+        _check(eng, m, mode, 4)
