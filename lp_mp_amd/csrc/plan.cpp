@@ -510,6 +510,13 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       out.launches.push_back(lr);
     }
   out.ops = std::move(ops);
+  // inside a launch the order of the records is free (they are independent): sub-wave kernels run several
+  // factors per wavefront, so neighbours in the list should have similar amounts of work
+  for (const auto& lr : out.launches)
+    if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32)
+      std::stable_sort(out.recs.begin() + lr.begin, out.recs.begin() + lr.end, [](const UpdRec& a, const UpdRec& b) {
+        return a.n_recv != b.n_recv ? a.n_recv > b.n_recv : a.n_send > b.n_send;
+      });
   // packed form for the dense fast classes
   static_assert(sizeof(UpdRec) == sizeof(Op), "a packet slot holds either record");
   for (auto& lr : out.launches) {
