@@ -119,6 +119,10 @@ int lpmp_schedule_info(lpmp_engine* e, int id, int64_t* n_levels, int64_t* n_lau
 int lpmp_schedule_destroy(lpmp_engine* e, int id);
 int lpmp_lower_bound(lpmp_engine* e, double* out);          /* LP::LowerBound, LP_MP.h:1507-1518 */
 int lpmp_factor_lower_bounds(lpmp_engine* e, double* out /*[n_factors], host*/); /* FactorTypeAdapter::LowerBound */
+/* The sweep kernels keep a per-factor lower bound current as a by-product, so lpmp_lower_bound after
+ * a pass is a sum over an array.  Call this after changing duals behind the engine's back (writes through
+ * lpmp_device_duals or a borrowed dual buffer): the next lpmp_lower_bound recomputes every factor. */
+int lpmp_invalidate_lower_bounds(lpmp_engine* e);
 int lpmp_synchronize(lpmp_engine* e);
 
 int64_t lpmp_dual_size(const lpmp_engine* e);

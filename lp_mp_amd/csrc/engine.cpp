@@ -17,8 +17,10 @@
 
 namespace lpmp {
 void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
-                  int64_t first, int64_t count, int flags, hipStream_t s);
-bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, int64_t count, int flags, hipStream_t s);
+                  double* lb, int64_t first, int64_t count, int flags, hipStream_t s);
+bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, double* lb, int64_t count, int flags, hipStream_t s);
+void launch_lb_collect_stale(const double* lb, int64_t n, int32_t* list, unsigned long long* counter, hipStream_t s);
+void launch_factor_lb_list(const void* recs, const double* dual, const double* cdata, double* out, const int32_t* list, int64_t count, hipStream_t s);
 void launch_factor_lb(const void* recs, const double* dual, const double* cdata, double* out, int64_t count, hipStream_t s);
 bool launch_dense_lb(int L, const void* recs, const double* dual, const double* cdata, double* out, int64_t first, int64_t count, hipStream_t s);
 void launch_sum_stage(const double* in, double* out, int64_t n, int64_t per_block, int64_t n_blocks, hipStream_t s);
@@ -161,6 +163,10 @@ struct lpmp_engine {
   int32_t* d_tabs = nullptr;
   LbRecHost* d_lbrecs = nullptr;
   double* d_lb = nullptr; double* d_part = nullptr; double* h_part = nullptr;
+  // tracked per-factor lower bounds (kernels.hip): d_lb[f] is valid or NaN; lb_all_stale: recompute everything
+  int32_t* d_stale = nullptr; unsigned long long* d_stale_n = nullptr; unsigned long long* h_stale_n = nullptr;
+  bool lb_all_stale = true;
+  bool use_lb_tracking = true;
   struct LbRun { int cls; int64_t first, count; };
   std::vector<LbRun> lb_runs;
   DevSchedule sched[2][LPMP_REPAM_COUNT];
@@ -195,6 +201,10 @@ struct lpmp_engine {
     if (d_lb) { (void)hipFree(d_lb); d_lb = nullptr; }
     if (d_part) { (void)hipFree(d_part); d_part = nullptr; }
     if (h_part) { (void)hipHostFree(h_part); h_part = nullptr; }
+    if (d_stale) { (void)hipFree(d_stale); d_stale = nullptr; }
+    if (d_stale_n) { (void)hipFree(d_stale_n); d_stale_n = nullptr; }
+    if (h_stale_n) { (void)hipHostFree(h_stale_n); h_stale_n = nullptr; }
+    lb_all_stale = true;
     lb_runs.clear();
     plan.reset();
     mode = -1;
@@ -282,8 +292,8 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
     hipEvent_t a = nullptr, b = nullptr;
     if (timed) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, stream)); }
     if (!(e->use_packed && lr.stride > 0 &&
-          launch_sweep_packed(lr.kclass, s.packets + lr.pk_begin, lr.stride, e->d_dual, e->d_const, lr.end - lr.begin, e->rtype, stream)))
-      launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, lr.begin, lr.end - lr.begin, e->rtype, stream);
+          launch_sweep_packed(lr.kclass, s.packets + lr.pk_begin, lr.stride, e->d_dual, e->d_const, e->d_lb, lr.end - lr.begin, e->rtype, stream)))
+      launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, e->d_lb, lr.begin, lr.end - lr.begin, e->rtype, stream);
     if (timed) {
       HIP_CHECK(hipEventRecord(b, stream));
       e->pending.push_back({a, b, lr.kclass, lr.end - lr.begin, lr.n_recv, lr.bytes});
@@ -446,6 +456,8 @@ int lpmp_create(int device, lpmp_engine** out) {
     e->use_fused = !(nf && nf[0] == '1');
     const char* nr = std::getenv("LPMP_NO_ROTATION");
     e->use_rotation = !(nr && nr[0] == '1');
+    const char* nt = std::getenv("LPMP_NO_LB_TRACKING");
+    e->use_lb_tracking = !(nt && nt[0] == '1');
     const char* np = std::getenv("LPMP_NO_PACKED");
     e->use_packed = !(np && np[0] == '1');
     *out = e.release();
@@ -524,6 +536,11 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
     HIP_CHECK(hipMalloc((void**)&e->d_lb, (size_t)p.nf * sizeof(double)));
     HIP_CHECK(hipMalloc((void**)&e->d_part, 1024 * sizeof(double)));
     HIP_CHECK(hipHostMalloc((void**)&e->h_part, 1024 * sizeof(double), hipHostMallocDefault));
+    HIP_CHECK(hipMalloc((void**)&e->d_stale, (size_t)p.nf * sizeof(int32_t)));
+    HIP_CHECK(hipMalloc((void**)&e->d_stale_n, sizeof(unsigned long long)));
+    HIP_CHECK(hipHostMalloc((void**)&e->h_stale_n, sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_CHECK(hipMemset(e->d_lb, 0xFF, (size_t)p.nf * sizeof(double)));   // all NaN: nothing tracked yet
+    e->lb_all_stale = true;
     e->plan = std::move(pl);
   });
 }
@@ -661,11 +678,26 @@ int lpmp_schedule_destroy(lpmp_engine* e, int id) {
 }
 
 static void compute_factor_lbs(lpmp_engine* e) {
+  if (e->use_lb_tracking && !e->lb_all_stale) {
+    // the sweep kernels kept d_lb current except for the entries they marked NaN: recompute only those
+    const int64_t nf = e->plan->p.nf;
+    HIP_CHECK(hipMemsetAsync(e->d_stale_n, 0, sizeof(unsigned long long), e->stream));
+    launch_lb_collect_stale(e->d_lb, nf, e->d_stale, e->d_stale_n, e->stream);
+    HIP_CHECK(hipMemcpyAsync(e->h_stale_n, e->d_stale_n, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    const int64_t n_stale = (int64_t)*e->h_stale_n;
+    if (n_stale <= nf / 8) {
+      launch_factor_lb_list(e->d_lbrecs, e->d_dual, e->d_const, e->d_lb, e->d_stale, n_stale, e->stream);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
   for (const auto& r : e->lb_runs) {
     if (r.cls == 0 || !launch_dense_lb(r.cls, e->d_lbrecs, e->d_dual, e->d_const, e->d_lb, r.first, r.count, e->stream))
       launch_factor_lb(e->d_lbrecs + r.first, e->d_dual, e->d_const, e->d_lb + r.first, r.count, e->stream);
   }
   HIP_CHECK(hipGetLastError());
+  e->lb_all_stale = false;
 }
 
 int lpmp_lower_bound(lpmp_engine* e, double* out) {
@@ -720,7 +752,11 @@ int lpmp_upload_duals(lpmp_engine* e, const double* in) {
     HIP_CHECK(hipSetDevice(e->device));
     HIP_CHECK(hipMemcpyAsync(e->d_dual, in, (size_t)lpmp_dual_size(e) * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->lb_all_stale = true;
   });
+}
+int lpmp_invalidate_lower_bounds(lpmp_engine* e) {
+  return guarded([&] { require_model(e); e->lb_all_stale = true; });
 }
 void* lpmp_device_duals(lpmp_engine* e) { return e ? e->d_dual : nullptr; }
 const lpmp_plan* lpmp_engine_plan(const lpmp_engine* e) { return e ? e->plan.get() : nullptr; }

@@ -27,6 +27,16 @@ constexpr int GEN_MAXD = 512;       // generic kernel: max dual size / message l
 constexpr int GEN_WAVES = 4;
 constexpr int SWEEP_RESIDUAL = 1;   // kernel flag: --reparametrizationType residual
 
+// Tracked lower bounds.  lb[f] holds FactorContainer::LowerBound of factor f, or NaN when it has to be
+// recomputed.  A sweep kernel knows the bound of every factor it touches for free:
+//   own vector factor            min(theta) after the update
+//   pairwise peer after a receive on side s:  min_x (m_s_new[x] + q[x]) with q the min-marginal part it just
+//                                computed  ( = min_a (m1[a] + min_b (T[a][b] + m2[b])), reference LP_MP.h:1507-1518 )
+//   pairwise peer after a send   unknown without a table scan -> NaN
+// so LP::LowerBound after a pass is a sum over an array instead of another read of all tables.
+#define LPMP_NAN (__builtin_nan(""))
+
+
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -75,6 +85,14 @@ __device__ __forceinline__ double row_allreduce_min(double v) {
   if constexpr (CL >= 4) v = fmin(v, dpp_mov_f64<0x4E>(v));   // lane ^ 2
   if constexpr (CL >= 8) v = fmin(v, dpp_mov_f64<0x141>(v));  // row_half_mirror: other quad of the 8
   if constexpr (CL >= 16) v = fmin(v, dpp_mov_f64<0x140>(v)); // row_mirror: other half of the 16
+  return v;
+}
+template <int G, int L>
+__device__ __forceinline__ double vec_min(double v) {   // min over the first L lanes of a G-lane group (others pass +inf)
+  constexpr int W = L < G ? L : G;
+  v = row_allreduce_min<(W < 16 ? W : 16)>(v);
+  if constexpr (W > 16) v = fmin(v, shfl_xor_f64(v, 16));
+  if constexpr (W > 32) v = fmin(v, shfl_xor_f64(v, 32));
   return v;
 }
 
@@ -141,7 +159,8 @@ __device__ void minnorm_delta(GenLds& L, SPtr src, int n, double omega, int lane
 
 __global__ void __launch_bounds__(64 * GEN_WAVES)
 sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
-                     const double* __restrict__ cdata, const int32_t* __restrict__ tabs, int64_t first, int64_t count, int flags) {
+                     const double* __restrict__ cdata, const int32_t* __restrict__ tabs, double* __restrict__ lb,
+                     int64_t first, int64_t count, int flags) {
   __shared__ GenLds lds[GEN_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t idx = (int64_t)blockIdx.x * GEN_WAVES + wave;
@@ -159,6 +178,7 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
   // one receive or send: compute delta from `src` (peer for a receive; snapshot or live own state for a send),
   // then +delta to the side that did not compute it and -delta to the side that did
   auto run_op = [&](const Op& op, const bool recv, const double* own_src, const double omega) {
+    if (lane == 0) lb[op.peer] = LPMP_NAN;
     const int code = op.info & 15, role = (op.info >> 4) & 1, side = (op.info >> 5) & 1, imp = (op.info >> 6) & 1;
     const int pkind = (op.info >> 8) & 15;
     double* peer = dual + op.peer_dual;
@@ -222,6 +242,7 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
     }
   }
   (void)oflags;
+  if (lane == 0) lb[rec.factor] = LPMP_NAN;
   for (int i = lane; i < on; i += 64) own_g[i] = L.own[i];
 }
 
@@ -246,7 +267,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 template <int L>
 __global__ void __launch_bounds__(256)
 sweep_dense_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
-                   const double* __restrict__ cdata, int64_t first, int64_t count, int flags) {
+                   const double* __restrict__ cdata, double* __restrict__ lb, int64_t first, int64_t count, int flags) {
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2;            // lanes per table row
   constexpr int RPL = 2 * G / L;       // rows per load step
@@ -314,11 +335,17 @@ sweep_dense_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
       if (rl == 0) { lds_q[grp][2 * c2] = vx; lds_q[grp][2 * c2 + 1] = vy; }
     }
     wave_sync();
+    double pb = LPMP_INF;                            // peer's bound after this receive
     if (act && g < L) {
-      const double delta = ms_v + lds_q[grp][g];   // omega = 1: delta = min-marginal
+      const double qv = lds_q[grp][g];
+      const double delta = ms_v + qv;                // omega = 1: delta = min-marginal
       theta += delta;                                // RepamLeft(+delta)
-      ms[g] = ms_v - delta;                          // RepamRight(-delta)
+      const double mn = ms_v - delta;
+      ms[g] = mn;                                    // RepamRight(-delta)
+      pb = mn + qv;
     }
+    pb = vec_min<G, L>(pb);
+    if (act && g == 0) lb[op.peer] = pb;
     wave_sync();
   }
   // sends: delta = omega * theta_snapshot; peer += delta; theta -= delta
@@ -331,6 +358,7 @@ sweep_dense_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
       const double delta = op.omega * snap;
       ms[g] += delta;
       theta -= delta;
+      if (g == 0) lb[op.peer] = LPMP_NAN;
     }
     if (flags & SWEEP_RESIDUAL) {   // second round from the live factor with the running weight sum
       double residual = 0.0;
@@ -346,6 +374,7 @@ sweep_dense_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
     }
     own_g[g] = theta;
   }
+  { const double ob = vec_min<G, L>(vl ? theta : LPMP_INF); if (live && g == 0) lb[rec.factor] = ob; }
 }
 
 
@@ -371,7 +400,7 @@ template <int G> __device__ __forceinline__ int64_t uni64(int64_t v) {
 template <int L, int KMAX>
 __global__ void __launch_bounds__(256)
 sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual, const double* __restrict__ cdata,
-                      int64_t count, int stride, int flags) {
+                      double* __restrict__ lb, int64_t count, int stride, int flags) {
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
   constexpr int KS = 4;                          // sends whose target vectors are prefetched / forwarded
@@ -476,10 +505,13 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
         if (rl == 0) { lds_q[grp][2 * c2] = vx; lds_q[grp][2 * c2 + 1] = vy; }
       }
       wave_sync();
+      double pb = LPMP_INF;                       // peer's bound after this receive
       if (act && g < L) {
-        const double delta = msv[j] + lds_q[grp][g];
+        const double qv = lds_q[grp][g];
+        const double delta = msv[j] + qv;
         theta += delta;
         const double mn = msv[j] - delta;
+        pb = mn + qv;
         bool stored = false;
         if constexpr (FW) {
           if (defer[j]) {                        // c + j < NFW by construction on the host
@@ -489,6 +521,10 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
           }
         }
         if (!stored) dual[pdual[j] + (side[j] == 0 ? 0 : L) + g] = mn;
+      }
+      if (!(FW && defer[j])) {                    // a deferred receive is followed by a send that dirties the peer
+        pb = vec_min<G, L>(pb);
+        if (act && g == 0) lb[uni<G>(lop[c + j].peer)] = pb;
       }
       wave_sync();
     }
@@ -513,6 +549,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
         const double delta = o.omega * snap;
         ms[g] = cur + delta;
         theta -= delta;
+        if (g == 0) lb[uni<G>(o.peer)] = LPMP_NAN;
       }
     }
     for (int k = KS; k < n_send; ++k) {
@@ -521,6 +558,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
       const double delta = o.omega * snap;
       ms[g] += delta;
       theta -= delta;
+      if (g == 0) lb[o.peer] = LPMP_NAN;
     }
     if (flags & SWEEP_RESIDUAL) {
       double residual = 0.0;
@@ -535,6 +573,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
     }
     own_g[g] = theta;
   }
+  { const double ob = vec_min<G, L>(vl ? theta : LPMP_INF); if (live && g == 0) lb[uni<G>(hdr->factor)] = ob; }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -545,7 +584,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
 template <int L>
 __global__ void __launch_bounds__(256)
 sweep_potts_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
-                   const double* __restrict__ cdata, int64_t first, int64_t count, int flags) {
+                   const double* __restrict__ cdata, double* __restrict__ lb, int64_t first, int64_t count, int flags) {
   constexpr int GPB = 256 / L;
   const int grp = threadIdx.x / L, g = threadIdx.x % L;
   const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
@@ -582,12 +621,17 @@ sweep_potts_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
     const unsigned long long gmask = (L == 64 ? ~0ull : ((1ull << L) - 1ull)) << grp_shift;
     const int first_holder = __ffsll((long long)(holders & gmask)) - 1;
     const double min_except = ((int)(threadIdx.x & 63) == first_holder) ? a2 : a1;
+    double pb = LPMP_INF;
     if (act) {
       const double q = fmin(0.0 + mo_v, diff + min_except);
       const double delta = ms_v + q;
       theta += delta;
-      ms[g] = ms_v - delta;
+      const double mn = ms_v - delta;
+      ms[g] = mn;
+      pb = mn + q;
     }
+    pb = vec_min<L, L>(pb);
+    if (act && g == 0) lb[op.peer] = pb;
   }
   if (live) {
     const double snap = theta;
@@ -598,6 +642,7 @@ sweep_potts_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
       const double delta = op.omega * snap;
       ms[g] += delta;
       theta -= delta;
+      if (g == 0) lb[op.peer] = LPMP_NAN;
     }
     if (flags & SWEEP_RESIDUAL) {   // second round from the live factor with the running weight sum
       double residual = 0.0;
@@ -613,6 +658,7 @@ sweep_potts_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
     }
     own_g[g] = theta;
   }
+  { const double ob = vec_min<L, L>(live ? theta : LPMP_INF); if (live && g == 0) lb[rec.factor] = ob; }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -660,6 +706,45 @@ factor_lb_kernel(const LbRec* __restrict__ recs, const double* __restrict__ dual
     lb = best;
   }
   if (lane == 0) out[f] = lb;
+}
+
+// the same for an explicit list of factors (the ones whose tracked bound is stale)
+__global__ void __launch_bounds__(256)
+factor_lb_list_kernel(const LbRec* __restrict__ recs, const double* __restrict__ dual, const double* __restrict__ cdata,
+                      double* __restrict__ out, const int32_t* __restrict__ list, int64_t count) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= count) return;
+  const int32_t f = list[i];
+  const LbRec r = recs[f];
+  const int kind = r.kind_flags & 15, flags = r.kind_flags >> 4;
+  const double* d = dual + r.dual_off;
+  double lb;
+  if (kind == LPMP_F_VECTOR) {
+    double v = LPMP_INF;
+    for (int k = lane; k < r.d0; k += 64) v = fmin(v, d[k]);
+    lb = wave_min(v);
+    if ((flags & LPMP_FF_IMPLICIT_ORIGIN) && 0.0 < lb) lb = 0.0;
+  } else {
+    const int d0 = r.d0, d1 = r.d1;
+    double best = LPMP_INF;
+    for (int a = 0; a < d0; ++a) {
+      double v = LPMP_INF;
+      for (int b = lane; b < d1; b += 64) v = fmin(v, pw_cost(cdata, r.const_off, kind, d1, a, b) + d[d0 + b]);
+      v = wave_min(v);
+      best = fmin(best, d[a] + v);
+    }
+    lb = best;
+  }
+  if (lane == 0) out[f] = lb;
+}
+
+// indices of the factors whose tracked bound is NaN
+__global__ void __launch_bounds__(256)
+lb_collect_stale_kernel(const double* __restrict__ lb, int64_t n, int32_t* __restrict__ list, unsigned long long* __restrict__ counter) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (lb[i] != lb[i]) list[atomicAdd(counter, 1ull)] = (int32_t)i;
 }
 
 // dense L x L pairwise bound with the streaming layout of sweep_dense_kernel (G lanes per factor)
@@ -727,19 +812,19 @@ __global__ void synth_fill_kernel(double* __restrict__ out, int64_t n, uint64_t 
 
 // ---- launch wrappers (called from engine.cpp) -----------------------------------------------------
 void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
-                  int64_t first, int64_t count, int flags, hipStream_t s) {
+                  double* lb, int64_t first, int64_t count, int flags, hipStream_t s) {
   if (count <= 0) return;
   auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
   switch (kclass) {
-    case KC_DENSE_32: hipLaunchKernelGGL(sweep_dense_kernel<32>, blocks(256 / DenseCfg<32>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
-    case KC_DENSE_16: hipLaunchKernelGGL(sweep_dense_kernel<16>, blocks(256 / DenseCfg<16>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
-    case KC_DENSE_8: hipLaunchKernelGGL(sweep_dense_kernel<8>, blocks(256 / DenseCfg<8>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
-    case KC_DENSE_4: hipLaunchKernelGGL(sweep_dense_kernel<4>, blocks(256 / DenseCfg<4>::G), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
-    case KC_POTTS_32: hipLaunchKernelGGL(sweep_potts_kernel<32>, blocks(256 / 32), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
-    case KC_POTTS_16: hipLaunchKernelGGL(sweep_potts_kernel<16>, blocks(256 / 16), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
-    case KC_POTTS_8: hipLaunchKernelGGL(sweep_potts_kernel<8>, blocks(256 / 8), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
-    case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, first, count, flags); break;
-    default: hipLaunchKernelGGL(sweep_generic_kernel, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, first, count, flags); break;
+    case KC_DENSE_32: hipLaunchKernelGGL(sweep_dense_kernel<32>, blocks(256 / DenseCfg<32>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
+    case KC_DENSE_16: hipLaunchKernelGGL(sweep_dense_kernel<16>, blocks(256 / DenseCfg<16>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
+    case KC_DENSE_8: hipLaunchKernelGGL(sweep_dense_kernel<8>, blocks(256 / DenseCfg<8>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
+    case KC_DENSE_4: hipLaunchKernelGGL(sweep_dense_kernel<4>, blocks(256 / DenseCfg<4>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
+    case KC_POTTS_32: hipLaunchKernelGGL(sweep_potts_kernel<32>, blocks(256 / 32), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
+    case KC_POTTS_16: hipLaunchKernelGGL(sweep_potts_kernel<16>, blocks(256 / 16), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
+    case KC_POTTS_8: hipLaunchKernelGGL(sweep_potts_kernel<8>, blocks(256 / 8), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
+    case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
+    default: hipLaunchKernelGGL(sweep_generic_kernel, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, lb, first, count, flags); break;
   }
 }
 
@@ -748,12 +833,12 @@ static int dense_kmax() {
   return k;
 }
 
-bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, int64_t count, int flags, hipStream_t s) {
+bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, double* lb, int64_t count, int flags, hipStream_t s) {
   if (count <= 0) return true;
   if (stride > 1 + PK_MAX_OPS) return false;
   auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
   const int km = dense_kmax();
-#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, dual, cdata, count, stride, flags)
+#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, dual, cdata, lb, count, stride, flags)
   switch (kclass) {
     case KC_DENSE_32: if (km >= 4) PK_LAUNCH(32, 4); else if (km == 1) PK_LAUNCH(32, 1); else PK_LAUNCH(32, 2); return true;
     case KC_DENSE_16: if (km >= 4) PK_LAUNCH(16, 4); else PK_LAUNCH(16, 2); return true;
@@ -778,6 +863,16 @@ bool launch_dense_lb(int L, const void* recs, const double* dual, const double* 
     case 8: hipLaunchKernelGGL(dense_lb_kernel<8>, blocks(256 / DenseCfg<8>::G), dim3(256), 0, s, (const LbRec*)recs, dual, cdata, out, first, count); return true;
     default: return false;
   }
+}
+
+void launch_lb_collect_stale(const double* lb, int64_t n, int32_t* list, unsigned long long* counter, hipStream_t s) {
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(lb_collect_stale_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lb, n, list, counter);
+}
+void launch_factor_lb_list(const void* recs, const double* dual, const double* cdata, double* out, const int32_t* list, int64_t count, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(factor_lb_list_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, (const LbRec*)recs, dual, cdata, out, list, count);
 }
 
 void launch_sum_stage(const double* in, double* out, int64_t n, int64_t per_block, int64_t n_blocks, hipStream_t s) {

@@ -415,7 +415,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       Op op{};
       op.peer_dual = f_doff[peer];
       op.omega = w;
-      op.msg = e.msg;
+      op.peer = peer;
       op.len = f_dim0[m_left[e.msg]];
       op.pd0 = f_dim0[peer]; op.pd1 = f_dim1[peer];
       const int32_t right = m_right[e.msg];

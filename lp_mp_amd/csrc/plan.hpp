@@ -52,7 +52,7 @@ struct alignas(16) Op {       // one active receive or send
   int32_t info;       // opcode | role<<4 | side<<5 | peer_implicit_origin<<6 | peer_kind<<8
   int32_t pd0;        // peer dim0
   int32_t pd1;        // peer dim1 (dense pairwise peer) / n_left of the table (labeling)
-  int32_t msg;        // message index (diagnostics)
+  int32_t peer;       // peer factor index (slot of its tracked lower bound)
   int32_t len;        // message length (= dim of the left factor's variable)
   int32_t pad;
 };

@@ -32,7 +32,7 @@ EXPORTS = [
     "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_set_reparametrization_type", "lpmp_compute_pass", "lpmp_compute_forward_pass",
     "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_create_fused", "lpmp_schedule_run",
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
-    "lpmp_synchronize", "lpmp_dual_size", "lpmp_download_duals", "lpmp_upload_duals", "lpmp_device_duals",
+    "lpmp_invalidate_lower_bounds", "lpmp_synchronize", "lpmp_dual_size", "lpmp_download_duals", "lpmp_upload_duals", "lpmp_device_duals",
     "lpmp_engine_plan", "lpmp_engine_plan_mut", "lpmp_enable_kernel_timing", "lpmp_get_kernel_timing",
     "lpmp_reset_kernel_timing", "lpmp_synth_fill",
 ]
@@ -93,6 +93,7 @@ def lib():
         L.lpmp_schedule_destroy.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_lower_bound.argtypes = [C.c_void_p, C.c_void_p]
         L.lpmp_factor_lower_bounds.argtypes = [C.c_void_p, C.c_void_p]
+        L.lpmp_invalidate_lower_bounds.argtypes = [C.c_void_p]
         L.lpmp_synchronize.argtypes = [C.c_void_p]
         L.lpmp_download_duals.argtypes = [C.c_void_p, C.c_void_p]
         L.lpmp_upload_duals.argtypes = [C.c_void_p, C.c_void_p]
@@ -298,6 +299,10 @@ class Engine:
         out = np.empty(self.model.n_factors, np.float64)
         _chk(self.L.lpmp_factor_lower_bounds(self.h, out.ctypes.data))
         return out
+
+    def invalidate_lower_bounds(self):
+        """duals were changed outside the engine (borrowed buffer): recompute every factor's bound next time"""
+        _chk(self.L.lpmp_invalidate_lower_bounds(self.h))
 
     def synchronize(self):
         _chk(self.L.lpmp_synchronize(self.h))

@@ -344,6 +344,8 @@ class PartitionedSweep:
                 self.boundary_step(comm)
 
     def local_lower_bound(self):
+        if hasattr(self.engine, "invalidate_lower_bounds"):
+            self.engine.invalidate_lower_bounds()   # the boundary step edits theta with torch ops
         return self.engine.lower_bound()
 
     def updates_per_pass(self):

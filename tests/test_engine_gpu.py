@@ -45,7 +45,7 @@ def _check(eng, m, mode, passes, exact=True):
     if exact:
         assert np.array_equal(d, do)
     flb = eng.factor_lower_bounds()
-    oflb = np.array([o.factor_lower_bound(f) for f in range(min(m.n_factors, 400))])
+    oflb = np.array([o.factor_lower_bound(f) for f in range(min(m.n_factors, 3000))])
     assert np.max(np.abs(flb[:oflb.shape[0]] - oflb)) <= DUAL_ATOL
     return prev
 
@@ -398,3 +398,40 @@ def test_c5_style_mixed_model(eng):
     m = b.finish()
     for mode in MODES:
         _check(eng, m, mode, 4)
+
+
+def test_tracked_lower_bounds_equal_recomputed_ones():
+    """lpmp_lower_bound after a pass sums bounds the sweep kernels tracked as a by-product; an engine with
+    LPMP_NO_LB_TRACKING=1 recomputes every factor from memory.  Both must agree with the oracle per factor."""
+    import os
+    for m in (S.grid_model(16, 12, 32, order="colour_major", seed=51), S.grid_model(11, 13, 8, pairwise="potts", seed=52),
+              S.grid_model(9, 10, 16, order="row_major", seed=53)):
+        engines = []
+        for env in ("0", "1"):
+            os.environ["LPMP_NO_LB_TRACKING"] = env
+            e = E.Engine(0)
+            e.upload(m)
+            engines.append(e)
+        os.environ.pop("LPMP_NO_LB_TRACKING")
+        o = Oracle(m)
+        for mode in (M.REPAM_ANISOTROPIC, M.REPAM_UNIFORM):
+            o.set_reparametrization(mode)
+            for e in engines:
+                e.set_reparametrization(mode)
+            for step in (1, 3, 1):
+                o.ComputePass(step)
+                ref = np.array([o.factor_lower_bound(f) for f in range(m.n_factors)])
+                for e in engines:
+                    e.compute_pass(step)
+                    assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+                    assert np.max(np.abs(e.factor_lower_bounds() - ref)) <= DUAL_ATOL
+            o.ComputeForwardPass()
+            for e in engines:
+                e.forward_pass()
+                assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+        d = o.duals() * 0.75
+        o.set_duals(d)
+        for e in engines:
+            e.upload_duals(d)
+            assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+            e.close()
