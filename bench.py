@@ -151,7 +151,7 @@ def main():
         parallelism = "1 GPU"
     else:
         from lp_mp_amd import multi_gpu as MG
-        runner = MG.StripSweep(torch, dist, H, W, L, args.pairwise, args.order, mode, seed=1)
+        runner = MG.StripSweep(torch, dist, H, W, L, args.pairwise, args.order, mode, seed=1, boundary_every="pass")
         updates_per_pass = runner.global_updates_per_pass
         bytes_per_pass = runner.global_bytes_per_pass
         levels = runner.levels

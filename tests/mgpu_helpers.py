@@ -69,13 +69,14 @@ def global_replay(global_model, parts, main_rows, n_passes, omega_b, boundary_ev
         for p in parts:
             for u, key in zip(p.in_unary, p.in_key):
                 cut.setdefault(int(p.local_to_global[u]), []).append(2 * int(key) + 1)
+        w_of = (lambda g: omega_b) if omega_b is not None else (lambda g: 1.0 / (len(cut[g]) + 1.0))
         F, OM, MK, off = [], [], [], [0]
         for g in sorted(cut):
             gm = glist(g)
             o_row = np.zeros(gm.shape[0]); m_row = np.zeros(gm.shape[0], np.uint8)
             for i, x in enumerate(gm):
                 if int(x) in cut[g]:
-                    o_row[i] = omega_b; m_row[i] = 1
+                    o_row[i] = w_of(g); m_row[i] = 1
             F.append(g); OM.append(o_row); MK.append(m_row); off.append(off[-1] + gm.shape[0])
         if F:
             o.compute_pass_custom(np.array(F, np.int32), off, np.concatenate(OM), off, np.concatenate(MK))

@@ -29,7 +29,7 @@ def _strip_setup(H, W, L, world, pairwise, order, seed):
     return gm, parts
 
 
-def _cpu_sweeps(parts, omega_b, every="pass"):
+def _cpu_sweeps(parts, omega_b, every="sweep"):
     sweeps, duals = [], []
     for p in parts:
         d = p.model.dual_data.copy()
@@ -88,10 +88,16 @@ def test_random_graph_general_partition_with_multi_cut_unaries():
     parts = MG.partition_mrf(n, L, ei, ej, part_of, world, un, tables=tables)
     assert max(np.bincount(p.in_unary).max() if p.in_unary.size else 0 for p in parts) >= 2
     attach_local_lists(parts)
-    sweeps, duals = _cpu_sweeps(parts, 0.25)
-    MG.run_lockstep(sweeps, 2)
-    o = global_replay(g, parts, [s.main_rows for s in sweeps], 2, 0.25)
+    sweeps, duals = _cpu_sweeps(parts, None)
+    lbs = [sum(s.local_lower_bound() for s in sweeps)]
+    for _ in range(4):
+        MG.run_lockstep(sweeps, 1)
+        lbs.append(sum(s.local_lower_bound() for s in sweeps))
+    assert all(b >= a - 1e-9 for a, b in zip(lbs, lbs[1:]))          # every step is a valid dual-ascent step
+    o = global_replay(g, parts, [s.main_rows for s in sweeps], 4, None, "sweep")
     assert np.array_equal(gather_global_duals(g, parts, duals), o.duals())
+    with pytest.raises(ValueError):
+        _cpu_sweeps(parts, 0.9)                                       # weights of a multi-cut unary would exceed 1
 
 
 WORKER = r"""
@@ -104,7 +110,7 @@ rank, world = dist.get_rank(), dist.get_world_size()
 H, W, L = 5, 6, 4
 part = MG.strip_local_part(H, W, L, "dense", "colour_major", rank, world, 3)
 d = part.model.dual_data.copy()
-sw = MG.PartitionedSweep(torch, part, OracleEngine(part.model, d), torch.from_numpy(d), M.REPAM_ANISOTROPIC, 0.5)
+sw = MG.PartitionedSweep(torch, part, OracleEngine(part.model, d), torch.from_numpy(d), M.REPAM_ANISOTROPIC, 0.5, "pass")
 comm = MG.DistComm(dist, torch)
 sw.compute_pass(comm, 3)
 lb = comm.all_reduce_sum(sw.local_lower_bound())
@@ -125,11 +131,11 @@ def test_two_process_gloo_run_equals_lockstep(tmp_path):
                           timeout=300)
     gm, parts = _strip_setup(5, 6, 4, 2, "dense", "colour_major", 3)
     attach_local_lists(parts)
-    sweeps, duals = _cpu_sweeps(parts, 0.5)
+    sweeps, duals = _cpu_sweeps(parts, 0.5, "pass")
     MG.run_lockstep(sweeps, 3)
     for k in range(2):
         assert np.array_equal(np.load(tmp_path / f"duals_{k}.npy"), duals[k])
-    o = global_replay(gm, parts, [s.main_rows for s in sweeps], 3, 0.5)
+    o = global_replay(gm, parts, [s.main_rows for s in sweeps], 3, 0.5, "pass")
     assert abs(np.load(tmp_path / "lb.npy")[0] - o.LowerBound()) <= 1e-9 * abs(o.LowerBound())
 
 
@@ -159,5 +165,54 @@ def test_partitioned_sweep_on_device_equals_oracle_replay(pairwise, L, order, wo
     assert np.array_equal(got, o.duals())
     lb = sum(s.local_lower_bound() for s in sweeps)
     assert abs(lb - o.LowerBound()) <= 1e-5 * max(1.0, abs(lb))
+    for e in engines:
+        e.close()
+
+
+def test_graph_partition_is_balanced_and_finds_locality():
+    # a grid given as an anonymous graph: strips/bands should come out, far fewer cut edges than a random split
+    H = W = 40
+    a, b = S.grid_edges(H, W)
+    part = MG.graph_partition(H * W, a, b, 4)
+    assert np.bincount(part, minlength=4).max() - np.bincount(part, minlength=4).min() <= 1
+    cut = int((part[a] != part[b]).sum())
+    rnd = np.random.default_rng(0).integers(0, 4, H * W)
+    assert cut < 0.2 * int((rnd[a] != rnd[b]).sum())
+
+
+@pytest.mark.gpu
+def test_c4_style_random_graph_partitioned_on_device():
+    """BASELINE configs[3] in miniature: random sparse graph, 16 labels, dense tables, split into 4 parts with the
+    built-in partitioner (METIS is not available), real HIP engines, oracle replay on the unpartitioned model."""
+    from lp_mp_amd import engine as E
+    n, m_edges, L, world = 600, 2400, 16, 4
+    g = S.random_graph_model(n, m_edges, L, seed=21)
+    ei = g.m_left[0::2].astype(np.int64)
+    ej = g.m_left[1::2].astype(np.int64)
+    part_of = MG.graph_partition(n, ei, ej, world)
+    parts = MG.partition_mrf(n, L, ei, ej, part_of, world, g.dual_data[: n * L], tables=g.const_data)
+    attach_local_lists(parts)
+    dev = torch.device("cuda:0")
+    sweeps, tensors, engines = [], [], []
+    for p in parts:
+        dual = torch.from_numpy(p.model.dual_data.copy()).to(dev)
+        eng = E.Engine(0)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual)
+        sweeps.append(MG.PartitionedSweep(torch, p, eng, dual, M.REPAM_ANISOTROPIC))
+        tensors.append(dual); engines.append(eng)
+    lb0 = sum(s.local_lower_bound() for s in sweeps)
+    MG.run_lockstep(sweeps, 3)
+    torch.cuda.synchronize()
+    o = global_replay(g, parts, [s.main_rows for s in sweeps], 3, None, "sweep")
+    assert np.array_equal(gather_global_duals(g, parts, [t.cpu().numpy() for t in tensors]), o.duals())
+    lb = sum(s.local_lower_bound() for s in sweeps)
+    assert abs(lb - o.LowerBound()) <= 1e-5 * max(1.0, abs(lb))
+    ref = Oracle(g)
+    ref.set_reparametrization(M.REPAM_ANISOTROPIC)
+    ref.ComputePass(3)
+    gap = (ref.LowerBound() - lb) / abs(ref.LowerBound())
+    print("dual-bound gap to the unpartitioned sweep after 3 passes: %.2f %%" % (100 * gap))
+    assert lb > lb0 and gap < 0.5       # dual ascent, and in the neighbourhood of the unpartitioned bound
     for e in engines:
         e.close()
