@@ -435,3 +435,33 @@ def test_tracked_lower_bounds_equal_recomputed_ones():
             e.upload_duals(d)
             assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
             e.close()
+
+
+def test_size_limits_isolated_factors_and_empty_schedules(eng):
+    # largest factors the generic kernel takes: 512 doubles of dual (256-label pairwise, 512-label unary)
+    _check(eng, S.grid_model(2, 3, 256, pairwise="potts", seed=61), M.REPAM_ANISOTROPIC, 2)
+    _check(eng, S.grid_model(2, 2, 200, seed=62), M.REPAM_UNIFORM, 1)
+    # beyond it: refused loudly, not silently computed elsewhere
+    big = M.ModelBuilder(1, [M.MsgType(0, 0, M.SCHED_LEFT, 0, 0, M.M_MINNORM, 0)])
+    f = big.add_vector_factors(0, np.zeros((2, 600)))
+    big.add_messages(0, f[0], f[1])
+    eng.upload(big.finish())
+    with pytest.raises(E.EngineError) as ei:
+        eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    assert ei.value.code == -2                                   # LPMP_ERR_UNSUPPORTED
+    # factors without messages: never updated, still counted in the bound; a model without messages: passes are no-ops
+    b = M.ModelBuilder(2, S.mrf_mtypes())
+    u = b.add_vector_factors(0, np.array([[3.0, 1.0, 2.0], [5.0, 4.0, 6.0], [0.5, 0.7, 0.2], [9.0, 8.0, 7.0]]))
+    pw = b.add_dense_pairwise(1, np.arange(9.0).reshape(1, 3, 3))
+    b.add_messages(0, u[0], pw[0]); b.add_messages(1, u[2], pw[0])
+    b.add_relations(u[0], pw[0]); b.add_relations(pw[0], u[2])
+    _check(eng, b.finish(), M.REPAM_ANISOTROPIC, 3)
+    b = M.ModelBuilder(1, [])
+    b.add_vector_factors(0, np.array([[3.0, 1.0], [5.0, 4.0]]))
+    b.constant = 2.5
+    eng.upload(b.finish())
+    eng.set_reparametrization(M.REPAM_DAMPED_UNIFORM)
+    eng.compute_pass(3)
+    assert eng.lower_bound() == 2.5 + 1.0 + 4.0                  # constant_ + sum of minima (LP_MP.h:1510)
+    eng.compute_pass_custom(np.zeros(0, np.int32), [0], [], [0], [])   # empty iterator range
+    assert eng.lower_bound() == 7.5

@@ -137,3 +137,28 @@ def test_engine_fails_loudly_without_gpu():
     with pytest.raises(E.EngineError) as ei:
         E.Engine(0)
     assert "no CPU path" in str(ei.value) or ei.value.code == -3
+
+
+def test_cyclic_relations_and_isolated_factors_match_oracle():
+    """The reference's topological sort never detects a cycle (tempMarked is never set,
+    topological_sort.hxx:100-144): a cyclic relation set just yields the DFS order.  Isolated factors (no
+    messages) are not updated and keep their place in the ordering."""
+    m = S.grid_model(4, 4, 3, seed=9)
+    b_rel = np.concatenate([m.rel_fwd, np.array([[5, 0], [0, 5], [30, 2]], np.int32)])
+    m.rel_fwd = np.ascontiguousarray(b_rel)
+    o, p = Oracle(m), E.Plan(m)
+    for d in (0, 1):
+        assert np.array_equal(o.order(d), p.order(d))
+        assert np.array_equal(o.update_order(d), p.update_order(d))
+    b = M.ModelBuilder(2, S.mrf_mtypes())
+    u = b.add_vector_factors(0, np.arange(12.0).reshape(4, 3))
+    pw = b.add_dense_pairwise(1, np.ones((1, 3, 3)))
+    b.add_messages(0, u[0], pw[0]); b.add_messages(1, u[2], pw[0])
+    b.add_relations(u[0], pw[0]); b.add_relations(pw[0], u[2])
+    m2 = b.finish()                                  # u[1], u[3] are isolated
+    o, p = Oracle(m2), E.Plan(m2)
+    for d in (0, 1):
+        assert np.array_equal(o.order(d), p.order(d))
+        assert sorted(p.update_order(d)) == [0, 2]
+        for mode in MODES:
+            assert np.array_equal(o.omega(d, mode)[1], p.omega(d, mode)[1])
