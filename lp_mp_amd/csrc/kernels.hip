@@ -48,22 +48,9 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   hi = __shfl_xor(hi, mask, 64);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double shfl_f64(double v, int src) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl(lo, src, 64);
-  hi = __shfl(hi, src, 64);
-  return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fmin(v, shfl_xor_f64(v, m));
-  return v;
-}
-// min over aligned groups of G lanes (G power of two <= 64)
-template <int G>
-__device__ __forceinline__ double group_min(double v) {
-#pragma unroll
-  for (int m = G / 2; m >= 1; m >>= 1) v = fmin(v, shfl_xor_f64(v, m));
   return v;
 }
 
