@@ -70,6 +70,8 @@ int lpmp_plan_anisotropic_weights(const lpmp_plan* p, int64_t n, const int32_t* 
 int lpmp_plan_schedule_info(lpmp_plan* p, int direction, int mode, int64_t* n_levels, int64_t* n_launches,
                             int64_t* n_receives, int64_t* n_sends, int64_t* algorithmic_bytes);
 
+/* dependent step (1-based level; 0 = no active message) of every entry of the update order in that sweep */
+int lpmp_plan_get_update_levels(lpmp_plan* p, int direction, int mode, int32_t* out /*[n_updated]*/);
 /* the same for a whole pass (forward then backward sweep scheduled as one sequence; back-to-back updates
  * of one factor across the two sweeps are folded into one record) */
 int lpmp_plan_pass_schedule_info(lpmp_plan* p, int mode, int64_t* n_levels, int64_t* n_launches,

@@ -424,6 +424,18 @@ int lpmp_plan_schedule_info(lpmp_plan* p, int d, int mode, int64_t* n_levels, in
   });
 }
 
+int lpmp_plan_get_update_levels(lpmp_plan* p, int d, int mode, int32_t* out) {
+  return guarded([&] {
+    if (!p || !out || d < 0 || d > 1 || mode < 0 || mode >= LPMP_REPAM_COUNT) throw std::runtime_error("bad argument");
+    plan_schedule(p, d, mode);
+    const Schedule& s = p->sched_cache[d][mode];
+    std::vector<int32_t> level_of(p->p.nf, 0);
+    for (const auto& lr : s.launches) for (int64_t i = lr.begin; i < lr.end; ++i) level_of[s.recs[i].factor] = lr.level;
+    const auto& upd = p->p.upd[d];
+    for (size_t i = 0; i < upd.size(); ++i) out[i] = level_of[upd[i]];
+  });
+}
+
 int lpmp_plan_pass_schedule_info(lpmp_plan* p, int mode, int64_t* n_levels, int64_t* n_launches, int64_t* n_recv,
                                  int64_t* n_send, int64_t* alg_bytes) {
   return guarded([&] {

@@ -28,7 +28,7 @@ EXPORTS = [
     "lpmp_last_error", "lpmp_version", "lpmp_plan_create", "lpmp_plan_destroy", "lpmp_plan_n_factors",
     "lpmp_plan_n_updated", "lpmp_plan_get_order", "lpmp_plan_get_update_order", "lpmp_plan_omega_nnz",
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
-    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_pass_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
+    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
     "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_set_reparametrization_type", "lpmp_compute_pass", "lpmp_compute_forward_pass",
     "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_create_fused", "lpmp_schedule_run",
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
@@ -76,6 +76,7 @@ def lib():
         L.lpmp_plan_anisotropic_weights.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
         L.lpmp_plan_schedule_info.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.lpmp_plan_pass_schedule_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.lpmp_plan_get_update_levels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.lpmp_create.argtypes = [C.c_int, C.c_void_p]
         L.lpmp_destroy.argtypes = [C.c_void_p]
         L.lpmp_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -187,6 +188,11 @@ class Plan:
         _chk(self.L.lpmp_plan_anisotropic_weights(self.h, factors.shape[0], factors.ctypes.data, None, None, None,
                                                   om_off.ctypes.data, om.ctypes.data, mk_off.ctypes.data, mk.ctypes.data))
         return om_off, om, mk_off, mk
+
+    def update_levels(self, d: int, mode: int) -> np.ndarray:
+        out = np.empty(self.L.lpmp_plan_n_updated(self.h, d), np.int32)
+        _chk(self.L.lpmp_plan_get_update_levels(self.h, d, mode, out.ctypes.data))
+        return out
 
     def schedule_info(self, d: int, mode: int) -> dict:
         v = [C.c_int64() for _ in range(5)]

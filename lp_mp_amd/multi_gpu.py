@@ -278,11 +278,34 @@ class PartitionedSweep:
             rows = _select_rows(upd, om_off, om, mk_off, mk, keep)
             self.main_rows.append(rows)
             self.main.append(engine.schedule_create(*rows))
-        # forward then backward main sweep as one (fused) sequence
+        # forward then backward main sweep as one (fused) sequence, and its steady-state variants: the first level
+        # of the forward sweep that touches nothing the boundary step touches (X) commutes with the boundary step,
+        # so it is run at the END of the previous pass, where it fuses with the backward sweep's last level
+        # (same factors): pass k = [forward minus X, backward, X of pass k+1].
         f0, f1 = self.main_rows
-        cat_rows = (np.concatenate([f0[0], f1[0]]), np.concatenate([f0[1], f0[1][-1] + f1[1][1:]]), np.concatenate([f0[2], f1[2]]),
-                    np.concatenate([f0[3], f0[3][-1] + f1[3][1:]]), np.concatenate([f0[4], f1[4]]))
-        self.main_pass = engine.schedule_create(*cat_rows, fuse=True)
+        self.rows = {"F": f0, "B": f1, "FB": _cat_rows(f0, f1)}
+        self.sched = {"F": self.main[0], "B": self.main[1]}
+        if boundary_every == "pass":
+            self.sched["FB"] = engine.schedule_create(*self.rows["FB"], fuse=True)
+            lev = plan.update_levels(M.FORWARD, mode)[~ghost[plan.update_order(M.FORWARD)]]
+            touched = np.zeros(p.model.n_factors, bool)            # what the boundary step reads or writes
+            touched[p.n_local: n_vec] = True
+            touched[p.in_unary] = True
+            m_l, m_r = p.model.m_left, p.model.m_right
+            cut_pw = np.zeros(p.model.n_factors, bool)
+            cut_pw[m_r[ghost[m_l]]] = True                            # pairwise factors adjacent to a ghost
+            touched |= cut_pw
+            near = np.zeros(p.model.n_factors, bool)                  # factors with a message to a touched factor
+            near[m_l[touched[m_r]]] = True
+            near[m_r[touched[m_l]]] = True
+            x = (lev == 1) & ~touched[f0[0]] & ~near[f0[0]]
+            if x.any() and not x.all():
+                fx, frest = _subset_rows(f0, x), _subset_rows(f0, ~x)
+                self.rows["first"] = _cat_rows(f0, f1, fx)
+                self.rows["mid"] = _cat_rows(frest, f1, fx)
+                self.rows["last"] = _cat_rows(frest, f1)
+                for k in ("first", "mid", "last"):
+                    self.sched[k] = engine.schedule_create(*self.rows[k], fuse=True)
         # 2. boundary passes on the ghosts: every ghost has exactly one message (side 1 of its cut edge)
         g = np.arange(p.n_local, n_vec, dtype=np.int32)
         ones_off = np.arange(g.shape[0] + 1, dtype=np.int64)
@@ -312,9 +335,18 @@ class PartitionedSweep:
         self.info = [engine.schedule_info(s) for s in self.main]
         self.info_ghost = [engine.schedule_info(self.ghost_recv), engine.schedule_info(self.ghost_send)]
 
-    # -- pieces of one directional sweep, split so that LocalComm can interleave several parts --------
-    def main_sweep(self, d):
-        self.engine.schedule_run(self.main[d])
+    # -- the steps of n passes: ("run", key of self.rows / self.sched) and ("boundary",) ------------------------
+    def program(self, n: int):
+        if self.boundary_every == "sweep":
+            return [step for _ in range(n) for step in (("run", "F"), ("boundary",), ("run", "B"), ("boundary",))]
+        if n >= 2 and "mid" in self.sched:
+            keys = ["first"] + ["mid"] * (n - 2) + ["last"]
+        else:
+            keys = ["FB"] * n
+        return [step for k in keys for step in (("run", k), ("boundary",))]
+
+    def run(self, key):
+        self.engine.schedule_run(self.sched[key])
 
     def boundary_pack(self):
         """owner: ghost <- min-marginal toward the remote variable; returns rows to ship (by peer, key)."""
@@ -344,14 +376,6 @@ class PartitionedSweep:
         self.engine.schedule_run(self.ghost_send)
 
     # -- stand-alone driver over a DistComm -------------------------------------------------------------
-    def sweep(self, comm, d):
-        self.main_sweep(d)
-        send = self.boundary_pack()
-        recv = comm.exchange(send, self.out_counts, self.in_counts)
-        reply = self.boundary_reply(recv)
-        back = comm.exchange(reply, self.in_counts, self.out_counts)
-        self.boundary_fold(back)
-
     def boundary_step(self, comm):
         send = self.boundary_pack()
         recv = comm.exchange(send, self.out_counts, self.in_counts)
@@ -360,12 +384,10 @@ class PartitionedSweep:
         self.boundary_fold(back)
 
     def compute_pass(self, comm, n=1):
-        for _ in range(n):
-            if self.boundary_every == "sweep":
-                self.sweep(comm, M.FORWARD)
-                self.sweep(comm, M.BACKWARD)
+        for step in self.program(n):
+            if step[0] == "run":
+                self.run(step[1])
             else:
-                self.engine.schedule_run(self.main_pass)
                 self.boundary_step(comm)
 
     def local_lower_bound(self):
@@ -383,6 +405,21 @@ class PartitionedSweep:
     def bytes_per_pass(self):
         steps = 2 if self.boundary_every == "sweep" else 1
         return sum(i["algorithmic_bytes"] for i in self.info) + steps * sum(i["algorithmic_bytes"] for i in self.info_ghost)
+
+
+def _cat_rows(*rows):
+    """concatenate (factors, om_off, om, mk_off, mk) row sets into one sequence"""
+    f = np.concatenate([r[0] for r in rows])
+    def offs(k):
+        out, base = [np.zeros(1, np.int64)], 0
+        for r in rows:
+            out.append(base + r[k][1:]); base += int(r[k][-1])
+        return np.concatenate(out).astype(np.int64)
+    return (f, offs(1), np.concatenate([r[2] for r in rows]), offs(3), np.concatenate([r[4] for r in rows]))
+
+
+def _subset_rows(rows, keep):
+    return _select_rows(rows[0], rows[1], rows[2], rows[3], rows[4], keep)
 
 
 def _select_rows(upd, om_off, om, mk_off, mk, keep):
@@ -418,14 +455,13 @@ def run_lockstep(sweeps: List[PartitionedSweep], n_passes: int):
             assert got[-1].shape[0] == int(sum(counts_in[dst]))
         return got
 
-    per_sweep = sweeps[0].boundary_every == "sweep"
-    for _ in range(n_passes):
-        for d in ((M.FORWARD, M.BACKWARD) if per_sweep else (None,)):
-            for s in sweeps:
-                if per_sweep:
-                    s.main_sweep(d)
-                else:
-                    s.engine.schedule_run(s.main_pass)
+    programs = [s.program(n_passes) for s in sweeps]
+    assert all(len(p) == len(programs[0]) and [x[0] for x in p] == [x[0] for x in programs[0]] for p in programs)
+    for i, step in enumerate(programs[0]):
+        if step[0] == "run":
+            for s, prog in zip(sweeps, programs):
+                s.run(prog[i][1])
+        else:
             sent = [s.boundary_pack() for s in sweeps]
             recv = shuffle(sent, [s.out_counts for s in sweeps], [s.in_counts for s in sweeps])
             rep = [s.boundary_reply(r) for s, r in zip(sweeps, recv)]

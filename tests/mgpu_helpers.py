@@ -37,27 +37,28 @@ class OracleEngine:
         return self.o.LowerBound()
 
 
-def global_replay(global_model, parts, main_rows, n_passes, omega_b, boundary_every="pass"):
-    """Runs the partition schedule on the global model with the oracle:
-    ComputePass(concatenated part lists, expanded rows) for the forward and the backward main sweep, and
-    ComputePass(non-owner boundary unaries, cut slots only) after each sweep ("sweep") or after both ("pass")."""
+def global_replay(global_model, parts, sweeps, n_passes):
+    """Runs the partition schedule on the UNPARTITIONED model with the oracle: every ("run", key) step of the parts'
+    programs becomes one iterator-range ComputePass over the concatenation of the parts' row sets (expanded to the
+    global message lists), every ("boundary",) step one ComputePass over the non-owner boundary unaries with only
+    their cut slots active."""
     o = Oracle(global_model)
     g_off, g_ent = o.msg_lists()
 
     def glist(f):
         return g_ent[g_off[f]:g_off[f + 1]] // 2          # message ids in list order (MRF: every entry sends+receives)
 
-    def main_sweep(d):
+    def main_step(i, programs):
         F, OM, MK, off = [], [], [], [0]
-        for p, rows_d in zip(parts, main_rows):
-            f_loc, om_off, om, mk_off, mk = rows_d[d]
+        for p, sw, prog in zip(parts, sweeps, programs):
+            f_loc, om_off, om, mk_off, mk = sw.rows[prog[i][1]]
             l_off, l_ent = p._local_lists
             for r, fl in enumerate(f_loc):
                 g = int(p.local_to_global[fl])
                 lm = p.local_msg_to_global[l_ent[l_off[fl]:l_off[fl + 1]] // 2]
                 gm = glist(g)
                 o_row = np.zeros(gm.shape[0]); m_row = np.zeros(gm.shape[0], np.uint8)
-                pos = {int(x): i for i, x in enumerate(gm)}
+                pos = {int(x): k for k, x in enumerate(gm)}
                 lo = om[om_off[r]:om_off[r + 1]]; lk = mk[mk_off[r]:mk_off[r + 1]]
                 for j, x in enumerate(lm):
                     o_row[pos[int(x)]] = lo[j]; m_row[pos[int(x)]] = lk[j]
@@ -66,27 +67,27 @@ def global_replay(global_model, parts, main_rows, n_passes, omega_b, boundary_ev
 
     def boundary():
         cut = {}
-        for p in parts:
-            for u, key in zip(p.in_unary, p.in_key):
-                cut.setdefault(int(p.local_to_global[u]), []).append(2 * int(key) + 1)
-        w_of = (lambda g: omega_b) if omega_b is not None else (lambda g: 1.0 / (len(cut[g]) + 1.0))
+        for p, sw in zip(parts, sweeps):
+            for u, key, w in zip(p.in_unary, p.in_key, sw.in_omega):
+                cut.setdefault(int(p.local_to_global[u]), {})[2 * int(key) + 1] = float(w)
         F, OM, MK, off = [], [], [], [0]
         for g in sorted(cut):
             gm = glist(g)
             o_row = np.zeros(gm.shape[0]); m_row = np.zeros(gm.shape[0], np.uint8)
-            for i, x in enumerate(gm):
+            for k, x in enumerate(gm):
                 if int(x) in cut[g]:
-                    o_row[i] = w_of(g); m_row[i] = 1
+                    o_row[k] = cut[g][int(x)]; m_row[k] = 1
             F.append(g); OM.append(o_row); MK.append(m_row); off.append(off[-1] + gm.shape[0])
         if F:
             o.compute_pass_custom(np.array(F, np.int32), off, np.concatenate(OM), off, np.concatenate(MK))
 
-    for _ in range(n_passes):
-        main_sweep(M.FORWARD)
-        if boundary_every == "sweep":
-            boundary()
-        main_sweep(M.BACKWARD)
-        boundary()
+    for n in ([n_passes] if isinstance(n_passes, int) else n_passes):      # one entry per compute_pass call
+        programs = [sw.program(n) for sw in sweeps]
+        for i, step in enumerate(programs[0]):
+            if step[0] == "run":
+                main_step(i, programs)
+            else:
+                boundary()
     return o
 
 
