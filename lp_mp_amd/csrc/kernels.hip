@@ -509,10 +509,12 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
         }
         if (!stored) dual[pdual[j] + (side[j] == 0 ? 0 : L) + g] = mn;
       }
+#ifndef LPMP_ABLATE_LB_TRACK
       if (!(FW && defer[j])) {                    // a deferred receive is followed by a send that dirties the peer
         pb = vec_min<G, L>(pb);
         if (act && g == 0) lb[uni<G>(lop[c + j].peer)] = pb;
       }
+#endif
       wave_sync();
     }
   };
@@ -536,7 +538,9 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
         const double delta = o.omega * snap;
         ms[g] = cur + delta;
         theta -= delta;
+#ifndef LPMP_ABLATE_LB_TRACK
         if (g == 0) lb[uni<G>(o.peer)] = LPMP_NAN;
+#endif
       }
     }
     for (int k = KS; k < n_send; ++k) {
@@ -560,7 +564,9 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
     }
     own_g[g] = theta;
   }
+#ifndef LPMP_ABLATE_LB_TRACK
   { const double ob = vec_min<G, L>(vl ? theta : LPMP_INF); if (live && g == 0) lb[uni<G>(hdr->factor)] = ob; }
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------
