@@ -654,6 +654,163 @@ sweep_potts_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
   { const double ob = vec_min<L, L>(live ? theta : LPMP_INF); if (live && g == 0) lb[rec.factor] = ob; }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Potts fast path, packed form: as sweep_potts_kernel, with the factor's record + ops in one packet and the
+// vectors / coupling of up to 4 receives and 4 sends requested before anything is reduced (a 512 x 512 grid is
+// launch-latency bound: what counts is the length of one factor's dependent chain).
+// -------------------------------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ void two_min_merge(double& a1, double& a2) {   // two smallest over the L-lane group (multiset)
+  auto step = [&](double b1, double b2) {
+    const double n1 = fmin(a1, b1);
+    const double n2 = fmin(fmax(a1, b1), fmin(a2, b2));
+    a1 = n1; a2 = n2;
+  };
+  step(dpp_mov_f64<0xB1>(a1), dpp_mov_f64<0xB1>(a2));
+  if constexpr (L >= 4) step(dpp_mov_f64<0x4E>(a1), dpp_mov_f64<0x4E>(a2));
+  if constexpr (L >= 8) step(dpp_mov_f64<0x141>(a1), dpp_mov_f64<0x141>(a2));
+  if constexpr (L >= 16) step(dpp_mov_f64<0x140>(a1), dpp_mov_f64<0x140>(a2));
+  if constexpr (L >= 32) step(shfl_xor_f64(a1, 16), shfl_xor_f64(a2, 16));
+}
+
+template <int L>
+__global__ void __launch_bounds__(256)
+sweep_potts_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual, const double* __restrict__ cdata,
+                      double* __restrict__ lb, int64_t count, int stride, int flags) {
+  constexpr int GPB = 256 / L;
+  constexpr int KR = 4, KS = 4;
+  constexpr int PIECES = 3 * (1 + PK_MAX_OPS);
+  __shared__ double2_t lds_pk[GPB][PIECES];
+  const int grp = threadIdx.x / L, g = threadIdx.x % L;
+  const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
+  const bool live = idx < count;
+  const int pieces = 3 * stride;
+  if (live) {
+    const double2_t* src = reinterpret_cast<const double2_t*>(packets + idx * stride);
+    for (int p = g; p < pieces; p += L) lds_pk[grp][p] = src[p];
+  }
+  wave_sync();
+  const UpdRec* hdr = reinterpret_cast<const UpdRec*>(&lds_pk[grp][0]);
+  const Op* lop = reinterpret_cast<const Op*>(&lds_pk[grp][3]);
+  const int n_recv = live ? (int)hdr->n_recv : 0;
+  const int n_send = live ? (int)hdr->n_send : 0;
+  const bool preload_ok = live && (hdr->kind_flags & UPD_PRELOAD_OK) != 0;
+  double* own_g = dual + (live ? hdr->dual_off : 0);
+  double theta = live ? own_g[g] : 0.0;
+  double sm[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    sm[k] = 0.0;
+    if (preload_ok && k < n_send) {
+      const Op& o = lop[n_recv + k];
+      sm[k] = dual[o.peer_dual + (((o.info >> 5) & 1) ? L : 0) + g];
+    }
+  }
+  double mnew[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) mnew[k] = 0.0;
+  int max_recv = n_recv;
+#pragma unroll
+  for (int m = 32; m >= L; m >>= 1) max_recv = max(max_recv, __shfl_xor(max_recv, m, 64));
+  const int lane = threadIdx.x & 63;
+  const unsigned long long gmask = (L == 64 ? ~0ull : ((1ull << L) - 1ull)) << (lane - g);
+
+  auto chunk = [&](const int c, auto fw_tag) {
+    constexpr bool FW = decltype(fw_tag)::value;
+    double msv[KR], mov[KR], diff[KR];
+    int64_t msoff[KR];
+    int defer[KR];
+#pragma unroll
+    for (int j = 0; j < KR; ++j) {               // request everything first
+      msv[j] = 0.0; mov[j] = 0.0; diff[j] = 0.0; msoff[j] = 0; defer[j] = 0;
+      if (c + j < n_recv) {
+        const Op& o = lop[c + j];
+        const int side = (o.info >> 5) & 1;
+        msoff[j] = o.peer_dual + (side == 0 ? 0 : L) + g;
+        msv[j] = dual[msoff[j]];
+        mov[j] = dual[o.peer_dual + (side == 0 ? L : 0) + g];
+        diff[j] = cdata[o.peer_const];
+        defer[j] = FW ? o.pad : 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KR; ++j) {
+      if (c + j >= max_recv) break;
+      const bool act = c + j < n_recv;
+      double a1 = mov[j], a2 = LPMP_INF;
+      two_min_merge<L>(a1, a2);
+      // exactly one lane may take the role of "the" minimum: the lowest lane holding a1
+      const unsigned long long holders = __ballot(mov[j] == a1);
+      const int first_holder = __ffsll((long long)(holders & gmask)) - 1;
+      const double min_except = (lane == first_holder) ? a2 : a1;
+      double pb = LPMP_INF;
+      if (act) {
+        const double q = fmin(0.0 + mov[j], diff[j] + min_except);
+        const double delta = msv[j] + q;
+        theta += delta;
+        const double mn = msv[j] - delta;
+        pb = mn + q;
+        bool stored = false;
+        if constexpr (FW) {
+          if (defer[j]) {
+#pragma unroll
+            for (int q2 = 0; q2 < KR; ++q2) if (q2 == c + j) mnew[q2] = mn;
+            stored = true;
+          }
+        }
+        if (!stored) dual[msoff[j]] = mn;
+      }
+      if (!(FW && defer[j])) {
+        pb = vec_min<L, L>(pb);
+        if (act && g == 0) lb[lop[c + j].peer] = pb;
+      }
+    }
+  };
+  if (max_recv > 0) chunk(0, std::true_type{});
+  for (int c = KR; c < max_recv; c += KR) chunk(c, std::false_type{});
+
+  if (live) {
+    const double snap = theta;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (k < n_send) {
+        const Op& o = lop[n_recv + k];
+        double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? L : 0);
+        const int fw = o.pad;
+        double cur;
+        if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
+        else cur = preload_ok ? sm[k] : ms[g];
+        const double delta = o.omega * snap;
+        ms[g] = cur + delta;
+        theta -= delta;
+        if (g == 0) lb[o.peer] = LPMP_NAN;
+      }
+    }
+    for (int k = KS; k < n_send; ++k) {
+      const Op& o = lop[n_recv + k];
+      double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? L : 0);
+      const double delta = o.omega * snap;
+      ms[g] += delta;
+      theta -= delta;
+      if (g == 0) lb[o.peer] = LPMP_NAN;
+    }
+    if (flags & SWEEP_RESIDUAL) {
+      double residual = 0.0;
+      for (int k = 0; k < n_send; ++k) {
+        const Op& o = lop[n_recv + k];
+        double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? L : 0);
+        residual += o.omega;
+        const double delta = residual * theta;
+        ms[g] += delta;
+        theta -= delta;
+      }
+    }
+    own_g[g] = theta;
+  }
+  { const double ob = vec_min<L, L>(live ? theta : LPMP_INF); if (live && g == 0) lb[hdr->factor] = ob; }
+}
+
 // -------------------------------------------------------------------------------------------------
 // Lower bound (reference LP::LowerBound, LP_MP.h:1507-1518): per-factor bound, then a fixed-order sum.
 // -------------------------------------------------------------------------------------------------
@@ -837,6 +994,12 @@ bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual
     case KC_DENSE_16: if (km >= 4) PK_LAUNCH(16, 4); else PK_LAUNCH(16, 2); return true;
     case KC_DENSE_8: PK_LAUNCH(8, 4); return true;
     case KC_DENSE_4: PK_LAUNCH(4, 4); return true;
+#define PPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL>), blocks(256 / LL), dim3(256), 0, s, packets, dual, cdata, lb, count, stride, flags)
+    case KC_POTTS_32: PPK_LAUNCH(32); return true;
+    case KC_POTTS_16: PPK_LAUNCH(16); return true;
+    case KC_POTTS_8: PPK_LAUNCH(8); return true;
+    case KC_POTTS_4: PPK_LAUNCH(4); return true;
+#undef PPK_LAUNCH
     default: return false;
   }
 #undef PK_LAUNCH

@@ -517,10 +517,10 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       std::stable_sort(out.recs.begin() + lr.begin, out.recs.begin() + lr.end, [](const UpdRec& a, const UpdRec& b) {
         return a.n_recv != b.n_recv ? a.n_recv > b.n_recv : a.n_send > b.n_send;
       });
-  // packed form for the dense fast classes
+  // packed form for the fast classes
   static_assert(sizeof(UpdRec) == sizeof(Op), "a packet slot holds either record");
   for (auto& lr : out.launches) {
-    if (lr.kclass < KC_DENSE_4 || lr.kclass > KC_DENSE_32) continue;
+    if (lr.kclass == KC_GENERIC) continue;   // dense and Potts fast classes
     int kmax = 0;
     for (int64_t i = lr.begin; i < lr.end; ++i) kmax = std::max<int>(kmax, out.recs[i].n_recv + out.recs[i].n_send);
     if (kmax > PK_MAX_OPS) continue;

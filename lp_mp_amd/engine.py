@@ -20,8 +20,8 @@ KCLASS_NAMES = ["generic", "dense4", "dense8", "dense16", "dense32", "potts4", "
 # kernel symbols as rocprofv3 prints them: dense classes run the packed kernel (KMAX 2 at L >= 16, 4 below) whenever a
 # launch's factors have at most 8 active messages, else sweep_dense_kernel<L>
 KERNEL_NAMES = ["sweep_generic_kernel", "sweep_dense_pk_kernel<4, 4>", "sweep_dense_pk_kernel<8, 4>",
-                "sweep_dense_pk_kernel<16, 2>", "sweep_dense_pk_kernel<32, 2>", "sweep_potts_kernel<4>",
-                "sweep_potts_kernel<8>", "sweep_potts_kernel<16>", "sweep_potts_kernel<32>"]
+                "sweep_dense_pk_kernel<16, 2>", "sweep_dense_pk_kernel<32, 2>", "sweep_potts_pk_kernel<4>",
+                "sweep_potts_pk_kernel<8>", "sweep_potts_pk_kernel<16>", "sweep_potts_pk_kernel<32>"]
 MEM_HOST, MEM_DEVICE = 0, 1
 
 EXPORTS = [
