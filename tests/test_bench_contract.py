@@ -1,0 +1,49 @@
+"""bench.py pieces that do not need a GPU: the CPU-baseline leg, the PMC traffic lookup, and (on the GPU box) the
+shape of the JSON line the driver parses."""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from lp_mp_amd import model as M, synthetic as S  # noqa: E402
+
+
+def _args(**kw):
+    d = dict(grid=1024, labels=32, pairwise="dense", order="colour_major", mode="anisotropic", cpu_sample_grid=24)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def test_cpu_baseline_leg_runs_the_oracle_on_a_bounded_sample():
+    a = _args(cpu_sample_grid=16)
+    out = bench.cpu_baseline(a, S, M)
+    assert out["kind"] == "port" and out["cores"] == 1 and out["unit"] == "msg-updates/s" and out["value"] > 0
+    assert "16x16" in out["sample"]
+
+
+def test_pmc_traffic_lookup_matches_committed_profile():
+    traffic, src = bench.pmc_traffic("sweep_dense_pk_kernel<32, 2>", _args())
+    assert src is not None and os.path.exists(os.path.join(ROOT, src))
+    assert 1e9 < traffic < 3e10
+    assert bench.pmc_traffic("sweep_dense_pk_kernel<32, 2>", _args(grid=512)) == (None, None)
+
+
+@pytest.mark.gpu
+def test_bench_json_line_contract():
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "128", "--steps", "3", "--warmup", "1",
+                                   "--cpu-sample-grid", "16"], text=True, cwd=ROOT, timeout=600)
+    d = json.loads(out.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["cpu_baseline"]["kind"] == "port"
