@@ -18,7 +18,8 @@
 namespace lpmp {
 void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
                   double* lb, int64_t first, int64_t count, int flags, hipStream_t s);
-bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, double* lb, int64_t count, int flags, hipStream_t s);
+bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, const Op* ops, int stride, double* dual, const double* cdata,
+                         double* lb, int64_t count, int flags, hipStream_t s);
 void launch_lb_collect_stale(const double* lb, int64_t n, int32_t* list, unsigned long long* counter, hipStream_t s);
 void launch_factor_lb_list(const void* recs, const double* dual, const double* cdata, double* out, const int32_t* list, int64_t count, hipStream_t s);
 void launch_factor_lb(const void* recs, const double* dual, const double* cdata, double* out, int64_t count, hipStream_t s);
@@ -291,8 +292,9 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
     if (only_level > 0 && lr.level != only_level) continue;
     hipEvent_t a = nullptr, b = nullptr;
     if (timed) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, stream)); }
-    if (!(e->use_packed && lr.stride > 0 &&
-          launch_sweep_packed(lr.kclass, s.packets + lr.pk_begin, lr.stride, e->d_dual, e->d_const, e->d_lb, lr.end - lr.begin, e->rtype, stream)))
+    if (!(e->use_packed && lr.stride != 0 &&
+          launch_sweep_packed(lr.kclass, lr.stride > 0 ? s.packets + lr.pk_begin : nullptr, s.recs + lr.begin, s.ops, lr.stride, e->d_dual,
+                              e->d_const, e->d_lb, lr.end - lr.begin, e->rtype, stream)))
       launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, e->d_lb, lr.begin, lr.end - lr.begin, e->rtype, stream);
     if (timed) {
       HIP_CHECK(hipEventRecord(b, stream));

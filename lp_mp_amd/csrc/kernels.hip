@@ -384,15 +384,44 @@ template <int G> __device__ __forceinline__ int64_t uni64(int64_t v) {
   } else return v;
 }
 
+// Stage one factor's record + ops in the lane group's LDS slab.
+//   stride > 0: packet mode, record and ops contiguous at packets[idx * stride]   (one hop)
+//   stride < 0: indirect mode, record at recs[idx], then its ops at ops[op_begin]   (two hops, any op count <= cap)
+template <int G>
+__device__ __forceinline__ void load_packet(double2_t* slab, const Op* __restrict__ packets, const UpdRec* __restrict__ recs,
+                                            const Op* __restrict__ ops, int64_t idx, int stride, bool live, int g) {
+  if (stride > 0) {
+    if (live) {
+      const double2_t* src = reinterpret_cast<const double2_t*>(packets + idx * stride);
+      for (int p = g; p < 3 * stride; p += G) slab[p] = src[p];
+    }
+    wave_sync();
+  } else {
+    if (live) {
+      const double2_t* src = reinterpret_cast<const double2_t*>(recs + idx);
+      if (g < 3) slab[g] = src[g];
+    }
+    wave_sync();
+    if (live) {
+      const UpdRec* hdr = reinterpret_cast<const UpdRec*>(slab);
+      const int n_ops = hdr->n_recv + hdr->n_send;
+      const double2_t* src = reinterpret_cast<const double2_t*>(ops + hdr->op_begin);
+      for (int p = g; p < 3 * n_ops; p += G) slab[3 + p] = src[p];
+    }
+    wave_sync();
+  }
+}
+
 template <int L, int KMAX>
 __global__ void __launch_bounds__(256)
-sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual, const double* __restrict__ cdata,
-                      double* __restrict__ lb, int64_t count, int stride, int flags) {
+sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
+                      double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
+                      int64_t count, int stride, int flags) {
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
   constexpr int KS = 4;                          // sends whose target vectors are prefetched / forwarded
   constexpr int NFW = 4;                         // receives whose result can be forwarded in registers
-  constexpr int PIECES = 3 * (1 + PK_MAX_OPS);   // 16-B pieces of the largest packet
+  constexpr int PIECES = 3 * (1 + pk_indirect_cap(L));   // 16-B pieces of the largest packet / op list
   __shared__ double2_t lds_pk[GPB][PIECES];
   __shared__ double lds_mo[GPB][L];
   __shared__ double lds_q[GPB][L];
@@ -400,12 +429,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual,
   const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
   const bool live = idx < count;
   const int c2 = g % CL, rl = g / CL;
-  const int pieces = 3 * stride;
-  if (live) {
-    const double2_t* src = reinterpret_cast<const double2_t*>(packets + idx * stride);
-    for (int p = g; p < pieces; p += G) lds_pk[grp][p] = src[p];
-  }
-  wave_sync();
+  load_packet<G>(lds_pk[grp], packets, recs, ops, idx, stride, live, g);
   const UpdRec* hdr = reinterpret_cast<const UpdRec*>(&lds_pk[grp][0]);
   const Op* lop = reinterpret_cast<const Op*>(&lds_pk[grp][3]);
   const int n_recv = live ? uni<G>((int)hdr->n_recv) : 0;
@@ -676,21 +700,17 @@ __device__ __forceinline__ void two_min_merge(double& a1, double& a2) {   // two
 
 template <int L>
 __global__ void __launch_bounds__(256)
-sweep_potts_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual, const double* __restrict__ cdata,
-                      double* __restrict__ lb, int64_t count, int stride, int flags) {
+sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
+                      double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
+                      int64_t count, int stride, int flags) {
   constexpr int GPB = 256 / L;
   constexpr int KR = 4, KS = 4;
-  constexpr int PIECES = 3 * (1 + PK_MAX_OPS);
+  constexpr int PIECES = 3 * (1 + pk_indirect_cap(L));
   __shared__ double2_t lds_pk[GPB][PIECES];
   const int grp = threadIdx.x / L, g = threadIdx.x % L;
   const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
   const bool live = idx < count;
-  const int pieces = 3 * stride;
-  if (live) {
-    const double2_t* src = reinterpret_cast<const double2_t*>(packets + idx * stride);
-    for (int p = g; p < pieces; p += L) lds_pk[grp][p] = src[p];
-  }
-  wave_sync();
+  load_packet<L>(lds_pk[grp], packets, recs, ops, idx, stride, live, g);
   const UpdRec* hdr = reinterpret_cast<const UpdRec*>(&lds_pk[grp][0]);
   const Op* lop = reinterpret_cast<const Op*>(&lds_pk[grp][3]);
   const int n_recv = live ? (int)hdr->n_recv : 0;
@@ -983,18 +1003,19 @@ static int dense_kmax() {
   return k;
 }
 
-bool launch_sweep_packed(int kclass, const Op* packets, int stride, double* dual, const double* cdata, double* lb, int64_t count, int flags, hipStream_t s) {
+bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, const Op* ops, int stride, double* dual, const double* cdata,
+                         double* lb, int64_t count, int flags, hipStream_t s) {
   if (count <= 0) return true;
   if (stride > 1 + PK_MAX_OPS) return false;
   auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
   const int km = dense_kmax();
-#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, dual, cdata, lb, count, stride, flags)
+#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
   switch (kclass) {
     case KC_DENSE_32: if (km >= 4) PK_LAUNCH(32, 4); else if (km == 1) PK_LAUNCH(32, 1); else PK_LAUNCH(32, 2); return true;
     case KC_DENSE_16: if (km >= 4) PK_LAUNCH(16, 4); else PK_LAUNCH(16, 2); return true;
     case KC_DENSE_8: PK_LAUNCH(8, 4); return true;
     case KC_DENSE_4: PK_LAUNCH(4, 4); return true;
-#define PPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL>), blocks(256 / LL), dim3(256), 0, s, packets, dual, cdata, lb, count, stride, flags)
+#define PPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
     case KC_POTTS_32: PPK_LAUNCH(32); return true;
     case KC_POTTS_16: PPK_LAUNCH(16); return true;
     case KC_POTTS_8: PPK_LAUNCH(8); return true;

@@ -517,39 +517,43 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       std::stable_sort(out.recs.begin() + lr.begin, out.recs.begin() + lr.end, [](const UpdRec& a, const UpdRec& b) {
         return a.n_recv != b.n_recv ? a.n_recv > b.n_recv : a.n_send > b.n_send;
       });
-  // packed form for the fast classes
+  // flags of the fast-class records, kept in recs / ops themselves (packets are plain copies)
   static_assert(sizeof(UpdRec) == sizeof(Op), "a packet slot holds either record");
   for (auto& lr : out.launches) {
     if (lr.kclass == KC_GENERIC) continue;   // dense and Potts fast classes
     int kmax = 0;
-    for (int64_t i = lr.begin; i < lr.end; ++i) kmax = std::max<int>(kmax, out.recs[i].n_recv + out.recs[i].n_send);
-    if (kmax > PK_MAX_OPS) continue;
+    for (int64_t i = lr.begin; i < lr.end; ++i) {
+      UpdRec& r = out.recs[i];
+      Op* o = out.ops.data() + r.op_begin;
+      kmax = std::max<int>(kmax, r.n_recv + r.n_send);
+      auto same = [&](int a, int b) { return o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1); };
+      bool preload_ok = true;   // a send may be requested early unless a receive of this update writes the same vector
+      for (int a = 0; a < r.n_recv && preload_ok; ++a)
+        for (int b = r.n_recv; b < r.n_recv + r.n_send; ++b)
+          if (same(a, b)) { preload_ok = false; break; }
+      if (preload_ok) r.kind_flags |= UPD_PRELOAD_OK;
+      // register forwarding: send b targets the vector receive a (one of the first 4) has just rewritten ->
+      // the receive keeps its result in a register (pad = 1: no store) and the send reads it from there
+      // (pad = a + 1); at most one send per receive, and only if no other receive/send touches that vector
+      for (int b = r.n_recv; b < r.n_recv + r.n_send && b - r.n_recv < 4; ++b) {
+        int hit = -1, n_hit = 0, n_send_same = 0;
+        for (int a = 0; a < r.n_recv; ++a) if (same(a, b)) { hit = a; ++n_hit; }
+        for (int b2 = r.n_recv; b2 < r.n_recv + r.n_send; ++b2) if (same(b2, b)) ++n_send_same;
+        if (n_hit == 1 && n_send_same == 1 && hit < 4) { o[hit].pad = 1; o[b].pad = hit + 1; }
+      }
+    }
+    if (kmax > PK_MAX_OPS) {                 // too many ops for a packet: indirect mode if they fit the LDS slab
+      if (kmax <= pk_indirect_cap(out.recs[lr.begin].d0)) lr.stride = -1;
+      continue;
+    }
     lr.stride = 1 + kmax;
     lr.pk_begin = (int64_t)out.packets.size();
     out.packets.resize(out.packets.size() + (size_t)(lr.end - lr.begin) * lr.stride);
     for (int64_t i = lr.begin; i < lr.end; ++i) {
       Op* slot = out.packets.data() + lr.pk_begin + (i - lr.begin) * lr.stride;
-      UpdRec r = out.recs[i];
-      const Op* o = out.ops.data() + r.op_begin;
-      bool preload_ok = true;   // a send may be prefetched unless a receive of this update writes the same vector
-      for (int a = 0; a < r.n_recv; ++a)
-        for (int b = r.n_recv; b < r.n_recv + r.n_send; ++b)
-          if (o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1)) preload_ok = false;
-      if (preload_ok) r.kind_flags |= UPD_PRELOAD_OK;
+      const UpdRec& r = out.recs[i];
       std::memcpy(slot, &r, sizeof(Op));
-      for (int k = 0; k < r.n_recv + r.n_send; ++k) { slot[1 + k] = o[k]; slot[1 + k].pad = 0; }
-      // register forwarding: send b targets the vector receive a (one of the first 4) has just rewritten ->
-      // the receive keeps its result in a register (pad = 1: no store) and the send reads it from there
-      // (pad = a + 1); at most one send per receive, and only if no later receive/send touches that vector
-      for (int b = r.n_recv; b < r.n_recv + r.n_send && b - r.n_recv < 4; ++b) {
-        int hit = -1, n_hit = 0;
-        for (int a = 0; a < r.n_recv; ++a)
-          if (o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1)) { hit = a; ++n_hit; }
-        int n_send_same = 0;
-        for (int b2 = r.n_recv; b2 < r.n_recv + r.n_send; ++b2)
-          if (o[b2].peer_dual == o[b].peer_dual && ((o[b2].info >> 5) & 1) == ((o[b].info >> 5) & 1)) ++n_send_same;
-        if (n_hit == 1 && n_send_same == 1 && hit < 4) { slot[1 + hit].pad = 1; slot[1 + b].pad = hit + 1; }
-      }
+      for (int k = 0; k < r.n_recv + r.n_send; ++k) slot[1 + k] = out.ops[r.op_begin + k];
     }
   }
 }

@@ -76,6 +76,10 @@ struct LevelRange {            // one kernel launch: a range of UpdRec indices o
   int32_t stride = 0; int64_t pk_begin = 0;
 };
 constexpr int PK_MAX_OPS = 8;                 // packets hold at most this many ops per factor
+// launches whose factors have more ops than that (but at most this many: the LDS slab of a lane group) run the
+// same kernels in INDIRECT mode (LevelRange::stride < 0): record from recs[], then all its ops from ops[] in one
+// coalesced load — two dependent hops instead of one per op
+constexpr int pk_indirect_cap(int labels) { return labels >= 16 ? 32 : labels >= 8 ? 16 : 8; }
 constexpr int32_t UPD_PRELOAD_OK = 1 << 16;   // UpdRec::kind_flags: no send targets a vector a receive writes
 
 struct Schedule {             // executable form of one (factor list, omega, mask) sweep

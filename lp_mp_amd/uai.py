@@ -1,0 +1,68 @@
+"""UAI (MARKOV) reader for unary / pairwise models: the text format of the reference's MRF tests
+(reference test/graphical_model.cpp:11-30).  Table entries are taken as costs, as the reference's test does;
+variables without a unary table get a zero unary ("not all unaries are present, hence zero unaries must be
+added", graphical_model.cpp:10).  Builds the model through the LP mirror in variable order with relations
+u_i -> p_ij -> u_j (i < j), i.e. what LP_MP-MRF's problem constructor feeds LP<FMC_SRMP>."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+from . import lp as LPM
+from . import model as M
+
+
+def parse_uai(text: str) -> Tuple[List[int], List[Tuple[Tuple[int, ...], np.ndarray]]]:
+    tok = text.split()
+    if not tok or tok[0] != "MARKOV":
+        raise RuntimeError("UAI input must start with MARKOV")
+    pos = 1
+    n = int(tok[pos]); pos += 1
+    card = [int(t) for t in tok[pos:pos + n]]; pos += n
+    n_f = int(tok[pos]); pos += 1
+    scopes = []
+    for _ in range(n_f):
+        k = int(tok[pos]); pos += 1
+        scopes.append(tuple(int(t) for t in tok[pos:pos + k])); pos += k
+    tables = []
+    for sc in scopes:
+        size = int(tok[pos]); pos += 1
+        vals = np.array([float(t) for t in tok[pos:pos + size]]); pos += size
+        if size != int(np.prod([card[v] for v in sc])):
+            raise RuntimeError("UAI table size does not match its scope")
+        tables.append((sc, vals.reshape([card[v] for v in sc])))
+    return card, tables
+
+
+def FMC_SRMP():
+    U = LPM.FactorContainer(LPM.UnarySimplexFactor, 0)
+    P = LPM.FactorContainer(LPM.PairwiseSimplexFactor, 1)
+    ML = LPM.MessageContainer(LPM.UnaryPairwiseMessage(0), 0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, 0)
+    MR = LPM.MessageContainer(LPM.UnaryPairwiseMessage(1), 0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, 1)
+    return LPM.FMC("FMC_SRMP", [U, P], [ML, MR]), U, P, ML, MR
+
+
+def build_lp_from_uai(text: str, device: int = 0) -> LPM.LP:
+    card, tables = parse_uai(text)
+    fmc, U, P, ML, MR = FMC_SRMP()
+    lp = LPM.LP(fmc, device)
+    unary = [np.zeros(c) for c in card]
+    for sc, t in tables:
+        if len(sc) == 1:
+            unary[sc[0]] = unary[sc[0]] + t
+        elif len(sc) != 2:
+            raise RuntimeError("only unary and pairwise UAI factors are supported")
+    u = [lp.add_factor(U, c) for c in unary]
+    for sc, t in tables:
+        if len(sc) != 2:
+            continue
+        i, j = sc
+        if i > j:
+            i, j, t = j, i, t.T
+        p = lp.add_factor(P, card[i], card[j], np.ascontiguousarray(t))
+        lp.add_message(ML, u[i], p)
+        lp.add_message(MR, u[j], p)
+        lp.AddFactorRelation(u[i], p)
+        lp.AddFactorRelation(p, u[j])
+    return lp
