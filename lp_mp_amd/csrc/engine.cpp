@@ -553,7 +553,8 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
     HIP_CHECK(hipMalloc((void**)&e->d_stale, (size_t)p.nf * sizeof(int32_t)));
     HIP_CHECK(hipMalloc((void**)&e->d_stale_n, sizeof(unsigned long long)));
     HIP_CHECK(hipHostMalloc((void**)&e->h_stale_n, sizeof(unsigned long long), hipHostMallocDefault));
-    HIP_CHECK(hipMemset(e->d_lb, 0xFF, (size_t)p.nf * sizeof(double)));   // all NaN: nothing tracked yet
+    HIP_CHECK(hipMemsetAsync(e->d_lb, 0xFF, (size_t)p.nf * sizeof(double), e->stream));   // all NaN: nothing tracked yet
+    HIP_CHECK(hipStreamSynchronize(e->stream));
     e->lb_all_stale = true;
     e->plan = std::move(pl);
   });

@@ -90,7 +90,6 @@ struct GenLds {
   double own[GEN_MAXD];
   double snap[GEN_MAXD];
   double dl[GEN_MAXD];
-  double val[GEN_MAXD];
 };
 
 // pairwise cost T(a,b) of a pairwise factor (dense table or Potts scalar)
