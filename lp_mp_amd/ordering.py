@@ -1,0 +1,76 @@
+"""Variable orders that expose parallelism.
+
+The sweep is Gauss-Seidel over the factor ORDER, which is input data (AddFactorRelation, reference
+include/LP_MP.h:698-702): the engine runs whatever order it is given, level by level.  A grid in row-major
+variable order has H+W-1 dependent levels per direction; the same grid in a 2-colour order has 2.  These helpers
+compute a colour-major variable order for an arbitrary pairwise graph: variables sorted by colour, so that with
+relations u_i -> p_ij -> u_j (i < j) every colour class is one level.  Different order = different (equally valid)
+trajectory of the dual ascent, not a different algorithm.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def two_colouring(n: int, ei: np.ndarray, ej: np.ndarray):
+    """colours in {0,1} if the graph is bipartite, else None (BFS depth parity per component)."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import breadth_first_order, connected_components
+    a = coo_matrix((np.ones(ei.shape[0], np.int8), (ei, ej)), shape=(n, n)).tocsr()
+    a = a + a.T
+    n_comp, comp = connected_components(a, directed=False)
+    depth = np.zeros(n, np.int64)
+    seen = np.zeros(n, bool)
+    # one BFS per component root; components are usually few (1 for grids)
+    roots = np.full(n_comp, -1, np.int64)
+    first = np.unique(comp, return_index=True)[1]
+    roots[comp[first]] = first
+    for r in roots:
+        order, pred = breadth_first_order(a, int(r), directed=False, return_predecessors=True)
+        d = np.zeros(n, np.int64)
+        for v in order[1:]:                      # BFS order: the predecessor's depth is final when v is reached
+            d[v] = d[pred[v]] + 1
+        depth[order] = d[order]
+        seen[order] = True
+    col = depth & 1
+    return col if np.all(col[ei] != col[ej]) else None
+
+
+def greedy_colouring(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0) -> np.ndarray:
+    """Luby / Jones-Plassmann style parallel greedy colouring with numpy: in every round the uncoloured vertices that
+    beat all their uncoloured neighbours (random priorities) take the smallest colour their neighbours do not use.
+    At most 63 colours (max degree < 63 is plenty for sparse MRFs)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    prio = rng.permutation(n)
+    colour = np.full(n, -1, np.int64)
+    a = np.concatenate([ei, ej]); b = np.concatenate([ej, ei])          # directed both ways
+    while True:
+        un = colour < 0
+        if not un.any():
+            return colour
+        both = un[a] & un[b]
+        loser = np.zeros(n, bool)
+        loser[a[both & (prio[a] < prio[b])]] = True
+        cand = un & ~loser
+        used = np.zeros(n, np.uint64)
+        m = cand[a] & ~un[b]                                            # coloured neighbours of candidates
+        if m.any():
+            np.bitwise_or.at(used, a[m], np.uint64(1) << colour[b[m]].astype(np.uint64))
+        free = ~used[cand]
+        low = free & (~free + np.uint64(1))                             # lowest set bit
+        c = np.log2(low.astype(np.float64)).astype(np.int64)
+        if np.any(c >= 63):
+            raise RuntimeError("graph needs more than 63 colours")
+        colour[cand] = c
+
+
+def colour_major_order(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0) -> np.ndarray:
+    """rank[v] = position of variable v in a colour-major order (2 colours if the graph is bipartite)."""
+    ei = np.asarray(ei, np.int64); ej = np.asarray(ej, np.int64)
+    col = two_colouring(n, ei, ej)
+    if col is None:
+        col = greedy_colouring(n, ei, ej, seed)
+    order = np.argsort(col, kind="stable")
+    rank = np.empty(n, np.int64)
+    rank[order] = np.arange(n)
+    return rank

@@ -10,6 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 m_e = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 passes = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+colour = len(sys.argv) > 5 and sys.argv[5] == "colour"
 t0 = time.time()
 rng = np.random.Generator(np.random.PCG64(1))
 e = rng.integers(0, n, size=(int(m_e * 1.02) + 16, 2))
@@ -18,6 +19,13 @@ key = np.minimum(e[:, 0], e[:, 1]) * n + np.maximum(e[:, 0], e[:, 1])
 key = np.unique(key)[:m_e]
 ei, ej = key // n, key % n
 m_e = ei.shape[0]
+if colour:   # relabel the variables in a colour-major order (lp_mp_amd/ordering.py): few, wide levels
+    from lp_mp_amd import ordering
+    tc = time.time()
+    rank = ordering.colour_major_order(n, ei, ej)
+    ri, rj = rank[ei], rank[ej]
+    ei, ej = np.minimum(ri, rj), np.maximum(ri, rj)
+    print("colour-major order %.1fs" % (time.time() - tc), flush=True)
 model = S.mrf_model(n, L, ei, ej, np.zeros(n * L), device_const=True)
 print("model %.1fs  factors %d messages %d" % (time.time() - t0, model.n_factors, model.n_messages), flush=True)
 dev = torch.device("cuda:0")
