@@ -375,8 +375,10 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     int32_t lv = 0;
     for (int32_t g : touched) lv = std::max(lv, last_level[g]);
     const int32_t prev = last_update_of[f];
-    bool merge = fuse && prev >= 0 && nr + ns > 0 && n_send_of[prev] == 0 && level[prev] == lv &&
-                 n_recv_of[prev] + nr + ns <= 32000;
+    // u2 must not receive: the packed kernels request the vectors of several receives of a record at once, so a
+    // record may not receive through the same message twice (forward and backward masks can both select it)
+    bool merge = fuse && prev >= 0 && nr == 0 && ns > 0 && n_send_of[prev] == 0 && level[prev] == lv &&
+                 n_recv_of[prev] + ns <= 32000;
     if (merge)
       for (int32_t g : touched)
         if (last_level[g] == lv && last_toucher[g] != prev) { merge = false; break; }
@@ -522,6 +524,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   for (auto& lr : out.launches) {
     if (lr.kclass == KC_GENERIC) continue;   // dense and Potts fast classes
     int kmax = 0;
+    bool dup_recv = false;
     for (int64_t i = lr.begin; i < lr.end; ++i) {
       UpdRec& r = out.recs[i];
       Op* o = out.ops.data() + r.op_begin;
@@ -532,6 +535,11 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         for (int b = r.n_recv; b < r.n_recv + r.n_send; ++b)
           if (same(a, b)) { preload_ok = false; break; }
       if (preload_ok) r.kind_flags |= UPD_PRELOAD_OK;
+      // two receives, or two sends, into one vector (duplicate messages between the same two factors)
+      for (int a = 0; a < r.n_recv && !dup_recv; ++a)
+        for (int a2 = a + 1; a2 < r.n_recv; ++a2) if (same(a, a2)) { dup_recv = true; break; }
+      for (int b = r.n_recv; b < r.n_recv + r.n_send && !dup_recv; ++b)
+        for (int b2 = b + 1; b2 < r.n_recv + r.n_send; ++b2) if (same(b, b2)) { dup_recv = true; break; }
       // register forwarding: send b targets the vector receive a (one of the first 4) has just rewritten ->
       // the receive keeps its result in a register (pad = 1: no store) and the send reads it from there
       // (pad = a + 1); at most one send per receive, and only if no other receive/send touches that vector
@@ -542,6 +550,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         if (n_hit == 1 && n_send_same == 1 && hit < 4) { o[hit].pad = 1; o[b].pad = hit + 1; }
       }
     }
+    if (dup_recv) continue;                  // only the op-by-op kernels are safe for that: stride stays 0
     if (kmax > PK_MAX_OPS) {                 // too many ops for a packet: indirect mode if they fit the LDS slab
       if (kmax <= pk_indirect_cap(out.recs[lr.begin].d0)) lr.stride = -1;
       continue;

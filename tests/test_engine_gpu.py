@@ -465,3 +465,21 @@ def test_size_limits_isolated_factors_and_empty_schedules(eng):
     assert eng.lower_bound() == 2.5 + 1.0 + 4.0                  # constant_ + sum of minima (LP_MP.h:1510)
     eng.compute_pass_custom(np.zeros(0, np.int32), [0], [], [0], [])   # empty iterator range
     assert eng.lower_bound() == 7.5
+
+
+def test_duplicate_messages_into_one_vector(eng):
+    """two messages of one type between the same unary and pairwise factor (both sides variable count): both
+    receives rewrite the same vector, so the kernels that request several receives at once must step aside"""
+    mt = [M.MsgType(0, 1, M.SCHED_LEFT, 0, 0, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, M.SCHED_LEFT, 0, 0, M.M_UNARY_PAIRWISE, 1)]
+    for L in (8, 32, 5):
+        rng = np.random.default_rng(L)
+        b = M.ModelBuilder(2, mt)
+        u = b.add_vector_factors(0, rng.uniform(0, 1, (6, L)))
+        for k in range(5):
+            p = b.add_dense_pairwise(1, rng.uniform(0, 1, (1, L, L)))[0]
+            b.add_messages(0, u[k], p); b.add_messages(1, u[k + 1], p)
+            b.add_messages(0, u[k], p)                      # duplicate
+            b.add_relations(u[k], p); b.add_relations(p, u[k + 1])
+        m = b.finish()
+        for mode in MODES:
+            _check(eng, m, mode, 3)

@@ -1,0 +1,121 @@
+"""Randomised parity: random factor graphs mixing every device kind, every message schedule, random label counts,
+random relations, every weight mode, both send rules, and random iterator-range passes — HIP engine vs oracle,
+duals bit for bit."""
+import numpy as np
+import pytest
+
+from lp_mp_amd import engine as E
+from lp_mp_amd import model as M
+from oracle.binding import Oracle
+
+pytestmark = pytest.mark.gpu
+MODES = (M.REPAM_ANISOTROPIC, M.REPAM_ANISOTROPIC2, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM)
+SCHEDS = (M.SCHED_LEFT, M.SCHED_RIGHT, M.SCHED_FULL, M.SCHED_ONLY_SEND, M.SCHED_NONE)
+
+
+def random_model(rng):
+    """unaries of two label counts, dense + Potts pairwise, vector-vector min-norm links, labeling-list factors"""
+    La, Lb = int(rng.choice([2, 3, 4, 5, 8, 16])), int(rng.choice([3, 4, 7, 8]))
+    s_up = [int(rng.choice(SCHEDS[:3])) for _ in range(4)]
+    s_mn = int(rng.choice(SCHEDS))
+    s_lab = int(rng.choice(SCHEDS[:4]))
+    # factor types: 0 unary(La) 1 unary(Lb) 2 pairwise(La,La) dense/potts 3 pairwise(La,Lb) dense 4 edge-label 5 triplet
+    mt = [M.MsgType(0, 2, s_up[0], 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 2, s_up[1], 0, 1, M.M_UNARY_PAIRWISE, 1),
+          M.MsgType(0, 3, s_up[2], 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(1, 3, s_up[3], 0, 1, M.M_UNARY_PAIRWISE, 1),
+          M.MsgType(0, 0, s_mn, 0, 0, M.M_MINNORM, 0)] + \
+         [M.MsgType(4, 5, s_lab, 0, 1, M.M_LABELING, k) for k in range(3)]
+    b = M.ModelBuilder(6, mt)
+    trip = [(0, 1, 1), (1, 0, 1), (1, 1, 0), (1, 1, 1)]
+    for k in range(3):
+        b.add_labeling_table([(1,)], trip, (k,))
+    na, nb = int(rng.integers(4, 14)), int(rng.integers(2, 8))
+    ua = b.add_vector_factors(0, rng.uniform(-1, 1, (na, La)))
+    ub = b.add_vector_factors(1, rng.uniform(-1, 1, (nb, Lb)))
+    rel = []
+    for _ in range(int(rng.integers(3, 2 * na))):
+        i, j = sorted(rng.choice(na, 2, replace=False))
+        if rng.uniform() < 0.5:
+            p = b.add_dense_pairwise(2, rng.uniform(-1, 1, (1, La, La)))[0]
+        else:
+            p = b.add_potts_pairwise(2, La, [rng.uniform(-1, 1)])[0]
+        b.add_messages(0, ua[i], p); b.add_messages(1, ua[j], p)
+        rel += [(ua[i], p), (p, ua[j])]
+    for _ in range(int(rng.integers(1, na))):
+        i, j = int(rng.integers(na)), int(rng.integers(nb))
+        p = b.add_dense_pairwise(3, rng.uniform(-1, 1, (1, La, Lb)))[0]
+        b.add_messages(2, ua[i], p); b.add_messages(3, ub[j], p)
+        rel += [(ua[i], p), (p, ub[j])]
+    for _ in range(int(rng.integers(0, na))):
+        i, j = rng.choice(na, 2, replace=False)
+        b.add_messages(4, ua[i], ua[j])
+    ne = int(rng.integers(3, 9))
+    e = b.add_vector_factors(4, rng.uniform(-1, 1, (ne, 1)), implicit_origin=bool(rng.integers(2)))
+    for _ in range(int(rng.integers(1, 5))):
+        t = b.add_vector_factors(5, rng.uniform(-0.5, 0.5, (1, 4)), implicit_origin=bool(rng.integers(2)))[0]
+        for k, ei in enumerate(rng.choice(ne, 3, replace=False)):
+            b.add_messages(5 + k, e[ei], t)
+            rel.append((e[ei], t))
+    if rng.uniform() < 0.8 and rel:                       # relations (a DAG by construction), sometimes none at all
+        keep = rng.uniform(size=len(rel)) < rng.uniform(0.3, 1.0)
+        r = np.array([x for x, k in zip(rel, keep) if k], np.int32).reshape(-1, 2)
+        if r.shape[0]:
+            b.add_relations(r[:, 0], r[:, 1])
+    b.constant = float(rng.uniform(-1, 1))
+    return b.finish()
+
+
+def random_rows(rng, plan_like, oracle, m):
+    """a random iterator-range pass: random factor subset in random order, random masks, random weights (row sums <= 1)"""
+    off, ent = oracle.msg_lists()
+    n = m.n_factors
+    f = rng.permutation(n)[: int(rng.integers(1, n + 1))].astype(np.int32)
+    caps = {M.SCHED_LEFT: (0, 1, 0, 1), M.SCHED_RIGHT: (1, 0, 1, 0), M.SCHED_FULL: (1, 1, 1, 1),
+            M.SCHED_ONLY_SEND: (1, 1, 0, 0), M.SCHED_NONE: (0, 0, 0, 0)}     # to_left, to_right, from_left, from_right
+    om, mk, oo, mo = [], [], [0], [0]
+    for fi in f:
+        ns = nr = 0
+        for x in ent[off[fi]:off[fi + 1]]:
+            msg, role = int(x) // 2, int(x) % 2
+            c = caps[m.mtypes[m.m_type[msg]].schedule]
+            ns += c[1] if role == 0 else c[0]
+            nr += c[3] if role == 0 else c[2]
+        w = rng.uniform(0, 1, ns) * (rng.uniform(size=ns) < 0.7)
+        if w.sum() > 0:
+            w = w / w.sum() * rng.uniform(0.2, 1.0)
+        om += list(w); mk += list((rng.uniform(size=nr) < 0.6).astype(np.uint8))
+        oo.append(len(om)); mo.append(len(mk))
+    return f, np.array(oo, np.int64), np.array(om, np.float64), np.array(mo, np.int64), np.array(mk, np.uint8)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_models_all_modes_and_custom_passes(seed):
+    rng = np.random.default_rng(1000 + seed)
+    m = random_model(rng)
+    eng = E.Engine(0)
+    try:
+        for rtype in (0, 1):
+            for mode in MODES:
+                o = Oracle(m)
+                o.set_reparametrization_type(rtype)
+                o.set_reparametrization(mode)
+                eng.upload(m)
+                eng.set_reparametrization_type(rtype)
+                eng.set_reparametrization(mode)
+                assert abs(eng.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+                eng.compute_pass(2); o.ComputePass(2)
+                eng.forward_pass(); o.ComputeForwardPass()
+                assert np.array_equal(eng.download_duals(), o.duals()), (seed, rtype, mode)
+                for _ in range(2):
+                    rows = random_rows(rng, None, o, m)
+                    eng.compute_pass_custom(*rows); o.compute_pass_custom(*rows)
+                eng.backward_pass(); o.ComputeBackwardPass()
+                eng.compute_pass(1); o.ComputePass(1)
+                assert np.array_equal(eng.download_duals(), o.duals()), (seed, rtype, mode)
+                lb, lbo = eng.lower_bound(), o.LowerBound()
+                assert abs(lb - lbo) <= 1e-9 * max(1.0, abs(lbo))
+                flb = eng.factor_lower_bounds()
+                ref = np.array([o.factor_lower_bound(f) for f in range(m.n_factors)])
+                assert np.max(np.abs(flb - ref)) <= 1e-12
+    finally:
+        eng.set_reparametrization_type(0)
+        eng.close()
