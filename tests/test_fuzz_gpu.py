@@ -119,3 +119,67 @@ def test_random_models_all_modes_and_custom_passes(seed):
     finally:
         eng.set_reparametrization_type(0)
         eng.close()
+
+
+def random_mrf(rng):
+    """pure unary / pairwise MRF on a random graph with ONE label count of a fast kernel class: every unary runs the
+    packed dense / Potts kernels, under odd orders (random subset of the relations), with occasional duplicate
+    messages and a random mix of dense and Potts edges or all of one kind"""
+    from lp_mp_amd import synthetic as S
+    L = int(rng.choice([4, 8, 16, 32]))
+    n = int(rng.integers(5, 40))
+    kind = rng.choice(["dense", "potts", "mixed"])
+    b = M.ModelBuilder(2, S.mrf_mtypes() if rng.uniform() < 0.7 else
+                       [M.MsgType(0, 1, M.SCHED_LEFT, 0, 0, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, M.SCHED_LEFT, 0, 0, M.M_UNARY_PAIRWISE, 1)])
+    u = b.add_vector_factors(0, rng.uniform(0, 1, (n, L)))
+    rel = []
+    for _ in range(int(rng.integers(n, 3 * n))):
+        i, j = sorted(rng.choice(n, 2, replace=False))
+        dense = kind == "dense" or (kind == "mixed" and rng.uniform() < 0.5)
+        p = b.add_dense_pairwise(1, rng.uniform(0, 1, (1, L, L)))[0] if dense else b.add_potts_pairwise(1, L, [rng.uniform(-0.5, 1)])[0]
+        b.add_messages(0, u[i], p); b.add_messages(1, u[j], p)
+        if rng.uniform() < 0.08:
+            b.add_messages(0, u[i], p)                      # duplicate message into the same vector
+        rel += [(u[i], p), (p, u[j])]
+    keep = rng.uniform(size=len(rel)) < rng.choice([1.0, 0.9, 0.5, 0.0])
+    r = np.array([x for x, k in zip(rel, keep) if k], np.int32).reshape(-1, 2)
+    if r.shape[0]:
+        b.add_relations(r[:, 0], r[:, 1])
+    return b.finish()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_mrfs_fast_kernels_multi_pass_calls_and_fused_custom_schedules(seed):
+    rng = np.random.default_rng(5000 + seed)
+    m = random_mrf(rng)
+    eng = E.Engine(0)
+    try:
+        for rtype in (0, 1):
+            for mode in MODES:
+                o = Oracle(m)
+                o.set_reparametrization_type(rtype); o.set_reparametrization(mode)
+                eng.upload(m)
+                eng.set_reparametrization_type(rtype); eng.set_reparametrization(mode)
+                for n in (1, 3, 2):
+                    eng.compute_pass(n); o.ComputePass(n)
+                    assert np.array_equal(eng.download_duals(), o.duals()), (seed, rtype, mode, n)
+                    assert abs(eng.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+                # a fused custom schedule over [forward rows, backward rows, random rows]
+                rows = []
+                for d in (M.FORWARD, M.BACKWARD):
+                    oo, om = o.omega(d, mode); mo, mk = o.mask(d, mode)
+                    rows.append((o.update_order(d), oo, om, mo, mk))
+                rows.append(random_rows(rng, None, o, m))
+                from lp_mp_amd.multi_gpu import _cat_rows
+                cat = _cat_rows(*rows)
+                sid = eng.schedule_create(*cat, fuse=True)
+                for _ in range(2):
+                    eng.schedule_run(sid); o.compute_pass_custom(*cat)
+                assert np.array_equal(eng.download_duals(), o.duals()), (seed, rtype, mode, "fused custom")
+                eng.schedule_destroy(sid)
+                flb = eng.factor_lower_bounds()
+                ref = np.array([o.factor_lower_bound(f) for f in range(m.n_factors)])
+                assert np.max(np.abs(flb - ref)) <= 1e-12
+    finally:
+        eng.set_reparametrization_type(0)
+        eng.close()
