@@ -219,3 +219,30 @@ def test_c4_style_random_graph_partitioned_on_device():
     assert lb > lb0 and gap < 0.5       # dual ascent, and in the neighbourhood of the unpartitioned bound
     for e in engines:
         e.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_partitions_random_graphs_exact_and_ascending(seed):
+    """random sparse graphs (dense or Potts edges), random or locality-based partitions into 2-5 parts, both boundary
+    placements: the lock-stepped parts equal the oracle's replay on the unpartitioned model bit for bit, and every
+    step is a dual-ascent step."""
+    rng = np.random.default_rng(7000 + seed)
+    n, L, world = int(rng.integers(20, 60)), int(rng.choice([2, 3, 4])), int(rng.integers(2, 6))
+    pairwise = "potts" if seed % 2 else "dense"
+    g = S.random_graph_model(n, int(rng.integers(n, 3 * n)), L, seed=seed, pairwise=pairwise)
+    ei, ej = g.m_left[0::2].astype(np.int64), g.m_left[1::2].astype(np.int64)
+    part_of = rng.integers(0, world, n) if seed % 3 else MG.graph_partition(n, ei, ej, world)
+    kw = dict(potts=g.const_data) if pairwise == "potts" else dict(tables=g.const_data)
+    parts = MG.partition_mrf(n, L, ei, ej, part_of, world, g.dual_data[: n * L], **kw)
+    attach_local_lists(parts)
+    every = "pass" if seed % 2 else "sweep"
+    sweeps, duals = _cpu_sweeps(parts, None, every)
+    calls = [1, 3, 2]
+    lbs = [sum(s.local_lower_bound() for s in sweeps)]
+    for c in calls:
+        MG.run_lockstep(sweeps, c)
+        lbs.append(sum(s.local_lower_bound() for s in sweeps))
+    assert all(b >= a - 1e-9 for a, b in zip(lbs, lbs[1:]))
+    o = global_replay(g, parts, sweeps, calls)
+    assert np.array_equal(gather_global_duals(g, parts, duals), o.duals())
+    assert abs(lbs[-1] - o.LowerBound()) <= 1e-9 * max(1.0, abs(lbs[-1]))
