@@ -214,8 +214,12 @@ class DistComm:
         if self.stage_cpu and send.is_cuda:
             dev = send.device
             return self.exchange(send.cpu(), send_counts, recv_counts).to(dev)
-        out = send.new_empty((int(sum(recv_counts)), send.shape[1]))
-        self.dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(map(int, recv_counts)),
+        # zero-row views of 1-row buffers: a rank without cut edges toward anybody still takes part in the collective,
+        # and its tensors keep a valid device pointer
+        n_out = int(sum(recv_counts))
+        out = send.new_empty((max(n_out, 1), send.shape[1]))[:n_out]
+        src = send.contiguous() if send.shape[0] > 0 else send.new_empty((1, send.shape[1]))[:0]
+        self.dist.all_to_all_single(out, src, output_split_sizes=list(map(int, recv_counts)),
                                     input_split_sizes=list(map(int, send_counts)))
         return out
 
