@@ -1,5 +1,5 @@
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)  # debugging aid for test_fuzz_gpu.py
 import numpy as np
 from tests.test_fuzz_gpu import random_model
 from lp_mp_amd import engine as E, model as M
