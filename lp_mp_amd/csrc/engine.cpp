@@ -426,6 +426,16 @@ int lpmp_plan_schedule_info(lpmp_plan* p, int d, int mode, int64_t* n_levels, in
   });
 }
 
+int lpmp_plan_schedule_classes(lpmp_plan* p, int d, int mode, int64_t* factors) {
+  static_assert(LPMP_KCLASS_COUNT == KC_COUNT, "public class count");
+  return guarded([&] {
+    if (!p || !factors || d < 0 || d > 1 || mode < 0 || mode >= LPMP_REPAM_COUNT) throw std::runtime_error("bad argument");
+    plan_schedule(p, d, mode);
+    for (int c = 0; c < KC_COUNT; ++c) factors[c] = 0;
+    for (const auto& lr : p->sched_cache[d][mode].launches) factors[lr.kclass] += lr.end - lr.begin;
+  });
+}
+
 int lpmp_plan_get_update_levels(lpmp_plan* p, int d, int mode, int32_t* out) {
   return guarded([&] {
     if (!p || !out || d < 0 || d > 1 || mode < 0 || mode >= LPMP_REPAM_COUNT) throw std::runtime_error("bad argument");

@@ -411,7 +411,9 @@ __device__ __forceinline__ void load_packet(double2_t* slab, const Op* __restric
   }
 }
 
-template <int L, int KMAX>
+// VAR: L is the padded width; the label count of the factor (<= L) and the dims of each peer table (d0 x d1, both
+// <= L, the own side's equal to the label count) are read at run time, lanes beyond them carry +inf / 0
+template <int L, int KMAX, bool VAR>
 __global__ void __launch_bounds__(256)
 sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
                       double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
@@ -435,16 +437,17 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
   const int n_send = live ? uni<G>((int)hdr->n_send) : 0;
   const bool preload_ok = live && (uni<G>(hdr->kind_flags) & UPD_PRELOAD_OK) != 0;
   double* own_g = dual + (live ? uni64<G>(hdr->dual_off) : 0);
-  const bool vl = live && g < L;
+  const int Lr = VAR ? (live ? uni<G>(hdr->d0) : 0) : L;      // label count of this factor
+  const bool vl = live && g < Lr;
   double theta = vl ? own_g[g] : 0.0;
   // target vectors of the first KS sends
   double sm[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
     sm[k] = 0.0;
-    if (preload_ok && k < n_send && g < L) {
+    if (preload_ok && k < n_send && g < Lr) {
       const Op& o = lop[n_recv + k];
-      sm[k] = dual[uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? L : 0) + g];
+      sm[k] = dual[uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0) + g];
     }
   }
   double mnew[NFW];                              // results of receives whose store is deferred to a send
@@ -462,22 +465,37 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
     double2_t t[KMAX][NL];
     double msv[KMAX], mov[KMAX];
     int64_t pdual[KMAX];
-    int side[KMAX], defer[KMAX];
+    int side[KMAX], defer[KMAX], roff[KMAX];     // roff: offset of the own-side message vector in the peer's dual
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {             // request everything first
       const bool act = c + j < n_recv;
-      pdual[j] = 0; side[j] = 0; defer[j] = 0; msv[j] = 0.0; mov[j] = 0.0;
+      pdual[j] = 0; side[j] = 0; defer[j] = 0; roff[j] = 0; msv[j] = 0.0; mov[j] = 0.0;
       if (act) {
         const Op& o = lop[c + j];
         pdual[j] = uni64<G>(o.peer_dual);
         side[j] = (uni<G>(o.info) >> 5) & 1;
         defer[j] = FW ? uni<G>(o.pad) : 0;
         const double* T = cdata + uni64<G>(o.peer_const);
+        if constexpr (VAR) {
+          const int R = uni<G>(o.pd0), C = uni<G>(o.pd1);
+          roff[j] = side[j] == 0 ? 0 : R;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) t[j][i] = *reinterpret_cast<const double2_t*>(T + (int64_t)i * 2 * G + 2 * g);
-        if (g < L) {
-          msv[j] = dual[pdual[j] + (side[j] == 0 ? 0 : L) + g];
-          mov[j] = dual[pdual[j] + (side[j] == 0 ? L : 0) + g];
+          for (int i = 0; i < NL; ++i) {
+            const int row = i * RPL + rl;
+            const double* Tr = T + (int64_t)row * C + 2 * c2;
+            t[j][i].x = (row < R && 2 * c2 < C) ? Tr[0] : LPMP_INF;
+            t[j][i].y = (row < R && 2 * c2 + 1 < C) ? Tr[1] : LPMP_INF;
+          }
+          if (g < Lr) msv[j] = dual[pdual[j] + roff[j] + g];
+          if (g < (side[j] == 0 ? C : R)) mov[j] = dual[pdual[j] + (side[j] == 0 ? R : 0) + g];
+        } else {
+          roff[j] = side[j] == 0 ? 0 : L;
+#pragma unroll
+          for (int i = 0; i < NL; ++i) t[j][i] = *reinterpret_cast<const double2_t*>(T + (int64_t)i * 2 * G + 2 * g);
+          if (g < L) {
+            msv[j] = dual[pdual[j] + (side[j] == 0 ? 0 : L) + g];
+            mov[j] = dual[pdual[j] + (side[j] == 0 ? L : 0) + g];
+          }
         }
       } else {
 #pragma unroll
@@ -516,7 +534,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
       }
       wave_sync();
       double pb = LPMP_INF;                       // peer's bound after this receive
-      if (act && g < L) {
+      if (act && g < Lr) {
         const double qv = lds_q[grp][g];
         const double delta = msv[j] + qv;
         theta += delta;
@@ -530,7 +548,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
             stored = true;
           }
         }
-        if (!stored) dual[pdual[j] + (side[j] == 0 ? 0 : L) + g] = mn;
+        if (!stored) dual[pdual[j] + roff[j] + g] = mn;
       }
 #ifndef LPMP_ABLATE_LB_TRACK
       if (!(FW && defer[j])) {                    // a deferred receive is followed by a send that dirties the peer
@@ -553,7 +571,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
     for (int k = 0; k < KS; ++k) {
       if (k < n_send) {
         const Op& o = lop[n_recv + k];
-        double* ms = dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? L : 0);
+        double* ms = dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0);
         const int fw = uni<G>(o.pad);
         double cur;
         if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
@@ -568,7 +586,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
     }
     for (int k = KS; k < n_send; ++k) {
       const Op& o = lop[n_recv + k];
-      double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? L : 0);
+      double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? (VAR ? o.pd0 : L) : 0);
       const double delta = o.omega * snap;
       ms[g] += delta;
       theta -= delta;
@@ -578,7 +596,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
       double residual = 0.0;
       for (int k = 0; k < n_send; ++k) {
         const Op& o = lop[n_recv + k];
-        double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? L : 0);
+        double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? (VAR ? o.pd0 : L) : 0);
         residual += o.omega;
         const double delta = residual * theta;
         ms[g] += delta;
@@ -697,7 +715,8 @@ __device__ __forceinline__ void two_min_merge(double& a1, double& a2) {   // two
   if constexpr (L >= 32) step(shfl_xor_f64(a1, 16), shfl_xor_f64(a2, 16));
 }
 
-template <int L>
+// VAR: L is the padded width, the label count (<= L) is read at run time; lanes beyond it carry +inf
+template <int L, bool VAR>
 __global__ void __launch_bounds__(256)
 sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
                       double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
@@ -716,14 +735,16 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
   const int n_send = live ? (int)hdr->n_send : 0;
   const bool preload_ok = live && (hdr->kind_flags & UPD_PRELOAD_OK) != 0;
   double* own_g = dual + (live ? hdr->dual_off : 0);
-  double theta = live ? own_g[g] : 0.0;
+  const int Lr = VAR ? (live ? (int)hdr->d0 : 0) : L;
+  const bool vl = live && g < Lr;
+  double theta = vl ? own_g[g] : 0.0;
   double sm[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
     sm[k] = 0.0;
-    if (preload_ok && k < n_send) {
+    if (preload_ok && k < n_send && vl) {
       const Op& o = lop[n_recv + k];
-      sm[k] = dual[o.peer_dual + (((o.info >> 5) & 1) ? L : 0) + g];
+      sm[k] = dual[o.peer_dual + (((o.info >> 5) & 1) ? Lr : 0) + g];
     }
   }
   double mnew[KR];
@@ -742,13 +763,15 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
     int defer[KR];
 #pragma unroll
     for (int j = 0; j < KR; ++j) {               // request everything first
-      msv[j] = 0.0; mov[j] = 0.0; diff[j] = 0.0; msoff[j] = 0; defer[j] = 0;
+      msv[j] = 0.0; mov[j] = VAR ? LPMP_INF : 0.0; diff[j] = 0.0; msoff[j] = 0; defer[j] = 0;
       if (c + j < n_recv) {
         const Op& o = lop[c + j];
         const int side = (o.info >> 5) & 1;
-        msoff[j] = o.peer_dual + (side == 0 ? 0 : L) + g;
-        msv[j] = dual[msoff[j]];
-        mov[j] = dual[o.peer_dual + (side == 0 ? L : 0) + g];
+        msoff[j] = o.peer_dual + (side == 0 ? 0 : Lr) + g;
+        if (vl) {
+          msv[j] = dual[msoff[j]];
+          mov[j] = dual[o.peer_dual + (side == 0 ? Lr : 0) + g];
+        }
         diff[j] = cdata[o.peer_const];
         defer[j] = FW ? o.pad : 0;
       }
@@ -756,7 +779,7 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
 #pragma unroll
     for (int j = 0; j < KR; ++j) {
       if (c + j >= max_recv) break;
-      const bool act = c + j < n_recv;
+      const bool act = c + j < n_recv && vl;
       double a1 = mov[j], a2 = LPMP_INF;
       two_min_merge<L>(a1, a2);
       // exactly one lane may take the role of "the" minimum: the lowest lane holding a1
@@ -782,20 +805,20 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
       }
       if (!(FW && defer[j])) {
         pb = vec_min<L, L>(pb);
-        if (act && g == 0) lb[lop[c + j].peer] = pb;
+        if (c + j < n_recv && g == 0) lb[lop[c + j].peer] = pb;
       }
     }
   };
   if (max_recv > 0) chunk(0, std::true_type{});
   for (int c = KR; c < max_recv; c += KR) chunk(c, std::false_type{});
 
-  if (live) {
+  if (vl) {
     const double snap = theta;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       if (k < n_send) {
         const Op& o = lop[n_recv + k];
-        double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? L : 0);
+        double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? Lr : 0);
         const int fw = o.pad;
         double cur;
         if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
@@ -808,7 +831,7 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
     }
     for (int k = KS; k < n_send; ++k) {
       const Op& o = lop[n_recv + k];
-      double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? L : 0);
+      double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? Lr : 0);
       const double delta = o.omega * snap;
       ms[g] += delta;
       theta -= delta;
@@ -818,7 +841,7 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
       double residual = 0.0;
       for (int k = 0; k < n_send; ++k) {
         const Op& o = lop[n_recv + k];
-        double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? L : 0);
+        double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? Lr : 0);
         residual += o.omega;
         const double delta = residual * theta;
         ms[g] += delta;
@@ -827,7 +850,7 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
     }
     own_g[g] = theta;
   }
-  { const double ob = vec_min<L, L>(live ? theta : LPMP_INF); if (live && g == 0) lb[hdr->factor] = ob; }
+  { const double ob = vec_min<L, L>(vl ? theta : LPMP_INF); if (live && g == 0) lb[hdr->factor] = ob; }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1008,18 +1031,30 @@ bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, cons
   if (stride > 1 + PK_MAX_OPS) return false;
   auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
   const int km = dense_kmax();
-#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
+#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK, false>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
   switch (kclass) {
     case KC_DENSE_32: if (km >= 4) PK_LAUNCH(32, 4); else if (km == 1) PK_LAUNCH(32, 1); else PK_LAUNCH(32, 2); return true;
     case KC_DENSE_16: if (km >= 4) PK_LAUNCH(16, 4); else PK_LAUNCH(16, 2); return true;
     case KC_DENSE_8: PK_LAUNCH(8, 4); return true;
     case KC_DENSE_4: PK_LAUNCH(4, 4); return true;
-#define PPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
+#define PPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL, false>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
     case KC_POTTS_32: PPK_LAUNCH(32); return true;
     case KC_POTTS_16: PPK_LAUNCH(16); return true;
     case KC_POTTS_8: PPK_LAUNCH(8); return true;
     case KC_POTTS_4: PPK_LAUNCH(4); return true;
 #undef PPK_LAUNCH
+#define VPK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK, true>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
+    case KC_DENSE_V32: VPK_LAUNCH(32, 2); return true;
+    case KC_DENSE_V16: VPK_LAUNCH(16, 2); return true;
+    case KC_DENSE_V8: VPK_LAUNCH(8, 4); return true;
+    case KC_DENSE_V4: VPK_LAUNCH(4, 4); return true;
+#undef VPK_LAUNCH
+#define VPPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL, true>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
+    case KC_POTTS_V32: VPPK_LAUNCH(32); return true;
+    case KC_POTTS_V16: VPPK_LAUNCH(16); return true;
+    case KC_POTTS_V8: VPPK_LAUNCH(8); return true;
+    case KC_POTTS_V4: VPPK_LAUNCH(4); return true;
+#undef VPPK_LAUNCH
     default: return false;
   }
 #undef PK_LAUNCH

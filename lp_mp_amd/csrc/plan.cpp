@@ -405,7 +405,9 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   std::vector<Op> ops(op_start[N]);
   std::vector<int32_t> cur_r(N, 0), cur_s(N, 0);
   std::vector<int64_t> rec_bytes(N, 0);
-  std::vector<uint8_t> all_dense(N, 1), all_potts(N, 1);
+  std::vector<uint8_t> all_dense(N, 1), all_potts(N, 1);     // exact classes: every peer L x L, L the own label count
+  std::vector<uint8_t> var_dense(N, 1), var_potts(N, 1);     // padded classes: runtime dims
+  std::vector<int32_t> max_dim(N, 0);                        // largest peer table dim of the record
   for (int64_t u = 0; u < N; ++u) {
     const int32_t f = uf[u];
     const int32_t o = owner[u];
@@ -427,8 +429,11 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         op.peer_const = e.role == 0 ? f_coff[peer] : -1;
         if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && f_dim0[peer] == own_d0 && f_dim1[peer] == own_d0 && (f_coff[peer] % 2) == 0)) all_dense[o] = 0;
         if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == own_d0)) all_potts[o] = 0;
+        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && (side == 0 ? f_dim0[peer] : f_dim1[peer]) == own_d0)) var_dense[o] = 0;
+        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == own_d0 && f_dim1[peer] == own_d0)) var_potts[o] = 0;
+        max_dim[o] = std::max(max_dim[o], std::max(f_dim0[peer], f_dim1[peer]));
       } else {
-        all_dense[o] = all_potts[o] = 0;
+        all_dense[o] = all_potts[o] = var_dense[o] = var_potts[o] = 0;
         if (mt.kind == LPMP_M_LABELING) {
           op.peer_const = tab_off[mt.param];
           op.pd1 = tab_nleft[mt.param];
@@ -464,25 +469,45 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     out.alg_bytes += bytes;
   }
   // bucket the owner records by (level, class); updates without any active op are dropped
-  const int64_t n_keys = (int64_t)max_level * KC_COUNT;
-  std::vector<int64_t> key_count(n_keys + 1, 0), key_recv(n_keys, 0), key_send(n_keys, 0), key_bytes(n_keys, 0);
   std::vector<int32_t> kclass(N, KC_GENERIC);
   auto cls_of = [&](int64_t u) -> int32_t {
     const int d0 = f_dim0[uf[u]];
+    if (f_kind[uf[u]] != LPMP_F_VECTOR) return KC_GENERIC;
     const bool pow = d0 == 4 || d0 == 8 || d0 == 16 || d0 == 32;
-    if (f_kind[uf[u]] != LPMP_F_VECTOR || !pow) return KC_GENERIC;
-    if (all_dense[u]) return d0 == 4 ? KC_DENSE_4 : d0 == 8 ? KC_DENSE_8 : d0 == 16 ? KC_DENSE_16 : KC_DENSE_32;
-    if (all_potts[u]) return d0 == 4 ? KC_POTTS_4 : d0 == 8 ? KC_POTTS_8 : d0 == 16 ? KC_POTTS_16 : KC_POTTS_32;
+    if (pow && all_dense[u]) return d0 == 4 ? KC_DENSE_4 : d0 == 8 ? KC_DENSE_8 : d0 == 16 ? KC_DENSE_16 : KC_DENSE_32;
+    if (pow && all_potts[u]) return d0 == 4 ? KC_POTTS_4 : d0 == 8 ? KC_POTTS_8 : d0 == 16 ? KC_POTTS_16 : KC_POTTS_32;
+    const int w = std::max(d0, max_dim[u]);
+    if (w > 32 || w < 1) return KC_GENERIC;
+    const int slot = w <= 4 ? 0 : w <= 8 ? 1 : w <= 16 ? 2 : 3;
+    if (var_dense[u]) return KC_DENSE_V4 + slot;
+    if (var_potts[u]) return KC_POTTS_V4 + slot;
     return KC_GENERIC;
   };
-  auto key = [&](int64_t u) { return (int64_t)(level[u] - 1) * KC_COUNT + kclass[u]; };
   auto is_rec = [&](int64_t u) { return owner[u] == u && n_recv_of[u] + n_send_of[u] > 0; };
+  // compact keys: only the (level, class) pairs that occur (deep schedules have millions of levels)
+  static_assert(KC_COUNT <= 32, "class mask");
+  std::vector<uint32_t> level_mask(max_level + 1, 0);
   for (int64_t u = 0; u < N; ++u) {
     if (!is_rec(u)) continue;
     if (n_recv_of[u] > 32767 || n_send_of[u] > 32767) fail("factor has too many messages");
     kclass[u] = cls_of(u);
-    ++key_count[key(u) + 1];
-    key_recv[key(u)] += n_recv_of[u]; key_send[key(u)] += n_send_of[u]; key_bytes[key(u)] += rec_bytes[u];
+    level_mask[level[u] - 1] |= 1u << kclass[u];
+  }
+  std::vector<int64_t> level_base(max_level + 1, 0);
+  for (int64_t l = 0; l < max_level; ++l) level_base[l + 1] = level_base[l] + __builtin_popcount(level_mask[l]);
+  const int64_t n_keys = level_base[max_level];
+  auto key = [&](int64_t u) {
+    const int64_t l = level[u] - 1;
+    return level_base[l] + __builtin_popcount(level_mask[l] & ((1u << kclass[u]) - 1u));
+  };
+  std::vector<int64_t> key_count(n_keys + 1, 0), key_recv(n_keys, 0), key_send(n_keys, 0), key_bytes(n_keys, 0);
+  std::vector<int32_t> key_level(n_keys, 0), key_class(n_keys, 0);
+  for (int64_t u = 0; u < N; ++u) {
+    if (!is_rec(u)) continue;
+    const int64_t k = key(u);
+    ++key_count[k + 1];
+    key_level[k] = level[u]; key_class[k] = kclass[u];
+    key_recv[k] += n_recv_of[u]; key_send[k] += n_send_of[u]; key_bytes[k] += rec_bytes[u];
     out.n_recv += n_recv_of[u]; out.n_send += n_send_of[u];
   }
   std::partial_sum(key_count.begin(), key_count.end(), key_count.begin());
@@ -503,19 +528,18 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       out.recs[cur[key(u)]++] = r;
     }
   }
-  for (int64_t k = 0; k < n_keys; ++k)
-    if (key_count[k + 1] > key_count[k]) {
-      LevelRange lr;
-      lr.kclass = (int32_t)(k % KC_COUNT); lr.begin = key_count[k]; lr.end = key_count[k + 1];
-      lr.level = (int32_t)(k / KC_COUNT) + 1;
-      lr.n_recv = key_recv[k]; lr.n_send = key_send[k]; lr.bytes = key_bytes[k];
-      out.launches.push_back(lr);
-    }
+  for (int64_t k = 0; k < n_keys; ++k) {
+    LevelRange lr;
+    lr.kclass = key_class[k]; lr.begin = key_count[k]; lr.end = key_count[k + 1];
+    lr.level = key_level[k];
+    lr.n_recv = key_recv[k]; lr.n_send = key_send[k]; lr.bytes = key_bytes[k];
+    out.launches.push_back(lr);
+  }
   out.ops = std::move(ops);
   // inside a launch the order of the records is free (they are independent): sub-wave kernels run several
   // factors per wavefront, so neighbours in the list should have similar amounts of work
   for (const auto& lr : out.launches)
-    if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32)
+    if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32 && lr.kclass != KC_DENSE_V32)
       std::stable_sort(out.recs.begin() + lr.begin, out.recs.begin() + lr.end, [](const UpdRec& a, const UpdRec& b) {
         return a.n_recv != b.n_recv ? a.n_recv > b.n_recv : a.n_send > b.n_send;
       });
@@ -523,6 +547,21 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   static_assert(sizeof(UpdRec) == sizeof(Op), "a packet slot holds either record");
   for (auto& lr : out.launches) {
     if (lr.kclass == KC_GENERIC) continue;   // dense and Potts fast classes
+    auto same_vec = [](const Op* o, int a, int b) { return o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1); };
+    if (kc_is_var(lr.kclass)) {
+      // the padded classes only exist in packed / indirect form: what those cannot run goes to the generic kernel
+      bool ok = true;
+      for (int64_t i = lr.begin; i < lr.end && ok; ++i) {
+        const UpdRec& r = out.recs[i];
+        const Op* o = out.ops.data() + r.op_begin;
+        if (r.n_recv + r.n_send > pk_indirect_cap(kc_width(lr.kclass))) ok = false;
+        for (int a = 0; a < r.n_recv && ok; ++a)
+          for (int a2 = a + 1; a2 < r.n_recv; ++a2) if (same_vec(o, a, a2)) { ok = false; break; }
+        for (int b = r.n_recv; b < r.n_recv + r.n_send && ok; ++b)
+          for (int b2 = b + 1; b2 < r.n_recv + r.n_send; ++b2) if (same_vec(o, b, b2)) { ok = false; break; }
+      }
+      if (!ok) { lr.kclass = KC_GENERIC; continue; }
+    }
     int kmax = 0;
     bool dup_recv = false;
     for (int64_t i = lr.begin; i < lr.end; ++i) {
@@ -552,7 +591,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     }
     if (dup_recv) continue;                  // only the op-by-op kernels are safe for that: stride stays 0
     if (kmax > PK_MAX_OPS) {                 // too many ops for a packet: indirect mode if they fit the LDS slab
-      if (kmax <= pk_indirect_cap(out.recs[lr.begin].d0)) lr.stride = -1;
+      if (kmax <= pk_indirect_cap(kc_width(lr.kclass))) lr.stride = -1;
       continue;
     }
     lr.stride = 1 + kmax;

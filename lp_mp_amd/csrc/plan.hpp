@@ -63,8 +63,16 @@ enum KClass : int32_t {
   KC_GENERIC = 0,
   KC_DENSE_4, KC_DENSE_8, KC_DENSE_16, KC_DENSE_32,
   KC_POTTS_4, KC_POTTS_8, KC_POTTS_16, KC_POTTS_32,
+  // any label count <= the padded width (runtime dims, also rectangular d0 x d1 tables for the dense classes)
+  KC_DENSE_V4, KC_DENSE_V8, KC_DENSE_V16, KC_DENSE_V32,
+  KC_POTTS_V4, KC_POTTS_V8, KC_POTTS_V16, KC_POTTS_V32,
   KC_COUNT
 };
+// lanes-per-vector width of a fast class (0: generic)
+constexpr int kc_width(int kclass) {
+  return kclass == KC_GENERIC ? 0 : 4 << ((kclass - 1) % 4);
+}
+constexpr bool kc_is_var(int kclass) { return kclass >= KC_DENSE_V4; }
 
 struct LevelRange {            // one kernel launch: a range of UpdRec indices of one level and class
   int32_t kclass; int64_t begin, end;

@@ -15,20 +15,27 @@ from . import build as _build
 from .model import FlatModel
 
 _LIB = None
-N_KCLASS = 9
-KCLASS_NAMES = ["generic", "dense4", "dense8", "dense16", "dense32", "potts4", "potts8", "potts16", "potts32"]
+N_KCLASS = 17
+KCLASS_NAMES = ["generic", "dense4", "dense8", "dense16", "dense32", "potts4", "potts8", "potts16", "potts32",
+                "dense_v4", "dense_v8", "dense_v16", "dense_v32", "potts_v4", "potts_v8", "potts_v16", "potts_v32"]
 # kernel symbols as rocprofv3 prints them: dense classes run the packed kernel (KMAX 2 at L >= 16, 4 below) whenever a
-# launch's factors have at most 8 active messages, else sweep_dense_kernel<L>
-KERNEL_NAMES = ["sweep_generic_kernel", "sweep_dense_pk_kernel<4, 4>", "sweep_dense_pk_kernel<8, 4>",
-                "sweep_dense_pk_kernel<16, 2>", "sweep_dense_pk_kernel<32, 2>", "sweep_potts_pk_kernel<4>",
-                "sweep_potts_pk_kernel<8>", "sweep_potts_pk_kernel<16>", "sweep_potts_pk_kernel<32>"]
+# launch's factors have at most 8 active messages, else sweep_dense_kernel<L>; the _v classes (any label count up to
+# the padded width, rectangular tables) are the same kernels with run-time dims
+KERNEL_NAMES = ["sweep_generic_kernel", "sweep_dense_pk_kernel<4, 4, false>", "sweep_dense_pk_kernel<8, 4, false>",
+                "sweep_dense_pk_kernel<16, 2, false>", "sweep_dense_pk_kernel<32, 2, false>",
+                "sweep_potts_pk_kernel<4, false>", "sweep_potts_pk_kernel<8, false>", "sweep_potts_pk_kernel<16, false>",
+                "sweep_potts_pk_kernel<32, false>",
+                "sweep_dense_pk_kernel<4, 4, true>", "sweep_dense_pk_kernel<8, 4, true>",
+                "sweep_dense_pk_kernel<16, 2, true>", "sweep_dense_pk_kernel<32, 2, true>",
+                "sweep_potts_pk_kernel<4, true>", "sweep_potts_pk_kernel<8, true>", "sweep_potts_pk_kernel<16, true>",
+                "sweep_potts_pk_kernel<32, true>"]
 MEM_HOST, MEM_DEVICE = 0, 1
 
 EXPORTS = [
     "lpmp_last_error", "lpmp_version", "lpmp_plan_create", "lpmp_plan_destroy", "lpmp_plan_n_factors",
     "lpmp_plan_n_updated", "lpmp_plan_get_order", "lpmp_plan_get_update_order", "lpmp_plan_omega_nnz",
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
-    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
+    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_schedule_classes", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
     "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_set_reparametrization_type", "lpmp_compute_pass", "lpmp_compute_forward_pass",
     "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_create_fused", "lpmp_schedule_run",
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
@@ -77,6 +84,7 @@ def lib():
         L.lpmp_plan_schedule_info.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.lpmp_plan_pass_schedule_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.lpmp_plan_get_update_levels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.lpmp_plan_schedule_classes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.lpmp_create.argtypes = [C.c_int, C.c_void_p]
         L.lpmp_destroy.argtypes = [C.c_void_p]
         L.lpmp_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -198,6 +206,16 @@ class Plan:
         v = [C.c_int64() for _ in range(5)]
         _chk(self.L.lpmp_plan_schedule_info(self.h, d, mode, *[C.addressof(x) for x in v]))
         return dict(zip(("n_levels", "n_launches", "n_receives", "n_sends", "algorithmic_bytes"), [x.value for x in v]))
+
+
+def _schedule_classes(self, d: int, mode: int) -> dict:
+    """updated factors of the sweep per device kernel class (only the classes that occur)"""
+    out = np.zeros(N_KCLASS, np.int64)
+    _chk(self.L.lpmp_plan_schedule_classes(self.h, d, mode, out.ctypes.data))
+    return {KCLASS_NAMES[c]: int(out[c]) for c in range(N_KCLASS) if out[c]}
+
+
+Plan.schedule_classes = _schedule_classes
 
 
 def _pass_info(self, mode: int) -> dict:

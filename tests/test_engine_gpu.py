@@ -82,13 +82,30 @@ def test_potts_ties_and_negative_coupling(eng):
 
 
 @pytest.mark.parametrize("L", [2, 3, 5, 7, 12, 33, 64])
-def test_generic_kernel_odd_sizes(eng, L):
+def test_odd_label_counts(eng, L):
+    # up to 32 labels: the run-time-dims classes of the padded width; above: the generic kernel
     _check(eng, S.grid_model(6, 7, L, seed=L), M.REPAM_ANISOTROPIC, 2)
+    cls = eng.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC)
+    want = "generic" if L > 32 else "dense_v%d" % (4 if L <= 4 else 8 if L <= 8 else 16 if L <= 16 else 32)
+    assert list(cls) == [want] and cls[want] == 42
     _check(eng, S.grid_model(6, 7, L, pairwise="potts", seed=L), M.REPAM_DAMPED_UNIFORM, 2)
+    cls = eng.plan.schedule_classes(M.FORWARD, M.REPAM_DAMPED_UNIFORM)
+    assert list(cls) == [want.replace("dense", "potts")]
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 6, 9, 15, 17, 21, 31])
+@pytest.mark.parametrize("pairwise", ["dense", "potts"])
+@pytest.mark.parametrize("order", ["row_major", "colour_major"])
+def test_any_label_count_fast_path(eng, L, pairwise, order):
+    m = S.grid_model(11, 13, L, pairwise=pairwise, order=order, seed=100 + L)
+    for mode in MODES:
+        _check(eng, m, mode, 3)
+    cls = eng.plan.schedule_classes(M.BACKWARD, M.REPAM_UNIFORM)
+    assert "generic" not in cls and all("_v" in c for c in cls)
 
 
 def test_rectangular_tables(eng):
-    # pairwise factors between variables of different label counts (generic kernel)
+    # pairwise factors between variables of different label counts (run-time-dims dense classes)
     b = M.ModelBuilder(2, S.mrf_mtypes())
     rng = np.random.default_rng(5)
     dims = [3, 6, 4, 9, 2]

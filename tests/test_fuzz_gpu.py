@@ -183,3 +183,57 @@ def test_random_mrfs_fast_kernels_multi_pass_calls_and_fused_custom_schedules(se
     finally:
         eng.set_reparametrization_type(0)
         eng.close()
+
+
+def random_mrf_any_labels(rng):
+    """unary / pairwise MRF where every variable has its own label count (1..40): rectangular dense tables between
+    any two variables, Potts between variables of equal count -> the run-time-dims kernel classes of every padded
+    width, next to exact classes and (above 32 labels, or for variables with both kinds of edges) the generic one"""
+    from lp_mp_amd import synthetic as S
+    n = int(rng.integers(6, 30))
+    pool = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 11, 16, 21, 27, 32, 40], size=int(rng.integers(1, 5)))
+    kind = rng.choice(["dense", "potts", "mixed"])
+    labels = rng.choice(pool if kind != "potts" else pool[:1], size=n)
+    b = M.ModelBuilder(2, S.mrf_mtypes())
+    u = [b.add_vector_factors(0, rng.uniform(0, 1, (1, int(L))))[0] for L in labels]
+    rel = []
+    for _ in range(int(rng.integers(n, 3 * n))):
+        i, j = sorted(rng.choice(n, 2, replace=False))
+        Li, Lj = int(labels[i]), int(labels[j])
+        potts = Li == Lj and (kind == "potts" or (kind == "mixed" and rng.uniform() < 0.5))
+        p = b.add_potts_pairwise(1, Li, [rng.uniform(-0.5, 1)])[0] if potts else b.add_dense_pairwise(1, rng.uniform(0, 1, (1, Li, Lj)))[0]
+        b.add_messages(0, u[i], p); b.add_messages(1, u[j], p)
+        rel += [(u[i], p), (p, u[j])]
+    keep = rng.uniform(size=len(rel)) < rng.choice([1.0, 0.9, 0.5])
+    r = np.array([x for x, k in zip(rel, keep) if k], np.int32).reshape(-1, 2)
+    if r.shape[0]:
+        b.add_relations(r[:, 0], r[:, 1])
+    return b.finish()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_mrfs_any_label_count_runtime_dims_kernels(seed):
+    rng = np.random.default_rng(9000 + seed)
+    m = random_mrf_any_labels(rng)
+    eng = E.Engine(0)
+    try:
+        for rtype in (0, 1):
+            for mode in MODES:
+                o = Oracle(m)
+                o.set_reparametrization_type(rtype); o.set_reparametrization(mode)
+                eng.upload(m)
+                eng.set_reparametrization_type(rtype); eng.set_reparametrization(mode)
+                for n in (1, 2):
+                    eng.compute_pass(n); o.ComputePass(n)
+                    assert np.array_equal(eng.download_duals(), o.duals()), (seed, rtype, mode, n)
+                    assert abs(eng.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+                rows = random_rows(rng, None, o, m)
+                eng.compute_pass_custom(*rows); o.compute_pass_custom(*rows)
+                eng.forward_pass(); o.ComputeForwardPass()
+                assert np.array_equal(eng.download_duals(), o.duals()), (seed, rtype, mode, "custom")
+                flb = eng.factor_lower_bounds()
+                ref = np.array([o.factor_lower_bound(f) for f in range(m.n_factors)])
+                assert np.max(np.abs(flb - ref)) <= 1e-12
+    finally:
+        eng.set_reparametrization_type(0)
+        eng.close()
