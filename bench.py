@@ -48,11 +48,11 @@ def build_device_grid(torch, H, W, L, pairwise, order, seed, engine_mod, synthet
     n = H * W
     n_e = len(synthetic.grid_edges(H, W)[0])
     if pairwise == "dense":
-        m = synthetic.grid_model(H, W, L, order=order, seed=seed, device_const=True)
+        m = synthetic.grid_model(H, W, L, order=order, seed=seed, device_const=True, compute_primal=True)
         const = torch.empty(n_e * L * L, dtype=torch.float64, device=dev)
         dual = torch.zeros(n * L + n_e * 2 * L, dtype=torch.float64, device=dev)
     else:
-        m = synthetic.grid_model(H, W, L, pairwise="potts", order=order, seed=seed)
+        m = synthetic.grid_model(H, W, L, pairwise="potts", order=order, seed=seed, compute_primal=True)
         const = torch.empty(n_e, dtype=torch.float64, device=dev)
         dual = torch.zeros(n * L + n_e * 2 * L, dtype=torch.float64, device=dev)
     engine_mod.synth_fill(const.data_ptr(), const.numel(), seed, n * L, stream_ptr)
@@ -207,6 +207,20 @@ def main():
     kt = eng.kernel_timing()
     eng.enable_kernel_timing(False)
 
+    # outside the timed region: one pass with primal rounding (what MpRoundingSolver runs every 5th iteration,
+    # reference solver.hxx:387-397) and LP::EvaluatePrimal
+    rounding = None
+    if world == 1:
+        eng.compute_pass_and_primal(args.steps + args.warmup)      # first call builds the label-propagation lists
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.compute_pass_and_primal(args.steps + args.warmup + 1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        cost = eng.evaluate_primal()
+        rounding = {"ms_pass_and_primal": (t1 - t0) * 1e3, "ms_evaluate_primal": (time.perf_counter() - t1) * 1e3,
+                    "primal_cost": cost, "lower_bound": eng.lower_bound()}
+
     gap = dual_bound_gap(torch, dist, args, mode, world, rank) if world > 1 else \
         {"dual_bound_gap": 0.0, "gap_config": "1 GPU: the unpartitioned sweep itself"}
     out = None
@@ -236,6 +250,7 @@ def main():
             "lower_bound_before": lb0, "lower_bound_after": lb1,
             "dual_bound_gap": gap["dual_bound_gap"], "dual_bound_gap_detail": gap,
             "kernels": kt,
+            "rounding": rounding,
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

@@ -132,6 +132,24 @@ int lpmp_factor_lower_bounds(lpmp_engine* e, double* out /*[n_factors], host*/);
 int lpmp_invalidate_lower_bounds(lpmp_engine* e);
 int lpmp_synchronize(lpmp_engine* e);
 
+/* ---- primal rounding inside the sweep -----------------------------------------------------------
+ * UpdateFactorPrimal (include/factors_messages.hxx:2332-2373): the same receives and (always 'shared') sends; in
+ * between, every factor of a COMPUTE_PRIMAL_SOLUTION type (lpmp_model.ftype_computes_primal) takes the first
+ * minimiser of its reparametrised costs as its label unless it already holds one of this time stamp
+ * (conditionally_init_primal :3302-3309, MaximizePotentialAndComputePrimal :2382-2389), and the label is copied into
+ * the adjacent pairwise factors (propagate_primal_through_messages :2391-2403, :1313-1328).  Built for unary /
+ * pairwise models whose COMPUTE_PRIMAL types are vector factors on the left of unary-pairwise messages (LP_MP-MRF's
+ * FMC_SRMP); anything else returns LPMP_ERR_UNSUPPORTED.  Time stamps as in the reference: 2*iteration+1 / +2. */
+int lpmp_compute_forward_pass_and_primal(lpmp_engine* e, uint64_t iteration);   /* LP::ComputeForwardPassAndPrimal, LP_MP.h:914-923 */
+int lpmp_compute_backward_pass_and_primal(lpmp_engine* e, uint64_t iteration);  /* LP::ComputeBackwardPassAndPrimal, LP_MP.h:925-934 */
+int lpmp_compute_pass_and_primal(lpmp_engine* e, uint64_t iteration);           /* LP::ComputePassAndPrimal, LP_MP.h:936-940 */
+int lpmp_check_primal_consistency(lpmp_engine* e, int* consistent);             /* LP::CheckPrimalConsistency, LP_MP.h:1067-1082 */
+int lpmp_evaluate_primal(lpmp_engine* e, double* cost);                         /* LP::EvaluatePrimal, LP_MP.h:1521-1536 (+inf when inconsistent / unset) */
+/* the factors' primal_ members, what serialize_primal lists: [2*n_factors] int32, vector factor (label, 0), pairwise
+ * factor (x0, x1); an unset entry holds the dimension (init_primal) */
+int lpmp_download_primal(lpmp_engine* e, int32_t* host_out);
+int lpmp_upload_primal(lpmp_engine* e, const int32_t* host_in);
+
 int64_t lpmp_dual_size(const lpmp_engine* e);
 /* serialize_dual + save_archive / load_archive (include/serialization.hxx:228-424): packed duals */
 int lpmp_download_duals(lpmp_engine* e, double* host_out);

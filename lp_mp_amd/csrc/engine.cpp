@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -17,9 +18,13 @@
 
 namespace lpmp {
 void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
-                  double* lb, int64_t first, int64_t count, int flags, hipStream_t s);
+                  double* lb, int32_t* primal, int64_t first, int64_t count, int flags, hipStream_t s);
 bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, const Op* ops, int stride, double* dual, const double* cdata,
-                         double* lb, int64_t count, int flags, hipStream_t s);
+                         double* lb, int32_t* primal, int64_t count, int flags, hipStream_t s);
+void launch_primal_init(const PrimalInit* list, int64_t n, int32_t* primal, hipStream_t s);
+void launch_primal_propagate(const PrimalLink* links, int64_t n, int32_t* primal, hipStream_t s);
+void launch_primal_check(const PrimalLink* links, int64_t n, const int32_t* primal, int* bad, hipStream_t s);
+void launch_primal_cost(const void* recs, const double* dual, const double* cdata, const int32_t* primal, double* out, int64_t count, hipStream_t s);
 void launch_lb_collect_stale(const double* lb, int64_t n, int32_t* list, unsigned long long* counter, hipStream_t s);
 void launch_factor_lb_list(const void* recs, const double* dual, const double* cdata, double* out, const int32_t* list, int64_t count, hipStream_t s);
 void launch_factor_lb(const void* recs, const double* dual, const double* cdata, double* out, int64_t count, hipStream_t s);
@@ -61,8 +66,10 @@ struct DevSchedule {
   std::vector<LevelRange> launches;
   int64_t n_levels = 0, n_recv = 0, n_send = 0, alg_bytes = 0;
   hipGraphExec_t graph = nullptr;
+  hipGraphExec_t graph_primal = nullptr;   // the same launches with the SWEEP_PRIMAL flag
   void release() {
     if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
+    if (graph_primal) { (void)hipGraphExecDestroy(graph_primal); graph_primal = nullptr; }
     if (recs) { (void)hipFree(recs); recs = nullptr; }
     if (ops) { (void)hipFree(ops); ops = nullptr; }
     if (packets) { (void)hipFree(packets); packets = nullptr; }
@@ -168,6 +175,14 @@ struct lpmp_engine {
   int32_t* d_stale = nullptr; unsigned long long* d_stale_n = nullptr; unsigned long long* h_stale_n = nullptr;
   bool lb_all_stale = true;
   bool use_lb_tracking = true;
+  // primal rounding: the factors' primal_ members, the lazily initialised set, the message links
+  int32_t* d_primal = nullptr;
+  PrimalInit* d_pinit = nullptr; int64_t n_pinit = 0;
+  PrimalLink* d_plinks = nullptr; int64_t n_plinks = 0, n_pprop = 0;   // all messages; the first n_pprop propagate labels
+  double* d_pcost = nullptr; int* d_pbad = nullptr; int* h_pbad = nullptr;
+  uint64_t primal_t = 0;          // primal_access_ of every factor a primal pass touches (they move together)
+  bool have_primal = false;
+  bool primal_pass = false;       // the launches being issued belong to an ...AndPrimal pass
   struct LbRun { int cls; int64_t first, count; };
   std::vector<LbRun> lb_runs;
   DevSchedule sched[2][LPMP_REPAM_COUNT];
@@ -202,6 +217,13 @@ struct lpmp_engine {
     if (d_lb) { (void)hipFree(d_lb); d_lb = nullptr; }
     if (d_part) { (void)hipFree(d_part); d_part = nullptr; }
     if (h_part) { (void)hipHostFree(h_part); h_part = nullptr; }
+    if (d_primal) { (void)hipFree(d_primal); d_primal = nullptr; }
+    if (d_pinit) { (void)hipFree(d_pinit); d_pinit = nullptr; }
+    if (d_plinks) { (void)hipFree(d_plinks); d_plinks = nullptr; }
+    if (d_pcost) { (void)hipFree(d_pcost); d_pcost = nullptr; }
+    if (d_pbad) { (void)hipFree(d_pbad); d_pbad = nullptr; }
+    if (h_pbad) { (void)hipHostFree(h_pbad); h_pbad = nullptr; }
+    have_primal = false; primal_t = 0; n_pinit = n_plinks = n_pprop = 0;
     if (d_stale) { (void)hipFree(d_stale); d_stale = nullptr; }
     if (d_stale_n) { (void)hipFree(d_stale_n); d_stale_n = nullptr; }
     if (h_stale_n) { (void)hipHostFree(h_stale_n); h_stale_n = nullptr; }
@@ -292,10 +314,12 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
     if (only_level > 0 && lr.level != only_level) continue;
     hipEvent_t a = nullptr, b = nullptr;
     if (timed) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, stream)); }
+    // UpdateFactorPrimal always sends 'shared' (reference factors_messages.hxx:2357-2359), whatever the send rule
+    const int flags = e->primal_pass ? SWEEP_PRIMAL : e->rtype;
     if (!(e->use_packed && lr.stride != 0 &&
           launch_sweep_packed(lr.kclass, lr.stride > 0 ? s.packets + lr.pk_begin : nullptr, s.recs + lr.begin, s.ops, lr.stride, e->d_dual,
-                              e->d_const, e->d_lb, lr.end - lr.begin, e->rtype, stream)))
-      launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, e->d_lb, lr.begin, lr.end - lr.begin, e->rtype, stream);
+                              e->d_const, e->d_lb, e->d_primal, lr.end - lr.begin, flags, stream)))
+      launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->d_primal, lr.begin, lr.end - lr.begin, flags, stream);
     if (timed) {
       HIP_CHECK(hipEventRecord(b, stream));
       e->pending.push_back({a, b, lr.kclass, lr.end - lr.begin, lr.n_recv, lr.bytes});
@@ -310,17 +334,18 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
   if (s.launches.empty()) return;
   if (e->timing) { issue_launches(e, s, true, e->stream); if (e->pending.size() > 4096) e->drain_timing(); return; }
   if (e->use_graph && s.launches.size() > 8) {
-    if (!s.graph) {
+    hipGraphExec_t& exec = e->primal_pass ? s.graph_primal : s.graph;
+    if (!exec) {
       hipGraph_t g = nullptr;
       if (!e->capture_stream) HIP_CHECK(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
       HIP_CHECK(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
       try { issue_launches(e, s, false, e->capture_stream); }
       catch (...) { (void)hipStreamEndCapture(e->capture_stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
       HIP_CHECK(hipStreamEndCapture(e->capture_stream, &g));
-      HIP_CHECK(hipGraphInstantiate(&s.graph, g, nullptr, nullptr, 0));
+      HIP_CHECK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
       HIP_CHECK(hipGraphDestroy(g));
     }
-    HIP_CHECK(hipGraphLaunch(s.graph, e->stream));
+    HIP_CHECK(hipGraphLaunch(exec, e->stream));
     return;
   }
   issue_launches(e, s, false, e->stream);
@@ -626,6 +651,148 @@ int lpmp_compute_pass(lpmp_engine* e, int n) {
     } else {
       for (int i = 0; i < n; ++i) { run_schedule(e, e->sched[0][e->mode]); run_schedule(e, e->sched[1][e->mode]); }
     }
+  });
+}
+
+// ---- primal rounding inside the sweep ------------------------------------------------------------------------------
+// What the reference does per updated factor (UpdateFactorPrimal) is split in three: the lazy init of everything the
+// pass touches (one kernel, only when the time stamp grows — all touched factors carry the same stamp), the label of
+// every COMPUTE_PRIMAL unary inside the sweep kernels (state after its receives), and the copy of the labels into the
+// pairwise factors afterwards.  The copy can wait because a pairwise factor's primal_[side] has a single writer and
+// nothing reads it before EvaluatePrimal: with a `left` schedule the recursion of propagate_primal_through_messages
+// stops at the pairwise factor (its other side is unset or already equal).
+static void ensure_primal(lpmp_engine* e) {
+  if (e->have_primal) return;
+  const Plan& p = e->plan->p;
+  for (const auto& mt : p.mtypes)
+    if (mt.kind != LPMP_M_UNARY_PAIRWISE)
+      throw UnsupportedError("primal rounding is built for unary / pairwise models (DESIGN.md 9)");
+  std::vector<PrimalLink> prop, rest;
+  std::vector<uint8_t> written(2 * (size_t)p.nf, 0), touched((size_t)p.nf, 0);
+  for (int64_t m = 0; m < p.nm; ++m) {
+    const int32_t l = p.m_left[m], r = p.m_right[m];
+    const int side = p.mtypes[p.m_type[m]].param;
+    if (p.f_kind[l] != LPMP_F_VECTOR || p.f_kind[r] == LPMP_F_VECTOR) throw UnsupportedError("primal rounding: unary-pairwise message between unexpected factor kinds");
+    if (p.ftype_primal[p.f_type[r]]) throw UnsupportedError("primal rounding: pairwise factor types with COMPUTE_PRIMAL_SOLUTION are not built");
+    const PrimalLink k{l, r, side, p.f_dim0[l]};
+    if (p.ftype_primal[p.f_type[l]]) {
+      if (written[2 * (size_t)r + side]++) throw UnsupportedError("primal rounding: two unaries on one side of a pairwise factor");
+      prop.push_back(k);
+      touched[r] = 1;
+    } else rest.push_back(k);
+  }
+  for (int64_t f = 0; f < p.nf; ++f) if (p.updated[f]) touched[f] = 1;
+  auto unset = [&](int64_t f) { return PrimalInit{(int32_t)f, p.f_dim0[f], p.f_kind[f] == LPMP_F_VECTOR ? 0 : p.f_dim1[f], 0}; };
+  std::vector<PrimalInit> init, all((size_t)p.nf);
+  for (int64_t f = 0; f < p.nf; ++f) { all[f] = unset(f); if (touched[f]) init.push_back(unset(f)); }
+  e->n_pprop = (int64_t)prop.size();
+  prop.insert(prop.end(), rest.begin(), rest.end());
+  e->n_plinks = (int64_t)prop.size();
+  e->n_pinit = (int64_t)init.size();
+  HIP_CHECK(hipMalloc((void**)&e->d_primal, std::max<size_t>(1, 2 * (size_t)p.nf) * sizeof(int32_t)));
+  HIP_CHECK(hipMalloc((void**)&e->d_pcost, std::max<size_t>(1, (size_t)p.nf) * sizeof(double)));
+  HIP_CHECK(hipMalloc((void**)&e->d_pbad, sizeof(int)));
+  HIP_CHECK(hipHostMalloc((void**)&e->h_pbad, sizeof(int)));
+  if (!prop.empty()) {
+    HIP_CHECK(hipMalloc((void**)&e->d_plinks, prop.size() * sizeof(PrimalLink)));
+    HIP_CHECK(hipMemcpy(e->d_plinks, prop.data(), prop.size() * sizeof(PrimalLink), hipMemcpyHostToDevice));
+  }
+  // every factor starts unset (init_primal), then only the touched ones are ever re-initialised
+  PrimalInit* d_all = nullptr;
+  if (p.nf > 0) {
+    HIP_CHECK(hipMalloc((void**)&d_all, all.size() * sizeof(PrimalInit)));
+    HIP_CHECK(hipMemcpy(d_all, all.data(), all.size() * sizeof(PrimalInit), hipMemcpyHostToDevice));
+    launch_primal_init(d_all, p.nf, e->d_primal, e->stream);
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    HIP_CHECK(hipFree(d_all));
+  }
+  if (!init.empty()) {
+    HIP_CHECK(hipMalloc((void**)&e->d_pinit, init.size() * sizeof(PrimalInit)));
+    HIP_CHECK(hipMemcpy(e->d_pinit, init.data(), init.size() * sizeof(PrimalInit), hipMemcpyHostToDevice));
+  }
+  e->primal_t = 0;
+  e->have_primal = true;
+}
+
+static void run_primal_sweep(lpmp_engine* e, int d, uint64_t t) {
+  require_mode(e);
+  HIP_CHECK(hipSetDevice(e->device));
+  ensure_primal(e);
+  if (t > e->primal_t) {   // conditionally_init_primal: primal_access_ < timestamp
+    launch_primal_init(e->d_pinit, e->n_pinit, e->d_primal, e->stream);
+    e->primal_t = t;
+  }
+  e->primal_pass = true;
+  try { run_schedule(e, e->sched[d][e->mode]); } catch (...) { e->primal_pass = false; throw; }
+  e->primal_pass = false;
+  launch_primal_propagate(e->d_plinks, e->n_pprop, e->d_primal, e->stream);
+  HIP_CHECK(hipGetLastError());
+}
+
+int lpmp_compute_forward_pass_and_primal(lpmp_engine* e, uint64_t iteration) {
+  return guarded([&] { run_primal_sweep(e, 0, 2 * iteration + 1); });
+}
+int lpmp_compute_backward_pass_and_primal(lpmp_engine* e, uint64_t iteration) {
+  return guarded([&] { run_primal_sweep(e, 1, 2 * iteration + 2); });
+}
+int lpmp_compute_pass_and_primal(lpmp_engine* e, uint64_t iteration) {
+  return guarded([&] { run_primal_sweep(e, 0, 2 * iteration + 1); run_primal_sweep(e, 1, 2 * iteration + 2); });
+}
+
+static bool primal_consistent(lpmp_engine* e) {
+  HIP_CHECK(hipMemsetAsync(e->d_pbad, 0, sizeof(int), e->stream));
+  launch_primal_check(e->d_plinks, e->n_plinks, e->d_primal, e->d_pbad, e->stream);
+  HIP_CHECK(hipMemcpyAsync(e->h_pbad, e->d_pbad, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+  return *e->h_pbad == 0;
+}
+int lpmp_check_primal_consistency(lpmp_engine* e, int* consistent) {
+  return guarded([&] {
+    require_model(e);
+    if (!consistent) throw std::runtime_error("null argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    ensure_primal(e);
+    *consistent = primal_consistent(e) ? 1 : 0;
+  });
+}
+int lpmp_evaluate_primal(lpmp_engine* e, double* cost) {
+  return guarded([&] {
+    require_model(e);
+    if (!cost) throw std::runtime_error("null argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    ensure_primal(e);
+    if (!primal_consistent(e)) { *cost = std::numeric_limits<double>::infinity(); return; }
+    const int64_t nf = e->plan->p.nf;
+    launch_primal_cost(e->d_lbrecs, e->d_dual, e->d_const, e->d_primal, e->d_pcost, nf, e->stream);
+    int64_t nb = std::min<int64_t>(1024, (nf + 255) / 256);
+    const int64_t per = (nf + nb - 1) / nb;
+    nb = (nf + per - 1) / per;
+    launch_sum_stage(e->d_pcost, e->d_part, nf, per, nb, e->stream);
+    HIP_CHECK(hipMemcpyAsync(e->h_part, e->d_part, (size_t)nb * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    double c = e->plan->p.constant;
+    for (int64_t i = 0; i < nb; ++i) c += e->h_part[i];
+    *cost = c;
+  });
+}
+int lpmp_download_primal(lpmp_engine* e, int32_t* out) {
+  return guarded([&] {
+    require_model(e);
+    if (!out) throw std::runtime_error("null argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    ensure_primal(e);
+    HIP_CHECK(hipMemcpyAsync(out, e->d_primal, 2 * (size_t)e->plan->p.nf * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+  });
+}
+int lpmp_upload_primal(lpmp_engine* e, const int32_t* in) {
+  return guarded([&] {
+    require_model(e);
+    if (!in) throw std::runtime_error("null argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    ensure_primal(e);
+    HIP_CHECK(hipMemcpyAsync(e->d_primal, in, 2 * (size_t)e->plan->p.nf * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
   });
 }
 

@@ -25,7 +25,6 @@ namespace lpmp {
 #define LPMP_INF (__builtin_inf())
 constexpr int GEN_MAXD = 512;       // generic kernel: max dual size / message length held in LDS per wave
 constexpr int GEN_WAVES = 4;
-constexpr int SWEEP_RESIDUAL = 1;   // kernel flag: --reparametrizationType residual
 
 // Tracked lower bounds.  lb[f] holds FactorContainer::LowerBound of factor f, or NaN when it has to be
 // recomputed.  A sweep kernel knows the bound of every factor it touches for free:
@@ -81,6 +80,23 @@ __device__ __forceinline__ double vec_min(double v) {   // min over the first L 
   if constexpr (W > 16) v = fmin(v, shfl_xor_f64(v, 16));
   if constexpr (W > 32) v = fmin(v, shfl_xor_f64(v, 32));
   return v;
+}
+
+// MaximizePotentialAndComputePrimal of a vector factor held one element per lane (first `valid` lanes of a G-lane
+// group, padded width W): index of the FIRST minimum, like std::min_element (reference test/test_model.hxx:27-33)
+template <int G, int W>
+__device__ __forceinline__ int group_argmin(double v, bool valid, int g) {
+  const double x = valid ? v : LPMP_INF;
+  const double mn = vec_min<G, W>(x);
+  const unsigned long long hit = __ballot(valid && x == mn);
+  const int base = (int)(threadIdx.x & 63) - g;
+  const unsigned long long gm = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << base;
+  return __ffsll((long long)(hit & gm)) - 1 - base;
+}
+// the label is only taken when the factor has none yet (primal_ unset = label count)
+__device__ __forceinline__ void store_label(int32_t* __restrict__ primal, int factor, int n_labels, int label) {
+  int32_t* pr = primal + 2 * (int64_t)factor;
+  if (*pr >= n_labels) *pr = label;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -146,7 +162,7 @@ __device__ void minnorm_delta(GenLds& L, SPtr src, int n, double omega, int lane
 __global__ void __launch_bounds__(64 * GEN_WAVES)
 sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
                      const double* __restrict__ cdata, const int32_t* __restrict__ tabs, double* __restrict__ lb,
-                     int64_t first, int64_t count, int flags) {
+                     int32_t* __restrict__ primal, int64_t first, int64_t count, int flags) {
   __shared__ GenLds lds[GEN_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t idx = (int64_t)blockIdx.x * GEN_WAVES + wave;
@@ -211,14 +227,27 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
     }
     wave_sync();
   };
+  // MaximizePotentialAndComputePrimal between the receives and the sends (vector factors of a COMPUTE_PRIMAL type)
+  auto round_label = [&]() {
+    if (!((flags & SWEEP_PRIMAL) && (rec.kind_flags & UPD_PRIMAL) && okind == LPMP_F_VECTOR)) return;
+    double bv = LPMP_INF; int bi = 0x7fffffff;
+    for (int i = lane; i < on; i += 64) { const double v = L.own[i]; if (bi == 0x7fffffff || v < bv) { bv = v; bi = i; } }
+    const double mn = wave_min(bv);
+    int cand = (bi != 0x7fffffff && bv == mn) ? bi : 0x7fffffff;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cand = min(cand, __shfl_xor(cand, m, 64));
+    if (lane == 0) store_label(primal, rec.factor, on, cand);
+  };
   for (int k = 0; k < n_ops; ++k) {
     if (k == rec.n_recv) {   // state after the receives: what every shared send is computed from
+      round_label();
       for (int i = lane; i < on; i += 64) L.snap[i] = L.own[i];
       wave_sync();
     }
     const Op op = ops[rec.op_begin + k];
     run_op(op, k < rec.n_recv, L.snap, op.omega);
   }
+  if (rec.n_recv == n_ops) round_label();
   if (flags & SWEEP_RESIDUAL) {   // reference send_messages_residual, factors_messages.hxx:2960-3007
     double residual = 0.0;
     for (int k = rec.n_recv; k < n_ops; ++k) {
@@ -253,7 +282,8 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 template <int L>
 __global__ void __launch_bounds__(256)
 sweep_dense_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
-                   const double* __restrict__ cdata, double* __restrict__ lb, int64_t first, int64_t count, int flags) {
+                   const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal,
+                   int64_t first, int64_t count, int flags) {
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2;            // lanes per table row
   constexpr int RPL = 2 * G / L;       // rows per load step
@@ -333,6 +363,10 @@ sweep_dense_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
     pb = vec_min<G, L>(pb);
     if (act && g == 0) lb[op.peer] = pb;
     wave_sync();
+  }
+  if (flags & SWEEP_PRIMAL) {
+    const int lab = group_argmin<G, L>(theta, vl, g);
+    if (live && g == 0 && (rec.kind_flags & UPD_PRIMAL)) store_label(primal, rec.factor, L, lab);
   }
   // sends: delta = omega * theta_snapshot; peer += delta; theta -= delta
   if (vl) {
@@ -417,7 +451,7 @@ template <int L, int KMAX, bool VAR>
 __global__ void __launch_bounds__(256)
 sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
                       double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
-                      int64_t count, int stride, int flags) {
+                      int32_t* __restrict__ primal, int64_t count, int stride, int flags) {
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
   constexpr int KS = 4;                          // sends whose target vectors are prefetched / forwarded
@@ -565,6 +599,10 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
   if constexpr (2 * KMAX < NFW) { if (max_recv > 2 * KMAX) chunk(2 * KMAX, std::true_type{}); if (max_recv > 3 * KMAX) chunk(3 * KMAX, std::true_type{}); }
   for (int c = (KMAX >= NFW ? KMAX : NFW); c < max_recv; c += KMAX) chunk(c, std::false_type{});
 
+  if (flags & SWEEP_PRIMAL) {
+    const int lab = group_argmin<G, L>(theta, vl, g);
+    if (live && g == 0 && (uni<G>(hdr->kind_flags) & UPD_PRIMAL)) store_label(primal, uni<G>(hdr->factor), Lr, lab);
+  }
   if (vl) {
     const double snap = theta;
 #pragma unroll
@@ -618,7 +656,8 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
 template <int L>
 __global__ void __launch_bounds__(256)
 sweep_potts_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
-                   const double* __restrict__ cdata, double* __restrict__ lb, int64_t first, int64_t count, int flags) {
+                   const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal,
+                   int64_t first, int64_t count, int flags) {
   constexpr int GPB = 256 / L;
   const int grp = threadIdx.x / L, g = threadIdx.x % L;
   const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
@@ -666,6 +705,10 @@ sweep_potts_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, 
     }
     pb = vec_min<L, L>(pb);
     if (act && g == 0) lb[op.peer] = pb;
+  }
+  if (flags & SWEEP_PRIMAL) {
+    const int lab = group_argmin<L, L>(theta, live, g);
+    if (live && g == 0 && (rec.kind_flags & UPD_PRIMAL)) store_label(primal, rec.factor, L, lab);
   }
   if (live) {
     const double snap = theta;
@@ -720,7 +763,7 @@ template <int L, bool VAR>
 __global__ void __launch_bounds__(256)
 sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
                       double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
-                      int64_t count, int stride, int flags) {
+                      int32_t* __restrict__ primal, int64_t count, int stride, int flags) {
   constexpr int GPB = 256 / L;
   constexpr int KR = 4, KS = 4;
   constexpr int PIECES = 3 * (1 + pk_indirect_cap(L));
@@ -812,6 +855,10 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
   if (max_recv > 0) chunk(0, std::true_type{});
   for (int c = KR; c < max_recv; c += KR) chunk(c, std::false_type{});
 
+  if (flags & SWEEP_PRIMAL) {
+    const int lab = group_argmin<L, L>(theta, vl, g);
+    if (live && g == 0 && (hdr->kind_flags & UPD_PRIMAL)) store_label(primal, hdr->factor, Lr, lab);
+  }
   if (vl) {
     const double snap = theta;
 #pragma unroll
@@ -973,6 +1020,52 @@ dense_lb_kernel(const LbRec* __restrict__ recs, const double* __restrict__ dual,
   if (live && g == 0) out[first + idx] = best;
 }
 
+// ---- primal rounding: bookkeeping around the sweep (engine.cpp) ------------------------------------
+// conditionally_init_primal of every factor a primal pass touches (reference factors_messages.hxx:3302-3309; all of
+// them carry the same time stamp, so the host decides whether this runs)
+__global__ void __launch_bounds__(256)
+primal_init_kernel(const PrimalInit* __restrict__ list, int64_t n, int32_t* __restrict__ primal) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const PrimalInit r = list[i];
+  primal[2 * (int64_t)r.f] = r.a;
+  primal[2 * (int64_t)r.f + 1] = r.b;
+}
+// propagate_primal_through_messages of the rounded unaries: right.primal_[side] = left.primal when that is set
+// (MessageContainer::ComputeRightFromLeftPrimal, reference factors_messages.hxx:1313-1328)
+__global__ void __launch_bounds__(256)
+primal_propagate_kernel(const PrimalLink* __restrict__ links, int64_t n, int32_t* __restrict__ primal) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const PrimalLink l = links[i];
+  const int32_t x = primal[2 * (int64_t)l.u];
+  if (x < l.dim) primal[2 * (int64_t)l.p + l.side] = x;
+}
+// LP::CheckPrimalConsistency (reference LP_MP.h:1067-1082): every message's two sides agree
+__global__ void __launch_bounds__(256)
+primal_check_kernel(const PrimalLink* __restrict__ links, int64_t n, const int32_t* __restrict__ primal, int* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const PrimalLink l = links[i];
+  if (primal[2 * (int64_t)l.u] != primal[2 * (int64_t)l.p + l.side]) *bad = 1;
+}
+// FactorContainer::EvaluatePrimal per factor: reparametrised cost at the factor's primal, +inf when a side is unset
+__global__ void __launch_bounds__(256)
+primal_cost_kernel(const LbRec* __restrict__ recs, const double* __restrict__ dual, const double* __restrict__ cdata,
+                   const int32_t* __restrict__ primal, double* __restrict__ out, int64_t count) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= count) return;
+  const LbRec r = recs[f];
+  const int kind = r.kind_flags & 15;
+  const double* d = dual + r.dual_off;
+  const int a = primal[2 * f], b = primal[2 * f + 1];
+  double c;
+  if (kind == LPMP_F_VECTOR) c = a < r.d0 ? d[a] : LPMP_INF;
+  else if (a >= r.d0 || b >= r.d1) c = LPMP_INF;
+  else c = pw_cost(cdata, r.const_off, kind, r.d1, a, b) + d[a] + d[r.d0 + b];
+  out[f] = c;
+}
+
 // deterministic two-stage sum: block b sums a fixed contiguous slice in a fixed tree order
 __global__ void __launch_bounds__(256)
 sum_stage_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t n, int64_t per_block) {
@@ -1004,19 +1097,19 @@ __global__ void synth_fill_kernel(double* __restrict__ out, int64_t n, uint64_t 
 
 // ---- launch wrappers (called from engine.cpp) -----------------------------------------------------
 void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
-                  double* lb, int64_t first, int64_t count, int flags, hipStream_t s) {
+                  double* lb, int32_t* primal, int64_t first, int64_t count, int flags, hipStream_t s) {
   if (count <= 0) return;
   auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
   switch (kclass) {
-    case KC_DENSE_32: hipLaunchKernelGGL(sweep_dense_kernel<32>, blocks(256 / DenseCfg<32>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
-    case KC_DENSE_16: hipLaunchKernelGGL(sweep_dense_kernel<16>, blocks(256 / DenseCfg<16>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
-    case KC_DENSE_8: hipLaunchKernelGGL(sweep_dense_kernel<8>, blocks(256 / DenseCfg<8>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
-    case KC_DENSE_4: hipLaunchKernelGGL(sweep_dense_kernel<4>, blocks(256 / DenseCfg<4>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
-    case KC_POTTS_32: hipLaunchKernelGGL(sweep_potts_kernel<32>, blocks(256 / 32), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
-    case KC_POTTS_16: hipLaunchKernelGGL(sweep_potts_kernel<16>, blocks(256 / 16), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
-    case KC_POTTS_8: hipLaunchKernelGGL(sweep_potts_kernel<8>, blocks(256 / 8), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
-    case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, lb, first, count, flags); break;
-    default: hipLaunchKernelGGL(sweep_generic_kernel, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, lb, first, count, flags); break;
+    case KC_DENSE_32: hipLaunchKernelGGL(sweep_dense_kernel<32>, blocks(256 / DenseCfg<32>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
+    case KC_DENSE_16: hipLaunchKernelGGL(sweep_dense_kernel<16>, blocks(256 / DenseCfg<16>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
+    case KC_DENSE_8: hipLaunchKernelGGL(sweep_dense_kernel<8>, blocks(256 / DenseCfg<8>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
+    case KC_DENSE_4: hipLaunchKernelGGL(sweep_dense_kernel<4>, blocks(256 / DenseCfg<4>::G), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
+    case KC_POTTS_32: hipLaunchKernelGGL(sweep_potts_kernel<32>, blocks(256 / 32), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
+    case KC_POTTS_16: hipLaunchKernelGGL(sweep_potts_kernel<16>, blocks(256 / 16), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
+    case KC_POTTS_8: hipLaunchKernelGGL(sweep_potts_kernel<8>, blocks(256 / 8), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
+    case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
+    default: hipLaunchKernelGGL(sweep_generic_kernel, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, lb, primal, first, count, flags); break;
   }
 }
 
@@ -1026,30 +1119,30 @@ static int dense_kmax() {
 }
 
 bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, const Op* ops, int stride, double* dual, const double* cdata,
-                         double* lb, int64_t count, int flags, hipStream_t s) {
+                         double* lb, int32_t* primal, int64_t count, int flags, hipStream_t s) {
   if (count <= 0) return true;
   if (stride > 1 + PK_MAX_OPS) return false;
   auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
   const int km = dense_kmax();
-#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK, false>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
+#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK, false>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
   switch (kclass) {
     case KC_DENSE_32: if (km >= 4) PK_LAUNCH(32, 4); else if (km == 1) PK_LAUNCH(32, 1); else PK_LAUNCH(32, 2); return true;
     case KC_DENSE_16: if (km >= 4) PK_LAUNCH(16, 4); else PK_LAUNCH(16, 2); return true;
     case KC_DENSE_8: PK_LAUNCH(8, 4); return true;
     case KC_DENSE_4: PK_LAUNCH(4, 4); return true;
-#define PPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL, false>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
+#define PPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL, false>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
     case KC_POTTS_32: PPK_LAUNCH(32); return true;
     case KC_POTTS_16: PPK_LAUNCH(16); return true;
     case KC_POTTS_8: PPK_LAUNCH(8); return true;
     case KC_POTTS_4: PPK_LAUNCH(4); return true;
 #undef PPK_LAUNCH
-#define VPK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK, true>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
+#define VPK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK, true>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
     case KC_DENSE_V32: VPK_LAUNCH(32, 2); return true;
     case KC_DENSE_V16: VPK_LAUNCH(16, 2); return true;
     case KC_DENSE_V8: VPK_LAUNCH(8, 4); return true;
     case KC_DENSE_V4: VPK_LAUNCH(4, 4); return true;
 #undef VPK_LAUNCH
-#define VPPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL, true>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, count, stride, flags)
+#define VPPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL, true>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
     case KC_POTTS_V32: VPPK_LAUNCH(32); return true;
     case KC_POTTS_V16: VPPK_LAUNCH(16); return true;
     case KC_POTTS_V8: VPPK_LAUNCH(8); return true;
@@ -1084,6 +1177,20 @@ void launch_lb_collect_stale(const double* lb, int64_t n, int32_t* list, unsigne
 void launch_factor_lb_list(const void* recs, const double* dual, const double* cdata, double* out, const int32_t* list, int64_t count, hipStream_t s) {
   if (count <= 0) return;
   hipLaunchKernelGGL(factor_lb_list_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, (const LbRec*)recs, dual, cdata, out, list, count);
+}
+
+static dim3 blocks256(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+void launch_primal_init(const PrimalInit* list, int64_t n, int32_t* primal, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(primal_init_kernel, blocks256(n), dim3(256), 0, s, list, n, primal);
+}
+void launch_primal_propagate(const PrimalLink* links, int64_t n, int32_t* primal, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(primal_propagate_kernel, blocks256(n), dim3(256), 0, s, links, n, primal);
+}
+void launch_primal_check(const PrimalLink* links, int64_t n, const int32_t* primal, int* bad, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(primal_check_kernel, blocks256(n), dim3(256), 0, s, links, n, primal, bad);
+}
+void launch_primal_cost(const void* recs, const double* dual, const double* cdata, const int32_t* primal, double* out, int64_t count, hipStream_t s) {
+  if (count > 0) hipLaunchKernelGGL(primal_cost_kernel, blocks256(count), dim3(256), 0, s, (const LbRec*)recs, dual, cdata, primal, out, count);
 }
 
 void launch_sum_stage(const double* in, double* out, int64_t n, int64_t per_block, int64_t n_blocks, hipStream_t s) {

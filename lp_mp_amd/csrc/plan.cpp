@@ -483,7 +483,9 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     if (var_potts[u]) return KC_POTTS_V4 + slot;
     return KC_GENERIC;
   };
-  auto is_rec = [&](int64_t u) { return owner[u] == u && n_recv_of[u] + n_send_of[u] > 0; };
+  // a COMPUTE_PRIMAL factor is updated even without any active message (FactorUpdated, reference
+  // factors_messages.hxx:3125-3130): the primal passes round its label
+  auto is_rec = [&](int64_t u) { return owner[u] == u && (n_recv_of[u] + n_send_of[u] > 0 || ftype_primal[f_type[uf[u]]]); };
   // compact keys: only the (level, class) pairs that occur (deep schedules have millions of levels)
   static_assert(KC_COUNT <= 32, "class mask");
   std::vector<uint32_t> level_mask(max_level + 1, 0);
@@ -524,7 +526,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       r.op_begin = (int32_t)op_start[u];
       r.n_recv = (int16_t)n_recv_of[u]; r.n_send = (int16_t)n_send_of[u];
       r.factor = f;
-      r.kind_flags = f_kind[f] | (f_flags[f] << 4);
+      r.kind_flags = f_kind[f] | (f_flags[f] << 4) | (ftype_primal[f_type[f]] ? UPD_PRIMAL : 0);
       out.recs[cur[key(u)]++] = r;
     }
   }

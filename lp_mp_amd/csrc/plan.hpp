@@ -89,6 +89,16 @@ constexpr int PK_MAX_OPS = 8;                 // packets hold at most this many 
 // coalesced load — two dependent hops instead of one per op
 constexpr int pk_indirect_cap(int labels) { return labels >= 16 ? 32 : labels >= 8 ? 16 : 8; }
 constexpr int32_t UPD_PRELOAD_OK = 1 << 16;   // UpdRec::kind_flags: no send targets a vector a receive writes
+constexpr int32_t UPD_PRIMAL = 1 << 17;       // UpdRec::kind_flags: the factor type has COMPUTE_PRIMAL_SOLUTION
+
+// kernel flags of the sweep kernels
+constexpr int SWEEP_RESIDUAL = 1;   // --reparametrizationType residual
+constexpr int SWEEP_PRIMAL = 2;     // UpdateFactorPrimal (reference factors_messages.hxx:2332-2373): factors of a
+                                    // COMPUTE_PRIMAL type round their label from the state after the receives
+
+// primal rounding (engine.cpp / kernels.hip): one unary-pairwise message, and one lazily initialised factor
+struct PrimalLink { int32_t u, p, side, dim; };   // left (vector) factor, right (pairwise) factor, side, label count of u
+struct PrimalInit { int32_t f, a, b, pad; };      // primal_ of factor f when unset: (a, b)
 
 struct Schedule {             // executable form of one (factor list, omega, mask) sweep
   std::vector<UpdRec> recs;   // sorted by (level, kclass)

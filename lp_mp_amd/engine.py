@@ -41,7 +41,9 @@ EXPORTS = [
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
     "lpmp_invalidate_lower_bounds", "lpmp_synchronize", "lpmp_dual_size", "lpmp_download_duals", "lpmp_upload_duals", "lpmp_device_duals",
     "lpmp_engine_plan", "lpmp_engine_plan_mut", "lpmp_enable_kernel_timing", "lpmp_get_kernel_timing",
-    "lpmp_reset_kernel_timing", "lpmp_synth_fill",
+    "lpmp_reset_kernel_timing", "lpmp_synth_fill", "lpmp_compute_forward_pass_and_primal",
+    "lpmp_compute_backward_pass_and_primal", "lpmp_compute_pass_and_primal", "lpmp_check_primal_consistency",
+    "lpmp_evaluate_primal", "lpmp_download_primal", "lpmp_upload_primal",
 ]
 
 
@@ -112,6 +114,10 @@ def lib():
         L.lpmp_engine_plan.argtypes = [C.c_void_p]
         L.lpmp_engine_plan_mut.restype = C.c_void_p
         L.lpmp_engine_plan_mut.argtypes = [C.c_void_p]
+        for name in ("lpmp_compute_forward_pass_and_primal", "lpmp_compute_backward_pass_and_primal", "lpmp_compute_pass_and_primal"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_uint64]
+        for name in ("lpmp_check_primal_consistency", "lpmp_evaluate_primal", "lpmp_download_primal", "lpmp_upload_primal"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
         L.lpmp_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_get_kernel_timing.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.lpmp_reset_kernel_timing.argtypes = [C.c_void_p]
@@ -318,6 +324,37 @@ class Engine:
         out = C.c_double()
         _chk(self.L.lpmp_lower_bound(self.h, C.addressof(out)))
         return out.value
+
+    # ---- primal rounding inside the sweep (reference LP_MP.h:914-940, 1067-1082, 1521-1536) ----
+    def forward_pass_and_primal(self, iteration: int):
+        _chk(self.L.lpmp_compute_forward_pass_and_primal(self.h, int(iteration)))
+
+    def backward_pass_and_primal(self, iteration: int):
+        _chk(self.L.lpmp_compute_backward_pass_and_primal(self.h, int(iteration)))
+
+    def compute_pass_and_primal(self, iteration: int):
+        _chk(self.L.lpmp_compute_pass_and_primal(self.h, int(iteration)))
+
+    def check_primal_consistency(self) -> bool:
+        out = C.c_int()
+        _chk(self.L.lpmp_check_primal_consistency(self.h, C.addressof(out)))
+        return bool(out.value)
+
+    def evaluate_primal(self) -> float:
+        out = C.c_double()
+        _chk(self.L.lpmp_evaluate_primal(self.h, C.addressof(out)))
+        return out.value
+
+    def download_primal(self) -> np.ndarray:
+        """[n_factors, 2] primal_ members: vector (label, 0), pairwise (x0, x1); unset = the dimension"""
+        out = np.empty((self.model.n_factors, 2), np.int32)
+        _chk(self.L.lpmp_download_primal(self.h, out.ctypes.data))
+        return out
+
+    def upload_primal(self, primal: np.ndarray):
+        primal = np.ascontiguousarray(primal, np.int32)
+        assert primal.shape == (self.model.n_factors, 2)
+        _chk(self.L.lpmp_upload_primal(self.h, primal.ctypes.data))
 
     def factor_lower_bounds(self) -> np.ndarray:
         out = np.empty(self.model.n_factors, np.float64)

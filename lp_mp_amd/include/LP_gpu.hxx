@@ -351,6 +351,21 @@ class LP_gpu {
   void ComputeForwardPass() { ready_mode(); check(lpmp_compute_forward_pass(engine_)); duals_on_device_ = true; }
   void ComputeBackwardPass() { ready_mode(); check(lpmp_compute_backward_pass(engine_)); duals_on_device_ = true; }
 
+  // primal rounding inside the sweep (reference LP_MP.h:914-940, 1067-1082, 1521-1536): needs FactorContainers declared
+  // with COMPUTE_PRIMAL_SOLUTION = true, like LP_MP-MRF's FMC_SRMP::UnaryFactor
+  void ComputeForwardPassAndPrimal(const INDEX iteration) { ready_mode(); check(lpmp_compute_forward_pass_and_primal(engine_, iteration)); duals_on_device_ = true; }
+  void ComputeBackwardPassAndPrimal(const INDEX iteration) { ready_mode(); check(lpmp_compute_backward_pass_and_primal(engine_, iteration)); duals_on_device_ = true; }
+  void ComputePassAndPrimal(const INDEX iteration) { ComputeForwardPassAndPrimal(iteration); ComputeBackwardPassAndPrimal(iteration); }
+  bool CheckPrimalConsistency() { ready(); int ok = 0; check(lpmp_check_primal_consistency(engine_, &ok)); return ok != 0; }
+  REAL EvaluatePrimal() { ready(); REAL c = 0; check(lpmp_evaluate_primal(engine_, &c)); return c; }
+  // the factors' primal_ members in factor order: vector factor (label, 0), pairwise factor (x0, x1); unset = dimension
+  std::vector<std::array<int32_t, 2>> primal() {
+    ready();
+    std::vector<std::array<int32_t, 2>> out(f_.size());
+    check(lpmp_download_primal(engine_, out.empty() ? nullptr : out[0].data()));
+    return out;
+  }
+
   // LP::ComputePass(factorIt, factorItEnd, omegaIt, receive_it), reference LP_MP.h:981-1005.
   // omegaIt / receive_it iterate over ranges (anything with begin()/end()), one per listed factor.
   template <class FACTOR_ITERATOR, class OMEGA_ITERATOR, class RECEIVE_MASK_ITERATOR>
@@ -605,18 +620,28 @@ class Solver {
       if (options[i] == "--reparametrizationType") lp_.set_reparametrization_type(options[i + 1]);
   }
   LP_TYPE& GetLP() { return lp_; }
+  virtual ~Solver() = default;
+  // PreIterate / Iterate / PostIterate / RegisterPrimal hooks of the reference's Solver (include/solver.hxx:230-337)
+  virtual void PreIterate(LpControl c) { lp_.set_reparametrization(c.repam); }
+  virtual void Iterate(LpControl) { lp_.ComputePass(iter); }
+  virtual void PostIterate(LpControl c) { if (c.computeLowerBound) lowerBound_ = lp_.LowerBound(); }
+  void RegisterPrimal() {   // solver.hxx:320-337
+    const REAL cost = lp_.EvaluatePrimal();
+    if (cost < bestPrimalCost_ && lp_.CheckPrimalConsistency()) { bestPrimalCost_ = cost; solution_ = lp_.primal(); }
+  }
   int Solve() {
     lp_.Begin();
     LpControl c = visitor_.begin(lp_);
     while (!c.end && !c.error) {
-      lp_.set_reparametrization(c.repam);                      // PreIterate
-      lp_.ComputePass(iter);                                   // Iterate
-      if (c.computeLowerBound) lowerBound_ = lp_.LowerBound(); // PostIterate
+      PreIterate(c);
+      Iterate(c);
+      PostIterate(c);
       c = visitor_.visit(c, lowerBound_, bestPrimalCost_);
       ++iter;
     }
     if (!c.error) {
       lp_.End();
+      if (rounds()) RegisterPrimal();
       lowerBound_ = lp_.LowerBound();
       visitor_.end(lowerBound_, bestPrimalCost_);
     }
@@ -625,12 +650,36 @@ class Solver {
   REAL lower_bound() const { return lowerBound_; }
   REAL primal_cost() const { return bestPrimalCost_; }
   VISITOR& GetVisitor() { return visitor_; }
+  const std::vector<std::array<int32_t, 2>>& solution() const { return solution_; }
   INDEX iter = 0;
- private:
+ protected:
+  // the reference registers a primal after End() in every solver (solver.hxx:247); without rounding passes every
+  // primal_ is unset and the cost +inf, so the base class skips the evaluation
+  virtual bool rounds() const { return false; }
   LP_TYPE lp_;
   VISITOR visitor_;
   REAL lowerBound_ = -std::numeric_limits<REAL>::infinity();
   REAL bestPrimalCost_ = std::numeric_limits<REAL>::infinity();
+  std::vector<std::array<int32_t, 2>> solution_;
+};
+
+// local rounding interleaved with message passing (reference include/solver.hxx:380-400)
+template <class SOLVER>
+class MpRoundingSolver : public SOLVER {
+ public:
+  using SOLVER::SOLVER;
+  void Iterate(LpControl c) override {
+    if (c.computePrimal) {
+      this->lp_.ComputeForwardPassAndPrimal(this->iter);
+      this->RegisterPrimal();
+      this->lp_.ComputeBackwardPassAndPrimal(this->iter);
+      this->RegisterPrimal();
+    } else {
+      SOLVER::Iterate(c);
+    }
+  }
+ protected:
+  bool rounds() const override { return true; }
 };
 
 }  // namespace LP_MP

@@ -302,6 +302,28 @@ class LP:
     def LowerBound(self) -> float:
         return self._ready().lower_bound()
 
+    # -- primal rounding inside the sweep (reference LP_MP.h:914-940, 1067-1082, 1521-1536) ------------------
+    def ComputeForwardPassAndPrimal(self, iteration: int):
+        e = self._ready(); e.set_reparametrization(self._mode()); e.forward_pass_and_primal(iteration)
+
+    def ComputeBackwardPassAndPrimal(self, iteration: int):
+        e = self._ready(); e.set_reparametrization(self._mode()); e.backward_pass_and_primal(iteration)
+
+    def ComputePassAndPrimal(self, iteration: int):
+        self.ComputeForwardPassAndPrimal(iteration)
+        self.ComputeBackwardPassAndPrimal(iteration)
+
+    def CheckPrimalConsistency(self) -> bool:
+        return self._ready().check_primal_consistency()
+
+    def EvaluatePrimal(self) -> float:
+        return self._ready().evaluate_primal()
+
+    def primal(self) -> np.ndarray:
+        """[n_factors, 2] the factors' primal_ members in serialize_primal order: vector factor (label, 0), pairwise
+        factor (x0, x1); an unset entry holds the dimension."""
+        return self._ready().download_primal()
+
     def get_omega(self):
         """omega_storage{forward, backward, receive_mask_forward, receive_mask_backward} as CSR pairs."""
         p = self._ready().plan
@@ -391,35 +413,76 @@ class StandardVisitor:
 
 
 class Solver:
-    """Solver<LP_TYPE, VISITOR>::Solve (reference include/solver.hxx:230-287).  Primal rounding is outside the
-    sweep path: bestPrimalCost_ stays +inf, the visitor still switches to the rounding
-    reparametrisation on the iterations where the reference would round."""
+    """Solver<LP_TYPE, VISITOR>::Solve with its PreIterate / Iterate / PostIterate / RegisterPrimal hooks (reference
+    include/solver.hxx:230-337).  The base class never rounds (bestPrimalCost_ stays +inf unless a derived solver
+    registers a primal); the visitor still switches to the rounding reparametrisation where the reference would."""
 
     def __init__(self, lp: LP, visitor: Optional[StandardVisitor] = None):
         self.lp_ = lp
         self.visitor_ = visitor or StandardVisitor()
         self.lowerBound_ = -np.inf
         self.bestPrimalCost_ = np.inf
+        self.solution_ = None
         self.iter = 0
 
     def GetLP(self) -> LP:
         return self.lp_
 
+    def PreIterate(self, c: LpControl):
+        self.lp_.set_reparametrization(c.repam)
+
+    def Iterate(self, c: LpControl):
+        self.lp_.ComputePass(self.iter)
+
+    def PostIterate(self, c: LpControl):
+        if c.computeLowerBound:
+            self.lowerBound_ = self.lp_.LowerBound()
+
+    def RegisterPrimal(self):
+        """solver.hxx:320-337: keep the labeling if it is cheaper than the best one so far and consistent"""
+        cost = self.lp_.EvaluatePrimal()
+        if cost < self.bestPrimalCost_ and self.lp_.CheckPrimalConsistency():
+            self.bestPrimalCost_ = cost
+            self.solution_ = self.lp_.primal()
+
     def Solve(self) -> int:
         self.lp_.Begin()
         c = self.visitor_.begin(self.lp_)
         while not c.end and not c.error:
-            self.lp_.set_reparametrization(c.repam)          # PreIterate
-            self.lp_.ComputePass(self.iter)                  # Iterate
-            if c.computeLowerBound:                          # PostIterate
-                self.lowerBound_ = self.lp_.LowerBound()
+            self.PreIterate(c)
+            self.Iterate(c)
+            self.PostIterate(c)
             c = self.visitor_.visit(c, self.lowerBound_, self.bestPrimalCost_)
             self.iter += 1
         if not c.error:
             self.lp_.End()
+            if self._rounds:
+                self.RegisterPrimal()
             self.lowerBound_ = self.lp_.LowerBound()
             self.visitor_.end(self.lowerBound_, self.bestPrimalCost_)
         return int(not c.error)
 
+    _rounds = False   # the reference calls RegisterPrimal after End() in every solver (solver.hxx:247); without a
+                      # rounding pass every primal_ is unset and the cost is +inf, so the base class skips the call
+
     def lower_bound(self) -> float:
         return self.lowerBound_
+
+    def primal_cost(self) -> float:
+        return self.bestPrimalCost_
+
+
+class MpRoundingSolver(Solver):
+    """MpRoundingSolver<SOLVER>: local rounding interleaved with message passing (reference include/solver.hxx:380-400).
+    On the iterations the visitor marks computePrimal (every --primalComputationInterval-th, and the last one) the
+    pass is run as forward-and-primal, register, backward-and-primal, register."""
+    _rounds = True
+
+    def Iterate(self, c: LpControl):
+        if c.computePrimal:
+            self.lp_.ComputeForwardPassAndPrimal(self.iter)
+            self.RegisterPrimal()
+            self.lp_.ComputeBackwardPassAndPrimal(self.iter)
+            self.RegisterPrimal()
+        else:
+            super().Iterate(c)

@@ -62,14 +62,16 @@ def grid_edges(H: int, W: int) -> Tuple[np.ndarray, np.ndarray]:
 
 def mrf_model(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, unaries: np.ndarray,
               tables: Optional[np.ndarray] = None, potts: Optional[np.ndarray] = None,
-              device_const: bool = False) -> M.FlatModel:
+              device_const: bool = False, compute_primal: bool = False) -> M.FlatModel:
     """MRF over variables 0..n_vars-1 (already in variable order) with edges (i<j required).
+    ``compute_primal``: the unary FactorContainer's COMPUTE_PRIMAL_SOLUTION flag (as in LP_MP-MRF's FMC_SRMP);
+    needed for the ...AndPrimal passes.
     ``tables`` [E,L,L] (T[e,a,b]: a = label of i) or ``potts`` [E] diffs. With ``device_const`` the dense
     tables are not materialised on the host (they are generated in HBM; see Engine.upload)."""
     edge_i = np.asarray(edge_i, np.int64)
     edge_j = np.asarray(edge_j, np.int64)
     assert np.all(edge_i < edge_j)
-    b = M.ModelBuilder(2, mrf_mtypes())
+    b = M.ModelBuilder(2, mrf_mtypes(), [1, 0] if compute_primal else None)
     b.skip_const = device_const
     u = b.add_vector_factors(0, np.asarray(unaries, np.float64).reshape(n_vars, L))
     E = edge_i.shape[0]
@@ -94,7 +96,7 @@ def mrf_model(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, unari
 
 def grid_model(H: int, W: int, L: int, pairwise: str = "dense", order: str = "row_major", seed: int = 1,
                unaries: Optional[np.ndarray] = None, tables: Optional[np.ndarray] = None,
-               potts: Optional[np.ndarray] = None, device_const: bool = False) -> M.FlatModel:
+               potts: Optional[np.ndarray] = None, device_const: bool = False, compute_primal: bool = False) -> M.FlatModel:
     """H x W grid MRF.  Random costs are U(0,1) from the counter-based generator: unaries first
     (variable order), then the pairwise data edge by edge (edge order of grid_edges)."""
     var = grid_variable_order(H, W, order).reshape(-1)
@@ -108,11 +110,11 @@ def grid_model(H: int, W: int, L: int, pairwise: str = "dense", order: str = "ro
     if pairwise == "dense":
         if tables is None and not device_const:
             tables = u01(E * L * L, seed, n * L)
-        return mrf_model(n, L, i, j, unaries, tables=tables, device_const=device_const)
+        return mrf_model(n, L, i, j, unaries, tables=tables, device_const=device_const, compute_primal=compute_primal)
     if pairwise == "potts":
         if potts is None:
             potts = u01(E, seed, n * L)
-        return mrf_model(n, L, i, j, unaries, potts=potts)
+        return mrf_model(n, L, i, j, unaries, potts=potts, compute_primal=compute_primal)
     raise ValueError(pairwise)
 
 
@@ -122,7 +124,7 @@ def chain_model(n: int, L: int, diff: float = 1.0, seed: int = 1) -> M.FlatModel
     return mrf_model(n, L, i, i + 1, u01(n * L, seed, 0), potts=np.full(n - 1, diff))
 
 
-def random_graph_model(n: int, m: int, L: int, seed: int = 1, pairwise: str = "dense") -> M.FlatModel:
+def random_graph_model(n: int, m: int, L: int, seed: int = 1, pairwise: str = "dense", compute_primal: bool = False) -> M.FlatModel:
     """C4-style G(n, m): m distinct uniform random edges without self loops, variable order = index."""
     rng = np.random.Generator(np.random.PCG64(seed))
     got = np.zeros((0, 2), np.int64)
@@ -136,8 +138,8 @@ def random_graph_model(n: int, m: int, L: int, seed: int = 1, pairwise: str = "d
     e = got[np.sort(perm)]
     un = u01(n * L, seed, 0)
     if pairwise == "dense":
-        return mrf_model(n, L, e[:, 0], e[:, 1], un, tables=u01(m * L * L, seed, n * L))
-    return mrf_model(n, L, e[:, 0], e[:, 1], un, potts=u01(m, seed, n * L))
+        return mrf_model(n, L, e[:, 0], e[:, 1], un, tables=u01(m * L * L, seed, n * L), compute_primal=compute_primal)
+    return mrf_model(n, L, e[:, 0], e[:, 1], un, potts=u01(m, seed, n * L), compute_primal=compute_primal)
 
 
 # ---- labeling-list (multicut-style) models: reference include/factors/labeling_list_factor.hxx ----

@@ -45,6 +45,13 @@ def lib():
         L.orc_compute_pass.argtypes = [C.c_void_p, C.c_int]
         L.orc_forward_pass.argtypes = [C.c_void_p]
         L.orc_backward_pass.argtypes = [C.c_void_p]
+        for name in ("orc_forward_pass_and_primal", "orc_backward_pass_and_primal", "orc_compute_pass_and_primal"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_check_primal_consistency.argtypes = [C.c_void_p]
+        L.orc_evaluate_primal.restype = C.c_double
+        L.orc_evaluate_primal.argtypes = [C.c_void_p]
+        L.orc_get_primal.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_primal_access.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_duals.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_set_duals.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_order.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -99,6 +106,32 @@ class Oracle:
 
     def LowerBound(self) -> float:
         return float(self.L.orc_lower_bound(self.h))
+
+    def ComputeForwardPassAndPrimal(self, iteration: int):
+        self._chk(self.L.orc_forward_pass_and_primal(self.h, int(iteration)))
+
+    def ComputeBackwardPassAndPrimal(self, iteration: int):
+        self._chk(self.L.orc_backward_pass_and_primal(self.h, int(iteration)))
+
+    def ComputePassAndPrimal(self, iteration: int):
+        self._chk(self.L.orc_compute_pass_and_primal(self.h, int(iteration)))
+
+    def CheckPrimalConsistency(self) -> bool:
+        return bool(self.L.orc_check_primal_consistency(self.h))
+
+    def EvaluatePrimal(self) -> float:
+        return float(self.L.orc_evaluate_primal(self.h))
+
+    def primal(self) -> np.ndarray:
+        """[n_factors, 2] primal_ members: vector (label, 0), pairwise (x0, x1); unset = the dim"""
+        out = np.empty((self.L.orc_n_factors(self.h), 2), np.int32)
+        self.L.orc_get_primal(self.h, out.ctypes.data)
+        return out
+
+    def primal_access(self) -> np.ndarray:
+        out = np.empty(self.L.orc_n_factors(self.h), np.uint64)
+        self.L.orc_get_primal_access(self.h, out.ctypes.data)
+        return out
 
     def factor_lower_bound(self, f: int) -> float:
         return float(self.L.orc_factor_lower_bound(self.h, int(f)))

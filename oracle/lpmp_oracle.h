@@ -32,6 +32,14 @@ int orc_compute_pass(orc_t* o, int n_passes);           /* LP::ComputePass, defa
 int orc_forward_pass(orc_t* o);                         /* LP::ComputeForwardPass */
 int orc_backward_pass(orc_t* o);                        /* LP::ComputeBackwardPass */
 double orc_lower_bound(orc_t* o);                       /* LP::LowerBound */
+/* primal rounding inside the sweep (LP_MP.h:914-940, 1592-1602; factors_messages.hxx:2332-2373) */
+int orc_forward_pass_and_primal(orc_t* o, uint64_t iteration);   /* LP::ComputeForwardPassAndPrimal */
+int orc_backward_pass_and_primal(orc_t* o, uint64_t iteration);  /* LP::ComputeBackwardPassAndPrimal */
+int orc_compute_pass_and_primal(orc_t* o, uint64_t iteration);   /* LP::ComputePassAndPrimal */
+int orc_check_primal_consistency(orc_t* o);                      /* LP::CheckPrimalConsistency, LP_MP.h:1067-1082 */
+double orc_evaluate_primal(orc_t* o);                            /* LP::EvaluatePrimal, LP_MP.h:1521-1536 */
+void orc_get_primal(orc_t* o, int32_t* out /*[2*n_factors]*/);   /* the factors' primal_ members (unset = dim) */
+void orc_get_primal_access(orc_t* o, uint64_t* out /*[n_factors]*/);
 
 int64_t orc_n_factors(orc_t* o);
 int64_t orc_dual_size(orc_t* o);

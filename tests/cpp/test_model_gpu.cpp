@@ -35,6 +35,17 @@ struct FMC_SRMP {   // unary / pairwise MRF as LP_MP-MRF declares it (SURVEY.md 
   using ProblemDecompositionList = meta::list<>;
 };
 
+struct FMC_SRMP_ROUNDING {   // the same with COMPUTE_PRIMAL_SOLUTION on the unaries, as LP_MP-MRF's FMC_SRMP has it
+  constexpr static const char* name = "SRMP with rounding";
+  using UnaryFactor = FactorContainer<UnarySimplexFactor, FMC_SRMP_ROUNDING, 0, true>;
+  using PairwiseFactor = FactorContainer<PairwiseSimplexFactor, FMC_SRMP_ROUNDING, 1, false>;
+  using UnaryPairwiseMessageLeftContainer = MessageContainer<UnaryPairwiseMessage<Chirality::left>, 0, 1, message_passing_schedule::left, variableMessageNumber, 1, FMC_SRMP_ROUNDING, 0>;
+  using UnaryPairwiseMessageRightContainer = MessageContainer<UnaryPairwiseMessage<Chirality::right>, 0, 1, message_passing_schedule::left, variableMessageNumber, 1, FMC_SRMP_ROUNDING, 1>;
+  using FactorList = meta::list<UnaryFactor, PairwiseFactor>;
+  using MessageList = meta::list<UnaryPairwiseMessageLeftContainer, UnaryPairwiseMessageRightContainer>;
+  using ProblemDecompositionList = meta::list<>;
+};
+
 using edge_labelings = labelings<labeling<1>>;
 using triplet_labelings = labelings<labeling<0, 1, 1>, labeling<1, 0, 1>, labeling<1, 1, 0>, labeling<1, 1, 1>>;
 using multicut_edge_factor = labeling_factor<edge_labelings, true>;
@@ -137,6 +148,39 @@ int main(int argc, char** argv) {
       test(std::abs(s.lower_bound() - 0.0) <= eps);
       auto om = lp.get_omega();
       test(om.forward.size() == u.size());
+    }
+  }
+  {   // ---- MpRoundingSolver (reference solver.hxx:380-400) on a chain with a unique optimum ----
+    using FMC = FMC_SRMP_ROUNDING;
+    MpRoundingSolver<Solver<LP<FMC>, StandardVisitor>> s(std::vector<std::string>{
+        "--maxIter", "40", "--primalComputationInterval", "5", "--standardReparametrization", "anisotropic",
+        "--roundingReparametrization", "anisotropic"});
+    auto& lp = s.GetLP();
+    const int n = 6, L = 3;
+    std::vector<typename FMC::UnaryFactor*> u;
+    // unary i prefers label i % 3 by 0.1; every edge adds 1 unless x_{i+1} = (x_i + 1) % 3: optimum 0,1,2,0,1,2 at cost 0
+    for (int i = 0; i < n; ++i) {
+      std::vector<REAL> c(L, 0.1); c[i % L] = 0.0;
+      u.push_back(lp.template add_factor<typename FMC::UnaryFactor>(c));
+    }
+    for (int i = 0; i + 1 < n; ++i) {
+      auto* p = lp.template add_factor<typename FMC::PairwiseFactor>(L, L);
+      for (int a = 0; a < L; ++a) for (int b = 0; b < L; ++b) p->GetFactor()->cost(a, b) = b == (a + 1) % L ? 0.0 : 1.0;
+      lp.template add_message<typename FMC::UnaryPairwiseMessageLeftContainer>(u[i], p);
+      lp.template add_message<typename FMC::UnaryPairwiseMessageRightContainer>(u[i + 1], p);
+      lp.AddFactorRelation(u[i], p);
+      lp.AddFactorRelation(p, u[i + 1]);
+    }
+    if (!host_only) {
+      s.Solve();
+      test(std::abs(s.lower_bound() - 0.0) <= eps);
+      test(std::abs(s.primal_cost() - 0.0) <= eps);           // the visitor stops at primal <= lower bound + eps
+      test(s.iter < 40);
+      const auto& x = s.solution();
+      test(x.size() == (std::size_t)(2 * n - 1));
+      for (int i = 0; i < n; ++i) test(x[i][0] == i % L);
+      for (int i = 0; i + 1 < n; ++i) test(x[n + i][0] == i % L && x[n + i][1] == (i + 1) % L);
+      test(lp.CheckPrimalConsistency());
     }
   }
   if (!host_only) {   // ---- multicut-style triangle through the labeling-list family ----

@@ -138,3 +138,54 @@ def test_multicut_style_labeling_model_through_lp():
         o.ComputePass(1)
     assert np.array_equal(lp.duals(), o.duals())
     assert abs(lp.LowerBound() - o.LowerBound()) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_mp_rounding_solver_follows_the_oracle_iteration_by_iteration():
+    """MpRoundingSolver (reference solver.hxx:380-400): on computePrimal iterations forward-and-primal, register,
+    backward-and-primal, register; the same loop replayed on the oracle gives the same bounds, costs and labels."""
+    from oracle.binding import Oracle
+    U = LPM.FactorContainer(LPM.UnarySimplexFactor, 0, True)          # COMPUTE_PRIMAL_SOLUTION, as in FMC_SRMP
+    P = LPM.FactorContainer(LPM.PairwiseSimplexFactor, 1)
+    ML = LPM.MessageContainer(LPM.UnaryPairwiseMessage(0), 0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, 0)
+    MR = LPM.MessageContainer(LPM.UnaryPairwiseMessage(1), 0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, 1)
+    lp = LPM.LP(LPM.FMC("SRMP", [U, P], [ML, MR]))
+    H, W, L = 5, 6, 4
+    ref = S.grid_model(H, W, L, seed=8)
+    n = H * W
+    u = [lp.add_factor(U, ref.dual_data[i * L:(i + 1) * L]) for i in range(n)]
+    a, b = S.grid_edges(H, W)
+    tabs = ref.const_data.reshape(-1, L, L)
+    for k in range(len(a)):
+        p = lp.add_factor(P, L, L, tabs[k])
+        lp.add_message(ML, u[a[k]], p); lp.add_message(MR, u[b[k]], p)
+        lp.AddFactorRelation(u[a[k]], p); lp.AddFactorRelation(p, u[b[k]])
+    vis = LPM.StandardVisitor(maxIter=17)
+    s = LPM.MpRoundingSolver(lp, vis)
+    s.Solve()
+
+    o = Oracle(lp.flat_model())
+    v2 = LPM.StandardVisitor(maxIter=17)
+    c = v2.begin(None)
+    best, it, lbs, sol = np.inf, 0, [], None
+    while not c.end:
+        o.set_reparametrization(c.repam)
+        if c.computePrimal:
+            for step in (o.ComputeForwardPassAndPrimal, o.ComputeBackwardPassAndPrimal):
+                step(it)
+                cost = o.EvaluatePrimal()
+                if cost < best and o.CheckPrimalConsistency():
+                    best, sol = cost, o.primal().copy()
+        else:
+            o.ComputePass(1)
+        lbs.append(o.LowerBound())
+        c = v2.visit(c, lbs[-1], best)
+        it += 1
+    cost = o.EvaluatePrimal()
+    if cost < best and o.CheckPrimalConsistency():
+        best, sol = cost, o.primal().copy()
+    assert np.allclose(vis.lowerBound_, lbs, rtol=1e-9)
+    assert np.isfinite(best) and abs(s.primal_cost() - best) <= 1e-9 * max(1.0, abs(best))
+    assert np.array_equal(s.solution_, sol)
+    assert np.array_equal(lp.duals(), o.duals())
+    assert s.primal_cost() >= s.lower_bound() - 1e-9

@@ -1,0 +1,191 @@
+"""Primal rounding inside the sweep on the device (lpmp_compute_*_pass_and_primal, lpmp_evaluate_primal,
+lpmp_check_primal_consistency) against the oracle: labels bit for bit, duals bit for bit, cost within 1e-9."""
+import numpy as np
+import pytest
+
+from lp_mp_amd import engine as E
+from lp_mp_amd import model as M
+from lp_mp_amd import synthetic as S
+from oracle.binding import Oracle
+
+pytestmark = pytest.mark.gpu
+MODES = (M.REPAM_ANISOTROPIC, M.REPAM_ANISOTROPIC2, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = E.Engine(0)
+    yield e
+    e.close()
+
+
+def _same(eng, o, what):
+    assert np.array_equal(eng.download_primal(), o.primal()), what
+    assert np.array_equal(eng.download_duals(), o.duals()), what
+    assert eng.check_primal_consistency() == o.CheckPrimalConsistency()
+    c, co = eng.evaluate_primal(), o.EvaluatePrimal()
+    assert (c == co) if np.isinf(co) else abs(c - co) <= 1e-9 * max(1.0, abs(co)), (what, c, co)
+    return c
+
+
+def _run(eng, m, mode, iterations=3, rtype=0):
+    o = Oracle(m)
+    o.set_reparametrization_type(rtype); o.set_reparametrization(mode)
+    eng.upload(m)
+    eng.set_reparametrization_type(rtype); eng.set_reparametrization(mode)
+    _same(eng, o, "unset")
+    best = np.inf
+    for it in range(iterations):
+        eng.forward_pass_and_primal(it); o.ComputeForwardPassAndPrimal(it)
+        best = min(best, _same(eng, o, ("forward", it)))
+        eng.backward_pass_and_primal(it); o.ComputeBackwardPassAndPrimal(it)
+        best = min(best, _same(eng, o, ("backward", it)))
+        eng.compute_pass(1); o.ComputePass(1)                 # plain passes in between, as the solver loop does
+    lb = eng.lower_bound()
+    assert best >= lb - 1e-9 * max(1.0, abs(lb))
+    eng.set_reparametrization_type(0)
+    return best
+
+
+@pytest.mark.parametrize("L", [2, 4, 5, 8, 16, 21, 32, 40])
+@pytest.mark.parametrize("pairwise", ["dense", "potts"])
+@pytest.mark.parametrize("order", ["row_major", "colour_major"])
+def test_grids_every_kernel_class(eng, L, pairwise, order):
+    m = S.grid_model(9, 11, L, pairwise=pairwise, order=order, seed=40 + L, compute_primal=True)
+    for mode in MODES:
+        _run(eng, m, mode)
+
+
+def test_ties_take_the_first_minimum(eng):
+    H, W, L = 8, 8, 8
+    un = np.round(S.u01(H * W * L, 3) * 2.0) / 2.0            # costs in {0, 0.5, 1}: ties everywhere
+    for pairwise, extra in (("potts", dict(potts=np.where(S.u01(112, 4) < 0.5, 0.5, 1.0))),
+                            ("dense", dict(tables=np.round(S.u01(112 * L * L, 5) * 2.0) / 2.0))):
+        m = S.grid_model(H, W, L, pairwise=pairwise, unaries=un, compute_primal=True, **extra)
+        _run(eng, m, M.REPAM_ANISOTROPIC)
+        _run(eng, m, M.REPAM_UNIFORM)
+
+
+def test_random_graph_high_degree_and_residual_rule(eng):
+    # degrees above the packet limits (indirect mode / generic kernel), and the residual send rule, which primal
+    # passes ignore (UpdateFactorPrimal always calls SendMessages, reference factors_messages.hxx:2357-2359)
+    for L, pw in ((16, "dense"), (8, "potts"), (11, "dense")):
+        m = S.random_graph_model(60, 400, L, seed=L, pairwise=pw, compute_primal=True)
+        _run(eng, m, M.REPAM_ANISOTROPIC, rtype=1)
+        _run(eng, m, M.REPAM_DAMPED_UNIFORM)
+
+
+def test_same_time_stamp_keeps_labels_later_one_rerounds(eng):
+    m = S.grid_model(7, 6, 5, seed=9, compute_primal=True)
+    o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.upload(m); eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.forward_pass_and_primal(3); o.ComputeForwardPassAndPrimal(3)
+    first = eng.download_primal()
+    eng.compute_pass(2); o.ComputePass(2)
+    eng.forward_pass_and_primal(3); o.ComputeForwardPassAndPrimal(3)
+    assert np.array_equal(eng.download_primal(), first)
+    _same(eng, o, "same stamp")
+    eng.compute_pass_and_primal(4); o.ComputePassAndPrimal(4)
+    _same(eng, o, "later stamp")
+
+
+def test_mixed_edge_kinds_isolated_unaries_and_rectangular_tables(eng):
+    rng = np.random.default_rng(21)
+    dims = [3, 6, 4, 9, 2, 6, 6, 5]
+    b = M.ModelBuilder(2, S.mrf_mtypes(), [1, 0])
+    u = [b.add_vector_factors(0, rng.uniform(0, 1, (1, d)))[0] for d in dims]
+    for i, j in ((0, 1), (1, 2), (2, 3), (3, 4), (1, 5), (5, 6)):
+        if dims[i] == dims[j] and rng.uniform() < 0.7:
+            p = b.add_potts_pairwise(1, dims[i], [0.4])[0]
+        else:
+            p = b.add_dense_pairwise(1, rng.uniform(0, 1, (1, dims[i], dims[j])))[0]
+        b.add_messages(0, u[i], p); b.add_messages(1, u[j], p)
+        b.add_relations(u[i], p); b.add_relations(p, u[j])
+    m = b.finish()                                           # u[7] has no edge: still updated and rounded
+    for mode in MODES:
+        _run(eng, m, mode)
+    assert eng.download_primal()[u[7], 0] < dims[7]
+
+
+def test_without_compute_primal_types_nothing_is_rounded(eng):
+    m = S.grid_model(5, 5, 4, seed=2)                          # COMPUTE_PRIMAL false everywhere
+    o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.upload(m); eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.compute_pass_and_primal(0); o.ComputePassAndPrimal(0)
+    _same(eng, o, "no primal types")
+    assert eng.evaluate_primal() == np.inf
+
+
+def test_upload_primal_and_evaluate(eng):
+    H, W, L = 6, 5, 4
+    m = S.grid_model(H, W, L, seed=12, compute_primal=True)
+    eng.upload(m); eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.compute_pass(3)
+    n = H * W
+    var = S.grid_variable_order(H, W, "row_major").reshape(-1)
+    a, bb = S.grid_edges(H, W)
+    i, j = np.minimum(var[a], var[bb]), np.maximum(var[a], var[bb])
+    x = (np.arange(n) * 7) % L
+    pr = np.zeros((m.n_factors, 2), np.int32)
+    pr[:n, 0] = x; pr[n:, 0] = x[i]; pr[n:, 1] = x[j]
+    eng.upload_primal(pr)
+    un = S.u01(n * L, 12, 0).reshape(n, L)
+    T = S.u01(len(i) * L * L, 12, n * L).reshape(-1, L, L)
+    energy = un[np.arange(n), x].sum() + T[np.arange(len(i)), x[i], x[j]].sum()
+    assert eng.check_primal_consistency()
+    assert abs(eng.evaluate_primal() - energy) <= 1e-9       # invariant under the reparametrisation of 3 passes
+    pr[n, 0] = (pr[n, 0] + 1) % L
+    eng.upload_primal(pr)
+    assert not eng.check_primal_consistency() and eng.evaluate_primal() == np.inf
+
+
+def test_unsupported_models_are_refused(eng):
+    m = S.multicut_triangle_model(6, 4, seed=1)
+    eng.upload(m); eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    with pytest.raises(E.EngineError) as ei:
+        eng.forward_pass_and_primal(0)
+    assert ei.value.code == -2                                 # LPMP_ERR_UNSUPPORTED
+    b = M.ModelBuilder(2, S.mrf_mtypes(), [1, 1])             # pairwise type that computes its own primal
+    u = b.add_vector_factors(0, np.zeros((2, 3)))
+    p = b.add_dense_pairwise(1, np.zeros((1, 3, 3)))[0]
+    b.add_messages(0, u[0], p); b.add_messages(1, u[1], p)
+    eng.upload(b.finish()); eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    with pytest.raises(E.EngineError) as ei:
+        eng.evaluate_primal()
+    assert ei.value.code == -2
+
+
+def test_full_size_c3_rounding_properties():
+    # C3 (1024 x 1024, 32 labels, dense): no oracle at this size; cost >= bound, consistent, cost = energy of the labels
+    import torch
+    H = W = 1024; L = 32
+    m = S.grid_model(H, W, L, order="colour_major", seed=1, device_const=True, compute_primal=True)
+    n_e = len(S.grid_edges(H, W)[0])
+    const = torch.empty(n_e * L * L, dtype=torch.float64, device="cuda:0")
+    E.synth_fill(const.data_ptr(), const.numel(), 1, H * W * L, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    eng = E.Engine(0)
+    try:
+        eng.upload(m, const_dev=const.data_ptr(), keep=(const,))
+        eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+        eng.compute_pass(10)
+        costs = []
+        for it in range(3):
+            eng.compute_pass_and_primal(it)
+            assert eng.check_primal_consistency()
+            costs.append(eng.evaluate_primal())
+        lb = eng.lower_bound()
+        assert all(np.isfinite(c) and c >= lb for c in costs)
+        pr = eng.download_primal()
+        x = pr[:H * W, 0].astype(np.int64)
+        assert x.min() >= 0 and x.max() < L
+        # energy on the original costs: unaries on the host, tables gathered on the device
+        var = S.grid_variable_order(H, W, "colour_major").reshape(-1)
+        a, bb = S.grid_edges(H, W)
+        i, j = np.minimum(var[a], var[bb]), np.maximum(var[a], var[bb])
+        un = S.u01(H * W * L, 1, 0).reshape(-1, L)
+        idx = torch.from_numpy(np.arange(len(i)) * L * L + x[i] * L + x[j]).to("cuda:0")
+        energy = un[np.arange(H * W), x].sum() + float(const[idx].sum().item())
+        assert abs(costs[-1] - energy) <= 1e-7 * abs(energy)
+    finally:
+        eng.close()
