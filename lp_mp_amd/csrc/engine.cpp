@@ -668,7 +668,8 @@ static void ensure_primal(lpmp_engine* e) {
     if (mt.kind != LPMP_M_UNARY_PAIRWISE)
       throw UnsupportedError("primal rounding is built for unary / pairwise models (DESIGN.md 9)");
   std::vector<PrimalLink> prop, rest;
-  std::vector<uint8_t> written(2 * (size_t)p.nf, 0), touched((size_t)p.nf, 0);
+  std::vector<int32_t> writer(2 * (size_t)p.nf, -1);
+  std::vector<uint8_t> touched((size_t)p.nf, 0);
   for (int64_t m = 0; m < p.nm; ++m) {
     const int32_t l = p.m_left[m], r = p.m_right[m];
     const int side = p.mtypes[p.m_type[m]].param;
@@ -676,7 +677,9 @@ static void ensure_primal(lpmp_engine* e) {
     if (p.ftype_primal[p.f_type[r]]) throw UnsupportedError("primal rounding: pairwise factor types with COMPUTE_PRIMAL_SOLUTION are not built");
     const PrimalLink k{l, r, side, p.f_dim0[l]};
     if (p.ftype_primal[p.f_type[l]]) {
-      if (written[2 * (size_t)r + side]++) throw UnsupportedError("primal rounding: two unaries on one side of a pairwise factor");
+      int32_t& w = writer[2 * (size_t)r + side];   // the copy into the pairwise factor is deferred: one writer per slot
+      if (w >= 0 && w != l) throw UnsupportedError("primal rounding: two unaries on one side of a pairwise factor");
+      w = l;
       prop.push_back(k);
       touched[r] = 1;
     } else rest.push_back(k);
@@ -718,6 +721,9 @@ static void run_primal_sweep(lpmp_engine* e, int d, uint64_t t) {
   require_mode(e);
   HIP_CHECK(hipSetDevice(e->device));
   ensure_primal(e);
+  // the reference asserts primal_access_ <= timestamp (factors_messages.hxx:3304); in a release build a smaller
+  // stamp lowers primal_access_ of the rounded factors only and later passes depend on the update order
+  if (t < e->primal_t) throw std::runtime_error("primal pass: time stamps (2*iteration+1 / +2) must not decrease");
   if (t > e->primal_t) {   // conditionally_init_primal: primal_access_ < timestamp
     launch_primal_init(e->d_pinit, e->n_pinit, e->d_primal, e->stream);
     e->primal_t = t;

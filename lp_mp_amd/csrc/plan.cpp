@@ -390,7 +390,9 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       owner[u] = (int32_t)u; level[u] = lv + 1;
       n_recv_of[u] = nr; n_send_of[u] = ns;
       max_level = std::max(max_level, level[u]);
-      if (nr + ns > 0) {   // an update without active ops touches nothing
+      // an update without active ops touches nothing and is dropped, unless its factor type computes a primal:
+      // that record stays (it rounds the label in primal passes) and reads / writes its own duals
+      if (nr + ns > 0 || ftype_primal[f_type[f]]) {
         for (int32_t g : touched) { last_level[g] = level[u]; last_toucher[g] = (int32_t)u; }
         last_update_of[f] = (int32_t)u;
       }

@@ -121,7 +121,7 @@ def test_random_models_all_modes_and_custom_passes(seed):
         eng.close()
 
 
-def random_mrf(rng):
+def random_mrf(rng, primal=False):
     """pure unary / pairwise MRF on a random graph with ONE label count of a fast kernel class: every unary runs the
     packed dense / Potts kernels, under odd orders (random subset of the relations), with occasional duplicate
     messages and a random mix of dense and Potts edges or all of one kind"""
@@ -130,7 +130,8 @@ def random_mrf(rng):
     n = int(rng.integers(5, 40))
     kind = rng.choice(["dense", "potts", "mixed"])
     b = M.ModelBuilder(2, S.mrf_mtypes() if rng.uniform() < 0.7 else
-                       [M.MsgType(0, 1, M.SCHED_LEFT, 0, 0, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, M.SCHED_LEFT, 0, 0, M.M_UNARY_PAIRWISE, 1)])
+                       [M.MsgType(0, 1, M.SCHED_LEFT, 0, 0, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, M.SCHED_LEFT, 0, 0, M.M_UNARY_PAIRWISE, 1)],
+                       [1, 0] if primal else None)
     u = b.add_vector_factors(0, rng.uniform(0, 1, (n, L)))
     rel = []
     for _ in range(int(rng.integers(n, 3 * n))):
@@ -185,7 +186,7 @@ def test_random_mrfs_fast_kernels_multi_pass_calls_and_fused_custom_schedules(se
         eng.close()
 
 
-def random_mrf_any_labels(rng):
+def random_mrf_any_labels(rng, primal=False):
     """unary / pairwise MRF where every variable has its own label count (1..40): rectangular dense tables between
     any two variables, Potts between variables of equal count -> the run-time-dims kernel classes of every padded
     width, next to exact classes and (above 32 labels, or for variables with both kinds of edges) the generic one"""
@@ -194,7 +195,7 @@ def random_mrf_any_labels(rng):
     pool = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 11, 16, 21, 27, 32, 40], size=int(rng.integers(1, 5)))
     kind = rng.choice(["dense", "potts", "mixed"])
     labels = rng.choice(pool if kind != "potts" else pool[:1], size=n)
-    b = M.ModelBuilder(2, S.mrf_mtypes())
+    b = M.ModelBuilder(2, S.mrf_mtypes(), [1, 0] if primal else None)
     u = [b.add_vector_factors(0, rng.uniform(0, 1, (1, int(L))))[0] for L in labels]
     rel = []
     for _ in range(int(rng.integers(n, 3 * n))):
@@ -236,4 +237,42 @@ def test_random_mrfs_any_label_count_runtime_dims_kernels(seed):
                 assert np.max(np.abs(flb - ref)) <= 1e-12
     finally:
         eng.set_reparametrization_type(0)
+        eng.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_mrfs_primal_rounding(seed):
+    """...AndPrimal passes on random MRFs (duplicate messages, odd orders, every label count): labels, duals and
+    the primal cost against the oracle, interleaved with plain passes and random iterator-range passes"""
+    rng = np.random.default_rng(13000 + seed)
+    m = random_mrf(rng, primal=True) if seed % 2 else random_mrf_any_labels(rng, primal=True)
+    eng = E.Engine(0)
+    try:
+        for mode in MODES:
+            o = Oracle(m); o.set_reparametrization(mode)
+            eng.upload(m); eng.set_reparametrization(mode)
+            it, last = 0, 0                                 # time stamps must not decrease (reference assert)
+            for step in range(6):
+                what = int(rng.integers(4))
+                if what == 0 and last > 2 * it + 1:
+                    what = 1
+                if what == 0:
+                    eng.forward_pass_and_primal(it); o.ComputeForwardPassAndPrimal(it); last = 2 * it + 1
+                elif what == 1:
+                    eng.backward_pass_and_primal(it); o.ComputeBackwardPassAndPrimal(it); last = 2 * it + 2
+                elif what == 2:
+                    if last > 2 * it + 1:
+                        it += 1
+                    eng.compute_pass_and_primal(it); o.ComputePassAndPrimal(it); last = 2 * it + 2
+                else:
+                    rows = random_rows(rng, None, o, m)
+                    eng.compute_pass_custom(*rows); o.compute_pass_custom(*rows)
+                    eng.compute_pass(1); o.ComputePass(1)
+                it += int(rng.integers(2))                   # repeated time stamps keep the labels
+                assert np.array_equal(eng.download_primal(), o.primal()), (seed, mode, step, what)
+                assert np.array_equal(eng.download_duals(), o.duals()), (seed, mode, step, what)
+                assert eng.check_primal_consistency() == o.CheckPrimalConsistency()
+                c, co = eng.evaluate_primal(), o.EvaluatePrimal()
+                assert (c == co) if np.isinf(co) else abs(c - co) <= 1e-9 * max(1.0, abs(co))
+    finally:
         eng.close()

@@ -87,6 +87,8 @@ def test_same_time_stamp_keeps_labels_later_one_rerounds(eng):
     _same(eng, o, "same stamp")
     eng.compute_pass_and_primal(4); o.ComputePassAndPrimal(4)
     _same(eng, o, "later stamp")
+    with pytest.raises(E.EngineError, match="must not decrease"):   # the reference asserts primal_access_ <= timestamp
+        eng.forward_pass_and_primal(4)
 
 
 def test_mixed_edge_kinds_isolated_unaries_and_rectangular_tables(eng):
