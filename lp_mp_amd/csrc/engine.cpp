@@ -666,7 +666,7 @@ static void ensure_primal(lpmp_engine* e) {
   const Plan& p = e->plan->p;
   for (const auto& mt : p.mtypes)
     if (mt.kind != LPMP_M_UNARY_PAIRWISE)
-      throw UnsupportedError("primal rounding is built for unary / pairwise models (DESIGN.md 9)");
+      throw UnsupportedError("primal rounding is built for unary / pairwise models (DESIGN.md 8)");
   std::vector<PrimalLink> prop, rest;
   std::vector<int32_t> writer(2 * (size_t)p.nf, -1);
   std::vector<uint8_t> touched((size_t)p.nf, 0);

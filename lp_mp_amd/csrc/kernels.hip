@@ -1020,7 +1020,7 @@ dense_lb_kernel(const LbRec* __restrict__ recs, const double* __restrict__ dual,
   if (live && g == 0) out[first + idx] = best;
 }
 
-// ---- primal rounding: bookkeeping around the sweep (engine.cpp, DESIGN.md 9) ------------------------------------
+// ---- primal rounding: bookkeeping around the sweep (engine.cpp, DESIGN.md 8) ------------------------------------
 // conditionally_init_primal of every factor a primal pass touches (reference factors_messages.hxx:3302-3309; all of
 // them carry the same time stamp, so the host decides whether this runs)
 __global__ void __launch_bounds__(256)
