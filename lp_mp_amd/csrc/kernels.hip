@@ -901,6 +901,168 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
 }
 
 // -------------------------------------------------------------------------------------------------
+// Streaming dense path: one wave per unary, tables of any dims up to BIG_MAX_LABELS (class KC_DENSE_BIG: more than
+// 32 labels; also what the run-time-dims classes fall back to).  Works op by op like the generic kernel, but a
+// receive streams the table in blocks of 16 rows x 64 columns (16 coalesced 512-B row segments in flight per
+// wave) and reduces without a round trip per row:
+//   side 0 (own label = row):    16 per-lane partial minima, one per row, are transposed-and-reduced across the
+//                                wave in 4 halving exchanges + 2 all-reduce steps (17 shuffles per 16 rows
+//                                instead of 6 per row)
+//   side 1 (own label = column): lane-local minimum over the rows, m1[row] broadcast from LDS
+// -------------------------------------------------------------------------------------------------
+constexpr int BIG_WAVES = 4;
+struct BigLds { double theta[BIG_MAX_LABELS]; double mo[BIG_MAX_LABELS]; double q[BIG_MAX_LABELS]; };
+
+// v[r] = this lane's partial minimum of row r (16 rows).  Returns the minimum over all 64 lanes of ONE row:
+// row 8*bit0 + 4*bit1 + 2*bit2 + bit3 of the lane index.
+__device__ __forceinline__ double transpose_min16(double (&v)[16], int lane) {
+  {
+    const bool up = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const double keep = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
+      v[i] = fmin(keep, dpp_mov_f64<0xB1>(send));
+    }
+  }
+  {
+    const bool up = lane & 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
+      v[i] = fmin(keep, dpp_mov_f64<0x4E>(send));
+    }
+  }
+  {
+    const bool up = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
+      v[i] = fmin(keep, shfl_xor_f64(send, 4));
+    }
+  }
+  {
+    const bool up = lane & 8;
+    const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+    v[0] = fmin(keep, shfl_xor_f64(send, 8));
+  }
+  double r = v[0];
+  r = fmin(r, shfl_xor_f64(r, 16));
+  r = fmin(r, shfl_xor_f64(r, 32));
+  return r;
+}
+
+__global__ void __launch_bounds__(64 * BIG_WAVES)
+sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+                       const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal,
+                       int64_t first, int64_t count, int flags) {
+  __shared__ BigLds lds[BIG_WAVES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t idx = (int64_t)blockIdx.x * BIG_WAVES + wave;
+  if (idx >= count) return;
+  BigLds& S = lds[wave];
+  const UpdRec rec = recs[first + idx];
+  const int Lr = rec.d0;
+  double* own_g = dual + rec.dual_off;
+  for (int i = lane; i < Lr; i += 64) S.theta[i] = own_g[i];
+  const int my_row = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+  for (int k = 0; k < rec.n_recv; ++k) {
+    const Op op = ops[rec.op_begin + k];
+    const int side = (op.info >> 5) & 1;
+    const int R = op.pd0, C = op.pd1;
+    const double* T = cdata + op.peer_const;
+    double* ms = dual + op.peer_dual + (side == 0 ? 0 : R);
+    const double* mo = dual + op.peer_dual + (side == 0 ? R : 0);
+    const int Lo = side == 0 ? C : R;
+    for (int i = lane; i < Lo; i += 64) S.mo[i] = mo[i];
+    wave_sync();
+    if (side == 0) {
+      for (int a0 = 0; a0 < R; a0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = LPMP_INF;
+        for (int b0 = 0; b0 < C; b0 += 64) {
+          const int b = b0 + lane;
+          const bool cb = b < C;
+          const double m = cb ? S.mo[b] : 0.0;
+          double t[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = (cb && a0 + r < R) ? T[(int64_t)(a0 + r) * C + b] : LPMP_INF;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = fmin(v[r], t[r] + m);
+        }
+        const double full = transpose_min16(v, lane);
+        if (lane < 16 && a0 + my_row < R) S.q[a0 + my_row] = full;
+      }
+    } else {
+      for (int b0 = 0; b0 < C; b0 += 64) {
+        const int b = b0 + lane;
+        const bool cb = b < C;
+        double v = LPMP_INF;
+        for (int a0 = 0; a0 < R; a0 += 16) {
+          double t[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = (cb && a0 + r < R) ? T[(int64_t)(a0 + r) * C + b] : LPMP_INF;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const double m = a0 + r < R ? S.mo[a0 + r] : 0.0; v = fmin(v, t[r] + m); }
+        }
+        if (cb) S.q[b] = v;
+      }
+    }
+    wave_sync();
+    double pb = LPMP_INF;                              // peer's bound after this receive
+    for (int i = lane; i < Lr; i += 64) {
+      const double msv = ms[i], qv = S.q[i];
+      const double delta = msv + qv;                   // omega = 1: delta = min-marginal
+      S.theta[i] += delta;
+      const double mn = msv - delta;
+      ms[i] = mn;
+      pb = fmin(pb, mn + qv);
+    }
+    pb = wave_min(pb);
+    if (lane == 0) lb[op.peer] = pb;
+    wave_sync();
+  }
+  if ((flags & SWEEP_PRIMAL) && (rec.kind_flags & UPD_PRIMAL)) {   // first minimiser of theta after the receives
+    double bv = LPMP_INF; int bi = 0x7fffffff;
+    for (int i = lane; i < Lr; i += 64) { const double x = S.theta[i]; if (bi == 0x7fffffff || x < bv) { bv = x; bi = i; } }
+    const double mn = wave_min(bv);
+    int cand = (bi != 0x7fffffff && bv == mn) ? bi : 0x7fffffff;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cand = min(cand, __shfl_xor(cand, m, 64));
+    if (lane == 0) store_label(primal, rec.factor, Lr, cand);
+  }
+  // sends from the state after the receives (kept in q); a lane always owns the same elements: no barrier needed
+  for (int i = lane; i < Lr; i += 64) S.q[i] = S.theta[i];
+  for (int k = 0; k < rec.n_send; ++k) {
+    const Op op = ops[rec.op_begin + rec.n_recv + k];
+    double* ms = dual + op.peer_dual + (((op.info >> 5) & 1) ? op.pd0 : 0);
+    for (int i = lane; i < Lr; i += 64) {
+      const double delta = op.omega * S.q[i];
+      ms[i] += delta;
+      S.theta[i] -= delta;
+    }
+    if (lane == 0) lb[op.peer] = LPMP_NAN;
+  }
+  if (flags & SWEEP_RESIDUAL) {
+    double residual = 0.0;
+    for (int k = 0; k < rec.n_send; ++k) {
+      const Op op = ops[rec.op_begin + rec.n_recv + k];
+      double* ms = dual + op.peer_dual + (((op.info >> 5) & 1) ? op.pd0 : 0);
+      residual += op.omega;
+      for (int i = lane; i < Lr; i += 64) {
+        const double delta = residual * S.theta[i];
+        ms[i] += delta;
+        S.theta[i] -= delta;
+      }
+    }
+  }
+  double ob = LPMP_INF;
+  for (int i = lane; i < Lr; i += 64) { const double x = S.theta[i]; own_g[i] = x; ob = fmin(ob, x); }
+  ob = wave_min(ob);
+  if (lane == 0) lb[rec.factor] = ob;
+}
+
+// -------------------------------------------------------------------------------------------------
 // Lower bound (reference LP::LowerBound, LP_MP.h:1507-1518): per-factor bound, then a fixed-order sum.
 // -------------------------------------------------------------------------------------------------
 struct LbRec { int64_t dual_off; int64_t const_off; int32_t d0, d1; int32_t kind_flags; int32_t pad; };
@@ -1109,6 +1271,7 @@ void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, c
     case KC_POTTS_16: hipLaunchKernelGGL(sweep_potts_kernel<16>, blocks(256 / 16), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
     case KC_POTTS_8: hipLaunchKernelGGL(sweep_potts_kernel<8>, blocks(256 / 8), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
     case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
+    case KC_DENSE_BIG: hipLaunchKernelGGL(sweep_dense_big_kernel, blocks(BIG_WAVES), dim3(64 * BIG_WAVES), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
     default: hipLaunchKernelGGL(sweep_generic_kernel, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, lb, primal, first, count, flags); break;
   }
 }

@@ -479,7 +479,8 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     if (pow && all_dense[u]) return d0 == 4 ? KC_DENSE_4 : d0 == 8 ? KC_DENSE_8 : d0 == 16 ? KC_DENSE_16 : KC_DENSE_32;
     if (pow && all_potts[u]) return d0 == 4 ? KC_POTTS_4 : d0 == 8 ? KC_POTTS_8 : d0 == 16 ? KC_POTTS_16 : KC_POTTS_32;
     const int w = std::max(d0, max_dim[u]);
-    if (w > 32 || w < 1) return KC_GENERIC;
+    if (w < 1) return KC_GENERIC;
+    if (w > 32) return var_dense[u] && w <= BIG_MAX_LABELS ? KC_DENSE_BIG : KC_GENERIC;
     const int slot = w <= 4 ? 0 : w <= 8 ? 1 : w <= 16 ? 2 : 3;
     if (var_dense[u]) return KC_DENSE_V4 + slot;
     if (var_potts[u]) return KC_POTTS_V4 + slot;
@@ -543,14 +544,14 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   // inside a launch the order of the records is free (they are independent): sub-wave kernels run several
   // factors per wavefront, so neighbours in the list should have similar amounts of work
   for (const auto& lr : out.launches)
-    if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32 && lr.kclass != KC_DENSE_V32)
+    if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32 && lr.kclass != KC_DENSE_V32 && lr.kclass != KC_DENSE_BIG)
       std::stable_sort(out.recs.begin() + lr.begin, out.recs.begin() + lr.end, [](const UpdRec& a, const UpdRec& b) {
         return a.n_recv != b.n_recv ? a.n_recv > b.n_recv : a.n_send > b.n_send;
       });
   // flags of the fast-class records, kept in recs / ops themselves (packets are plain copies)
   static_assert(sizeof(UpdRec) == sizeof(Op), "a packet slot holds either record");
   for (auto& lr : out.launches) {
-    if (lr.kclass == KC_GENERIC) continue;   // dense and Potts fast classes
+    if (lr.kclass == KC_GENERIC || lr.kclass == KC_DENSE_BIG) continue;   // packed dense and Potts classes
     auto same_vec = [](const Op* o, int a, int b) { return o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1); };
     if (kc_is_var(lr.kclass)) {
       // the padded classes only exist in packed / indirect form: what those cannot run goes to the generic kernel
@@ -564,7 +565,8 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         for (int b = r.n_recv; b < r.n_recv + r.n_send && ok; ++b)
           for (int b2 = b + 1; b2 < r.n_recv + r.n_send; ++b2) if (same_vec(o, b, b2)) { ok = false; break; }
       }
-      if (!ok) { lr.kclass = KC_GENERIC; continue; }
+      // (the streaming dense kernel works op by op, so duplicates and any op count are fine for it)
+      if (!ok) { lr.kclass = lr.kclass <= KC_DENSE_V32 ? KC_DENSE_BIG : KC_GENERIC; continue; }
     }
     int kmax = 0;
     bool dup_recv = false;

@@ -66,13 +66,16 @@ enum KClass : int32_t {
   // any label count <= the padded width (runtime dims, also rectangular d0 x d1 tables for the dense classes)
   KC_DENSE_V4, KC_DENSE_V8, KC_DENSE_V16, KC_DENSE_V32,
   KC_POTTS_V4, KC_POTTS_V8, KC_POTTS_V16, KC_POTTS_V32,
+  // one wave per unary, dense tables of any dims up to BIG_MAX_LABELS streamed in 16-row blocks
+  KC_DENSE_BIG,
   KC_COUNT
 };
-// lanes-per-vector width of a fast class (0: generic)
+constexpr int BIG_MAX_LABELS = 512;
+// lanes-per-vector width of a packed fast class (0: generic / streaming class)
 constexpr int kc_width(int kclass) {
-  return kclass == KC_GENERIC ? 0 : 4 << ((kclass - 1) % 4);
+  return (kclass == KC_GENERIC || kclass >= KC_DENSE_BIG) ? 0 : 4 << ((kclass - 1) % 4);
 }
-constexpr bool kc_is_var(int kclass) { return kclass >= KC_DENSE_V4; }
+constexpr bool kc_is_var(int kclass) { return kclass >= KC_DENSE_V4 && kclass <= KC_POTTS_V32; }
 
 struct LevelRange {            // one kernel launch: a range of UpdRec indices of one level and class
   int32_t kclass; int64_t begin, end;

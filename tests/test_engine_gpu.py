@@ -83,14 +83,45 @@ def test_potts_ties_and_negative_coupling(eng):
 
 @pytest.mark.parametrize("L", [2, 3, 5, 7, 12, 33, 64])
 def test_odd_label_counts(eng, L):
-    # up to 32 labels: the run-time-dims classes of the padded width; above: the generic kernel
+    # up to 32 labels: the run-time-dims classes of the padded width; above: the streaming dense class, generic for Potts
     _check(eng, S.grid_model(6, 7, L, seed=L), M.REPAM_ANISOTROPIC, 2)
     cls = eng.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC)
-    want = "generic" if L > 32 else "dense_v%d" % (4 if L <= 4 else 8 if L <= 8 else 16 if L <= 16 else 32)
+    want = "dense_big" if L > 32 else "dense_v%d" % (4 if L <= 4 else 8 if L <= 8 else 16 if L <= 16 else 32)
     assert list(cls) == [want] and cls[want] == 42
     _check(eng, S.grid_model(6, 7, L, pairwise="potts", seed=L), M.REPAM_DAMPED_UNIFORM, 2)
     cls = eng.plan.schedule_classes(M.FORWARD, M.REPAM_DAMPED_UNIFORM)
-    assert list(cls) == [want.replace("dense", "potts")]
+    assert list(cls) == ["generic" if L > 32 else want.replace("dense", "potts")]
+
+
+@pytest.mark.parametrize("L", [33, 47, 64, 65, 100, 130, 200])
+@pytest.mark.parametrize("order", ["row_major", "colour_major"])
+def test_streaming_dense_kernel_many_labels(eng, L, order):
+    m = S.grid_model(5, 6, L, order=order, seed=200 + L)
+    for mode in MODES:
+        _check(eng, m, mode, 2)
+    assert list(eng.plan.schedule_classes(M.FORWARD, M.REPAM_UNIFORM)) == ["dense_big"]
+
+
+def test_streaming_dense_kernel_rectangular_residual_and_duplicates(eng):
+    # tables of very different dims around one hub, a duplicate message, residual sends; 512 labels = the limit
+    rng = np.random.default_rng(77)
+    dims = [70, 3, 512, 33, 70, 18]
+    b = M.ModelBuilder(2, S.mrf_mtypes())
+    u = [b.add_vector_factors(0, rng.uniform(0, 1, (1, d)))[0] for d in dims]
+    for i, j in ((0, 1), (0, 2), (0, 3), (0, 4), (1, 5), (3, 4), (2, 3)):
+        p = b.add_dense_pairwise(1, rng.uniform(0, 1, (1, dims[i], dims[j])))[0]
+        b.add_messages(0, u[i], p); b.add_messages(1, u[j], p)
+        if (i, j) == (0, 4):
+            b.add_messages(0, u[i], p)                      # duplicate message into the same vector
+        b.add_relations(u[i], p); b.add_relations(p, u[j])
+    m = b.finish()
+    for mode in MODES:
+        _check(eng, m, mode, 3)
+    o = Oracle(m); o.set_reparametrization_type(1); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.upload(m); eng.set_reparametrization_type(1); eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.compute_pass(3); o.ComputePass(3)
+    assert np.array_equal(eng.download_duals(), o.duals())
+    eng.set_reparametrization_type(0)
 
 
 @pytest.mark.parametrize("L", [1, 2, 3, 6, 9, 15, 17, 21, 31])

@@ -47,7 +47,7 @@ def _run(eng, m, mode, iterations=3, rtype=0):
     return best
 
 
-@pytest.mark.parametrize("L", [2, 4, 5, 8, 16, 21, 32, 40])
+@pytest.mark.parametrize("L", [2, 4, 5, 8, 16, 21, 32, 40, 70])
 @pytest.mark.parametrize("pairwise", ["dense", "potts"])
 @pytest.mark.parametrize("order", ["row_major", "colour_major"])
 def test_grids_every_kernel_class(eng, L, pairwise, order):
