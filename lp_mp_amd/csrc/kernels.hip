@@ -901,8 +901,9 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
 }
 
 // -------------------------------------------------------------------------------------------------
-// Streaming dense path: one wave per unary, tables of any dims up to BIG_MAX_LABELS (class KC_DENSE_BIG: more than
-// 32 labels; also what the run-time-dims classes fall back to).  Works op by op like the generic kernel, but a
+// Streaming path: one wave per unary, pairwise peers of any dims up to BIG_MAX_LABELS, dense or Potts, mixed
+// (class KC_DENSE_BIG: more than 32 labels, unaries with both kinds of edges; also what the run-time-dims classes
+// fall back to).  Works op by op like the generic kernel, but a
 // receive streams the table in blocks of 16 rows x 64 columns (16 coalesced 512-B row segments in flight per
 // wave) and reduces without a round trip per row:
 //   side 0 (own label = row):    16 per-lane partial minima, one per row, are transposed-and-reduced across the
@@ -975,7 +976,25 @@ sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ o
     const int Lo = side == 0 ? C : R;
     for (int i = lane; i < Lo; i += 64) S.mo[i] = mo[i];
     wave_sync();
-    if (side == 0) {
+    if (((op.info >> 8) & 15) == LPMP_F_PAIRWISE_POTTS) {
+      // q[x] = min(m_o[x], diff + min_{y != x} m_o[y]) from the two smallest entries of m_o (multiset) and the
+      // first index that holds the smallest (reference vector::two_min, vector.hxx:348-443)
+      const double diff = T[0];
+      double a1 = LPMP_INF, a2 = LPMP_INF; int i1 = 0x7fffffff;
+      for (int i = lane; i < Lo; i += 64) {
+        const double x = S.mo[i];
+        if (x < a1 || i1 == 0x7fffffff) { a2 = a1; a1 = x; i1 = i; } else if (x < a2) a2 = x;
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const double b1 = shfl_xor_f64(a1, m), b2 = shfl_xor_f64(a2, m);
+        const int j1 = __shfl_xor(i1, m, 64);
+        const double n2 = fmin(fmax(a1, b1), fmin(a2, b2));
+        if (b1 < a1 || (b1 == a1 && j1 < i1)) i1 = j1;
+        a1 = fmin(a1, b1); a2 = n2;
+      }
+      for (int i = lane; i < Lo; i += 64) S.q[i] = fmin(0.0 + S.mo[i], diff + (i == i1 ? a2 : a1));
+    } else if (side == 0) {
       for (int a0 = 0; a0 < R; a0 += 16) {
         double v[16];
 #pragma unroll

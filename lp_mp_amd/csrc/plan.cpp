@@ -409,6 +409,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   std::vector<int64_t> rec_bytes(N, 0);
   std::vector<uint8_t> all_dense(N, 1), all_potts(N, 1);     // exact classes: every peer L x L, L the own label count
   std::vector<uint8_t> var_dense(N, 1), var_potts(N, 1);     // padded classes: runtime dims
+  std::vector<uint8_t> up_any(N, 1);                         // streaming class: dense and Potts peers mixed
   std::vector<int32_t> max_dim(N, 0);                        // largest peer table dim of the record
   for (int64_t u = 0; u < N; ++u) {
     const int32_t f = uf[u];
@@ -434,8 +435,10 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && (side == 0 ? f_dim0[peer] : f_dim1[peer]) == own_d0)) var_dense[o] = 0;
         if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == own_d0 && f_dim1[peer] == own_d0)) var_potts[o] = 0;
         max_dim[o] = std::max(max_dim[o], std::max(f_dim0[peer], f_dim1[peer]));
+        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && (f_kind[peer] == LPMP_F_PAIRWISE_DENSE || f_kind[peer] == LPMP_F_PAIRWISE_POTTS) &&
+              (side == 0 ? f_dim0[peer] : f_dim1[peer]) == own_d0)) up_any[o] = 0;
       } else {
-        all_dense[o] = all_potts[o] = var_dense[o] = var_potts[o] = 0;
+        all_dense[o] = all_potts[o] = var_dense[o] = var_potts[o] = up_any[o] = 0;
         if (mt.kind == LPMP_M_LABELING) {
           op.peer_const = tab_off[mt.param];
           op.pd1 = tab_nleft[mt.param];
@@ -480,11 +483,11 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     if (pow && all_potts[u]) return d0 == 4 ? KC_POTTS_4 : d0 == 8 ? KC_POTTS_8 : d0 == 16 ? KC_POTTS_16 : KC_POTTS_32;
     const int w = std::max(d0, max_dim[u]);
     if (w < 1) return KC_GENERIC;
-    if (w > 32) return var_dense[u] && w <= BIG_MAX_LABELS ? KC_DENSE_BIG : KC_GENERIC;
+    if (w > 32) return up_any[u] && w <= BIG_MAX_LABELS ? KC_DENSE_BIG : KC_GENERIC;
     const int slot = w <= 4 ? 0 : w <= 8 ? 1 : w <= 16 ? 2 : 3;
     if (var_dense[u]) return KC_DENSE_V4 + slot;
     if (var_potts[u]) return KC_POTTS_V4 + slot;
-    return KC_GENERIC;
+    return up_any[u] ? KC_DENSE_BIG : KC_GENERIC;          // unaries with both dense and Potts edges
   };
   // a COMPUTE_PRIMAL factor is updated even without any active message (FactorUpdated, reference
   // factors_messages.hxx:3125-3130): the primal passes round its label
@@ -566,7 +569,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
           for (int b2 = b + 1; b2 < r.n_recv + r.n_send; ++b2) if (same_vec(o, b, b2)) { ok = false; break; }
       }
       // (the streaming dense kernel works op by op, so duplicates and any op count are fine for it)
-      if (!ok) { lr.kclass = lr.kclass <= KC_DENSE_V32 ? KC_DENSE_BIG : KC_GENERIC; continue; }
+      if (!ok) { lr.kclass = KC_DENSE_BIG; continue; }
     }
     int kmax = 0;
     bool dup_recv = false;

@@ -83,14 +83,14 @@ def test_potts_ties_and_negative_coupling(eng):
 
 @pytest.mark.parametrize("L", [2, 3, 5, 7, 12, 33, 64])
 def test_odd_label_counts(eng, L):
-    # up to 32 labels: the run-time-dims classes of the padded width; above: the streaming dense class, generic for Potts
+    # up to 32 labels: the run-time-dims classes of the padded width; above: the streaming class
     _check(eng, S.grid_model(6, 7, L, seed=L), M.REPAM_ANISOTROPIC, 2)
     cls = eng.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC)
     want = "dense_big" if L > 32 else "dense_v%d" % (4 if L <= 4 else 8 if L <= 8 else 16 if L <= 16 else 32)
     assert list(cls) == [want] and cls[want] == 42
     _check(eng, S.grid_model(6, 7, L, pairwise="potts", seed=L), M.REPAM_DAMPED_UNIFORM, 2)
     cls = eng.plan.schedule_classes(M.FORWARD, M.REPAM_DAMPED_UNIFORM)
-    assert list(cls) == ["generic" if L > 32 else want.replace("dense", "potts")]
+    assert list(cls) == ["dense_big" if L > 32 else want.replace("dense", "potts")]
 
 
 @pytest.mark.parametrize("L", [33, 47, 64, 65, 100, 130, 200])
@@ -169,6 +169,21 @@ def test_mixed_dense_and_potts_edges(eng):
         b.add_relations(u[var[a[k]]], p)
         b.add_relations(p, u[var[bb[k]]])
     _check(eng, b.finish(), M.REPAM_ANISOTROPIC, 3)
+    cls = eng.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC)
+    assert "generic" not in cls and cls.get("dense_big", 0) > 0       # unaries with both kinds of edges: streaming class
+    _check(eng, b.finish(), M.REPAM_DAMPED_UNIFORM, 3)
+
+
+@pytest.mark.parametrize("L", [33, 64, 100])
+def test_streaming_kernel_potts_many_labels_and_ties(eng, L):
+    H, W = 6, 5
+    E_ = len(S.grid_edges(H, W)[0])
+    un = np.round(S.u01(H * W * L, 3) * 3.0) / 3.0               # exact ties exercise the two-min tie rule
+    diffs = np.where(S.u01(E_, 4) < 0.5, -0.5, 0.75)
+    m = S.grid_model(H, W, L, pairwise="potts", unaries=un, potts=diffs)
+    for mode in MODES:
+        _check(eng, m, mode, 3)
+    assert list(eng.plan.schedule_classes(M.FORWARD, M.REPAM_UNIFORM)) == ["dense_big"]
 
 
 def test_chain_c1(eng):
