@@ -6,8 +6,9 @@ Units and gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM s
 cdna_hip_programming.md section 7: counters are in KiB; FETCH_SIZE reports exactly half the bytes of a
 wide coalesced streaming read on gfx950, WRITE_SIZE is exact:  bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring> <out.json> [last_n]
-last_n: only the last n launches of the kernel (e.g. the event-timed leg of bench.py)
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring> <out.json> [last_n [skip_tail]]
+last_n: only the last n launches of the kernel (e.g. the event-timed leg of bench.py), after dropping the final
+skip_tail launches (bench.py ends with two rounding passes = 8 launches of the directional sweeps)
 """
 import csv
 import json
@@ -26,6 +27,8 @@ def main():
     fetch_csv, write_csv, kernel, out = sys.argv[1:5]
     f = per_launch(fetch_csv, "FETCH_SIZE", kernel)
     w = per_launch(write_csv, "WRITE_SIZE", kernel)
+    if len(sys.argv) > 6 and int(sys.argv[6]) > 0:
+        f, w = f[:-int(sys.argv[6])], w[:-int(sys.argv[6])]
     if len(sys.argv) > 5:
         f, w = f[-int(sys.argv[5]):], w[-int(sys.argv[5]):]
     assert f and w and len(f) == len(w), (len(f), len(w))
