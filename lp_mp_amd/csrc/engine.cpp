@@ -204,6 +204,15 @@ struct lpmp_engine {
   std::vector<Pending> pending;
   std::vector<hipEvent_t> event_pool;
 
+  void release_primal() {
+    if (d_primal) { (void)hipFree(d_primal); d_primal = nullptr; }
+    if (d_pinit) { (void)hipFree(d_pinit); d_pinit = nullptr; }
+    if (d_plinks) { (void)hipFree(d_plinks); d_plinks = nullptr; }
+    if (d_pcost) { (void)hipFree(d_pcost); d_pcost = nullptr; }
+    if (d_pbad) { (void)hipFree(d_pbad); d_pbad = nullptr; }
+    if (h_pbad) { (void)hipHostFree(h_pbad); h_pbad = nullptr; }
+    have_primal = false; primal_t = 0; n_pinit = n_plinks = n_pprop = 0;
+  }
   void release_model() {
     for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m) sched[d][m].release();
     for (int m = 0; m < LPMP_REPAM_COUNT; ++m) { have_sched[m] = false; sched_pass[m].release(); sched_bf[m].release(); have_pass[m] = false; rotation_ok[m] = false; }
@@ -217,13 +226,7 @@ struct lpmp_engine {
     if (d_lb) { (void)hipFree(d_lb); d_lb = nullptr; }
     if (d_part) { (void)hipFree(d_part); d_part = nullptr; }
     if (h_part) { (void)hipHostFree(h_part); h_part = nullptr; }
-    if (d_primal) { (void)hipFree(d_primal); d_primal = nullptr; }
-    if (d_pinit) { (void)hipFree(d_pinit); d_pinit = nullptr; }
-    if (d_plinks) { (void)hipFree(d_plinks); d_plinks = nullptr; }
-    if (d_pcost) { (void)hipFree(d_pcost); d_pcost = nullptr; }
-    if (d_pbad) { (void)hipFree(d_pbad); d_pbad = nullptr; }
-    if (h_pbad) { (void)hipHostFree(h_pbad); h_pbad = nullptr; }
-    have_primal = false; primal_t = 0; n_pinit = n_plinks = n_pprop = 0;
+    release_primal();
     if (d_stale) { (void)hipFree(d_stale); d_stale = nullptr; }
     if (d_stale_n) { (void)hipFree(d_stale_n); d_stale_n = nullptr; }
     if (h_stale_n) { (void)hipHostFree(h_stale_n); h_stale_n = nullptr; }
@@ -663,6 +666,7 @@ int lpmp_compute_pass(lpmp_engine* e, int n) {
 // stops at the pairwise factor (its other side is unset or already equal).
 static void ensure_primal(lpmp_engine* e) {
   if (e->have_primal) return;
+  e->release_primal();   // a previous attempt may have stopped half way
   const Plan& p = e->plan->p;
   for (const auto& mt : p.mtypes)
     if (mt.kind != LPMP_M_UNARY_PAIRWISE)
@@ -701,13 +705,10 @@ static void ensure_primal(lpmp_engine* e) {
     HIP_CHECK(hipMemcpy(e->d_plinks, prop.data(), prop.size() * sizeof(PrimalLink), hipMemcpyHostToDevice));
   }
   // every factor starts unset (init_primal), then only the touched ones are ever re-initialised
-  PrimalInit* d_all = nullptr;
   if (p.nf > 0) {
-    HIP_CHECK(hipMalloc((void**)&d_all, all.size() * sizeof(PrimalInit)));
-    HIP_CHECK(hipMemcpy(d_all, all.data(), all.size() * sizeof(PrimalInit), hipMemcpyHostToDevice));
-    launch_primal_init(d_all, p.nf, e->d_primal, e->stream);
-    HIP_CHECK(hipStreamSynchronize(e->stream));
-    HIP_CHECK(hipFree(d_all));
+    std::vector<int32_t> h(2 * (size_t)p.nf);
+    for (int64_t f = 0; f < p.nf; ++f) { h[2 * f] = all[f].a; h[2 * f + 1] = all[f].b; }
+    HIP_CHECK(hipMemcpy(e->d_primal, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   if (!init.empty()) {
     HIP_CHECK(hipMalloc((void**)&e->d_pinit, init.size() * sizeof(PrimalInit)));

@@ -36,7 +36,7 @@ def parse_uai(text: str) -> Tuple[List[int], List[Tuple[Tuple[int, ...], np.ndar
 
 
 def FMC_SRMP():
-    U = LPM.FactorContainer(LPM.UnarySimplexFactor, 0)
+    U = LPM.FactorContainer(LPM.UnarySimplexFactor, 0, True)     # COMPUTE_PRIMAL_SOLUTION on the unaries: rounding
     P = LPM.FactorContainer(LPM.PairwiseSimplexFactor, 1)
     ML = LPM.MessageContainer(LPM.UnaryPairwiseMessage(0), 0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, 0)
     MR = LPM.MessageContainer(LPM.UnaryPairwiseMessage(1), 0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, 1)
@@ -66,3 +66,15 @@ def build_lp_from_uai(text: str, device: int = 0) -> LPM.LP:
         lp.AddFactorRelation(u[i], p)
         lp.AddFactorRelation(p, u[j])
     return lp
+
+
+def solve_uai(text: str, device: int = 0, **visitor_options):
+    """MAP estimation for a model in UAI format with the message-passing rounding solver — the reference's
+    ``MpRoundingSolver<Solver<LP<FMC_SRMP>, StandardVisitor>>`` + ``UaiMrfInput::ParseString`` (test/graphical_model.cpp:
+    47-56).  Returns (lower bound, primal cost, labeling of the variables)."""
+    lp = build_lp_from_uai(text, device)
+    s = LPM.MpRoundingSolver(lp, LPM.StandardVisitor(**visitor_options))
+    s.Solve()
+    n = len(parse_uai(text)[0])
+    x = None if s.solution_ is None else s.solution_[:n, 0].copy()      # unaries are the first n factors
+    return s.lower_bound(), s.primal_cost(), x

@@ -162,3 +162,34 @@ def test_cyclic_relations_and_isolated_factors_match_oracle():
         assert sorted(p.update_order(d)) == [0, 2]
         for mode in MODES:
             assert np.array_equal(o.omega(d, mode)[1], p.omega(d, mode)[1])
+
+
+def test_kernel_class_of_every_model_shape():
+    """which device kernel a sweep's updated factors run on (lpmp_plan_schedule_classes): exact power-of-two classes,
+    run-time-dims classes up to 32 labels, the streaming class up to 512 labels and for mixed dense / Potts
+    neighbourhoods, the generic kernel for everything else"""
+    from lp_mp_amd import engine as E
+    def cls(m, d=M.FORWARD, mode=M.REPAM_ANISOTROPIC):
+        return E.Plan(m).schedule_classes(d, mode)
+    for L, dense, potts in ((4, "dense4", "potts4"), (32, "dense32", "potts32"), (3, "dense_v4", "potts_v4"),
+                            (21, "dense_v32", "potts_v32"), (9, "dense_v16", "potts_v16"), (33, "dense_big", "dense_big"),
+                            (512, "dense_big", "dense_big"), (513, "generic", "generic")):
+        assert cls(S.grid_model(3, 4, L, seed=1)) == {dense: 12}, L
+        assert cls(S.grid_model(3, 4, L, pairwise="potts", seed=1)) == {potts: 12}, L
+    # rectangular tables: the padded width covers the largest dim of the unary's tables
+    b = M.ModelBuilder(2, S.mrf_mtypes())
+    u = [b.add_vector_factors(0, np.zeros((1, d)))[0] for d in (3, 20, 40)]
+    for i, j, d in ((0, 1, (3, 20)), (1, 2, (20, 40))):
+        p = b.add_dense_pairwise(1, np.zeros((1,) + d))[0]
+        b.add_messages(0, u[i], p); b.add_messages(1, u[j], p)
+        b.add_relations(u[i], p); b.add_relations(p, u[j])
+    assert cls(b.finish(), mode=M.REPAM_UNIFORM) == {"dense_v32": 1, "dense_big": 2}
+    # labeling lists (multicut) and min-norm links stay on the generic kernel
+    assert set(cls(S.multicut_triangle_model(6, 4, seed=1), d=M.BACKWARD)) == {"generic"}
+    # COMPUTE_PRIMAL factor types keep the record of an update without active messages (isolated unary)
+    b = M.ModelBuilder(2, S.mrf_mtypes(), [1, 0])
+    b.add_vector_factors(0, np.zeros((2, 5)))
+    assert cls(b.finish()) == {"dense_v8": 2}
+    b = M.ModelBuilder(2, S.mrf_mtypes())
+    b.add_vector_factors(0, np.zeros((2, 5)))
+    assert cls(b.finish()) == {}

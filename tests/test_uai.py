@@ -58,3 +58,13 @@ def test_uai_tree_is_solved_to_optimality_on_device():
     o.set_reparametrization(M.REPAM_ANISOTROPIC)
     o.ComputePass(10)
     assert o.LowerBound() == pytest.approx(0.644, abs=1e-9)
+
+
+@pytest.mark.gpu
+def test_uai_rounding_solver_finds_the_map_labeling():
+    # the reference's solver_options (graphical_model.cpp:32-43): 100 iterations, rounding every 5th, anisotropic
+    lb, cost, x = uai.solve_uai(UAI_TEST_INPUT, maxIter=100, primalComputationInterval=5,
+                                standardReparametrization="anisotropic", roundingReparametrization="anisotropic")
+    card, tables = uai.parse_uai(UAI_TEST_INPUT)
+    assert lb == pytest.approx(0.644, abs=1e-9) and cost == pytest.approx(0.644, abs=1e-9)
+    assert sum(t[tuple(x[v] for v in sc)] for sc, t in tables) == pytest.approx(0.644)
