@@ -71,9 +71,9 @@ int lpmp_plan_schedule_info(lpmp_plan* p, int direction, int mode, int64_t* n_le
                             int64_t* n_receives, int64_t* n_sends, int64_t* algorithmic_bytes);
 
 /* updated factors of that sweep per device kernel class (LPMP_KCLASS_COUNT entries: generic, dense 4/8/16/32,
- * Potts 4/8/16/32, the run-time-dims forms of the same eight, the streaming dense class for up to 512 labels;
- * DESIGN.md 5): which kernels a model runs on */
-#define LPMP_KCLASS_COUNT 18
+ * Potts 4/8/16/32, the run-time-dims forms of the same eight, the streaming class for up to 512 labels, the
+ * lane-per-factor class for tiny factors): which kernels a model runs on */
+#define LPMP_KCLASS_COUNT 19
 int lpmp_plan_schedule_classes(lpmp_plan* p, int direction, int mode, int64_t* factors /*[LPMP_KCLASS_COUNT]*/);
 
 /* dependent step (1-based level; 0 = no active message) of every entry of the update order in that sweep */

@@ -100,12 +100,43 @@ __device__ __forceinline__ void store_label(int32_t* __restrict__ primal, int fa
 }
 
 // -------------------------------------------------------------------------------------------------
-// Generic kernel: any factor kind, any message kind, either role.  One wave per updated factor.
+// Generic kernel: any factor kind, any message kind, either role.  Two shapes of the same code:
+//   G = 64: one wave per updated factor, state (own duals, snapshot, delta) in LDS, up to GEN_MAXD doubles;
+//   G = 1:  one LANE per updated factor for tiny factors (every dim <= SMALL_MAXD: labeling-list edge / triplet
+//           factors, two-label toy factors, small pairwise factors that are themselves updated) — 64 factors per
+//           wave, no cross-lane step at all, the per-lane state interleaved in LDS ([element][lane]: conflict free).
 // -------------------------------------------------------------------------------------------------
-struct GenLds {
-  double own[GEN_MAXD];
-  double snap[GEN_MAXD];
-  double dl[GEN_MAXD];
+constexpr int SMALL_WAVES = 1;
+template <int G> struct GenCtx;
+template <> struct GenCtx<64> {
+  static constexpr int STRIDE = 64, FPB = GEN_WAVES, THREADS = 64 * GEN_WAVES;
+  struct Lds { double own[GEN_MAXD]; double snap[GEN_MAXD]; double dl[GEN_MAXD]; };
+  Lds& s; const int lane;
+  __device__ __forceinline__ double& own(int i) const { return s.own[i]; }
+  __device__ __forceinline__ double& snap(int i) const { return s.snap[i]; }
+  __device__ __forceinline__ double& dl(int i) const { return s.dl[i]; }
+  __device__ __forceinline__ int first() const { return lane; }
+  __device__ __forceinline__ bool leader() const { return lane == 0; }
+  __device__ __forceinline__ static double gmin(double v) { return wave_min(v); }
+  __device__ __forceinline__ static int gmin(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
+    return v;
+  }
+  __device__ __forceinline__ static void sync() { wave_sync(); }
+};
+template <> struct GenCtx<1> {
+  static constexpr int STRIDE = 1, FPB = 64 * SMALL_WAVES, THREADS = 64 * SMALL_WAVES;
+  struct Lds { double own[SMALL_MAXD][64]; double snap[SMALL_MAXD][64]; double dl[SMALL_MAXD][64]; };
+  Lds& s; const int lane;
+  __device__ __forceinline__ double& own(int i) const { return s.own[i][lane]; }
+  __device__ __forceinline__ double& snap(int i) const { return s.snap[i][lane]; }
+  __device__ __forceinline__ double& dl(int i) const { return s.dl[i][lane]; }
+  __device__ __forceinline__ int first() const { return 0; }
+  __device__ __forceinline__ bool leader() const { return true; }
+  __device__ __forceinline__ static double gmin(double v) { return v; }
+  __device__ __forceinline__ static int gmin(int v) { return v; }
+  __device__ __forceinline__ static void sync() {}
 };
 
 // pairwise cost T(a,b) of a pairwise factor (dense table or Potts scalar)
@@ -115,137 +146,138 @@ __device__ __forceinline__ double pw_cost(const double* __restrict__ cdata, int6
 }
 
 // dl[x] = omega * (m_s[x] + min_y (T + m_o[y])) for side s of a pairwise factor whose message vectors are
-// read through pointer m (global: live peer, or LDS: own snapshot)
-template <class MPtr>
-__device__ void pw_min_marginal(GenLds& L, const double* __restrict__ cdata, int64_t coff, int kind, int d0, int d1,
-                                MPtr m, int side, double omega, int lane) {
+// read through m (global: live peer, or LDS: own snapshot / live own state)
+template <class C, class Src>
+__device__ __forceinline__ void pw_min_marginal(const C& c, const double* __restrict__ cdata, int64_t coff, int kind, int d0, int d1,
+                                                Src m, int side, double omega) {
   if (side == 0) {
     for (int a = 0; a < d0; ++a) {
       double v = LPMP_INF;
-      for (int b = lane; b < d1; b += 64) v = fmin(v, pw_cost(cdata, coff, kind, d1, a, b) + m[d0 + b]);
-      v = wave_min(v);
-      if (lane == 0) L.dl[a] = omega * (m[a] + v);
+      for (int b = c.first(); b < d1; b += C::STRIDE) v = fmin(v, pw_cost(cdata, coff, kind, d1, a, b) + m(d0 + b));
+      v = C::gmin(v);
+      if (c.leader()) c.dl(a) = omega * (m(a) + v);
     }
   } else {
-    for (int b = lane; b < d1; b += 64) {
+    for (int b = c.first(); b < d1; b += C::STRIDE) {
       double v = LPMP_INF;
-      for (int a = 0; a < d0; ++a) v = fmin(v, pw_cost(cdata, coff, kind, d1, a, b) + m[a]);
-      L.dl[b] = omega * (m[d0 + b] + v);
+      for (int a = 0; a < d0; ++a) v = fmin(v, pw_cost(cdata, coff, kind, d1, a, b) + m(a));
+      c.dl(b) = omega * (m(d0 + b) + v);
     }
   }
-  wave_sync();
+  C::sync();
 }
 
 // labeling_message::compute_msg (reference labeling_list_factor.hxx:411-443): dl[l] = omega*(min_{r:tab[r]==l} R[r] - not_taken)
-template <class RPtr>
-__device__ void labeling_to_left(GenLds& L, RPtr R, int nr, const int32_t* __restrict__ tab, int nl, int implicit_origin,
-                                 double omega, int lane) {
+template <class C, class Src>
+__device__ __forceinline__ void labeling_to_left(const C& c, Src R, int nr, const int32_t* __restrict__ tab, int nl, int implicit_origin,
+                                                 double omega) {
   double nt = implicit_origin ? 0.0 : LPMP_INF;
-  for (int r = 0; r < nr; ++r) if (tab[r] >= nl) nt = fmin(nt, R[r]);
-  for (int l = lane; l < nl; l += 64) {
+  for (int r = 0; r < nr; ++r) if (tab[r] >= nl) nt = fmin(nt, R(r));
+  for (int l = c.first(); l < nl; l += C::STRIDE) {
     double v = LPMP_INF;
-    for (int r = 0; r < nr; ++r) if (tab[r] == l) v = fmin(v, R[r]);
-    L.dl[l] = omega * (v - nt);
+    for (int r = 0; r < nr; ++r) if (tab[r] == l) v = fmin(v, R(r));
+    c.dl(l) = omega * (v - nt);
   }
-  wave_sync();
+  C::sync();
 }
 
-template <class SPtr>
-__device__ void minnorm_delta(GenLds& L, SPtr src, int n, double omega, int lane) {
+template <class C, class Src>
+__device__ __forceinline__ void minnorm_delta(const C& c, Src src, int n, double omega) {
   double mn = LPMP_INF;
-  for (int i = lane; i < n; i += 64) mn = fmin(mn, src[i]);
-  mn = wave_min(mn);
-  for (int i = lane; i < n; i += 64) L.dl[i] = omega * (src[i] - mn);
-  wave_sync();
+  for (int i = c.first(); i < n; i += C::STRIDE) mn = fmin(mn, src(i));
+  mn = C::gmin(mn);
+  for (int i = c.first(); i < n; i += C::STRIDE) c.dl(i) = omega * (src(i) - mn);
+  C::sync();
 }
 
-__global__ void __launch_bounds__(64 * GEN_WAVES)
+template <int G>
+__global__ void __launch_bounds__(GenCtx<G>::THREADS)
 sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
                      const double* __restrict__ cdata, const int32_t* __restrict__ tabs, double* __restrict__ lb,
                      int32_t* __restrict__ primal, int64_t first, int64_t count, int flags) {
-  __shared__ GenLds lds[GEN_WAVES];
+  using C = GenCtx<G>;
+  __shared__ typename C::Lds lds[G == 64 ? GEN_WAVES : SMALL_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t idx = (int64_t)blockIdx.x * GEN_WAVES + wave;
+  const int64_t idx = (int64_t)blockIdx.x * C::FPB + (G == 64 ? wave : (int)threadIdx.x);
   if (idx >= count) return;
-  GenLds& L = lds[wave];
+  const C c{lds[wave], lane};
   const UpdRec rec = recs[first + idx];
   const int okind = rec.kind_flags & 15;
-  const int oflags = rec.kind_flags >> 4;
   const int on = okind == LPMP_F_VECTOR ? rec.d0 : rec.d0 + rec.d1;   // own dual size
   double* own_g = dual + rec.dual_off;
-  for (int i = lane; i < on; i += 64) L.own[i] = own_g[i];
-  wave_sync();
+  for (int i = c.first(); i < on; i += C::STRIDE) c.own(i) = own_g[i];
+  C::sync();
 
   const int n_ops = rec.n_recv + rec.n_send;
-  // one receive or send: compute delta from `src` (peer for a receive; snapshot or live own state for a send),
+  // one receive or send: compute delta from the peer (receive) or from the snapshot / live own state (send),
   // then +delta to the side that did not compute it and -delta to the side that did
-  auto run_op = [&](const Op& op, const bool recv, const double* own_src, const double omega) {
-    if (lane == 0) lb[op.peer] = LPMP_NAN;
+  auto run_op = [&](const Op& op, const bool recv, const bool live_src, const double omega) {
+    if (c.leader()) lb[op.peer] = LPMP_NAN;
     const int code = op.info & 15, role = (op.info >> 4) & 1, side = (op.info >> 5) & 1, imp = (op.info >> 6) & 1;
     const int pkind = (op.info >> 8) & 15;
     double* peer = dual + op.peer_dual;
     const int len = op.len;
+    auto from_peer = [&](int i) { return peer[i]; };
+    auto from_own = [&](int i) { return live_src ? c.own(i) : c.snap(i); };
     // the message is computed by the peer for a receive and by the updated factor for a send
     const bool by_right = recv ? (role == 0) : (role == 1);
     if (code == OP_UP) {
       if (by_right) {   // min-marginal of the pairwise (right) factor
-        if (recv) pw_min_marginal(L, cdata, op.peer_const, pkind, op.pd0, op.pd1, (const double*)peer, side, omega, lane);
-        else pw_min_marginal(L, cdata, rec.const_off, okind, rec.d0, rec.d1, own_src, side, omega, lane);
+        if (recv) pw_min_marginal(c, cdata, op.peer_const, pkind, op.pd0, op.pd1, from_peer, side, omega);
+        else pw_min_marginal(c, cdata, rec.const_off, okind, rec.d0, rec.d1, from_own, side, omega);
       } else {          // omega * theta of the unary (left) factor
-        for (int i = lane; i < len; i += 64) L.dl[i] = omega * (recv ? peer[i] : own_src[i]);
-        wave_sync();
+        for (int i = c.first(); i < len; i += C::STRIDE) c.dl(i) = omega * (recv ? peer[i] : from_own(i));
+        C::sync();
       }
     } else if (code == OP_LABELING) {
       const int32_t* tab = tabs + op.peer_const;
       if (by_right) {
-        if (recv) labeling_to_left(L, (const double*)peer, op.pd0, tab, op.pd1, imp, omega, lane);
-        else labeling_to_left(L, own_src, rec.d0, tab, op.pd1, imp, omega, lane);
+        if (recv) labeling_to_left(c, from_peer, op.pd0, tab, op.pd1, imp, omega);
+        else labeling_to_left(c, from_own, rec.d0, tab, op.pd1, imp, omega);
       } else {
-        for (int i = lane; i < len; i += 64) L.dl[i] = omega * (recv ? peer[i] : own_src[i]);
-        wave_sync();
+        for (int i = c.first(); i < len; i += C::STRIDE) c.dl(i) = omega * (recv ? peer[i] : from_own(i));
+        C::sync();
       }
     } else {            // OP_MINNORM
-      if (recv) minnorm_delta(L, (const double*)peer, len, omega, lane);
-      else minnorm_delta(L, own_src, len, omega, lane);
+      if (recv) minnorm_delta(c, from_peer, len, omega);
+      else minnorm_delta(c, from_own, len, omega);
     }
     // (reference MessageContainerView::operator-=, factors_messages.hxx:495-508)
     const bool own_is_left = role == 0;
     const double s_left = by_right ? +1.0 : -1.0, s_right = -s_left;
-    if (own_is_left) { for (int i = lane; i < len; i += 64) L.own[i] += s_left * L.dl[i]; }
-    else { for (int i = lane; i < len; i += 64) peer[i] += s_left * L.dl[i]; }
+    if (own_is_left) { for (int i = c.first(); i < len; i += C::STRIDE) c.own(i) += s_left * c.dl(i); }
+    else { for (int i = c.first(); i < len; i += C::STRIDE) peer[i] += s_left * c.dl(i); }
     if (code == OP_UP) {
-      if (own_is_left) { double* m = peer + (side == 0 ? 0 : op.pd0); for (int i = lane; i < len; i += 64) m[i] += s_right * L.dl[i]; }
-      else { double* m = L.own + (side == 0 ? 0 : rec.d0); for (int i = lane; i < len; i += 64) m[i] += s_right * L.dl[i]; }
+      if (own_is_left) { double* m = peer + (side == 0 ? 0 : op.pd0); for (int i = c.first(); i < len; i += C::STRIDE) m[i] += s_right * c.dl(i); }
+      else { const int o = side == 0 ? 0 : rec.d0; for (int i = c.first(); i < len; i += C::STRIDE) c.own(o + i) += s_right * c.dl(i); }
     } else if (code == OP_LABELING) {
       const int32_t* tab = tabs + op.peer_const;
       const int nl = op.pd1;
-      if (own_is_left) { for (int r = lane; r < op.pd0; r += 64) if (tab[r] < nl) peer[r] += s_right * L.dl[tab[r]]; }
-      else { for (int r = lane; r < rec.d0; r += 64) if (tab[r] < nl) L.own[r] += s_right * L.dl[tab[r]]; }
+      if (own_is_left) { for (int r = c.first(); r < op.pd0; r += C::STRIDE) if (tab[r] < nl) peer[r] += s_right * c.dl(tab[r]); }
+      else { for (int r = c.first(); r < rec.d0; r += C::STRIDE) if (tab[r] < nl) c.own(r) += s_right * c.dl(tab[r]); }
     } else {
-      if (own_is_left) { for (int i = lane; i < len; i += 64) peer[i] += s_right * L.dl[i]; }
-      else { for (int i = lane; i < len; i += 64) L.own[i] += s_right * L.dl[i]; }
+      if (own_is_left) { for (int i = c.first(); i < len; i += C::STRIDE) peer[i] += s_right * c.dl(i); }
+      else { for (int i = c.first(); i < len; i += C::STRIDE) c.own(i) += s_right * c.dl(i); }
     }
-    wave_sync();
+    C::sync();
   };
   // MaximizePotentialAndComputePrimal between the receives and the sends (vector factors of a COMPUTE_PRIMAL type)
   auto round_label = [&]() {
     if (!((flags & SWEEP_PRIMAL) && (rec.kind_flags & UPD_PRIMAL) && okind == LPMP_F_VECTOR)) return;
     double bv = LPMP_INF; int bi = 0x7fffffff;
-    for (int i = lane; i < on; i += 64) { const double v = L.own[i]; if (bi == 0x7fffffff || v < bv) { bv = v; bi = i; } }
-    const double mn = wave_min(bv);
-    int cand = (bi != 0x7fffffff && bv == mn) ? bi : 0x7fffffff;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) cand = min(cand, __shfl_xor(cand, m, 64));
-    if (lane == 0) store_label(primal, rec.factor, on, cand);
+    for (int i = c.first(); i < on; i += C::STRIDE) { const double v = c.own(i); if (bi == 0x7fffffff || v < bv) { bv = v; bi = i; } }
+    const double mn = C::gmin(bv);
+    const int cand = C::gmin((bi != 0x7fffffff && bv == mn) ? bi : 0x7fffffff);
+    if (c.leader()) store_label(primal, rec.factor, on, cand);
   };
   for (int k = 0; k < n_ops; ++k) {
     if (k == rec.n_recv) {   // state after the receives: what every shared send is computed from
       round_label();
-      for (int i = lane; i < on; i += 64) L.snap[i] = L.own[i];
-      wave_sync();
+      for (int i = c.first(); i < on; i += C::STRIDE) c.snap(i) = c.own(i);
+      C::sync();
     }
     const Op op = ops[rec.op_begin + k];
-    run_op(op, k < rec.n_recv, L.snap, op.omega);
+    run_op(op, k < rec.n_recv, false, op.omega);
   }
   if (rec.n_recv == n_ops) round_label();
   if (flags & SWEEP_RESIDUAL) {   // reference send_messages_residual, factors_messages.hxx:2960-3007
@@ -253,12 +285,11 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
     for (int k = rec.n_recv; k < n_ops; ++k) {
       const Op op = ops[rec.op_begin + k];
       residual += op.omega;
-      run_op(op, false, L.own, residual);
+      run_op(op, false, true, residual);
     }
   }
-  (void)oflags;
-  if (lane == 0) lb[rec.factor] = LPMP_NAN;
-  for (int i = lane; i < on; i += 64) own_g[i] = L.own[i];
+  if (c.leader()) lb[rec.factor] = LPMP_NAN;
+  for (int i = c.first(); i < on; i += C::STRIDE) own_g[i] = c.own(i);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1291,7 +1322,8 @@ void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, c
     case KC_POTTS_8: hipLaunchKernelGGL(sweep_potts_kernel<8>, blocks(256 / 8), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
     case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
     case KC_DENSE_BIG: hipLaunchKernelGGL(sweep_dense_big_kernel, blocks(BIG_WAVES), dim3(64 * BIG_WAVES), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
-    default: hipLaunchKernelGGL(sweep_generic_kernel, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, lb, primal, first, count, flags); break;
+    case KC_SMALL: hipLaunchKernelGGL(sweep_generic_kernel<1>, blocks(GenCtx<1>::FPB), dim3(GenCtx<1>::THREADS), 0, s, recs, ops, dual, cdata, tabs, lb, primal, first, count, flags); break;
+    default: hipLaunchKernelGGL(sweep_generic_kernel<64>, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, lb, primal, first, count, flags); break;
   }
 }
 

@@ -410,6 +410,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   std::vector<uint8_t> all_dense(N, 1), all_potts(N, 1);     // exact classes: every peer L x L, L the own label count
   std::vector<uint8_t> var_dense(N, 1), var_potts(N, 1);     // padded classes: runtime dims
   std::vector<uint8_t> up_any(N, 1);                         // streaming class: dense and Potts peers mixed
+  std::vector<uint8_t> small_ok(N, 1);                       // lane-per-factor class: every size <= SMALL_MAXD
   std::vector<int32_t> max_dim(N, 0);                        // largest peer table dim of the record
   for (int64_t u = 0; u < N; ++u) {
     const int32_t f = uf[u];
@@ -446,6 +447,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         }
       }
       op.info = mt.kind | (e.role << 4) | (side << 5) | (imp << 6) | (f_kind[peer] << 8);
+      if (std::max(op.len, std::max(op.pd0, op.pd1)) > SMALL_MAXD || f_doff[f + 1] - f_doff[f] > SMALL_MAXD) small_ok[o] = 0;
       return op;
     };
     // algorithmic bytes, counted per update as the reference executes it: own dual read + written
@@ -477,17 +479,18 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   std::vector<int32_t> kclass(N, KC_GENERIC);
   auto cls_of = [&](int64_t u) -> int32_t {
     const int d0 = f_dim0[uf[u]];
-    if (f_kind[uf[u]] != LPMP_F_VECTOR) return KC_GENERIC;
+    if (f_kind[uf[u]] != LPMP_F_VECTOR) return small_ok[u] ? KC_SMALL : KC_GENERIC;   // updated pairwise factors
     const bool pow = d0 == 4 || d0 == 8 || d0 == 16 || d0 == 32;
     if (pow && all_dense[u]) return d0 == 4 ? KC_DENSE_4 : d0 == 8 ? KC_DENSE_8 : d0 == 16 ? KC_DENSE_16 : KC_DENSE_32;
     if (pow && all_potts[u]) return d0 == 4 ? KC_POTTS_4 : d0 == 8 ? KC_POTTS_8 : d0 == 16 ? KC_POTTS_16 : KC_POTTS_32;
     const int w = std::max(d0, max_dim[u]);
-    if (w < 1) return KC_GENERIC;
+    if (w < 1) return small_ok[u] ? KC_SMALL : KC_GENERIC;      // no unary-pairwise peer at all
     if (w > 32) return up_any[u] && w <= BIG_MAX_LABELS ? KC_DENSE_BIG : KC_GENERIC;
     const int slot = w <= 4 ? 0 : w <= 8 ? 1 : w <= 16 ? 2 : 3;
     if (var_dense[u]) return KC_DENSE_V4 + slot;
     if (var_potts[u]) return KC_POTTS_V4 + slot;
-    return up_any[u] ? KC_DENSE_BIG : KC_GENERIC;          // unaries with both dense and Potts edges
+    if (up_any[u]) return KC_DENSE_BIG;                      // unaries with both dense and Potts edges
+    return small_ok[u] ? KC_SMALL : KC_GENERIC;
   };
   // a COMPUTE_PRIMAL factor is updated even without any active message (FactorUpdated, reference
   // factors_messages.hxx:3125-3130): the primal passes round its label
@@ -547,17 +550,17 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   // inside a launch the order of the records is free (they are independent): sub-wave kernels run several
   // factors per wavefront, so neighbours in the list should have similar amounts of work
   for (const auto& lr : out.launches)
-    if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32 && lr.kclass != KC_DENSE_V32 && lr.kclass != KC_DENSE_BIG)
+    if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32 && lr.kclass != KC_DENSE_V32 && lr.kclass != KC_DENSE_BIG)   // incl. KC_SMALL
       std::stable_sort(out.recs.begin() + lr.begin, out.recs.begin() + lr.end, [](const UpdRec& a, const UpdRec& b) {
         return a.n_recv != b.n_recv ? a.n_recv > b.n_recv : a.n_send > b.n_send;
       });
   // flags of the fast-class records, kept in recs / ops themselves (packets are plain copies)
   static_assert(sizeof(UpdRec) == sizeof(Op), "a packet slot holds either record");
   for (auto& lr : out.launches) {
-    if (lr.kclass == KC_GENERIC || lr.kclass == KC_DENSE_BIG) continue;   // packed dense and Potts classes
+    if (lr.kclass == KC_GENERIC || lr.kclass >= KC_DENSE_BIG) continue;   // packed dense and Potts classes
     auto same_vec = [](const Op* o, int a, int b) { return o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1); };
     if (kc_is_var(lr.kclass)) {
-      // the padded classes only exist in packed / indirect form: what those cannot run goes to the generic kernel
+      // the padded classes only exist in packed / indirect form: what those cannot run goes to the streaming kernel
       bool ok = true;
       for (int64_t i = lr.begin; i < lr.end && ok; ++i) {
         const UpdRec& r = out.recs[i];

@@ -68,9 +68,12 @@ enum KClass : int32_t {
   KC_POTTS_V4, KC_POTTS_V8, KC_POTTS_V16, KC_POTTS_V32,
   // one wave per unary, dense tables of any dims up to BIG_MAX_LABELS streamed in 16-row blocks
   KC_DENSE_BIG,
+  // one LANE per updated factor: tiny factors of any kind (every dual size / message length <= SMALL_MAXD)
+  KC_SMALL,
   KC_COUNT
 };
 constexpr int BIG_MAX_LABELS = 512;
+constexpr int SMALL_MAXD = 8;
 // lanes-per-vector width of a packed fast class (0: generic / streaming class)
 constexpr int kc_width(int kclass) {
   return (kclass == KC_GENERIC || kclass >= KC_DENSE_BIG) ? 0 : 4 << ((kclass - 1) % 4);

@@ -176,6 +176,16 @@ def test_kernel_class_of_every_model_shape():
                             (512, "dense_big", "dense_big"), (513, "generic", "generic")):
         assert cls(S.grid_model(3, 4, L, seed=1)) == {dense: 12}, L
         assert cls(S.grid_model(3, 4, L, pairwise="potts", seed=1)) == {potts: 12}, L
+    # updated pairwise factors (`full` schedule): tiny ones one lane each, larger ones one wave each
+    for L, want in ((2, "small"), (4, "small"), (5, "generic")):
+        mt = [M.MsgType(0, 1, M.SCHED_FULL, 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, M.SCHED_FULL, 0, 1, M.M_UNARY_PAIRWISE, 1)]
+        b = M.ModelBuilder(2, mt)
+        u = b.add_vector_factors(0, np.zeros((2, L)))
+        p = b.add_dense_pairwise(1, np.zeros((1, L, L)))[0]
+        b.add_messages(0, u[0], p); b.add_messages(1, u[1], p)
+        b.add_relations(u[0], p); b.add_relations(p, u[1])
+        c = cls(b.finish(), mode=M.REPAM_UNIFORM)
+        assert c.get(want, 0) >= 1 and ("small" in c) == (want == "small"), (L, c)
     # rectangular tables: the padded width covers the largest dim of the unary's tables
     b = M.ModelBuilder(2, S.mrf_mtypes())
     u = [b.add_vector_factors(0, np.zeros((1, d)))[0] for d in (3, 20, 40)]
@@ -184,8 +194,16 @@ def test_kernel_class_of_every_model_shape():
         b.add_messages(0, u[i], p); b.add_messages(1, u[j], p)
         b.add_relations(u[i], p); b.add_relations(p, u[j])
     assert cls(b.finish(), mode=M.REPAM_UNIFORM) == {"dense_v32": 1, "dense_big": 2}
-    # labeling lists (multicut) and min-norm links stay on the generic kernel
-    assert set(cls(S.multicut_triangle_model(6, 4, seed=1), d=M.BACKWARD)) == {"generic"}
+    # labeling lists (multicut): tiny factors, one lane each; with more than 8 labelings the wave-per-factor kernel
+    assert set(cls(S.multicut_triangle_model(6, 4, seed=1), d=M.BACKWARD)) == {"small"}
+    mt = [M.MsgType(0, 1, M.SCHED_LEFT, 0, 1, M.M_LABELING, 0)]
+    b = M.ModelBuilder(2, mt)
+    labs = [tuple(int(c) for c in np.binary_repr(k, 4)) for k in range(1, 10)]      # 9 labelings of 4 edges
+    b.add_labeling_table([(1,)], labs, (0,))
+    e = b.add_vector_factors(0, np.zeros((1, 1)), implicit_origin=True)[0]
+    q = b.add_vector_factors(1, np.zeros((1, 9)), implicit_origin=True)[0]
+    b.add_messages(0, e, q); b.add_relations(e, q)
+    assert set(cls(b.finish(), d=M.BACKWARD)) == {"generic"}
     # COMPUTE_PRIMAL factor types keep the record of an update without active messages (isolated unary)
     b = M.ModelBuilder(2, S.mrf_mtypes(), [1, 0])
     b.add_vector_factors(0, np.zeros((2, 5)))
