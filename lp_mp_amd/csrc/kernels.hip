@@ -221,6 +221,40 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
     auto from_own = [&](int i) { return live_src ? c.own(i) : c.snap(i); };
     // the message is computed by the peer for a receive and by the updated factor for a send
     const bool by_right = recv ? (role == 0) : (role == 1);
+    if constexpr (G == 1) {
+      // labeling message with the updated factor on the left (multicut edge variable <-> triplet / quadruple factor),
+      // lane-per-factor form: deep schedules of such factors are bound by the chain of dependent loads of ONE
+      // update, so the match table and the peer's costs are requested together, unconditionally, as soon as the op
+      // is known (2 round trips per op instead of 4) and the reparametrisation reuses the loaded costs.  Same
+      // arithmetic as the general path below.
+      if (code == OP_LABELING && role == 0) {
+        const int32_t* tab = tabs + op.peer_const;
+        const int nr = op.pd0, nl = op.pd1;
+        int tv[SMALL_MAXD]; double Rv[SMALL_MAXD];
+#pragma unroll
+        for (int r = 0; r < SMALL_MAXD; ++r) { const bool in = r < nr; tv[r] = in ? tab[r] : nl; Rv[r] = in ? peer[r] : LPMP_INF; }
+        if (recv) {
+          double nt = imp ? 0.0 : LPMP_INF;
+#pragma unroll
+          for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] >= nl) nt = fmin(nt, Rv[r]);   // entries beyond nr hold +inf
+          for (int l = 0; l < nl; ++l) {
+            double v = LPMP_INF;
+#pragma unroll
+            for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] == l) v = fmin(v, Rv[r]);
+            c.dl(l) = omega * (v - nt);
+          }
+          for (int i = 0; i < len; ++i) c.own(i) += +1.0 * c.dl(i);
+#pragma unroll
+          for (int r = 0; r < SMALL_MAXD; ++r) if (r < nr && tv[r] < nl) peer[r] = Rv[r] + -1.0 * c.dl(tv[r]);
+        } else {
+          for (int i = 0; i < len; ++i) c.dl(i) = omega * from_own(i);
+          for (int i = 0; i < len; ++i) c.own(i) += -1.0 * c.dl(i);
+#pragma unroll
+          for (int r = 0; r < SMALL_MAXD; ++r) if (r < nr && tv[r] < nl) peer[r] = Rv[r] + +1.0 * c.dl(tv[r]);
+        }
+        return;
+      }
+    }
     if (code == OP_UP) {
       if (by_right) {   // min-marginal of the pairwise (right) factor
         if (recv) pw_min_marginal(c, cdata, op.peer_const, pkind, op.pd0, op.pd1, from_peer, side, omega);
@@ -270,13 +304,16 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
     const int cand = C::gmin((bi != 0x7fffffff && bv == mn) ? bi : 0x7fffffff);
     if (c.leader()) store_label(primal, rec.factor, on, cand);
   };
+  Op nxt{};
+  if (n_ops > 0) nxt = ops[rec.op_begin];
   for (int k = 0; k < n_ops; ++k) {
     if (k == rec.n_recv) {   // state after the receives: what every shared send is computed from
       round_label();
       for (int i = c.first(); i < on; i += C::STRIDE) c.snap(i) = c.own(i);
       C::sync();
     }
-    const Op op = ops[rec.op_begin + k];
+    const Op op = nxt;
+    if (k + 1 < n_ops) nxt = ops[rec.op_begin + k + 1];   // requested before this op's dependent chain starts
     run_op(op, k < rec.n_recv, false, op.omega);
   }
   if (rec.n_recv == n_ops) round_label();

@@ -180,3 +180,55 @@ def multicut_triangle_model(n_nodes: int, n_triangles: int, seed: int = 1) -> M.
             b.add_messages(k, e, t_ids[ti])
             b.add_relations(e, t_ids[ti])
     return b.finish()
+
+
+QUAD_LABELINGS = [(1, 1, 0, 0), (0, 1, 1, 0), (0, 0, 1, 1), (1, 0, 0, 1), (1, 1, 1, 1), (1, 0, 1, 0), (0, 1, 0, 1)]
+
+
+def c5_model(H: int, W: int, L: int, n_edge_vars: int, n_triplets: int, n_quads: int, seed: int = 1,
+             order: str = "colour_major", window: int = 64) -> M.FlatModel:
+    """C5 (BASELINE.json configs[4]): a C2-style Potts grid plus labeling-list higher-order factors of mixed arity
+    in ONE factor graph — binary edge variables (1 labeling, implicit origin, costs U(-1,1)), triplet factors
+    (4 labelings) on random local triples of them and quadruple factors (7 labelings) on random local quads,
+    relations edge -> higher-order factor (reference include/factors/labeling_list_factor.hxx:220, 346).
+    ``window``: a factor's members are drawn from ``window`` consecutive edge variables.  Small windows make long
+    chains of edge variables that share factors — tens of thousands of dependent steps per sweep, whatever executes
+    it; ``window = n_edge_vars`` (global triples) gives a handful."""
+    mt = mrf_mtypes() + [M.MsgType(2, 3, M.SCHED_LEFT, 0, 1, M.M_LABELING, k) for k in range(3)] + \
+        [M.MsgType(2, 4, M.SCHED_LEFT, 0, 1, M.M_LABELING, 3 + k) for k in range(4)]
+    b = M.ModelBuilder(5, mt)
+    for k in range(3):
+        b.add_labeling_table(EDGE_LABELINGS, TRIPLET_LABELINGS, (k,))
+    for k in range(4):
+        b.add_labeling_table(EDGE_LABELINGS, QUAD_LABELINGS, (k,))
+    n = H * W
+    var = grid_variable_order(H, W, order).reshape(-1)
+    a, bb = grid_edges(H, W)
+    i, j = np.minimum(var[a], var[bb]), np.maximum(var[a], var[bb])
+    u = b.add_vector_factors(0, u01(n * L, seed, 0).reshape(n, L))
+    p = b.add_potts_pairwise(1, L, u01(len(a), seed, n * L))
+    b.add_interleaved_messages(np.tile(np.array([0, 1], np.int32), len(a)), np.stack([u[i], u[j]], 1).reshape(-1), np.repeat(p, 2))
+    b.add_relations(np.stack([u[i], p], 1).reshape(-1), np.stack([p, u[j]], 1).reshape(-1))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    e = b.add_vector_factors(2, (2.0 * u01(n_edge_vars, seed + 1, 0) - 1.0).reshape(-1, 1), implicit_origin=True)
+
+    def local_sets(count, arity):
+        base = rng.integers(0, max(1, n_edge_vars - window), size=count)
+        off = rng.integers(0, window, size=(count, arity))                     # distinct offsets inside the window
+        while True:
+            srt = np.sort(off, axis=1)
+            bad = np.nonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))[0]
+            if bad.size == 0:
+                break
+            off[bad] = rng.integers(0, window, size=(bad.size, arity))
+        return np.minimum(base[:, None] + off, n_edge_vars - 1)
+
+    for ftype, dim, count, arity, first_mt in ((3, 4, n_triplets, 3, 2), (4, 7, n_quads, 4, 5)):
+        if count == 0:
+            continue
+        f = b.add_vector_factors(ftype, np.zeros((count, dim)), implicit_origin=True)
+        members = e[local_sets(count, arity)]
+        b.add_interleaved_messages(np.tile(np.arange(first_mt, first_mt + arity, dtype=np.int32), count),
+                                   members.reshape(-1), np.repeat(f, arity))
+        b.add_relations(members.reshape(-1), np.repeat(f, arity))
+    return b.finish()

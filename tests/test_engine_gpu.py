@@ -546,3 +546,44 @@ def test_duplicate_messages_into_one_vector(eng):
         m = b.finish()
         for mode in MODES:
             _check(eng, m, mode, 3)
+
+
+@pytest.mark.parametrize("window", [64, 150000])
+def test_c5_full_size(window):
+    """BASELINE.json configs[4] at full size on one GPU: 512 x 512 Potts grid + 100 k labeling-list factors of arity
+    3 and 4 over 150 k binary edge variables; duals bit-identical to the oracle.  Local triples / quads (window 64)
+    chain the edge variables into ~20 k dependent steps per backward sweep (hipGraph replay); global ones into ~10."""
+    m = S.c5_model(512, 512, 8, 150000, 70000, 30000, seed=4, window=window)
+    o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    e = E.Engine(0)
+    try:
+        e.upload(m); e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        lbs = [e.lower_bound()]
+        assert abs(lbs[0] - o.LowerBound()) <= LB_RTOL * max(1.0, abs(lbs[0]))
+        for _ in range(2):
+            e.compute_pass(1); o.ComputePass(1)
+            lbs.append(e.lower_bound())
+            assert abs(lbs[-1] - o.LowerBound()) <= LB_RTOL * max(1.0, abs(lbs[-1]))
+        assert np.array_equal(e.download_duals(), o.duals())
+        assert lbs[0] <= lbs[1] + 1e-7 and lbs[1] <= lbs[2] + 1e-7
+        cls = e.plan.schedule_classes(M.BACKWARD, M.REPAM_ANISOTROPIC)
+        assert cls == {"potts8": 262144, "small": cls["small"]} and cls["small"] > 100000
+        n_levels = e.plan.schedule_info(M.BACKWARD, M.REPAM_ANISOTROPIC)["n_levels"]
+        assert (n_levels > 5000) == (window == 64)
+    finally:
+        e.close()
+
+
+def test_c4_shape_mid_size():
+    """BASELINE.json configs[3]'s shape (random sparse graph, 16 labels, dense tables, mean degree 10) at 1/40 of
+    the size, where the oracle still finishes in seconds: duals bit-identical after two passes"""
+    m = S.random_graph_model(50000, 250000, 16, seed=3)
+    o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    e = E.Engine(0)
+    try:
+        e.upload(m); e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        e.compute_pass(2); o.ComputePass(2)
+        assert np.array_equal(e.download_duals(), o.duals())
+        assert abs(e.lower_bound() - o.LowerBound()) <= LB_RTOL * abs(o.LowerBound())
+    finally:
+        e.close()
