@@ -74,3 +74,21 @@ def colour_major_order(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0) ->
     rank = np.empty(n, np.int64)
     rank[order] = np.arange(n)
     return rank
+
+
+def colour_major_order_hyper(n: int, members: list, seed: int = 0) -> np.ndarray:
+    """The same for higher-order factors: ``members`` is a list of [count, arity] index arrays (one per factor
+    family); variables that share a factor get different colours (every factor is a clique of conflicts)."""
+    ei, ej = [], []
+    for mem in members:
+        mem = np.asarray(mem, np.int64)
+        for a in range(mem.shape[1]):
+            for b in range(a + 1, mem.shape[1]):
+                ei.append(mem[:, a]); ej.append(mem[:, b])
+    ei = np.concatenate(ei); ej = np.concatenate(ej)
+    keep = ei != ej
+    col = greedy_colouring(n, ei[keep], ej[keep], seed)
+    order = np.argsort(col, kind="stable")
+    rank = np.empty(n, np.int64)
+    rank[order] = np.arange(n)
+    return rank

@@ -186,14 +186,16 @@ QUAD_LABELINGS = [(1, 1, 0, 0), (0, 1, 1, 0), (0, 0, 1, 1), (1, 0, 0, 1), (1, 1,
 
 
 def c5_model(H: int, W: int, L: int, n_edge_vars: int, n_triplets: int, n_quads: int, seed: int = 1,
-             order: str = "colour_major", window: int = 64) -> M.FlatModel:
+             order: str = "colour_major", window: int = 64, colour_edge_vars: bool = False) -> M.FlatModel:
     """C5 (BASELINE.json configs[4]): a C2-style Potts grid plus labeling-list higher-order factors of mixed arity
     in ONE factor graph — binary edge variables (1 labeling, implicit origin, costs U(-1,1)), triplet factors
     (4 labelings) on random local triples of them and quadruple factors (7 labelings) on random local quads,
     relations edge -> higher-order factor (reference include/factors/labeling_list_factor.hxx:220, 346).
     ``window``: a factor's members are drawn from ``window`` consecutive edge variables.  Small windows make long
     chains of edge variables that share factors — tens of thousands of dependent steps per sweep, whatever executes
-    it; ``window = n_edge_vars`` (global triples) gives a handful."""
+    it; ``window = n_edge_vars`` (global triples) gives a handful.  ``colour_edge_vars``: the same factors with the
+    edge variables inserted in a colour-major order (variables sharing a factor get different colours,
+    ``ordering.colour_major_order_hyper``): the chains disappear, one level per colour."""
     mt = mrf_mtypes() + [M.MsgType(2, 3, M.SCHED_LEFT, 0, 1, M.M_LABELING, k) for k in range(3)] + \
         [M.MsgType(2, 4, M.SCHED_LEFT, 0, 1, M.M_LABELING, 3 + k) for k in range(4)]
     b = M.ModelBuilder(5, mt)
@@ -223,11 +225,16 @@ def c5_model(H: int, W: int, L: int, n_edge_vars: int, n_triplets: int, n_quads:
             off[bad] = rng.integers(0, window, size=(bad.size, arity))
         return np.minimum(base[:, None] + off, n_edge_vars - 1)
 
+    sets = {3: local_sets(n_triplets, 3), 4: local_sets(n_quads, 4)}
+    if colour_edge_vars:
+        from .ordering import colour_major_order_hyper
+        rank = colour_major_order_hyper(n_edge_vars, [v for v in sets.values() if v.shape[0]], seed)
+        sets = {k: rank[v] for k, v in sets.items()}
     for ftype, dim, count, arity, first_mt in ((3, 4, n_triplets, 3, 2), (4, 7, n_quads, 4, 5)):
         if count == 0:
             continue
         f = b.add_vector_factors(ftype, np.zeros((count, dim)), implicit_origin=True)
-        members = e[local_sets(count, arity)]
+        members = e[sets[arity]]
         b.add_interleaved_messages(np.tile(np.arange(first_mt, first_mt + arity, dtype=np.int32), count),
                                    members.reshape(-1), np.repeat(f, arity))
         b.add_relations(members.reshape(-1), np.repeat(f, arity))

@@ -548,12 +548,12 @@ def test_duplicate_messages_into_one_vector(eng):
             _check(eng, m, mode, 3)
 
 
-@pytest.mark.parametrize("window", [64, 150000])
-def test_c5_full_size(window):
+@pytest.mark.parametrize("window,coloured", [(64, False), (64, True), (150000, False)])
+def test_c5_full_size(window, coloured):
     """BASELINE.json configs[4] at full size on one GPU: 512 x 512 Potts grid + 100 k labeling-list factors of arity
     3 and 4 over 150 k binary edge variables; duals bit-identical to the oracle.  Local triples / quads (window 64)
     chain the edge variables into ~20 k dependent steps per backward sweep (hipGraph replay); global ones into ~10."""
-    m = S.c5_model(512, 512, 8, 150000, 70000, 30000, seed=4, window=window)
+    m = S.c5_model(512, 512, 8, 150000, 70000, 30000, seed=4, window=window, colour_edge_vars=coloured)
     o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
     e = E.Engine(0)
     try:
@@ -569,7 +569,9 @@ def test_c5_full_size(window):
         cls = e.plan.schedule_classes(M.BACKWARD, M.REPAM_ANISOTROPIC)
         assert cls == {"potts8": 262144, "small": cls["small"]} and cls["small"] > 100000
         n_levels = e.plan.schedule_info(M.BACKWARD, M.REPAM_ANISOTROPIC)["n_levels"]
-        assert (n_levels > 5000) == (window == 64)
+        assert (n_levels > 5000) == (window == 64 and not coloured)
+        if coloured:
+            assert n_levels <= 16                                # one level per colour of the edge variables
     finally:
         e.close()
 

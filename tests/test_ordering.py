@@ -26,3 +26,23 @@ def test_grid_gets_two_levels_and_random_graph_few():
     assert max(lv) <= int(col.max()) + 1 and max(lv) < min(lv_index)
     # an odd cycle is not bipartite
     assert ordering.two_colouring(3, np.array([0, 1, 0]), np.array([1, 2, 2])) is None
+
+
+def test_colour_major_order_for_higher_order_factors():
+    """variables that share a triplet / quadruple factor get different colours: in colour-major order no factor has
+    two members in the same colour class, and the classes are few"""
+    from lp_mp_amd.ordering import colour_major_order_hyper, greedy_colouring
+    rng = np.random.default_rng(4)
+    n = 5000
+    base = rng.integers(0, n - 32, size=(3000, 1))
+    tri = base[:2000] + np.argsort(rng.random((2000, 32)), axis=1)[:, :3]
+    quad = base[2000:] + np.argsort(rng.random((1000, 32)), axis=1)[:, :4]
+    rank = colour_major_order_hyper(n, [tri, quad], seed=1)
+    assert sorted(rank.tolist()) == list(range(n))
+    # recover the colour classes from the order: the rank sequence is sorted by colour
+    ei = np.concatenate([tri[:, a] for a in range(3) for b in range(a + 1, 3)] + [quad[:, a] for a in range(4) for b in range(a + 1, 4)])
+    ej = np.concatenate([tri[:, b] for a in range(3) for b in range(a + 1, 3)] + [quad[:, b] for a in range(4) for b in range(a + 1, 4)])
+    col = greedy_colouring(n, ei, ej, 1)
+    assert np.all(col[ei] != col[ej]) and col.max() < 24
+    order = np.argsort(rank)
+    assert np.all(np.diff(col[order]) >= 0)
