@@ -132,6 +132,9 @@ int lpmp_factor_lower_bounds(lpmp_engine* e, double* out /*[n_factors], host*/);
  * lpmp_device_duals or a borrowed dual buffer): the next lpmp_lower_bound recomputes every factor. */
 int lpmp_invalidate_lower_bounds(lpmp_engine* e);
 int lpmp_synchronize(lpmp_engine* e);
+/* diagnostic: 1 when the uploaded model is streamed with non-temporal loads / stores (tables + duals above 1 GiB, i.e.
+ * far larger than L2 + Infinity Cache; LPMP_NT=0/1 in the environment overrides), else 0; -1 without a model */
+int lpmp_streaming_access(const lpmp_engine* e);
 
 /* ---- primal rounding inside the sweep -----------------------------------------------------------
  * UpdateFactorPrimal (include/factors_messages.hxx:2332-2373): the same receives and (always 'shared') sends; in

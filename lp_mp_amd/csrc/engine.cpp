@@ -183,6 +183,7 @@ struct lpmp_engine {
   uint64_t primal_t = 0;          // primal_access_ of every factor a primal pass touches (they move together)
   bool have_primal = false;
   bool primal_pass = false;       // the launches being issued belong to an ...AndPrimal pass
+  int nt_flag = 0;                // SWEEP_NT when tables + duals are far larger than L2 + Infinity Cache
   struct LbRun { int cls; int64_t first, count; };
   std::vector<LbRun> lb_runs;
   DevSchedule sched[2][LPMP_REPAM_COUNT];
@@ -318,7 +319,7 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
     hipEvent_t a = nullptr, b = nullptr;
     if (timed) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, stream)); }
     // UpdateFactorPrimal always sends 'shared' (reference factors_messages.hxx:2357-2359), whatever the send rule
-    const int flags = e->primal_pass ? SWEEP_PRIMAL : e->rtype;
+    const int flags = (e->primal_pass ? SWEEP_PRIMAL : e->rtype) | e->nt_flag;
     if (!(e->use_packed && lr.stride != 0 &&
           launch_sweep_packed(lr.kclass, lr.stride > 0 ? s.packets + lr.pk_begin : nullptr, s.recs + lr.begin, s.ops, lr.stride, e->d_dual,
                               e->d_const, e->d_lb, e->d_primal, lr.end - lr.begin, flags, stream)))
@@ -552,6 +553,12 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
     const Plan& p = pl->p;
     const int64_t n_const = p.f_coff[p.nf], n_dual = p.f_doff[p.nf];
     if ((n_const > 0 && !m->const_data) || !m->dual_data) throw std::runtime_error("cost arrays missing");
+    // streamed-once access policy (kernels.hip, ld_stream): only when the state cannot live in the 256 MiB Infinity Cache
+    {
+      const char* env = getenv("LPMP_NT");
+      const bool big = (n_const + n_dual) * (int64_t)sizeof(double) > (int64_t)1 << 30;
+      e->nt_flag = (env ? atoi(env) != 0 : big) ? SWEEP_NT : 0;
+    }
     if (const_mem == LPMP_MEM_DEVICE) {
       e->d_const = const_cast<double*>(m->const_data);
       if (((uintptr_t)e->d_const & 15) != 0) throw std::runtime_error("device const buffer must be 16-byte aligned");
@@ -932,6 +939,8 @@ int lpmp_factor_lower_bounds(lpmp_engine* e, double* out) {
 int lpmp_synchronize(lpmp_engine* e) {
   return guarded([&] { if (!e) throw std::runtime_error("null engine"); HIP_CHECK(hipSetDevice(e->device)); HIP_CHECK(hipStreamSynchronize(e->stream)); if (e->timing) e->drain_timing(); });
 }
+
+int lpmp_streaming_access(const lpmp_engine* e) { return e && e->plan ? (e->nt_flag ? 1 : 0) : -1; }
 
 int64_t lpmp_dual_size(const lpmp_engine* e) { return e && e->plan ? e->plan->p.f_doff[e->plan->p.nf] : 0; }
 

@@ -35,6 +35,17 @@ constexpr int GEN_WAVES = 4;
 // so LP::LowerBound after a pass is a sum over an array instead of another read of all tables.
 #define LPMP_NAN (__builtin_nan(""))
 
+// Loads / stores of data that is touched once per launch and is far larger than L2 + Infinity Cache (tables and
+// message vectors of an HBM-sized model): non-temporal, so that they do not displace anything and the memory
+// pipeline does not try to keep them (measured on C3: -5 % time with nt table loads, -8 % with the vectors too).
+// NT = false for cache-resident models (C2: the whole state lives in the Infinity Cache between launches).
+template <bool NT, class T> __device__ __forceinline__ T ld_stream(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+}
+template <bool NT, class T> __device__ __forceinline__ void st_stream(T* p, T v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -515,7 +526,7 @@ __device__ __forceinline__ void load_packet(double2_t* slab, const Op* __restric
 
 // VAR: L is the padded width; the label count of the factor (<= L) and the dims of each peer table (d0 x d1, both
 // <= L, the own side's equal to the label count) are read at run time, lanes beyond them carry +inf / 0
-template <int L, int KMAX, bool VAR>
+template <int L, int KMAX, bool VAR, bool NT>
 __global__ void __launch_bounds__(256)
 sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
                       double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
@@ -585,18 +596,18 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
           for (int i = 0; i < NL; ++i) {
             const int row = i * RPL + rl;
             const double* Tr = T + (int64_t)row * C + 2 * c2;
-            t[j][i].x = (row < R && 2 * c2 < C) ? Tr[0] : LPMP_INF;
-            t[j][i].y = (row < R && 2 * c2 + 1 < C) ? Tr[1] : LPMP_INF;
+            t[j][i].x = (row < R && 2 * c2 < C) ? ld_stream<NT>(Tr) : LPMP_INF;
+            t[j][i].y = (row < R && 2 * c2 + 1 < C) ? ld_stream<NT>(Tr + 1) : LPMP_INF;
           }
-          if (g < Lr) msv[j] = dual[pdual[j] + roff[j] + g];
-          if (g < (side[j] == 0 ? C : R)) mov[j] = dual[pdual[j] + (side[j] == 0 ? R : 0) + g];
+          if (g < Lr) msv[j] = ld_stream<NT>(dual + pdual[j] + roff[j] + g);
+          if (g < (side[j] == 0 ? C : R)) mov[j] = ld_stream<NT>(dual + pdual[j] + (side[j] == 0 ? R : 0) + g);
         } else {
           roff[j] = side[j] == 0 ? 0 : L;
 #pragma unroll
-          for (int i = 0; i < NL; ++i) t[j][i] = *reinterpret_cast<const double2_t*>(T + (int64_t)i * 2 * G + 2 * g);
+          for (int i = 0; i < NL; ++i) t[j][i] = ld_stream<NT>(reinterpret_cast<const double2_t*>(T + (int64_t)i * 2 * G + 2 * g));
           if (g < L) {
-            msv[j] = dual[pdual[j] + (side[j] == 0 ? 0 : L) + g];
-            mov[j] = dual[pdual[j] + (side[j] == 0 ? L : 0) + g];
+            msv[j] = ld_stream<NT>(dual + pdual[j] + (side[j] == 0 ? 0 : L) + g);
+            mov[j] = ld_stream<NT>(dual + pdual[j] + (side[j] == 0 ? L : 0) + g);
           }
         }
       } else {
@@ -650,7 +661,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
             stored = true;
           }
         }
-        if (!stored) dual[pdual[j] + roff[j] + g] = mn;
+        if (!stored) st_stream<NT>(dual + pdual[j] + roff[j] + g, mn);
       }
 #ifndef LPMP_ABLATE_LB_TRACK
       if (!(FW && defer[j])) {                    // a deferred receive is followed by a send that dirties the peer
@@ -683,7 +694,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
         if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
         else cur = preload_ok ? sm[k] : ms[g];
         const double delta = o.omega * snap;
-        ms[g] = cur + delta;
+        st_stream<NT>(ms + g, cur + delta);
         theta -= delta;
 #ifndef LPMP_ABLATE_LB_TRACK
         if (g == 0) lb[uni<G>(o.peer)] = LPMP_NAN;
@@ -827,7 +838,7 @@ __device__ __forceinline__ void two_min_merge(double& a1, double& a2) {   // two
 }
 
 // VAR: L is the padded width, the label count (<= L) is read at run time; lanes beyond it carry +inf
-template <int L, bool VAR>
+template <int L, bool VAR, bool NT>
 __global__ void __launch_bounds__(256)
 sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
                       double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
@@ -880,8 +891,8 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
         const int side = (o.info >> 5) & 1;
         msoff[j] = o.peer_dual + (side == 0 ? 0 : Lr) + g;
         if (vl) {
-          msv[j] = dual[msoff[j]];
-          mov[j] = dual[o.peer_dual + (side == 0 ? Lr : 0) + g];
+          msv[j] = ld_stream<NT>(dual + msoff[j]);
+          mov[j] = ld_stream<NT>(dual + o.peer_dual + (side == 0 ? Lr : 0) + g);
         }
         diff[j] = cdata[o.peer_const];
         defer[j] = FW ? o.pad : 0;
@@ -912,7 +923,7 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
             stored = true;
           }
         }
-        if (!stored) dual[msoff[j]] = mn;
+        if (!stored) st_stream<NT>(dual + msoff[j], mn);
       }
       if (!(FW && defer[j])) {
         pb = vec_min<L, L>(pb);
@@ -939,7 +950,7 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
         if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
         else cur = preload_ok ? sm[k] : ms[g];
         const double delta = o.omega * snap;
-        ms[g] = cur + delta;
+        st_stream<NT>(ms + g, cur + delta);
         theta -= delta;
         if (g == 0) lb[o.peer] = LPMP_NAN;
       }
@@ -1020,6 +1031,7 @@ __device__ __forceinline__ double transpose_min16(double (&v)[16], int lane) {
   return r;
 }
 
+template <bool NT>
 __global__ void __launch_bounds__(64 * BIG_WAVES)
 sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
                        const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal,
@@ -1073,7 +1085,7 @@ sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ o
           const double m = cb ? S.mo[b] : 0.0;
           double t[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) t[r] = (cb && a0 + r < R) ? T[(int64_t)(a0 + r) * C + b] : LPMP_INF;
+          for (int r = 0; r < 16; ++r) t[r] = (cb && a0 + r < R) ? ld_stream<NT>(T + (int64_t)(a0 + r) * C + b) : LPMP_INF;
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = fmin(v[r], t[r] + m);
         }
@@ -1088,7 +1100,7 @@ sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ o
         for (int a0 = 0; a0 < R; a0 += 16) {
           double t[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) t[r] = (cb && a0 + r < R) ? T[(int64_t)(a0 + r) * C + b] : LPMP_INF;
+          for (int r = 0; r < 16; ++r) t[r] = (cb && a0 + r < R) ? ld_stream<NT>(T + (int64_t)(a0 + r) * C + b) : LPMP_INF;
 #pragma unroll
           for (int r = 0; r < 16; ++r) { const double m = a0 + r < R ? S.mo[a0 + r] : 0.0; v = fmin(v, t[r] + m); }
         }
@@ -1358,15 +1370,13 @@ void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, c
     case KC_POTTS_16: hipLaunchKernelGGL(sweep_potts_kernel<16>, blocks(256 / 16), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
     case KC_POTTS_8: hipLaunchKernelGGL(sweep_potts_kernel<8>, blocks(256 / 8), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
     case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
-    case KC_DENSE_BIG: hipLaunchKernelGGL(sweep_dense_big_kernel, blocks(BIG_WAVES), dim3(64 * BIG_WAVES), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
+    case KC_DENSE_BIG:
+      if (flags & SWEEP_NT) hipLaunchKernelGGL(sweep_dense_big_kernel<true>, blocks(BIG_WAVES), dim3(64 * BIG_WAVES), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags);
+      else hipLaunchKernelGGL(sweep_dense_big_kernel<false>, blocks(BIG_WAVES), dim3(64 * BIG_WAVES), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags);
+      break;
     case KC_SMALL: hipLaunchKernelGGL(sweep_generic_kernel<1>, blocks(GenCtx<1>::FPB), dim3(GenCtx<1>::THREADS), 0, s, recs, ops, dual, cdata, tabs, lb, primal, first, count, flags); break;
     default: hipLaunchKernelGGL(sweep_generic_kernel<64>, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, lb, primal, first, count, flags); break;
   }
-}
-
-static int dense_kmax() {
-  static int k = [] { const char* e = getenv("LPMP_DENSE_KMAX"); return e ? atoi(e) : 2; }();
-  return k;
 }
 
 bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, const Op* ops, int stride, double* dual, const double* cdata,
@@ -1374,26 +1384,31 @@ bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, cons
   if (count <= 0) return true;
   if (stride > 1 + PK_MAX_OPS) return false;
   auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
-  const int km = dense_kmax();
-#define PK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK, false>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
+  const bool nt = (flags & SWEEP_NT) != 0;
+#define PK_LAUNCH1(LL, KK, NTT) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK, false, NTT>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
+#define PK_LAUNCH(LL, KK) do { if (nt) PK_LAUNCH1(LL, KK, true); else PK_LAUNCH1(LL, KK, false); } while (0)
   switch (kclass) {
-    case KC_DENSE_32: if (km >= 4) PK_LAUNCH(32, 4); else if (km == 1) PK_LAUNCH(32, 1); else PK_LAUNCH(32, 2); return true;
-    case KC_DENSE_16: if (km >= 4) PK_LAUNCH(16, 4); else PK_LAUNCH(16, 2); return true;
+    // receives in flight per lane group: 2 at 16 / 32 labels (1 and 4 measured slower on C3), 4 below
+    case KC_DENSE_32: PK_LAUNCH(32, 2); return true;
+    case KC_DENSE_16: PK_LAUNCH(16, 2); return true;
     case KC_DENSE_8: PK_LAUNCH(8, 4); return true;
     case KC_DENSE_4: PK_LAUNCH(4, 4); return true;
-#define PPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL, false>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
+#define PPK_LAUNCH1(LL, NTT) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL, false, NTT>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
+#define PPK_LAUNCH(LL) do { if (nt) PPK_LAUNCH1(LL, true); else PPK_LAUNCH1(LL, false); } while (0)
     case KC_POTTS_32: PPK_LAUNCH(32); return true;
     case KC_POTTS_16: PPK_LAUNCH(16); return true;
     case KC_POTTS_8: PPK_LAUNCH(8); return true;
     case KC_POTTS_4: PPK_LAUNCH(4); return true;
 #undef PPK_LAUNCH
-#define VPK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK, true>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
+#undef PPK_LAUNCH1
+// (run-time dims: rows are not line-aligned, consecutive 8-B loads share lines — non-temporal loads cost 9 % there)
+#define VPK_LAUNCH(LL, KK) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK, true, false>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
     case KC_DENSE_V32: VPK_LAUNCH(32, 2); return true;
     case KC_DENSE_V16: VPK_LAUNCH(16, 2); return true;
     case KC_DENSE_V8: VPK_LAUNCH(8, 4); return true;
     case KC_DENSE_V4: VPK_LAUNCH(4, 4); return true;
 #undef VPK_LAUNCH
-#define VPPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL, true>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
+#define VPPK_LAUNCH(LL) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL, true, false>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
     case KC_POTTS_V32: VPPK_LAUNCH(32); return true;
     case KC_POTTS_V16: VPPK_LAUNCH(16); return true;
     case KC_POTTS_V8: VPPK_LAUNCH(8); return true;
@@ -1402,6 +1417,7 @@ bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, cons
     default: return false;
   }
 #undef PK_LAUNCH
+#undef PK_LAUNCH1
 }
 
 void launch_factor_lb(const void* recs, const double* dual, const double* cdata, double* out, int64_t count, hipStream_t s) {

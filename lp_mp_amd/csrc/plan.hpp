@@ -99,6 +99,7 @@ constexpr int32_t UPD_PRIMAL = 1 << 17;       // UpdRec::kind_flags: the factor 
 
 // kernel flags of the sweep kernels
 constexpr int SWEEP_RESIDUAL = 1;   // --reparametrizationType residual
+constexpr int SWEEP_NT = 4;         // host-side selector: the model is far larger than the caches -> non-temporal variants
 constexpr int SWEEP_PRIMAL = 2;     // UpdateFactorPrimal (reference factors_messages.hxx:2332-2373): factors of a
                                     // COMPUTE_PRIMAL type round their label from the state after the receives
 

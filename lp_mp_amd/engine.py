@@ -21,13 +21,15 @@ KCLASS_NAMES = ["generic", "dense4", "dense8", "dense16", "dense32", "potts4", "
                 "dense_big", "small"]
 # kernel symbols as rocprofv3 prints them: dense classes run the packed kernel (KMAX 2 at L >= 16, 4 below) whenever a
 # launch's factors have at most 8 active messages, else sweep_dense_kernel<L>; the _v classes (any label count up to
-# the padded width, rectangular tables) are the same kernels with run-time dims
-KERNEL_NAMES = ["sweep_generic_kernel<64>", "sweep_dense_pk_kernel<4, 4, false>", "sweep_dense_pk_kernel<8, 4, false>",
-                "sweep_dense_pk_kernel<16, 2, false>", "sweep_dense_pk_kernel<32, 2, false>",
+# the padded width, rectangular tables) are the same kernels with run-time dims; the exact dense kernels come in a
+# plain and a non-temporal-access form (last template argument), chosen by the size of the model: the names below
+# are prefixes
+KERNEL_NAMES = ["sweep_generic_kernel<64>", "sweep_dense_pk_kernel<4, 4, false", "sweep_dense_pk_kernel<8, 4, false",
+                "sweep_dense_pk_kernel<16, 2, false", "sweep_dense_pk_kernel<32, 2, false",
                 "sweep_potts_pk_kernel<4, false>", "sweep_potts_pk_kernel<8, false>", "sweep_potts_pk_kernel<16, false>",
                 "sweep_potts_pk_kernel<32, false>",
-                "sweep_dense_pk_kernel<4, 4, true>", "sweep_dense_pk_kernel<8, 4, true>",
-                "sweep_dense_pk_kernel<16, 2, true>", "sweep_dense_pk_kernel<32, 2, true>",
+                "sweep_dense_pk_kernel<4, 4, true, false>", "sweep_dense_pk_kernel<8, 4, true, false>",
+                "sweep_dense_pk_kernel<16, 2, true, false>", "sweep_dense_pk_kernel<32, 2, true, false>",
                 "sweep_potts_pk_kernel<4, true>", "sweep_potts_pk_kernel<8, true>", "sweep_potts_pk_kernel<16, true>",
                 "sweep_potts_pk_kernel<32, true>", "sweep_dense_big_kernel", "sweep_generic_kernel<1>"]
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -44,7 +46,7 @@ EXPORTS = [
     "lpmp_engine_plan", "lpmp_engine_plan_mut", "lpmp_enable_kernel_timing", "lpmp_get_kernel_timing",
     "lpmp_reset_kernel_timing", "lpmp_synth_fill", "lpmp_compute_forward_pass_and_primal",
     "lpmp_compute_backward_pass_and_primal", "lpmp_compute_pass_and_primal", "lpmp_check_primal_consistency",
-    "lpmp_evaluate_primal", "lpmp_download_primal", "lpmp_upload_primal",
+    "lpmp_evaluate_primal", "lpmp_download_primal", "lpmp_upload_primal", "lpmp_streaming_access",
 ]
 
 
@@ -119,6 +121,7 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_uint64]
         for name in ("lpmp_check_primal_consistency", "lpmp_evaluate_primal", "lpmp_download_primal", "lpmp_upload_primal"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+        L.lpmp_streaming_access.argtypes = [C.c_void_p]
         L.lpmp_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_get_kernel_timing.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.lpmp_reset_kernel_timing.argtypes = [C.c_void_p]
@@ -395,7 +398,12 @@ class Engine:
         out = {}
         for c in range(N_KCLASS):
             if arrs[0][c] > 0:
-                out[KCLASS_NAMES[c]] = dict(kernel=KERNEL_NAMES[c], ms=float(ms[c]), launches=int(arrs[0][c]),
+                name = KERNEL_NAMES[c]
+                if not name.endswith(">") and "<" in name:       # exact dense kernels: plain / non-temporal form
+                    name += ", true>" if self.L.lpmp_streaming_access(self.h) == 1 else ", false>"
+                elif name == "sweep_dense_big_kernel":
+                    name += "<true>" if self.L.lpmp_streaming_access(self.h) == 1 else "<false>"
+                out[KCLASS_NAMES[c]] = dict(kernel=name, ms=float(ms[c]), launches=int(arrs[0][c]),
                                             factors=int(arrs[1][c]), receives=int(arrs[2][c]), bytes=int(arrs[3][c]))
         return out
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of engine variants in ONE process (cdna_hip_programming.md 5.4 rule 24).
 Each variant = a dict of environment variables read at lpmp_create (LPMP_NO_FUSE, LPMP_NO_PACKED,
-LPMP_DENSE_KMAX, ...).  Variants share the read-only tables and have their own duals.
+LPMP_NT, ...).  Variants share the read-only tables and have their own duals.
 
 usage: ab_bench.py [--grid 1024] [--labels 32] [--order colour_major] [--rounds 5] [--steps 10] VAR=VAL[,VAR=VAL] ...
 """
