@@ -560,7 +560,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
     sm[k] = 0.0;
     if (preload_ok && k < n_send && g < Lr) {
       const Op& o = lop[n_recv + k];
-      sm[k] = dual[uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0) + g];
+      sm[k] = ld_stream<NT>(dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0) + g);
     }
   }
   double mnew[NFW];                              // results of receives whose store is deferred to a send
