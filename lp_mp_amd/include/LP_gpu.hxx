@@ -82,6 +82,16 @@ template <class... T> struct list { static constexpr std::size_t size() { return
 
 // ---- device-capable factor ops ---------------------------------------------------------------------
 struct device_vector_tag {};
+// entries of a vector-kind factor op: through dual() where the op has one (its size() may mean something else:
+// ConstantFactor::size() is 0, reference include/factors/constant_factor.hxx:14), else through size() / operator[]
+template <class T, class = void> struct has_dual_vector : std::false_type {};
+template <class T> struct has_dual_vector<T, std::void_t<decltype(std::declval<T&>().dual())>> : std::true_type {};
+template <class T> INDEX vector_entries(const T& op) {
+  if constexpr (has_dual_vector<T>::value) return const_cast<T&>(op).dual().size(); else return op.size();
+}
+template <class T> REAL& vector_entry(T& op, INDEX i) {
+  if constexpr (has_dual_vector<T>::value) return op.dual()[i]; else return op[i];
+}
 struct device_pairwise_dense_tag {};
 struct device_pairwise_potts_tag {};
 
@@ -99,6 +109,23 @@ class UnarySimplexFactor {   // reference test/simplex.cpp:8-12
   const std::vector<REAL>& dual() const { return cost_; }
  private:
   std::vector<REAL> cost_;
+};
+
+// reference include/factors/constant_factor.hxx:10-30: a factor without variables that carries an offset; its dual is
+// the offset itself (serialize_dual), its bound the offset.  On the device: a vector factor with one entry.
+class ConstantFactor {
+ public:
+  using device_kind = device_vector_tag;
+  static constexpr bool implicit_origin = false;
+  explicit ConstantFactor(const REAL offset = 0) : offset_(1, offset) {}
+  constexpr static INDEX size() { return 0; }
+  REAL LowerBound() const { return offset_[0]; }
+  REAL EvaluatePrimal() const { return offset_[0]; }
+  void AddToOffset(const REAL delta) { offset_[0] += delta; }
+  std::vector<REAL>& dual() { return offset_; }
+  const std::vector<REAL>& dual() const { return offset_; }
+ private:
+  std::vector<REAL> offset_;
 };
 
 struct test_factor : UnarySimplexFactor {   // reference test/test_model.hxx:10-16
@@ -247,7 +274,7 @@ class FactorContainer : public FactorTypeAdapter {
   const FactorType* GetFactor() const { return &factor_; }
   REAL LowerBound() const final { return factor_.LowerBound(); }
   INDEX dual_size() const final {
-    if constexpr (std::is_same_v<typename FACTOR_TYPE::device_kind, device_vector_tag>) return factor_.size();
+    if constexpr (std::is_same_v<typename FACTOR_TYPE::device_kind, device_vector_tag>) return vector_entries(factor_);
     else return const_cast<FACTOR_TYPE&>(factor_).dual().size();
   }
  private:
@@ -463,8 +490,8 @@ class LP_gpu {
     using K = typename FC::FactorType::device_kind;
     if constexpr (std::is_same_v<K, device_vector_tag>) {
       fl.kind.push_back(LPMP_F_VECTOR); fl.flags.push_back(FC::FactorType::implicit_origin ? LPMP_FF_IMPLICIT_ORIGIN : 0);
-      fl.d0.push_back((int32_t)op->size()); fl.d1.push_back(0);
-      for (INDEX i = 0; i < op->size(); ++i) fl.dual.push_back((*op)[i]);
+      fl.d0.push_back((int32_t)vector_entries(*op)); fl.d1.push_back(0);
+      for (INDEX i = 0; i < vector_entries(*op); ++i) fl.dual.push_back(vector_entry(*op, i));
     } else if constexpr (std::is_same_v<K, device_pairwise_dense_tag>) {
       fl.kind.push_back(LPMP_F_PAIRWISE_DENSE); fl.flags.push_back(0);
       fl.d0.push_back((int32_t)op->dim1()); fl.d1.push_back((int32_t)op->dim2());
@@ -481,7 +508,7 @@ class LP_gpu {
   const REAL* unflatten_factor(FactorTypeAdapter* fa, const REAL* p) {
     auto* op = static_cast<FC*>(fa)->GetFactor();
     using K = typename FC::FactorType::device_kind;
-    if constexpr (std::is_same_v<K, device_vector_tag>) { for (INDEX i = 0; i < op->size(); ++i) (*op)[i] = *p++; }
+    if constexpr (std::is_same_v<K, device_vector_tag>) { for (INDEX i = 0; i < vector_entries(*op); ++i) vector_entry(*op, i) = *p++; }
     else { for (auto& x : op->dual()) x = *p++; }
     return p;
   }

@@ -36,6 +36,17 @@ class UnarySimplexFactor:
         self.cost = np.asarray(cost, np.float64).reshape(-1)
 
 
+class ConstantFactor(UnarySimplexFactor):
+    """factor without variables that carries an offset (reference include/factors/constant_factor.hxx:10-30): dual =
+    the offset, LowerBound = the offset; on the device a vector factor with one entry."""
+
+    def __init__(self, offset: float = 0.0):
+        super().__init__([offset])
+
+    def AddToOffset(self, delta: float):
+        self.cost[0] += delta
+
+
 class test_factor(UnarySimplexFactor):
     """two-label toy factor (reference test/test_model.hxx:10-64)."""
 

@@ -35,6 +35,18 @@ struct FMC_SRMP {   // unary / pairwise MRF as LP_MP-MRF declares it (SURVEY.md 
   using ProblemDecompositionList = meta::list<>;
 };
 
+struct FMC_SRMP_CONST {   // unary / pairwise MRF plus the reference's ConstantFactor (include/factors/constant_factor.hxx)
+  constexpr static const char* name = "SRMP + constant";
+  using UnaryFactor = FactorContainer<UnarySimplexFactor, FMC_SRMP_CONST, 0>;
+  using PairwiseFactor = FactorContainer<PairwiseSimplexFactor, FMC_SRMP_CONST, 1>;
+  using ConstantFactorContainer = FactorContainer<ConstantFactor, FMC_SRMP_CONST, 2>;
+  using UnaryPairwiseMessageLeftContainer = MessageContainer<UnaryPairwiseMessage<Chirality::left>, 0, 1, message_passing_schedule::left, variableMessageNumber, 1, FMC_SRMP_CONST, 0>;
+  using UnaryPairwiseMessageRightContainer = MessageContainer<UnaryPairwiseMessage<Chirality::right>, 0, 1, message_passing_schedule::left, variableMessageNumber, 1, FMC_SRMP_CONST, 1>;
+  using FactorList = meta::list<UnaryFactor, PairwiseFactor, ConstantFactorContainer>;
+  using MessageList = meta::list<UnaryPairwiseMessageLeftContainer, UnaryPairwiseMessageRightContainer>;
+  using ProblemDecompositionList = meta::list<>;
+};
+
 struct FMC_SRMP_ROUNDING {   // the same with COMPUTE_PRIMAL_SOLUTION on the unaries, as LP_MP-MRF's FMC_SRMP has it
   constexpr static const char* name = "SRMP with rounding";
   using UnaryFactor = FactorContainer<UnarySimplexFactor, FMC_SRMP_ROUNDING, 0, true>;
@@ -148,6 +160,32 @@ int main(int argc, char** argv) {
       test(std::abs(s.lower_bound() - 0.0) <= eps);
       auto om = lp.get_omega();
       test(om.forward.size() == u.size());
+    }
+  }
+  {   // ---- ConstantFactor: an offset that takes part in the bound and is never touched by the sweep ----
+    using FMC = FMC_SRMP_CONST;
+    ConstantFactor cf(2.5);
+    test(cf.size() == 0 && cf.LowerBound() == 2.5);
+    cf.AddToOffset(-1.0);
+    test(cf.LowerBound() == 1.5 && cf.EvaluatePrimal() == 1.5);
+    LP<FMC> lp;
+    auto* u1 = lp.template add_factor<typename FMC::UnaryFactor>(std::vector<REAL>{0.0, 1.0});
+    auto* u2 = lp.template add_factor<typename FMC::UnaryFactor>(std::vector<REAL>{1.0, 0.0});
+    auto* p = lp.template add_factor<typename FMC::PairwiseFactor>(2, 2);
+    p->GetFactor()->cost(0, 1) = 1.0; p->GetFactor()->cost(1, 0) = 1.0;
+    auto* c = lp.template add_factor<typename FMC::ConstantFactorContainer>(1.5);
+    lp.template add_message<typename FMC::UnaryPairwiseMessageLeftContainer>(u1, p);
+    lp.template add_message<typename FMC::UnaryPairwiseMessageRightContainer>(u2, p);
+    lp.AddFactorRelation(u1, p); lp.AddFactorRelation(p, u2);
+    test(c->no_messages() == 0);
+    if (!host_only) {
+      lp.Begin();
+      lp.set_reparametrization(LPReparametrizationMode::Anisotropic);
+      test(std::abs(lp.LowerBound() - 1.5) <= eps);           // 0 + 0 + 0 + offset
+      for (int it = 0; it < 5; ++it) lp.ComputePass(it);
+      test(std::abs(lp.LowerBound() - 2.5) <= eps);           // optimum of the pair: 1, plus the offset
+      lp.End();
+      test(c->GetFactor()->LowerBound() == 1.5);
     }
   }
   {   // ---- MpRoundingSolver (reference solver.hxx:380-400) on a chain with a unique optimum ----

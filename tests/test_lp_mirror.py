@@ -189,3 +189,25 @@ def test_mp_rounding_solver_follows_the_oracle_iteration_by_iteration():
     assert np.array_equal(s.solution_, sol)
     assert np.array_equal(lp.duals(), o.duals())
     assert s.primal_cost() >= s.lower_bound() - 1e-9
+
+
+@pytest.mark.gpu
+def test_constant_factor_offsets_the_bound():
+    """ConstantFactor (reference include/factors/constant_factor.hxx): no variables, no messages, dual = the offset"""
+    U = LPM.FactorContainer(LPM.UnarySimplexFactor, 0)
+    P = LPM.FactorContainer(LPM.PairwiseSimplexFactor, 1)
+    K = LPM.FactorContainer(LPM.ConstantFactor, 2)
+    ML = LPM.MessageContainer(LPM.UnaryPairwiseMessage(0), 0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, 0)
+    MR = LPM.MessageContainer(LPM.UnaryPairwiseMessage(1), 0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, 1)
+    lp = LPM.LP(LPM.FMC("SRMP + constant", [U, P, K], [ML, MR]))
+    u1, u2 = lp.add_factor(U, [0.0, 1.0]), lp.add_factor(U, [1.0, 0.0])
+    p = lp.add_factor(P, 2, 2, [[0.0, 1.0], [1.0, 0.0]])
+    lp.add_factor(K, 1.5)
+    lp.add_message(ML, u1, p); lp.add_message(MR, u2, p)
+    lp.AddFactorRelation(u1, p); lp.AddFactorRelation(p, u2)
+    lp.Begin()
+    lp.set_reparametrization(LPM.LPReparametrizationMode.Anisotropic)
+    assert lp.LowerBound() == pytest.approx(1.5)
+    for it in range(5):
+        lp.ComputePass(it)
+    assert lp.LowerBound() == pytest.approx(2.5)
