@@ -337,7 +337,9 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
 void run_schedule(lpmp_engine* e, DevSchedule& s) {
   if (s.launches.empty()) return;
   if (e->timing) { issue_launches(e, s, true, e->stream); if (e->pending.size() > 4096) e->drain_timing(); return; }
-  if (e->use_graph && s.launches.size() > 8) {
+  // (graphs of up to ~20 k kernel nodes were exercised — C5; beyond 200 k the nodes are issued one by
+  // one instead of instantiating a graph of that size)
+  if (e->use_graph && s.launches.size() > 8 && s.launches.size() <= 200000) {
     hipGraphExec_t& exec = e->primal_pass ? s.graph_primal : s.graph;
     if (!exec) {
       hipGraph_t g = nullptr;
