@@ -43,8 +43,20 @@ def FMC_SRMP():
     return LPM.FMC("FMC_SRMP", [U, P], [ML, MR]), U, P, ML, MR
 
 
-def build_lp_from_uai(text: str, device: int = 0) -> LPM.LP:
+def build_lp_from_uai(text: str, device: int = 0, order: str = "index") -> LPM.LP:
+    """``order``: "index" — relations u_i -> p_ij -> u_j for i < j in the file's variable numbering, what LP_MP-MRF's
+    constructor does (a row-major grid then has H+W-1 dependent steps per sweep); "colour_major" — the same relations
+    along a colour-major ranking of the variables (ordering.colour_major_order: 2 steps per sweep on a bipartite
+    graph).  Both are valid block-coordinate-ascent orders; they give different dual trajectories."""
     card, tables = parse_uai(text)
+    if order not in ("index", "colour_major"):
+        raise ValueError(order)
+    rank = np.arange(len(card))
+    if order == "colour_major":
+        from .ordering import colour_major_order
+        pairs = np.array([sc for sc, _ in tables if len(sc) == 2], np.int64).reshape(-1, 2)
+        if pairs.shape[0]:
+            rank = colour_major_order(len(card), pairs[:, 0], pairs[:, 1])
     fmc, U, P, ML, MR = FMC_SRMP()
     lp = LPM.LP(fmc, device)
     unary = [np.zeros(c) for c in card]
@@ -58,7 +70,7 @@ def build_lp_from_uai(text: str, device: int = 0) -> LPM.LP:
         if len(sc) != 2:
             continue
         i, j = sc
-        if i > j:
+        if rank[i] > rank[j]:
             i, j, t = j, i, t.T
         p = lp.add_factor(P, card[i], card[j], np.ascontiguousarray(t))
         lp.add_message(ML, u[i], p)

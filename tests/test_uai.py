@@ -68,3 +68,33 @@ def test_uai_rounding_solver_finds_the_map_labeling():
     card, tables = uai.parse_uai(UAI_TEST_INPUT)
     assert lb == pytest.approx(0.644, abs=1e-9) and cost == pytest.approx(0.644, abs=1e-9)
     assert sum(t[tuple(x[v] for v in sc)] for sc, t in tables) == pytest.approx(0.644)
+
+
+def _grid_uai(H, W, L, seed):
+    rng = np.random.default_rng(seed)
+    edges = [(r * W + c, r * W + c + 1) for r in range(H) for c in range(W - 1)] + \
+            [(r * W + c, (r + 1) * W + c) for r in range(H - 1) for c in range(W)]
+    n = H * W
+    out = ["MARKOV", str(n), " ".join([str(L)] * n), str(n + len(edges))]
+    out += [f"1 {v}" for v in range(n)] + [f"2 {i} {j}" for i, j in edges]
+    for _ in range(n):
+        out += ["", str(L), " ".join(f"{x:.3f}" for x in rng.uniform(0, 1, L))]
+    for _ in edges:
+        out += ["", str(L * L), " ".join(f"{x:.3f}" for x in rng.uniform(0, 1, L * L))]
+    return "\n".join(out) + "\n"
+
+
+def test_uai_colour_major_relations_have_two_levels():
+    """a grid in the file's (row-major) variable numbering: H+W-1 dependent steps per sweep with index-order
+    relations, 2 with the colour-major option; same factors, same costs"""
+    from lp_mp_amd import engine as E, model as M
+    text = _grid_uai(5, 6, 3, seed=2)
+    levels, sizes = {}, {}
+    for order in ("index", "colour_major"):
+        m = uai.build_lp_from_uai(text, order=order).flat_model()
+        levels[order] = E.Plan(m).schedule_info(M.FORWARD, M.REPAM_ANISOTROPIC)["n_levels"]
+        sizes[order] = (m.n_factors, m.n_messages, float(np.sort(m.const_data).sum()))
+    assert levels == {"index": 5 + 6 - 1, "colour_major": 2}
+    assert sizes["index"] == pytest.approx(sizes["colour_major"])
+    with pytest.raises(ValueError):
+        uai.build_lp_from_uai(text, order="zigzag")
