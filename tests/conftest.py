@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """a clean checkout has no built extension: compile it once (hipcc cross-compiles without a GPU).  Building is
+    not a fallback — without hipcc the engine tests fail loudly."""
+    try:
+        from lp_mp_amd import build as B
+        if not os.path.exists(B.SO):
+            B.build()
+    except Exception as e:                                   # reported by the tests that need the library
+        print(f"conftest: could not build the HIP extension: {e}", file=sys.stderr)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
