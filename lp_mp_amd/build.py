@@ -30,6 +30,8 @@ def needs_build() -> bool:
 
 def build(force: bool = False) -> str:
     if force or needs_build():
-        cmd = [hipcc()] + FLAGS + ["-o", SO] + SOURCES
+        tmp = SO + ".tmp%d" % os.getpid()          # appear atomically: other ranks may be waiting for the file
+        cmd = [hipcc()] + FLAGS + ["-o", tmp] + SOURCES
         subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(tmp, SO)
     return SO
