@@ -50,6 +50,8 @@ class LocalPart:
     in_key: np.ndarray                  #   global edge id
     const_fill: Optional[list] = None   # [(offset, count, seed, first)] when tables are generated in HBM
     dual_fill: Optional[list] = None
+    in_pos: Optional[np.ndarray] = None # position of each incoming cut message in its left factor's global message list
+    key_is_msg: bool = False            # keys are global message ids (partition_model) instead of MRF edge ids
 
 
 def _sorted_by_peer_key(peer, *cols, key):
@@ -217,8 +219,9 @@ class DistComm:
         # zero-row views of 1-row buffers: a rank without cut edges toward anybody still takes part in the collective,
         # and its tensors keep a valid device pointer
         n_out = int(sum(recv_counts))
-        out = send.new_empty((max(n_out, 1), send.shape[1]))[:n_out]
-        src = send.contiguous() if send.shape[0] > 0 else send.new_empty((1, send.shape[1]))[:0]
+        tail = tuple(send.shape[1:])
+        out = send.new_empty((max(n_out, 1),) + tail)[:n_out]
+        src = send.contiguous() if send.shape[0] > 0 else send.new_empty((1,) + tail)[:0]
         self.dist.all_to_all_single(out, src, output_split_sizes=list(map(int, recv_counts)),
                                     input_split_sizes=list(map(int, send_counts)))
         return out
@@ -263,10 +266,19 @@ class PartitionedSweep:
         if np.any(np.bincount(part.in_unary, weights=self.in_omega) > 1.0 + 1e-8) if part.in_unary.size else False:
             raise ValueError("boundary send weights of one unary sum to more than 1")
         p = part
-        L = p.L
         n_vec = p.n_local + p.n_ghost
         self.dual = dual_tensor
-        self.theta = dual_tensor[: n_vec * L].view(n_vec, L)
+        if p.L > 0:                                          # MRF parts: vectors first, one label count
+            self.theta = dual_tensor[: n_vec * p.L].view(n_vec, p.L)
+        # the boundary arithmetic works on flat element indices of the dual buffer (factors may differ in size)
+        doff = p.model.dual_offsets()
+        dim = p.model.f_dim0.astype(np.int64)
+
+        def flat(factors):
+            factors = np.asarray(factors, np.int64)
+            lens = dim[factors]
+            first = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            return np.repeat(doff[factors], lens) + (np.arange(int(first[-1])) - np.repeat(first[:-1], lens)), lens, first
         dev = dual_tensor.device
         plan = engine.plan
         ghost = np.zeros(p.model.n_factors, bool)
@@ -317,25 +329,32 @@ class PartitionedSweep:
         self.ghost_rows_send = (g, ones_off, np.ones(g.shape[0]), ones_off, np.zeros(g.shape[0], np.uint8))
         self.ghost_recv = engine.schedule_create(*self.ghost_rows_recv)
         self.ghost_send = engine.schedule_create(*self.ghost_rows_send)
-        # 3. exchange plan
-        self.out_counts = np.bincount(p.out_peer, minlength=p.world).astype(np.int64)
-        self.in_counts = np.bincount(p.in_peer, minlength=p.world).astype(np.int64)
-        self.out_ghost_t = torch.from_numpy(p.out_ghost.astype(np.int64)).to(dev)
-        # rounds: a non-owner unary with several cut edges receives / sends them in its message-list order
-        # (side-1 messages, LIFO storage => descending global edge id; reference factors_messages.hxx:2030-2041)
+        # 3. exchange plan (counts in doubles)
+        out_e, out_len, _ = flat(p.out_ghost)
+        in_e, in_len, in_first = flat(p.in_unary)
+        self.out_counts = np.bincount(p.out_peer, weights=out_len, minlength=p.world).astype(np.int64)
+        self.in_counts = np.bincount(p.in_peer, weights=in_len, minlength=p.world).astype(np.int64)
+        self.out_elems_t = torch.from_numpy(out_e).to(dev)
+        self.n_in_elems = int(in_first[-1])
+        # rounds: a non-owner factor with several cut messages receives / sends them in its message-list order
+        # (MRF parts: side-1 messages in LIFO storage => descending global edge id, reference
+        # factors_messages.hxx:2030-2041; general parts carry the position explicitly)
         self.rounds = []
         if p.in_unary.shape[0]:
-            order = np.lexsort((-p.in_key, p.in_unary))
+            pos = p.in_pos if p.in_pos is not None else -p.in_key
+            order = np.lexsort((pos, p.in_unary))
             u_sorted = p.in_unary[order]
             first = np.r_[True, u_sorted[1:] != u_sorted[:-1]]
             start = np.maximum.accumulate(np.where(first, np.arange(order.shape[0]), 0))
             rnd = np.arange(order.shape[0]) - start
             for r in range(int(rnd.max()) + 1):
                 sel = order[rnd == r]
-                self.rounds.append((torch.from_numpy(p.in_unary[sel].astype(np.int64)).to(dev),
-                                    torch.from_numpy(sel.astype(np.int64)).to(dev)))
-            self.in_unary_t = torch.from_numpy(p.in_unary.astype(np.int64)).to(dev)
-            self.in_omega_t = torch.from_numpy(self.in_omega).to(dev).unsqueeze(1)
+                tgt = flat(p.in_unary[sel])[0]
+                src = np.repeat(in_first[sel], in_len[sel]) + (np.arange(int(in_len[sel].sum())) -
+                                                              np.repeat(np.concatenate([[0], np.cumsum(in_len[sel])[:-1]]), in_len[sel]))
+                self.rounds.append((torch.from_numpy(tgt).to(dev), torch.from_numpy(src.astype(np.int64)).to(dev)))
+            self.in_elems_t = torch.from_numpy(in_e).to(dev)
+            self.in_omega_t = torch.from_numpy(np.repeat(self.in_omega, in_len)).to(dev)
         self.info = [engine.schedule_info(s) for s in self.main]
         self.info_ghost = [engine.schedule_info(self.ghost_recv), engine.schedule_info(self.ghost_send)]
 
@@ -353,30 +372,30 @@ class PartitionedSweep:
         self.engine.schedule_run(self.sched[key])
 
     def boundary_pack(self):
-        """owner: ghost <- min-marginal toward the remote variable; returns rows to ship (by peer, key)."""
+        """owner: ghost <- min-marginal toward the remote variable; returns the doubles to ship (by peer, key)."""
         if self.part.n_ghost == 0:
-            return self.theta.new_zeros((0, self.part.L))
+            return self.dual.new_zeros((0,))
         self.engine.schedule_run(self.ghost_recv)
-        send = self.theta[self.out_ghost_t]
-        self.theta[self.out_ghost_t] = 0.0
+        send = self.dual[self.out_elems_t]
+        self.dual[self.out_elems_t] = 0.0
         return send
 
     def boundary_reply(self, recv):
         """non-owner: theta_j += delta (message-list order), delta' = omega_b * theta_j, theta_j -= delta'."""
         if not self.rounds:
-            return recv.new_zeros((0, self.part.L))
-        for idx, sel in self.rounds:
-            self.theta[idx] += recv[sel]
-        reply = self.in_omega_t * self.theta[self.in_unary_t]
-        for idx, sel in self.rounds:
-            self.theta[idx] -= reply[sel]
+            return recv.new_zeros((0,))
+        for tgt, src in self.rounds:
+            self.dual[tgt] += recv[src]
+        reply = self.in_omega_t * self.dual[self.in_elems_t]
+        for tgt, src in self.rounds:
+            self.dual[tgt] -= reply[src]
         return reply
 
     def boundary_fold(self, recv):
         """owner: ghost <- delta'; a weight-1 send folds it into the cut edge's pairwise factor."""
         if self.part.n_ghost == 0:
             return
-        self.theta[self.out_ghost_t] = recv
+        self.dual[self.out_elems_t] = recv
         self.engine.schedule_run(self.ghost_send)
 
     # -- stand-alone driver over a DistComm -------------------------------------------------------------
@@ -455,7 +474,7 @@ def run_lockstep(sweeps: List[PartitionedSweep], n_passes: int):
         got = []
         for dst in range(world):
             pieces = [rows[src][offs[src][dst]: offs[src][dst + 1]] for src in range(world)]
-            got.append(torch.cat(pieces) if pieces else rows[dst].new_zeros((0, rows[dst].shape[1])))
+            got.append(torch.cat(pieces) if pieces else rows[dst].new_zeros((0,) + tuple(rows[dst].shape[1:])))
             assert got[-1].shape[0] == int(sum(counts_in[dst]))
         return got
 

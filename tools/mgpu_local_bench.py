@@ -38,5 +38,4 @@ def timeit(fn, n=10):
 for k in ("FB", "first", "mid", "last"):
     if k in s0.sched: print("schedule %-5s %.3f ms  %s" % (k, timeit(lambda: s0.run(k)), s0.engine.schedule_info(s0.sched[k])))
 print("ghost recv+send %.3f ms" % timeit(lambda: (s0.engine.schedule_run(s0.ghost_recv), s0.engine.schedule_run(s0.ghost_send))))
-z = s0.theta.new_zeros((s0.part.in_unary.shape[0], L))
-print("boundary_pack %.3f ms  reply %.3f ms" % (timeit(lambda: s0.boundary_pack()), timeit(lambda: sweeps[1].boundary_reply(torch.zeros((sweeps[1].part.in_unary.shape[0], L), dtype=torch.float64, device=dev)))))
+print("boundary_pack %.3f ms  reply %.3f ms" % (timeit(lambda: s0.boundary_pack()), timeit(lambda: sweeps[1].boundary_reply(torch.zeros((sweeps[1].n_in_elems,), dtype=torch.float64, device=dev)))))
