@@ -10,7 +10,10 @@ same mechanism compute_partition_pass uses, :1932-1963):
                     (``ComputeAnisotropicWeights`` on the part's sub-graph, :1232-1415); ghost factors are
                     not updated, so parts touch disjoint memory and may run concurrently;
   2. boundary step — ``UpdateFactor`` of every non-owner endpoint u_j restricted to its cut messages:
-                    receive the owner's min-marginal (weight 1), then send back omega_b * theta_j.
+                    receive the owner's min-marginal (weight 1), then send back omega_b * theta_j
+                    (as two iterator-range passes: all receives, then all sends — the same thing for an MRF, where
+                    a pairwise factor has at most one remote endpoint; with higher-order factors two remote
+                    variables may share a factor).
      On the device the two halves of that update live on different GPUs, so the ghost carries the
      message: owner  ghost <- min-marginal (receive-only pass on the ghosts), ship ghost -> remote,
               remote theta_j += delta; delta' = omega_b * theta_j; theta_j -= delta'; ship delta' back
@@ -52,6 +55,7 @@ class LocalPart:
     dual_fill: Optional[list] = None
     in_pos: Optional[np.ndarray] = None # position of each incoming cut message in its left factor's global message list
     key_is_msg: bool = False            # keys are global message ids (partition_model) instead of MRF edge ids
+    ghost_order: Optional[np.ndarray] = None   # order in which the ghost passes visit the ghosts (default: by index)
 
 
 def _sorted_by_peer_key(peer, *cols, key):
@@ -97,6 +101,97 @@ def partition_mrf(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, p
         assert n_vec + le.shape[0] == m.n_factors
         parts.append(LocalPart(k, world, L, m, lv.shape[0], n_ghost, l2g, lm2g, out_peer, out_ghost, out_key,
                                in_peer, in_unary, in_key))
+    return parts
+
+
+def partition_model(gm: M.FlatModel, part: np.ndarray, world: int) -> List[LocalPart]:
+    """General partitioner: any factor graph whose messages all have the `left` schedule and whose factors are either
+    "variables" (left factor of their messages: MRF unaries, multicut edge factors, ...) or "higher factors" (right
+    factor: pairwise, triplet, ... factors), with unary-pairwise or labeling messages (the left factor sends
+    omega * theta through both).  ``part[f]`` = owning rank of variable f (ignored for higher factors).  A higher
+    factor belongs to the part of its lowest-numbered variable; every cut message gets a zero ghost copy of its remote
+    variable on the owner's side.  Local factor order: variables, ghosts, higher factors; messages keep the global
+    insertion order; a relation survives when both ends are local (a remote variable is represented by its ghost in
+    relations with the ghost's own higher factor)."""
+    from . import engine as E
+    part = np.asarray(part, np.int64)
+    nf, nm = gm.n_factors, gm.n_messages
+    ml, mr = gm.m_left.astype(np.int64), gm.m_right.astype(np.int64)
+    for t in gm.mtypes:
+        if t.schedule != M.SCHED_LEFT or t.kind not in (M.M_UNARY_PAIRWISE, M.M_LABELING):
+            raise ValueError("partition_model: only `left`-schedule unary-pairwise / labeling messages")
+    is_right = np.zeros(nf, bool); is_right[mr] = True
+    is_left = np.zeros(nf, bool); is_left[ml] = True
+    if np.any(is_left & is_right):
+        raise ValueError("partition_model: a factor is both left and right of messages")
+    if np.any(gm.f_kind[is_left] != M.F_VECTOR):
+        raise ValueError("partition_model: variables must be vector factors")
+    first_var = np.full(nf, nf, np.int64)
+    np.minimum.at(first_var, mr, ml)
+    owner = np.where(is_right, part[np.minimum(first_var, nf - 1)], part)      # of every factor
+    m_owner = owner[mr]
+    coff, doff = gm.const_offsets(), gm.dual_offsets()
+    g_off, g_ent = E.Plan(gm).msg_lists(nm)
+    pos_in_list = np.zeros(nm, np.int64)                   # position of message m in its left factor's message list
+    for f in np.nonzero(is_left)[0]:
+        ent = g_ent[g_off[f]:g_off[f + 1]] // 2
+        pos_in_list[ent] = np.arange(ent.shape[0])
+
+    def take(data, off, idx):
+        if data is None or idx.shape[0] == 0:
+            return np.zeros(0)
+        lens = off[idx + 1] - off[idx]
+        first = np.concatenate([[0], np.cumsum(lens)])
+        return data[np.repeat(off[idx], lens) + (np.arange(int(first[-1])) - np.repeat(first[:-1], lens))]
+
+    parts = []
+    for k in range(world):
+        lv = np.nonzero(~is_right & (part == k))[0]
+        rk = np.nonzero(is_right & (owner == k))[0]
+        mk = np.nonzero(m_owner == k)[0]                    # messages into owned higher factors, global order
+        cut = part[ml[mk]] != k
+        n_ghost = int(cut.sum())
+        ghost_of = ml[mk][cut]                              # remote variable behind every ghost
+        n_local = lv.shape[0]
+        lmap = np.full(nf, -1, np.int64)
+        lmap[lv] = np.arange(n_local)
+        lmap[rk] = n_local + n_ghost + np.arange(rk.shape[0])
+        left_loc = lmap[ml[mk]].copy()
+        left_loc[cut] = n_local + np.arange(n_ghost)
+        src = np.concatenate([lv, ghost_of, rk])            # global factor every local factor copies its shape from
+        dual = np.concatenate([take(gm.dual_data, doff, lv), np.zeros(int((doff[ghost_of + 1] - doff[ghost_of]).sum())),
+                               take(gm.dual_data, doff, rk)])
+        const = None if gm.const_data is None else take(gm.const_data, coff, rk)
+
+        def map_rel(rel):
+            out = []
+            ghost_idx = {(int(v), int(r)): n_local + i for i, (v, r) in enumerate(zip(ghost_of, mr[mk][cut]))}
+            for a, b in rel:
+                la, lb = lmap[a], lmap[b]
+                if la < 0 and (int(a), int(b)) in ghost_idx:
+                    la = ghost_idx[(int(a), int(b))]
+                if lb < 0 and (int(b), int(a)) in ghost_idx:
+                    lb = ghost_idx[(int(b), int(a))]
+                if la >= 0 and lb >= 0:
+                    out.append((la, lb))
+            return np.array(out, np.int32).reshape(-1, 2)
+
+        m = M.FlatModel(
+            n_ftypes=gm.n_ftypes, ftype_computes_primal=gm.ftype_computes_primal, mtypes=gm.mtypes,
+            tab_off=gm.tab_off, tab_data=gm.tab_data, tab_nleft=gm.tab_nleft,
+            f_type=np.ascontiguousarray(gm.f_type[src]), f_kind=np.ascontiguousarray(gm.f_kind[src]),
+            f_flags=np.ascontiguousarray(gm.f_flags[src]), f_dim0=np.ascontiguousarray(gm.f_dim0[src]),
+            f_dim1=np.ascontiguousarray(gm.f_dim1[src]), const_data=const, dual_data=np.ascontiguousarray(dual),
+            m_type=np.ascontiguousarray(gm.m_type[mk]), m_left=left_loc.astype(np.int32), m_right=lmap[mr[mk]].astype(np.int32),
+            rel_fwd=map_rel(gm.rel_fwd), rel_bwd=map_rel(gm.rel_bwd), constant=gm.constant if k == 0 else 0.0)
+        out_peer, out_ghost, out_key = _sorted_by_peer_key(part[ghost_of], (n_local + np.arange(n_ghost)).astype(np.int32), key=mk[cut])
+        inm = np.nonzero((part[ml] == k) & (m_owner != k))[0]
+        in_peer, in_unary, in_pos, in_key = _sorted_by_peer_key(m_owner[inm], lmap[ml[inm]].astype(np.int32), pos_in_list[inm], key=inm)
+        # a higher factor may have several remote variables: the ghost passes visit its ghosts in the order a pass over
+        # the remote variables themselves (by global index, cut messages in list order) would touch the factor
+        ghost_order = np.lexsort((pos_in_list[mk[cut]], ghost_of))
+        parts.append(LocalPart(k, world, 0, m, n_local, n_ghost, src, mk.astype(np.int64), out_peer, out_ghost, out_key,
+                               in_peer, in_unary, in_key, in_pos=in_pos, key_is_msg=True, ghost_order=ghost_order))
     return parts
 
 
@@ -324,6 +419,8 @@ class PartitionedSweep:
                     self.sched[k] = engine.schedule_create(*self.rows[k], fuse=True)
         # 2. boundary passes on the ghosts: every ghost has exactly one message (side 1 of its cut edge)
         g = np.arange(p.n_local, n_vec, dtype=np.int32)
+        if p.ghost_order is not None:
+            g = np.ascontiguousarray(g[p.ghost_order])
         ones_off = np.arange(g.shape[0] + 1, dtype=np.int64)
         self.ghost_rows_recv = (g, ones_off, np.zeros(g.shape[0]), ones_off, np.ones(g.shape[0], np.uint8))
         self.ghost_rows_send = (g, ones_off, np.ones(g.shape[0]), ones_off, np.zeros(g.shape[0], np.uint8))

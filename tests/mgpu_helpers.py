@@ -69,17 +69,23 @@ def global_replay(global_model, parts, sweeps, n_passes):
         cut = {}
         for p, sw in zip(parts, sweeps):
             for u, key, w in zip(p.in_unary, p.in_key, sw.in_omega):
-                cut.setdefault(int(p.local_to_global[u]), {})[2 * int(key) + 1] = float(w)
-        F, OM, MK, off = [], [], [], [0]
-        for g in sorted(cut):
-            gm = glist(g)
-            o_row = np.zeros(gm.shape[0]); m_row = np.zeros(gm.shape[0], np.uint8)
-            for k, x in enumerate(gm):
-                if int(x) in cut[g]:
-                    o_row[k] = cut[g][int(x)]; m_row[k] = 1
-            F.append(g); OM.append(o_row); MK.append(m_row); off.append(off[-1] + gm.shape[0])
-        if F:
-            o.compute_pass_custom(np.array(F, np.int32), off, np.concatenate(OM), off, np.concatenate(MK))
+                msg = int(key) if p.key_is_msg else 2 * int(key) + 1      # MRF parts key by edge: side-1 message
+                cut.setdefault(int(p.local_to_global[u]), {})[msg] = float(w)
+        # two iterator-range passes over the boundary variables (global index order): all receives, then all sends
+        for recv in (True, False):
+            F, OM, MK, off = [], [], [], [0]
+            for g in sorted(cut):
+                gm = glist(g)
+                o_row = np.zeros(gm.shape[0]); m_row = np.zeros(gm.shape[0], np.uint8)
+                for k, x in enumerate(gm):
+                    if int(x) in cut[g]:
+                        if recv:
+                            m_row[k] = 1
+                        else:
+                            o_row[k] = cut[g][int(x)]
+                F.append(g); OM.append(o_row); MK.append(m_row); off.append(off[-1] + gm.shape[0])
+            if F:
+                o.compute_pass_custom(np.array(F, np.int32), off, np.concatenate(OM), off, np.concatenate(MK))
 
     for n in ([n_passes] if isinstance(n_passes, int) else n_passes):      # one entry per compute_pass call
         programs = [sw.program(n) for sw in sweeps]

@@ -246,3 +246,100 @@ def test_random_partitions_random_graphs_exact_and_ascending(seed):
     o = global_replay(g, parts, sweeps, calls)
     assert np.array_equal(gather_global_duals(g, parts, duals), o.duals())
     assert abs(lbs[-1] - o.LowerBound()) <= 1e-9 * max(1.0, abs(lbs[-1]))
+
+
+def _general_models():
+    rng = np.random.default_rng(31)
+    out = {}
+    # a) plain MRF with mixed label counts and mixed dense / Potts edges
+    b = M.ModelBuilder(2, S.mrf_mtypes())
+    dims = rng.choice([2, 3, 5], size=18)
+    u = [b.add_vector_factors(0, rng.uniform(0, 1, (1, int(d))))[0] for d in dims]
+    for _ in range(40):
+        i, j = sorted(rng.choice(18, 2, replace=False))
+        if dims[i] == dims[j] and rng.uniform() < 0.4:
+            p = b.add_potts_pairwise(1, int(dims[i]), [rng.uniform(0, 1)])[0]
+        else:
+            p = b.add_dense_pairwise(1, rng.uniform(0, 1, (1, int(dims[i]), int(dims[j]))))[0]
+        b.add_messages(0, u[i], p); b.add_messages(1, u[j], p)
+        b.add_relations(u[i], p); b.add_relations(p, u[j])
+    out["mixed_mrf"] = b.finish()
+    # b) multicut-style labeling lists: edge variables, triplet factors
+    out["multicut"] = S.multicut_triangle_model(14, 25, seed=3)
+    # c) C5 in miniature: Potts grid + triplets + quadruples over binary edge variables, one factor graph
+    out["c5"] = S.c5_model(5, 6, 4, 40, 25, 10, seed=2, window=12)
+    return out
+
+
+@pytest.mark.parametrize("name", ["mixed_mrf", "multicut", "c5"])
+@pytest.mark.parametrize("world,every", [(2, "sweep"), (3, "pass")])
+def test_general_partitioner_any_left_schedule_model(name, world, every):
+    """partition_model on models that are not plain MRFs (ragged label counts, labeling-list factors): the parts run
+    in lockstep, the oracle replays the same schedule on the unpartitioned model, duals bit-identical"""
+    gm = _general_models()[name]
+    rng = np.random.default_rng(5)
+    part_of = rng.integers(0, world, gm.n_factors)
+    parts = MG.partition_model(gm, part_of, world)
+    assert sum(p.n_local for p in parts) + sum(int((p.model.f_kind != M.F_VECTOR).sum()) +
+               int(((p.model.f_kind == M.F_VECTOR) & (np.arange(p.model.n_factors) >= p.n_local + p.n_ghost)).sum()) for p in parts) == gm.n_factors
+    assert sum(p.n_ghost for p in parts) > 0 and sum(p.model.n_messages for p in parts) == gm.n_messages
+    attach_local_lists(parts)
+    sweeps, duals = _cpu_sweeps(parts, None, every)
+    lbs = [sum(s.local_lower_bound() for s in sweeps)]
+    ref = Oracle(gm)
+    assert abs(lbs[0] - ref.LowerBound()) <= 1e-9 * max(1.0, abs(lbs[0]))
+    for _ in range(3):
+        MG.run_lockstep(sweeps, 1)
+        lbs.append(sum(s.local_lower_bound() for s in sweeps))
+    assert all(b >= a - 1e-9 for a, b in zip(lbs, lbs[1:]))
+    o = global_replay(gm, parts, sweeps, [1, 1, 1])
+    assert np.array_equal(gather_global_duals(gm, parts, duals), o.duals())
+    assert abs(lbs[-1] - o.LowerBound()) <= 1e-9 * max(1.0, abs(lbs[-1]))
+
+
+def test_general_partitioner_rejects_what_it_cannot_split():
+    mt = [M.MsgType(0, 0, M.SCHED_LEFT, 0, 0, M.M_MINNORM, 0)]
+    b = M.ModelBuilder(1, mt)
+    f = b.add_vector_factors(0, np.zeros((3, 2)))
+    b.add_messages(0, f[0], f[1]); b.add_messages(0, f[1], f[2])
+    with pytest.raises(ValueError):
+        MG.partition_model(b.finish(), np.zeros(3, np.int64), 2)
+    mt = [M.MsgType(0, 1, M.SCHED_FULL, 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, M.SCHED_FULL, 0, 1, M.M_UNARY_PAIRWISE, 1)]
+    b = M.ModelBuilder(2, mt)
+    u = b.add_vector_factors(0, np.zeros((2, 2)))
+    p = b.add_dense_pairwise(1, np.zeros((1, 2, 2)))[0]
+    b.add_messages(0, u[0], p); b.add_messages(1, u[1], p)
+    with pytest.raises(ValueError):
+        MG.partition_model(b.finish(), np.zeros(3, np.int64), 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world,every", [("c5", 3, "pass"), ("multicut", 4, "sweep"), ("mixed_mrf", 2, "pass")])
+def test_general_partitioner_on_device(name, world, every):
+    """BASELINE configs[4] in miniature across several parts (grid + labeling-list factors in one factor graph), and the
+    other general models: real HIP engines, all parts on the one GPU, oracle replay on the unpartitioned model"""
+    from lp_mp_amd import engine as E
+    gm = _general_models()[name]
+    part_of = np.random.default_rng(9).integers(0, world, gm.n_factors)
+    parts = MG.partition_model(gm, part_of, world)
+    attach_local_lists(parts)
+    dev = torch.device("cuda:0")
+    sweeps, tensors, engines = [], [], []
+    for p in parts:
+        dual = torch.from_numpy(p.model.dual_data.copy()).to(dev)
+        eng = E.Engine(0)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual)
+        sweeps.append(MG.PartitionedSweep(torch, p, eng, dual, M.REPAM_ANISOTROPIC, None, every))
+        tensors.append(dual); engines.append(eng)
+    lbs = [sum(s.local_lower_bound() for s in sweeps)]
+    for _ in range(3):
+        MG.run_lockstep(sweeps, 1)
+        lbs.append(sum(s.local_lower_bound() for s in sweeps))
+    torch.cuda.synchronize()
+    o = global_replay(gm, parts, sweeps, [1, 1, 1])
+    assert np.array_equal(gather_global_duals(gm, parts, [t.cpu().numpy() for t in tensors]), o.duals())
+    assert abs(lbs[-1] - o.LowerBound()) <= 1e-5 * max(1.0, abs(lbs[-1]))
+    assert all(b >= a - 1e-9 for a, b in zip(lbs, lbs[1:]))
+    for e in engines:
+        e.close()
