@@ -627,3 +627,32 @@ class StripSweep:
 
     def lower_bound(self):
         return self.comm.all_reduce_sum(self.sweep.local_lower_bound())
+
+
+class ModelSweep:
+    """Driver for an arbitrary partitioned model: this rank's part of ``global_model`` (partition_model) on its own
+    GPU, cut messages exchanged through torch.distributed.  Every rank derives the partition from the same inputs."""
+
+    def __init__(self, torch, dist, global_model: M.FlatModel, part_of: np.ndarray, mode, omega_b=None,
+                 boundary_every="sweep", engine_factory=None):
+        self.torch, self.dist = torch, dist
+        self.comm = DistComm(dist, torch)
+        self.part = partition_model(global_model, part_of, self.comm.world)[self.comm.rank]
+        m = self.part.model
+        if engine_factory is None:                        # the HIP engine on this rank's device
+            from . import engine as E
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self.comm._dev = dev
+            self.dualt = torch.from_numpy(m.dual_data.copy()).to(dev)
+            self.engine = E.Engine(torch.cuda.current_device())
+            self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
+            self.engine.upload(m, dual_dev=self.dualt.data_ptr(), keep=self.dualt)
+        else:                                             # tests: an engine stand-in on a host buffer
+            self.dualt, self.engine = engine_factory(m)
+        self.sweep = PartitionedSweep(torch, self.part, self.engine, self.dualt, mode, omega_b, boundary_every)
+
+    def compute_pass(self, n=1):
+        self.sweep.compute_pass(self.comm, n)
+
+    def lower_bound(self):
+        return self.comm.all_reduce_sum(self.sweep.local_lower_bound())

@@ -313,6 +313,48 @@ def test_general_partitioner_rejects_what_it_cannot_split():
         MG.partition_model(b.finish(), np.zeros(3, np.int64), 2)
 
 
+WORKER_GENERAL = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from lp_mp_amd import model as M, multi_gpu as MG
+from tests.mgpu_helpers import OracleEngine
+from tests.test_multi_gpu import _general_models
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+gm = _general_models()["c5"]
+part_of = np.random.default_rng(5).integers(0, 2, gm.n_factors)
+def factory(m):
+    d = m.dual_data.copy()
+    return torch.from_numpy(d), OracleEngine(m, d)
+sw = MG.ModelSweep(torch, dist, gm, part_of, M.REPAM_ANISOTROPIC, None, "sweep", engine_factory=factory)
+sw.compute_pass(3)
+lb = sw.lower_bound()
+np.save(os.path.join({out!r}, f"gduals_{{rank}}.npy"), sw.dualt.numpy())
+if rank == 0:
+    np.save(os.path.join({out!r}, "glb.npy"), np.array([lb]))
+dist.destroy_process_group()
+"""
+
+
+def test_two_process_gloo_run_of_a_general_model(tmp_path):
+    """C5 in miniature over torch.distributed (gloo, world_size 2) through ModelSweep: ragged all-to-all exchange"""
+    script = tmp_path / "worker_general.py"
+    script.write_text(WORKER_GENERAL.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29534", str(script)], env=env, cwd=ROOT,
+                          timeout=300)
+    gm = _general_models()["c5"]
+    parts = MG.partition_model(gm, np.random.default_rng(5).integers(0, 2, gm.n_factors), 2)
+    attach_local_lists(parts)
+    sweeps, duals = _cpu_sweeps(parts, None, "sweep")
+    MG.run_lockstep(sweeps, 3)
+    for k in range(2):
+        assert np.array_equal(np.load(tmp_path / f"gduals_{k}.npy"), duals[k])
+    o = global_replay(gm, parts, sweeps, 3)
+    assert abs(np.load(tmp_path / "glb.npy")[0] - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,world,every", [("c5", 3, "pass"), ("multicut", 4, "sweep"), ("mixed_mrf", 2, "pass")])
 def test_general_partitioner_on_device(name, world, every):
