@@ -210,6 +210,24 @@ def graph_partition(n_vars: int, edge_i: np.ndarray, edge_j: np.ndarray, world: 
     return part
 
 
+def graph_partition_model(gm: M.FlatModel, world: int) -> np.ndarray:
+    """``part`` for partition_model: the variables of a factor graph (left factors of its messages) split by
+    graph_partition on the graph that links the variables of every higher factor in a chain; entries of higher
+    factors are unused (0)."""
+    ml, mr = gm.m_left.astype(np.int64), gm.m_right.astype(np.int64)
+    order = np.lexsort((ml, mr))                              # messages grouped by higher factor
+    a, b, same = ml[order][:-1], ml[order][1:], mr[order][:-1] == mr[order][1:]
+    is_right = np.zeros(gm.n_factors, bool); is_right[mr] = True
+    var = np.nonzero(~is_right)[0]
+    rank_of = np.full(gm.n_factors, -1, np.int64); rank_of[var] = np.arange(var.shape[0])
+    ei, ej = rank_of[a[same]], rank_of[b[same]]
+    keep = ei != ej
+    p = graph_partition(var.shape[0], np.minimum(ei, ej)[keep], np.maximum(ei, ej)[keep], world)
+    part = np.zeros(gm.n_factors, np.int64)
+    part[var] = p
+    return part
+
+
 # ---- row-strip grids: closed-form local parts (no global model is ever materialised) ------------
 def strip_sizes(H: int, W: int):
     return H * W, H * (W - 1) + W * (H - 1)

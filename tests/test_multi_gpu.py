@@ -385,3 +385,17 @@ def test_general_partitioner_on_device(name, world, every):
     assert all(b >= a - 1e-9 for a, b in zip(lbs, lbs[1:]))
     for e in engines:
         e.close()
+
+
+def test_graph_partition_of_a_general_model_is_balanced_and_local():
+    gm = S.c5_model(12, 12, 4, 600, 300, 150, seed=3, window=24)
+    world = 4
+    part = MG.graph_partition_model(gm, world)
+    is_right = np.zeros(gm.n_factors, bool); is_right[gm.m_right] = True
+    sizes = np.bincount(part[~is_right], minlength=world)
+    assert sizes.max() - sizes.min() <= 1
+    parts = MG.partition_model(gm, part, world)
+    cut = sum(p.n_ghost for p in parts)
+    rnd = np.random.default_rng(0).integers(0, world, gm.n_factors)
+    cut_rnd = sum(p.n_ghost for p in MG.partition_model(gm, rnd, world))
+    assert 0 < cut < 0.35 * cut_rnd
