@@ -133,9 +133,10 @@ def partition_model(gm: M.FlatModel, part: np.ndarray, world: int) -> List[Local
     coff, doff = gm.const_offsets(), gm.dual_offsets()
     g_off, g_ent = E.Plan(gm).msg_lists(nm)
     pos_in_list = np.zeros(nm, np.int64)                   # position of message m in its left factor's message list
-    for f in np.nonzero(is_left)[0]:
-        ent = g_ent[g_off[f]:g_off[f + 1]] // 2
-        pos_in_list[ent] = np.arange(ent.shape[0])
+    lens = np.diff(g_off)
+    within = np.arange(int(g_off[-1])) - np.repeat(g_off[:-1], lens)
+    left_entry = (g_ent % 2) == 0                            # role 0: the list's factor is the message's left factor
+    pos_in_list[g_ent[left_entry] // 2] = within[left_entry]
 
     def take(data, off, idx):
         if data is None or idx.shape[0] == 0:
@@ -163,18 +164,25 @@ def partition_model(gm: M.FlatModel, part: np.ndarray, world: int) -> List[Local
                                take(gm.dual_data, doff, rk)])
         const = None if gm.const_data is None else take(gm.const_data, coff, rk)
 
+        gkey = ghost_of * nf + mr[mk][cut]                  # (remote variable, its higher factor) of every ghost
+        gorder = np.argsort(gkey, kind="stable")
+        gkey_s = gkey[gorder]
+
+        def ghost_lookup(v, r):
+            if gkey_s.shape[0] == 0:
+                return np.full(v.shape[0], -1, np.int64)
+            key = v * nf + r
+            i = np.minimum(np.searchsorted(gkey_s, key), gkey_s.shape[0] - 1)
+            return np.where(gkey_s[i] == key, n_local + gorder[i], -1)
+
         def map_rel(rel):
-            out = []
-            ghost_idx = {(int(v), int(r)): n_local + i for i, (v, r) in enumerate(zip(ghost_of, mr[mk][cut]))}
-            for a, b in rel:
-                la, lb = lmap[a], lmap[b]
-                if la < 0 and (int(a), int(b)) in ghost_idx:
-                    la = ghost_idx[(int(a), int(b))]
-                if lb < 0 and (int(b), int(a)) in ghost_idx:
-                    lb = ghost_idx[(int(b), int(a))]
-                if la >= 0 and lb >= 0:
-                    out.append((la, lb))
-            return np.array(out, np.int32).reshape(-1, 2)
+            rel = np.asarray(rel, np.int64).reshape(-1, 2)
+            a, b = rel[:, 0], rel[:, 1]
+            la, lb = lmap[a].copy(), lmap[b].copy()
+            la = np.where(la < 0, ghost_lookup(a, b), la)
+            lb = np.where(lb < 0, ghost_lookup(b, a), lb)
+            keep = (la >= 0) & (lb >= 0)
+            return np.ascontiguousarray(np.stack([la[keep], lb[keep]], 1).astype(np.int32)).reshape(-1, 2)
 
         m = M.FlatModel(
             n_ftypes=gm.n_ftypes, ftype_computes_primal=gm.ftype_computes_primal, mtypes=gm.mtypes,
