@@ -211,3 +211,32 @@ def test_kernel_class_of_every_model_shape():
     b = M.ModelBuilder(2, S.mrf_mtypes())
     b.add_vector_factors(0, np.zeros((2, 5)))
     assert cls(b.finish()) == {}
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_plan_matches_oracle_on_random_models(block):
+    """the randomised models of the GPU parity tests (mixed kinds, every schedule, random relations, duplicates): message
+    lists, orders, weights and masks of the host analysis against the oracle's independent restatement — runs without
+    a GPU, 25 models per block and family"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_models", os.path.join(os.path.dirname(__file__), "test_fuzz_gpu.py"))
+    F = importlib.util.module_from_spec(spec); spec.loader.exec_module(F)
+    for seed in range(25 * block, 25 * block + 25):
+        for build in (F.random_model, F.random_mrf, F.random_mrf_any_labels):
+            m = build(np.random.default_rng(77000 + seed))
+            o, p = Oracle(m), E.Plan(m)
+            o_off, o_ent = o.msg_lists()
+            p_off, p_ent = p.msg_lists(m.n_messages)
+            assert np.array_equal(o_off, p_off) and np.array_equal(o_ent, p_ent), (seed, build.__name__)
+            for d in (M.FORWARD, M.BACKWARD):
+                assert np.array_equal(o.order(d), p.order(d)), (seed, build.__name__)
+                assert np.array_equal(o.update_order(d), p.update_order(d)), (seed, build.__name__)
+                for mode in MODES:
+                    a, b = o.omega(d, mode), p.omega(d, mode)
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (seed, build.__name__, d, mode)
+                    om = b[1]
+                    a, b = o.mask(d, mode), p.mask(d, mode)
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (seed, build.__name__, d, mode)
+                    # and the schedule is well formed: every active receive / send is scheduled exactly once
+                    info = p.schedule_info(d, mode)
+                    assert info["n_receives"] == int(b[1].sum()) and info["n_sends"] == int((om != 0).sum())
