@@ -154,6 +154,8 @@ def partition_model(gm: M.FlatModel, part: np.ndarray, world: int) -> List[Local
         n_ghost = int(cut.sum())
         ghost_of = ml[mk][cut]                              # remote variable behind every ghost
         n_local = lv.shape[0]
+        if n_local + rk.shape[0] == 0:
+            raise ValueError(f"partition_model: part {k} owns no factor")
         lmap = np.full(nf, -1, np.int64)
         lmap[lv] = np.arange(n_local)
         lmap[rk] = n_local + n_ghost + np.arange(rk.shape[0])

@@ -399,3 +399,36 @@ def test_graph_partition_of_a_general_model_is_balanced_and_local():
     rnd = np.random.default_rng(0).integers(0, world, gm.n_factors)
     cut_rnd = sum(p.n_ghost for p in MG.partition_model(gm, rnd, world))
     assert 0 < cut < 0.35 * cut_rnd
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_general_partitioner_on_randomised_models(seed):
+    """randomised MRFs of the GPU parity tests (odd orders, duplicate messages, every label count) and multicut /
+    C5-style models, random partitions into 2..4 parts, both boundary cadences: lock-step parts == oracle replay"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_models", os.path.join(ROOT, "tests", "test_fuzz_gpu.py"))
+    F = importlib.util.module_from_spec(spec); spec.loader.exec_module(F)
+    rng = np.random.default_rng(41000 + seed)
+    kind = seed % 4
+    if kind == 0:
+        gm = F.random_mrf(rng)
+    elif kind == 1:
+        gm = F.random_mrf_any_labels(rng)
+    elif kind == 2:
+        gm = S.multicut_triangle_model(int(rng.integers(8, 16)), int(rng.integers(10, 30)), seed=seed)
+    else:
+        gm = S.c5_model(4, 5, 3, 30, int(rng.integers(8, 20)), int(rng.integers(4, 10)), seed=seed, window=int(rng.choice([8, 30])))
+    world = int(rng.integers(2, 5))
+    every = "pass" if rng.uniform() < 0.5 else "sweep"
+    parts = MG.partition_model(gm, rng.integers(0, world, gm.n_factors), world)
+    attach_local_lists(parts)
+    sweeps, duals = _cpu_sweeps(parts, None, every)
+    lbs = [sum(s.local_lower_bound() for s in sweeps)]
+    for _ in range(2):
+        MG.run_lockstep(sweeps, 1)
+        lbs.append(sum(s.local_lower_bound() for s in sweeps))
+    MG.run_lockstep(sweeps, 2)
+    lbs.append(sum(s.local_lower_bound() for s in sweeps))
+    assert all(b >= a - 1e-9 for a, b in zip(lbs, lbs[1:])), (seed, lbs)
+    o = global_replay(gm, parts, sweeps, [1, 1, 2])
+    assert np.array_equal(gather_global_duals(gm, parts, duals), o.duals()), seed
