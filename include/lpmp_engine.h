@@ -76,6 +76,13 @@ int lpmp_plan_schedule_info(lpmp_plan* p, int direction, int mode, int64_t* n_le
 #define LPMP_KCLASS_COUNT 19
 int lpmp_plan_schedule_classes(lpmp_plan* p, int direction, int mode, int64_t* factors /*[LPMP_KCLASS_COUNT]*/);
 
+/* the same summary for an iterator-range pass (LP_MP.h:981-1005) given as factor list + weight rows + receive-mask
+ * rows, without a device: what lpmp_schedule_create[_fused] would build.  Arguments as lpmp_compute_pass_custom. */
+int lpmp_plan_custom_schedule_info(lpmp_plan* p, int64_t n, const int32_t* factors, const int64_t* omega_off,
+                                   const double* omega, const int64_t* mask_off, const uint8_t* mask, int fuse,
+                                   int64_t* n_levels, int64_t* n_launches, int64_t* n_receives, int64_t* n_sends,
+                                   int64_t* algorithmic_bytes);
+
 /* dependent step (1-based level; 0 = no active message) of every entry of the update order in that sweep */
 int lpmp_plan_get_update_levels(lpmp_plan* p, int direction, int mode, int32_t* out /*[n_updated]*/);
 /* the same for a whole pass (forward then backward sweep scheduled as one sequence; back-to-back updates

@@ -467,6 +467,24 @@ int lpmp_plan_schedule_classes(lpmp_plan* p, int d, int mode, int64_t* factors) 
   });
 }
 
+int lpmp_plan_custom_schedule_info(lpmp_plan* p, int64_t n, const int32_t* factors, const int64_t* om_off, const double* om,
+                                   const int64_t* mk_off, const uint8_t* mk, int fuse, int64_t* n_levels, int64_t* n_launches,
+                                   int64_t* n_recv, int64_t* n_send, int64_t* alg_bytes) {
+  return guarded([&] {
+    if (!p || n < 0 || (n > 0 && (!factors || !om_off || !mk_off))) throw std::runtime_error("bad argument");
+    Schedule s;
+    static const double dz = 0; static const uint8_t uz = 0;
+    static const int64_t zero_off[1] = {0};
+    p->p.make_schedule(std::vector<Plan::Segment>{Plan::Segment{factors, n, n > 0 ? om_off : zero_off, om ? om : &dz,
+                                                                n > 0 ? mk_off : zero_off, mk ? mk : &uz}}, fuse != 0, s);
+    if (n_levels) *n_levels = s.n_levels;
+    if (n_launches) *n_launches = (int64_t)s.launches.size();
+    if (n_recv) *n_recv = s.n_recv;
+    if (n_send) *n_send = s.n_send;
+    if (alg_bytes) *alg_bytes = s.alg_bytes;
+  });
+}
+
 int lpmp_plan_get_update_levels(lpmp_plan* p, int d, int mode, int32_t* out) {
   return guarded([&] {
     if (!p || !out || d < 0 || d > 1 || mode < 0 || mode >= LPMP_REPAM_COUNT) throw std::runtime_error("bad argument");

@@ -38,7 +38,7 @@ EXPORTS = [
     "lpmp_last_error", "lpmp_version", "lpmp_plan_create", "lpmp_plan_destroy", "lpmp_plan_n_factors",
     "lpmp_plan_n_updated", "lpmp_plan_get_order", "lpmp_plan_get_update_order", "lpmp_plan_omega_nnz",
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
-    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_schedule_classes", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
+    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_custom_schedule_info", "lpmp_plan_schedule_classes", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
     "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_set_reparametrization_type", "lpmp_compute_pass", "lpmp_compute_forward_pass",
     "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_create_fused", "lpmp_schedule_run",
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
@@ -90,6 +90,7 @@ def lib():
         L.lpmp_plan_pass_schedule_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.lpmp_plan_get_update_levels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.lpmp_plan_schedule_classes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.lpmp_plan_custom_schedule_info.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 5
         L.lpmp_create.argtypes = [C.c_int, C.c_void_p]
         L.lpmp_destroy.argtypes = [C.c_void_p]
         L.lpmp_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -216,6 +217,20 @@ class Plan:
         v = [C.c_int64() for _ in range(5)]
         _chk(self.L.lpmp_plan_schedule_info(self.h, d, mode, *[C.addressof(x) for x in v]))
         return dict(zip(("n_levels", "n_launches", "n_receives", "n_sends", "algorithmic_bytes"), [x.value for x in v]))
+
+
+def _custom_schedule_info(self, factors, om_off, om, mk_off, mk, fuse: bool = False) -> dict:
+    """summary of the schedule an iterator-range pass (factor list, weight rows, receive-mask rows) compiles to"""
+    factors = np.ascontiguousarray(factors, np.int32)
+    om_off = np.ascontiguousarray(om_off, np.int64); om = np.ascontiguousarray(om, np.float64)
+    mk_off = np.ascontiguousarray(mk_off, np.int64); mk = np.ascontiguousarray(mk, np.uint8)
+    v = [C.c_int64() for _ in range(5)]
+    _chk(self.L.lpmp_plan_custom_schedule_info(self.h, factors.shape[0], factors.ctypes.data, om_off.ctypes.data, om.ctypes.data,
+                                               mk_off.ctypes.data, mk.ctypes.data, int(bool(fuse)), *[C.addressof(x) for x in v]))
+    return dict(zip(("n_levels", "n_launches", "n_receives", "n_sends", "algorithmic_bytes"), [x.value for x in v]))
+
+
+Plan.custom_schedule_info = _custom_schedule_info
 
 
 def _schedule_classes(self, d: int, mode: int) -> dict:

@@ -240,3 +240,30 @@ def test_plan_matches_oracle_on_random_models(block):
                     # and the schedule is well formed: every active receive / send is scheduled exactly once
                     info = p.schedule_info(d, mode)
                     assert info["n_receives"] == int(b[1].sum()) and info["n_sends"] == int((om != 0).sum())
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_custom_pass_schedules_on_random_rows(block):
+    """iterator-range passes with random factor subsets in random order, random masks and weights, fused and not: the
+    compiled schedule holds exactly the active receives / sends of the rows (host only; also the sanitizer target)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_models", os.path.join(os.path.dirname(__file__), "test_fuzz_gpu.py"))
+    F = importlib.util.module_from_spec(spec); spec.loader.exec_module(F)
+    for seed in range(40 * block, 40 * block + 40):
+        rng = np.random.default_rng(88000 + seed)
+        m = (F.random_model, F.random_mrf, F.random_mrf_any_labels)[seed % 3](rng)
+        o, p = Oracle(m), E.Plan(m)
+        for _ in range(3):
+            rows = F.random_rows(rng, None, o, m)
+            for fuse in (False, True):
+                info = p.custom_schedule_info(*rows, fuse=fuse)
+                assert info["n_receives"] == int(rows[4].sum()) and info["n_sends"] == int((rows[2] != 0).sum()), (seed, fuse)
+        from lp_mp_amd.multi_gpu import _cat_rows
+        seq = []
+        for d in (M.FORWARD, M.BACKWARD):
+            oo, om = o.omega(d, M.REPAM_ANISOTROPIC); mo, mk = o.mask(d, M.REPAM_ANISOTROPIC)
+            seq.append((o.update_order(d), oo, om, mo, mk))
+        seq.append(F.random_rows(rng, None, o, m))
+        cat = _cat_rows(*seq)
+        info = p.custom_schedule_info(*cat, fuse=True)
+        assert info["n_receives"] == int(cat[4].sum()) and info["n_sends"] == int((cat[2] != 0).sum())
