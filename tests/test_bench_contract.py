@@ -47,3 +47,6 @@ def test_bench_json_line_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert d["cpu_baseline"]["kind"] == "port"
+    rd = d["rounding"]                                         # one pass with primal rounding, outside the timed region
+    assert rd["primal_cost"] >= rd["lower_bound"] and rd["ms_pass_and_primal"] > 0
+    assert d["roofline"]["kernel"].startswith("sweep_dense_pk_kernel<32, 2, false")
