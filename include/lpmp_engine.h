@@ -99,7 +99,12 @@ int lpmp_set_stream(lpmp_engine* e, void* hip_stream);
 
 /* add_factor / add_message / AddFactorRelation, flattened (include/LP_MP.h:239-285, :698-702), plus the
  * packed duals as serialize_dual lists them (include/factors_messages.hxx:3196-3223).
- * const_mem / dual_mem say where m->const_data / m->dual_data live. */
+ * const_mem / dual_mem say where m->const_data / m->dual_data live.
+ * Size limits of the device kernels (checked when the schedules are built, LPMP_ERR_UNSUPPORTED): a factor that is
+ * updated by the wave-per-factor kernels may hold at most 512 doubles of duals and its messages at most 512 entries
+ * (unaries with pairwise neighbours: 512 labels; everything else the generic kernel runs: 512 doubles); factors that
+ * are only peers (pairwise tables of updated unaries) are bounded by those label counts; at most 32767 active
+ * receives and 32767 active sends per updated factor. */
 int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int dual_mem);
 
 int lpmp_set_reparametrization(lpmp_engine* e, int mode);   /* LP::set_reparametrization, LP_MP.h:330 */
