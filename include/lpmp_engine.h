@@ -72,8 +72,8 @@ int lpmp_plan_schedule_info(lpmp_plan* p, int direction, int mode, int64_t* n_le
 
 /* updated factors of that sweep per device kernel class (LPMP_KCLASS_COUNT entries: generic, dense 4/8/16/32,
  * Potts 4/8/16/32, the run-time-dims forms of the same eight, the streaming class for up to 512 labels, the
- * lane-per-factor class for tiny factors): which kernels a model runs on */
-#define LPMP_KCLASS_COUNT 19
+ * lane-per-factor class for tiny factors, four classes of updated pairwise factors) */
+#define LPMP_KCLASS_COUNT 23
 int lpmp_plan_schedule_classes(lpmp_plan* p, int direction, int mode, int64_t* factors /*[LPMP_KCLASS_COUNT]*/);
 
 /* the same summary for an iterator-range pass (LP_MP.h:981-1005) given as factor list + weight rows + receive-mask

@@ -1162,6 +1162,105 @@ sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ o
 }
 
 // -------------------------------------------------------------------------------------------------
+// Updated dense pairwise factors, packed form (classes KC_PW_4..32; `right` / `full` schedules, e.g. MPLP-style
+// FMCs): the factor is on the right of all its (unary-pairwise) messages.  A receive pulls the whole unary in
+// (delta = 1 * theta_u), the sends push omega * min-marginal back.  Same lane layout as sweep_dense_pk_kernel with
+// run-time dims (d0 x d1 <= L x L): record + ops in one packet, the factor's OWN table requested right away and
+// read ONCE for both sides' min-marginals of the snapshot.
+// -------------------------------------------------------------------------------------------------
+template <int L>
+__global__ void __launch_bounds__(256)
+sweep_pairwise_pk_kernel(const Op* __restrict__ packets, double* __restrict__ dual, const double* __restrict__ cdata,
+                         double* __restrict__ lb, int64_t count, int stride) {
+  constexpr int G = DenseCfg<L>::G;
+  constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
+  constexpr int PIECES = 3 * (1 + PW_MAX_OPS);
+  __shared__ double2_t lds_pk[GPB][PIECES];
+  __shared__ double lds_m1[GPB][L];
+  __shared__ double lds_m2[GPB][L];
+  __shared__ double lds_q0[GPB][L];
+  __shared__ double lds_q1[GPB][L];
+  const int grp = threadIdx.x / G, g = threadIdx.x % G;
+  const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
+  const bool live = idx < count;
+  const int c2 = g % CL, rl = g / CL;
+  load_packet<G>(lds_pk[grp], packets, nullptr, nullptr, idx, stride, live, g);
+  const UpdRec* hdr = reinterpret_cast<const UpdRec*>(&lds_pk[grp][0]);
+  const Op* lop = reinterpret_cast<const Op*>(&lds_pk[grp][3]);
+  const int n_recv = live ? (int)hdr->n_recv : 0;
+  const int n_send = live ? (int)hdr->n_send : 0;
+  const int R = live ? hdr->d0 : 0, C = live ? hdr->d1 : 0;
+  double* own_g = dual + (live ? hdr->dual_off : 0);
+  const double* T = cdata + (live ? hdr->const_off : 0);
+  double2_t t[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int row = i * RPL + rl;
+    const double* Tr = T + (int64_t)row * C + 2 * c2;
+    t[i].x = (row < R && 2 * c2 < C) ? Tr[0] : LPMP_INF;
+    t[i].y = (row < R && 2 * c2 + 1 < C) ? Tr[1] : LPMP_INF;
+  }
+  double m1 = g < R ? own_g[g] : 0.0;            // message vector of side 0, element g
+  double m2 = g < C ? own_g[R + g] : 0.0;        // message vector of side 1, element g
+  // receives: delta = 1 * theta_u; the unary gives it up, the factor's vector of that side takes it
+#pragma unroll
+  for (int k = 0; k < PW_MAX_OPS; ++k) {
+    if (k < n_recv) {
+      const Op& o = lop[k];
+      const int side = (o.info >> 5) & 1;
+      if (g < o.len) {
+        double* th = dual + o.peer_dual + g;
+        const double v = *th;
+        const double dl = 1.0 * v;
+        *th = v + -1.0 * dl;
+        if (side == 0) m1 += +1.0 * dl; else m2 += +1.0 * dl;
+      }
+      if (g == 0) lb[o.peer] = LPMP_NAN;
+    }
+  }
+  // both min-marginal parts of the state after the receives: q0[a] = min_b T[a][b] + m2[b], q1[b] = min_a T[a][b] + m1[a]
+  const double m1s = m1, m2s = m2;
+  if (g < L) { lds_m1[grp][g] = m1s; lds_m2[grp][g] = m2s; }
+  wave_sync();
+  {
+    const double2_t mv = *reinterpret_cast<const double2_t*>(&lds_m2[grp][2 * c2]);
+    double vx = LPMP_INF, vy = LPMP_INF;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      double v = fmin(t[i].x + mv.x, t[i].y + mv.y);
+      v = row_allreduce_min<CL>(v);
+      if (c2 == 0) lds_q0[grp][i * RPL + rl] = v;
+      const double m1v = lds_m1[grp][i * RPL + rl];
+      vx = fmin(vx, t[i].x + m1v);
+      vy = fmin(vy, t[i].y + m1v);
+    }
+#pragma unroll
+    for (int m = G / 2; m >= CL; m >>= 1) { vx = fmin(vx, shfl_xor_f64(vx, m)); vy = fmin(vy, shfl_xor_f64(vy, m)); }
+    if (rl == 0) { lds_q1[grp][2 * c2] = vx; lds_q1[grp][2 * c2 + 1] = vy; }
+  }
+  wave_sync();
+  const double q0 = g < L ? lds_q0[grp][g] : 0.0, q1 = g < L ? lds_q1[grp][g] : 0.0;
+  // sends: delta = omega * min-marginal of the snapshot
+#pragma unroll
+  for (int k = 0; k < PW_MAX_OPS; ++k) {
+    if (k < n_send) {
+      const Op& o = lop[n_recv + k];
+      const int side = (o.info >> 5) & 1;
+      if (g < o.len) {
+        const double dl = o.omega * (side == 0 ? m1s + q0 : m2s + q1);
+        double* th = dual + o.peer_dual + g;
+        *th += +1.0 * dl;
+        if (side == 0) m1 += -1.0 * dl; else m2 += -1.0 * dl;
+      }
+      if (g == 0) lb[o.peer] = LPMP_NAN;
+    }
+  }
+  if (g < R) own_g[g] = m1;
+  if (g < C) own_g[R + g] = m2;
+  if (live && g == 0) lb[hdr->factor] = LPMP_NAN;
+}
+
+// -------------------------------------------------------------------------------------------------
 // Lower bound (reference LP::LowerBound, LP_MP.h:1507-1518): per-factor bound, then a fixed-order sum.
 // -------------------------------------------------------------------------------------------------
 struct LbRec { int64_t dual_off; int64_t const_off; int32_t d0, d1; int32_t kind_flags; int32_t pad; };
@@ -1385,6 +1484,18 @@ bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, cons
   if (stride > 1 + PK_MAX_OPS) return false;
   auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
   const bool nt = (flags & SWEEP_NT) != 0;
+  if (kc_is_pw(kclass)) {
+    // (the residual rule recomputes the min-marginals after every send: the op-by-op generic kernel does that)
+    if ((flags & SWEEP_RESIDUAL) || stride <= 0) return false;
+#define PWK_LAUNCH(LL) hipLaunchKernelGGL((sweep_pairwise_pk_kernel<LL>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, dual, cdata, lb, count, stride)
+    switch (kclass) {
+      case KC_PW_32: PWK_LAUNCH(32); return true;
+      case KC_PW_16: PWK_LAUNCH(16); return true;
+      case KC_PW_8: PWK_LAUNCH(8); return true;
+      default: PWK_LAUNCH(4); return true;
+    }
+#undef PWK_LAUNCH
+  }
 #define PK_LAUNCH1(LL, KK, NTT) hipLaunchKernelGGL((sweep_dense_pk_kernel<LL, KK, false, NTT>), blocks(256 / DenseCfg<LL>::G), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)
 #define PK_LAUNCH(LL, KK) do { if (nt) PK_LAUNCH1(LL, KK, true); else PK_LAUNCH1(LL, KK, false); } while (0)
   switch (kclass) {

@@ -411,6 +411,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   std::vector<uint8_t> var_dense(N, 1), var_potts(N, 1);     // padded classes: runtime dims
   std::vector<uint8_t> up_any(N, 1);                         // streaming class: dense and Potts peers mixed
   std::vector<uint8_t> small_ok(N, 1);                       // lane-per-factor class: every size <= SMALL_MAXD
+  std::vector<uint8_t> pw_right(N, 1);                       // updated dense pairwise factor, every op unary-pairwise with the factor on the right
   std::vector<int32_t> max_dim(N, 0);                        // largest peer table dim of the record
   for (int64_t u = 0; u < N; ++u) {
     const int32_t f = uf[u];
@@ -448,6 +449,8 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       }
       op.info = mt.kind | (e.role << 4) | (side << 5) | (imp << 6) | (f_kind[peer] << 8);
       if (std::max(op.len, std::max(op.pd0, op.pd1)) > SMALL_MAXD || f_doff[f + 1] - f_doff[f] > SMALL_MAXD) small_ok[o] = 0;
+      if (!(mt.kind == LPMP_M_UNARY_PAIRWISE && e.role == 1 && f_kind[f] == LPMP_F_PAIRWISE_DENSE && f_kind[peer] == LPMP_F_VECTOR &&
+            op.len == (side == 0 ? f_dim0[f] : f_dim1[f]))) pw_right[o] = 0;
       return op;
     };
     // algorithmic bytes, counted per update as the reference executes it: own dual read + written
@@ -472,6 +475,12 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       if (e.sends) { const double w = uom[u][ks++]; if (w != 0.0) { Op op = fill(e, w); bytes += op_bytes(op, false); base[n_recv_of[o] + cur_s[o]++] = op; ++n_act; } }
     }
     if (n_act > 0) bytes += 16 * (f_doff[f + 1] - f_doff[f]);
+    // an updated dense pairwise factor reads its own table once to compute the min-marginals it sends
+    if (ks > 0 && f_kind[f] == LPMP_F_PAIRWISE_DENSE) {
+      bool sends_any = false;
+      for (int64_t j = 0; j < ks; ++j) if (uom[u][j] != 0.0) { sends_any = true; break; }
+      if (sends_any) bytes += 8 * (int64_t)f_dim0[f] * f_dim1[f];
+    }
     rec_bytes[o] += bytes;
     out.alg_bytes += bytes;
   }
@@ -479,7 +488,13 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   std::vector<int32_t> kclass(N, KC_GENERIC);
   auto cls_of = [&](int64_t u) -> int32_t {
     const int d0 = f_dim0[uf[u]];
-    if (f_kind[uf[u]] != LPMP_F_VECTOR) return small_ok[u] ? KC_SMALL : KC_GENERIC;   // updated pairwise factors
+    if (f_kind[uf[u]] != LPMP_F_VECTOR) {                  // updated pairwise factors
+      if (small_ok[u]) return KC_SMALL;
+      const int w = std::max(f_dim0[uf[u]], f_dim1[uf[u]]);
+      if (pw_right[u] && f_kind[uf[u]] == LPMP_F_PAIRWISE_DENSE && w <= 32 && n_recv_of[u] + n_send_of[u] <= PW_MAX_OPS)
+        return KC_PW_4 + (w <= 4 ? 0 : w <= 8 ? 1 : w <= 16 ? 2 : 3);
+      return KC_GENERIC;
+    }
     const bool pow = d0 == 4 || d0 == 8 || d0 == 16 || d0 == 32;
     if (pow && all_dense[u]) return d0 == 4 ? KC_DENSE_4 : d0 == 8 ? KC_DENSE_8 : d0 == 16 ? KC_DENSE_16 : KC_DENSE_32;
     if (pow && all_potts[u]) return d0 == 4 ? KC_POTTS_4 : d0 == 8 ? KC_POTTS_8 : d0 == 16 ? KC_POTTS_16 : KC_POTTS_32;
@@ -550,13 +565,27 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   // inside a launch the order of the records is free (they are independent): sub-wave kernels run several
   // factors per wavefront, so neighbours in the list should have similar amounts of work
   for (const auto& lr : out.launches)
-    if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32 && lr.kclass != KC_DENSE_V32 && lr.kclass != KC_DENSE_BIG)   // incl. KC_SMALL
+    if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32 && lr.kclass != KC_DENSE_V32 && lr.kclass != KC_DENSE_BIG && lr.kclass != KC_PW_32)   // incl. KC_SMALL
       std::stable_sort(out.recs.begin() + lr.begin, out.recs.begin() + lr.end, [](const UpdRec& a, const UpdRec& b) {
         return a.n_recv != b.n_recv ? a.n_recv > b.n_recv : a.n_send > b.n_send;
       });
   // flags of the fast-class records, kept in recs / ops themselves (packets are plain copies)
   static_assert(sizeof(UpdRec) == sizeof(Op), "a packet slot holds either record");
   for (auto& lr : out.launches) {
+    if (kc_is_pw(lr.kclass)) {               // updated pairwise factors: plain packets (no preload / forwarding flags)
+      int kmax = 0;
+      for (int64_t i = lr.begin; i < lr.end; ++i) kmax = std::max<int>(kmax, out.recs[i].n_recv + out.recs[i].n_send);
+      lr.stride = 1 + kmax;
+      lr.pk_begin = (int64_t)out.packets.size();
+      out.packets.resize(out.packets.size() + (size_t)(lr.end - lr.begin) * lr.stride);
+      for (int64_t i = lr.begin; i < lr.end; ++i) {
+        Op* slot = out.packets.data() + lr.pk_begin + (i - lr.begin) * lr.stride;
+        const UpdRec& r = out.recs[i];
+        std::memcpy(slot, &r, sizeof(Op));
+        for (int k = 0; k < r.n_recv + r.n_send; ++k) slot[1 + k] = out.ops[r.op_begin + k];
+      }
+      continue;
+    }
     if (lr.kclass == KC_GENERIC || lr.kclass >= KC_DENSE_BIG) continue;   // packed dense and Potts classes
     auto same_vec = [](const Op* o, int a, int b) { return o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1); };
     if (kc_is_var(lr.kclass)) {

@@ -70,12 +70,18 @@ enum KClass : int32_t {
   KC_DENSE_BIG,
   // one LANE per updated factor: tiny factors of any kind (every dual size / message length <= SMALL_MAXD)
   KC_SMALL,
+  // UPDATED dense pairwise factors (`right` / `full` schedules: the factor pulls its unaries in and sends both
+  // min-marginals back), dims <= the padded width, at most PW_MAX_OPS ops: packet form, one read of the table
+  KC_PW_4, KC_PW_8, KC_PW_16, KC_PW_32,
   KC_COUNT
 };
 constexpr int BIG_MAX_LABELS = 512;
 constexpr int SMALL_MAXD = 8;
+constexpr int PW_MAX_OPS = 6;
+constexpr bool kc_is_pw(int kclass) { return kclass >= KC_PW_4 && kclass <= KC_PW_32; }
 // lanes-per-vector width of a packed fast class (0: generic / streaming class)
 constexpr int kc_width(int kclass) {
+  if (kclass >= KC_PW_4 && kclass <= KC_PW_32) return 4 << (kclass - KC_PW_4);
   return (kclass == KC_GENERIC || kclass >= KC_DENSE_BIG) ? 0 : 4 << ((kclass - 1) % 4);
 }
 constexpr bool kc_is_var(int kclass) { return kclass >= KC_DENSE_V4 && kclass <= KC_POTTS_V32; }

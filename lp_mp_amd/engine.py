@@ -15,10 +15,10 @@ from . import build as _build
 from .model import FlatModel
 
 _LIB = None
-N_KCLASS = 19
+N_KCLASS = 23
 KCLASS_NAMES = ["generic", "dense4", "dense8", "dense16", "dense32", "potts4", "potts8", "potts16", "potts32",
                 "dense_v4", "dense_v8", "dense_v16", "dense_v32", "potts_v4", "potts_v8", "potts_v16", "potts_v32",
-                "dense_big", "small"]
+                "dense_big", "small", "pairwise4", "pairwise8", "pairwise16", "pairwise32"]
 # kernel symbols as rocprofv3 prints them: dense classes run the packed kernel (KMAX 2 at L >= 16, 4 below) whenever a
 # launch's factors have at most 8 active messages, else sweep_dense_kernel<L>; the _v classes (any label count up to
 # the padded width, rectangular tables) are the same kernels with run-time dims; the exact dense kernels come in a
@@ -31,7 +31,9 @@ KERNEL_NAMES = ["sweep_generic_kernel<64>", "sweep_dense_pk_kernel<4, 4, false",
                 "sweep_dense_pk_kernel<4, 4, true, false>", "sweep_dense_pk_kernel<8, 4, true, false>",
                 "sweep_dense_pk_kernel<16, 2, true, false>", "sweep_dense_pk_kernel<32, 2, true, false>",
                 "sweep_potts_pk_kernel<4, true>", "sweep_potts_pk_kernel<8, true>", "sweep_potts_pk_kernel<16, true>",
-                "sweep_potts_pk_kernel<32, true>", "sweep_dense_big_kernel", "sweep_generic_kernel<1>"]
+                "sweep_potts_pk_kernel<32, true>", "sweep_dense_big_kernel", "sweep_generic_kernel<1>",
+                "sweep_pairwise_pk_kernel<4>", "sweep_pairwise_pk_kernel<8>", "sweep_pairwise_pk_kernel<16>",
+                "sweep_pairwise_pk_kernel<32>"]
 MEM_HOST, MEM_DEVICE = 0, 1
 
 EXPORTS = [

@@ -176,8 +176,8 @@ def test_kernel_class_of_every_model_shape():
                             (512, "dense_big", "dense_big"), (513, "generic", "generic")):
         assert cls(S.grid_model(3, 4, L, seed=1)) == {dense: 12}, L
         assert cls(S.grid_model(3, 4, L, pairwise="potts", seed=1)) == {potts: 12}, L
-    # updated pairwise factors (`full` schedule): tiny ones one lane each, larger ones one wave each
-    for L, want in ((2, "small"), (4, "small"), (5, "generic")):
+    # updated pairwise factors (`full` schedule): tiny ones one lane each, up to 32 labels the packed pairwise classes
+    for L, want in ((2, "small"), (4, "small"), (5, "pairwise8"), (16, "pairwise16"), (21, "pairwise32"), (33, "generic")):
         mt = [M.MsgType(0, 1, M.SCHED_FULL, 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, M.SCHED_FULL, 0, 1, M.M_UNARY_PAIRWISE, 1)]
         b = M.ModelBuilder(2, mt)
         u = b.add_vector_factors(0, np.zeros((2, L)))
