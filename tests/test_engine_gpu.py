@@ -589,3 +589,45 @@ def test_c4_shape_mid_size():
         assert abs(e.lower_bound() - o.LowerBound()) <= LB_RTOL * abs(o.LowerBound())
     finally:
         e.close()
+
+
+def _scheduled_grid(H, W, L, sched, seed, order="colour_major", dims=None):
+    """grid MRF whose unary-pairwise messages have the given schedule (right / full: the pairwise factors are updated)"""
+    mt = [M.MsgType(0, 1, sched, 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, sched, 0, 1, M.M_UNARY_PAIRWISE, 1)]
+    b = M.ModelBuilder(2, mt)
+    n = H * W
+    var = S.grid_variable_order(H, W, order).reshape(-1)
+    a, bb = S.grid_edges(H, W)
+    i, j = np.minimum(var[a], var[bb]), np.maximum(var[a], var[bb])
+    rng = np.random.default_rng(seed)
+    d = np.full(n, L) if dims is None else rng.choice(dims, size=n)
+    u = np.array([b.add_vector_factors(0, rng.uniform(0, 1, (1, int(x))))[0] for x in d])
+    p = np.array([b.add_dense_pairwise(1, rng.uniform(0, 1, (1, int(d[x]), int(d[y]))))[0] for x, y in zip(i, j)])
+    b.add_interleaved_messages(np.tile(np.array([0, 1], np.int32), len(a)), np.stack([u[i], u[j]], 1).reshape(-1), np.repeat(p, 2))
+    b.add_relations(np.stack([u[i], p], 1).reshape(-1), np.stack([p, u[j]], 1).reshape(-1))
+    return b.finish()
+
+
+@pytest.mark.parametrize("sched", [M.SCHED_RIGHT, M.SCHED_FULL])
+@pytest.mark.parametrize("L", [5, 8, 16, 21, 32])
+def test_updated_pairwise_factors_packed_kernel(eng, sched, L):
+    m = _scheduled_grid(7, 6, L, sched, seed=L)
+    for mode in MODES:
+        _check(eng, m, mode, 3)
+    cls = eng.plan.schedule_classes(M.BACKWARD, M.REPAM_UNIFORM)
+    want = "pairwise%d" % (8 if L <= 8 else 16 if L <= 16 else 32)
+    assert cls.get(want, 0) > 0 and "generic" not in cls
+    # residual sends recompute the min-marginals after every send: those launches run on the generic kernel
+    o = Oracle(m); o.set_reparametrization_type(1); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.upload(m); eng.set_reparametrization_type(1); eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.compute_pass(2); o.ComputePass(2)
+    assert np.array_equal(eng.download_duals(), o.duals())
+    eng.set_reparametrization_type(0)
+
+
+def test_updated_pairwise_factors_rectangular_tables(eng):
+    m = _scheduled_grid(6, 7, 0, M.SCHED_FULL, seed=3, order="row_major", dims=[2, 3, 7, 12, 30])
+    for mode in MODES:
+        _check(eng, m, mode, 3)
+    cls = eng.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC)
+    assert sum(v for k, v in cls.items() if k.startswith("pairwise")) > 0
