@@ -1162,7 +1162,7 @@ sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ o
 }
 
 // -------------------------------------------------------------------------------------------------
-// Updated dense pairwise factors, packed form (classes KC_PW_4..32; `right` / `full` schedules, e.g. MPLP-style
+// Updated pairwise factors (dense or Potts), packed form (classes KC_PW_4..32; `right` / `full` schedules, e.g. MPLP-style
 // FMCs): the factor is on the right of all its (unary-pairwise) messages.  A receive pulls the whole unary in
 // (delta = 1 * theta_u), the sends push omega * min-marginal back.  Same lane layout as sweep_dense_pk_kernel with
 // run-time dims (d0 x d1 <= L x L): record + ops in one packet, the factor's OWN table requested right away and
@@ -1193,12 +1193,22 @@ sweep_pairwise_pk_kernel(const Op* __restrict__ packets, double* __restrict__ du
   double* own_g = dual + (live ? hdr->dual_off : 0);
   const double* T = cdata + (live ? hdr->const_off : 0);
   double2_t t[NL];
+  if (live && (hdr->kind_flags & 15) == LPMP_F_PAIRWISE_POTTS) {   // diff * [a != b] (reference test/potts_factor.cpp:34-36)
+    const double diff = T[0];
 #pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    const int row = i * RPL + rl;
-    const double* Tr = T + (int64_t)row * C + 2 * c2;
-    t[i].x = (row < R && 2 * c2 < C) ? Tr[0] : LPMP_INF;
-    t[i].y = (row < R && 2 * c2 + 1 < C) ? Tr[1] : LPMP_INF;
+    for (int i = 0; i < NL; ++i) {
+      const int row = i * RPL + rl;
+      t[i].x = (row < R && 2 * c2 < C) ? (row == 2 * c2 ? 0.0 : diff) : LPMP_INF;
+      t[i].y = (row < R && 2 * c2 + 1 < C) ? (row == 2 * c2 + 1 ? 0.0 : diff) : LPMP_INF;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int row = i * RPL + rl;
+      const double* Tr = T + (int64_t)row * C + 2 * c2;
+      t[i].x = (row < R && 2 * c2 < C) ? Tr[0] : LPMP_INF;
+      t[i].y = (row < R && 2 * c2 + 1 < C) ? Tr[1] : LPMP_INF;
+    }
   }
   double m1 = g < R ? own_g[g] : 0.0;            // message vector of side 0, element g
   double m2 = g < C ? own_g[R + g] : 0.0;        // message vector of side 1, element g

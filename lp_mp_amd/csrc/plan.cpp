@@ -449,8 +449,8 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       }
       op.info = mt.kind | (e.role << 4) | (side << 5) | (imp << 6) | (f_kind[peer] << 8);
       if (std::max(op.len, std::max(op.pd0, op.pd1)) > SMALL_MAXD || f_doff[f + 1] - f_doff[f] > SMALL_MAXD) small_ok[o] = 0;
-      if (!(mt.kind == LPMP_M_UNARY_PAIRWISE && e.role == 1 && f_kind[f] == LPMP_F_PAIRWISE_DENSE && f_kind[peer] == LPMP_F_VECTOR &&
-            op.len == (side == 0 ? f_dim0[f] : f_dim1[f]))) pw_right[o] = 0;
+      if (!(mt.kind == LPMP_M_UNARY_PAIRWISE && e.role == 1 && f_kind[f] != LPMP_F_VECTOR && f_kind[peer] == LPMP_F_VECTOR &&
+            f_dim1[f] > 0 && op.len == (side == 0 ? f_dim0[f] : f_dim1[f]))) pw_right[o] = 0;
       return op;
     };
     // algorithmic bytes, counted per update as the reference executes it: own dual read + written
@@ -491,7 +491,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     if (f_kind[uf[u]] != LPMP_F_VECTOR) {                  // updated pairwise factors
       if (small_ok[u]) return KC_SMALL;
       const int w = std::max(f_dim0[uf[u]], f_dim1[uf[u]]);
-      if (pw_right[u] && f_kind[uf[u]] == LPMP_F_PAIRWISE_DENSE && w <= 32 && n_recv_of[u] + n_send_of[u] <= PW_MAX_OPS)
+      if (pw_right[u] && w <= 32 && n_recv_of[u] + n_send_of[u] <= PW_MAX_OPS)
         return KC_PW_4 + (w <= 4 ? 0 : w <= 8 ? 1 : w <= 16 ? 2 : 3);
       return KC_GENERIC;
     }

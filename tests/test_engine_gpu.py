@@ -625,6 +625,24 @@ def test_updated_pairwise_factors_packed_kernel(eng, sched, L):
     eng.set_reparametrization_type(0)
 
 
+@pytest.mark.parametrize("L", [5, 8, 21])
+def test_updated_potts_factors_packed_kernel(eng, L):
+    # MPLP-style schedule on Potts tables, incl. ties and negative couplings
+    mt = [M.MsgType(0, 1, M.SCHED_RIGHT, 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, M.SCHED_RIGHT, 0, 1, M.M_UNARY_PAIRWISE, 1)]
+    b = M.ModelBuilder(2, mt)
+    H, W = 6, 7
+    a, bb = S.grid_edges(H, W)
+    u = b.add_vector_factors(0, (np.round(S.u01(H * W * L, 5) * 3.0) / 3.0).reshape(-1, L))
+    p = b.add_potts_pairwise(1, L, np.where(S.u01(len(a), 6) < 0.5, -0.5, 0.75))
+    b.add_interleaved_messages(np.tile(np.array([0, 1], np.int32), len(a)), np.stack([u[a], u[bb]], 1).reshape(-1), np.repeat(p, 2))
+    b.add_relations(np.stack([u[a], p], 1).reshape(-1), np.stack([p, u[bb]], 1).reshape(-1))
+    m = b.finish()
+    for mode in MODES:
+        _check(eng, m, mode, 3)
+    cls = eng.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC)
+    assert "generic" not in cls and any(k.startswith("pairwise") for k in cls)
+
+
 def test_updated_pairwise_factors_rectangular_tables(eng):
     m = _scheduled_grid(6, 7, 0, M.SCHED_FULL, seed=3, order="row_major", dims=[2, 3, 7, 12, 30])
     for mode in MODES:
