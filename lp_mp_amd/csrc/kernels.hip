@@ -1046,8 +1046,11 @@ sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ o
   double* own_g = dual + rec.dual_off;
   for (int i = lane; i < Lr; i += 64) S.theta[i] = own_g[i];
   const int my_row = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+  Op nxt{};
+  if (rec.n_recv > 0) nxt = ops[rec.op_begin];
   for (int k = 0; k < rec.n_recv; ++k) {
-    const Op op = ops[rec.op_begin + k];
+    const Op op = nxt;
+    if (k + 1 < rec.n_recv) nxt = ops[rec.op_begin + k + 1];   // requested before this receive's table stream starts
     const int side = (op.info >> 5) & 1;
     const int R = op.pd0, C = op.pd1;
     const double* T = cdata + op.peer_const;
