@@ -191,3 +191,23 @@ def test_full_size_c3_rounding_properties():
         assert abs(costs[-1] - energy) <= 1e-7 * abs(energy)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("sched", [M.SCHED_FULL, M.SCHED_RIGHT])
+def test_rounding_when_the_pairwise_factors_are_updated_too(eng, sched):
+    """`full` / `right` schedules: the pairwise factors are updated (no primal of their own), the unaries round — under
+    `right` the unaries have no active message at all and are updated only because their type computes a primal"""
+    L, H, W = 6, 5, 6
+    mt = [M.MsgType(0, 1, sched, 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, sched, 0, 1, M.M_UNARY_PAIRWISE, 1)]
+    b = M.ModelBuilder(2, mt, [1, 0])
+    rng = np.random.default_rng(17)
+    var = S.grid_variable_order(H, W, "colour_major").reshape(-1)
+    a, bb = S.grid_edges(H, W)
+    i, j = np.minimum(var[a], var[bb]), np.maximum(var[a], var[bb])
+    u = b.add_vector_factors(0, rng.uniform(0, 1, (H * W, L)))
+    p = b.add_dense_pairwise(1, rng.uniform(0, 1, (len(a), L, L)))
+    b.add_interleaved_messages(np.tile(np.array([0, 1], np.int32), len(a)), np.stack([u[i], u[j]], 1).reshape(-1), np.repeat(p, 2))
+    b.add_relations(np.stack([u[i], p], 1).reshape(-1), np.stack([p, u[j]], 1).reshape(-1))
+    m = b.finish()
+    for mode in MODES:
+        _run(eng, m, mode)
