@@ -254,20 +254,30 @@ struct lpmp_engine {
 
 namespace {
 
-void upload_schedule(const Schedule& s, DevSchedule& d) {
+// Host -> device copies go through the engine's own stream and are waited for: the stream is non-blocking (no implicit
+// ordering with the null stream), and a synchronous hipMemcpy from pageable memory may return once the bytes are
+// staged, before they have landed — a kernel launched right after on the engine's stream could still read the old
+// contents.
+void h2d(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return;
+  HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream) {
   d.release();
   d.launches = s.launches; d.n_levels = s.n_levels; d.n_recv = s.n_recv; d.n_send = s.n_send; d.alg_bytes = s.alg_bytes;
   if (!s.recs.empty()) {
     HIP_CHECK(hipMalloc((void**)&d.recs, s.recs.size() * sizeof(UpdRec)));
-    HIP_CHECK(hipMemcpy(d.recs, s.recs.data(), s.recs.size() * sizeof(UpdRec), hipMemcpyHostToDevice));
+    h2d(d.recs, s.recs.data(), s.recs.size() * sizeof(UpdRec), stream);
   }
   if (!s.ops.empty()) {
     HIP_CHECK(hipMalloc((void**)&d.ops, s.ops.size() * sizeof(Op)));
-    HIP_CHECK(hipMemcpy(d.ops, s.ops.data(), s.ops.size() * sizeof(Op), hipMemcpyHostToDevice));
+    h2d(d.ops, s.ops.data(), s.ops.size() * sizeof(Op), stream);
   }
   if (!s.packets.empty()) {
     HIP_CHECK(hipMalloc((void**)&d.packets, s.packets.size() * sizeof(Op)));
-    HIP_CHECK(hipMemcpy(d.packets, s.packets.data(), s.packets.size() * sizeof(Op), hipMemcpyHostToDevice));
+    h2d(d.packets, s.packets.data(), s.packets.size() * sizeof(Op), stream);
   }
 }
 
@@ -291,7 +301,7 @@ void ensure_device_schedules(lpmp_engine* e, int mode) {
   for (int d = 0; d < 2; ++d) {
     plan_schedule(e->plan.get(), d, mode);
     check_generic_limits(e->plan->p, e->plan->sched_cache[d][mode]);
-    upload_schedule(e->plan->sched_cache[d][mode], e->sched[d][mode]);
+    upload_schedule(e->plan->sched_cache[d][mode], e->sched[d][mode], e->stream);
   }
   e->have_sched[mode] = true;
 }
@@ -300,11 +310,11 @@ void ensure_pass_schedule(lpmp_engine* e, int mode) {
   if (e->have_pass[mode]) return;
   plan_pass_schedule(e->plan.get(), mode);
   check_generic_limits(e->plan->p, e->plan->pass_cache[mode]);
-  upload_schedule(e->plan->pass_cache[mode], e->sched_pass[mode]);
+  upload_schedule(e->plan->pass_cache[mode], e->sched_pass[mode], e->stream);
   plan_rotation(e->plan.get(), mode);
   e->rotation_ok[mode] = e->plan->rotation_ok[mode];
   if (e->rotation_ok[mode]) {
-    upload_schedule(e->plan->bf_cache[mode], e->sched_bf[mode]);
+    upload_schedule(e->plan->bf_cache[mode], e->sched_bf[mode], e->stream);
     e->plan->bf_cache[mode] = Schedule();
   }
   // the host copy is only needed for its summary
@@ -585,18 +595,18 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
     } else if (n_const > 0) {
       HIP_CHECK(hipMalloc((void**)&e->d_const, (size_t)n_const * sizeof(double)));
       e->own_const = true;
-      HIP_CHECK(hipMemcpy(e->d_const, m->const_data, (size_t)n_const * sizeof(double), hipMemcpyHostToDevice));
+      h2d(e->d_const, m->const_data, (size_t)n_const * sizeof(double), e->stream);
     }
     if (dual_mem == LPMP_MEM_DEVICE) {
       e->d_dual = const_cast<double*>(m->dual_data);
     } else {
       HIP_CHECK(hipMalloc((void**)&e->d_dual, (size_t)n_dual * sizeof(double)));
       e->own_dual = true;
-      HIP_CHECK(hipMemcpy(e->d_dual, m->dual_data, (size_t)n_dual * sizeof(double), hipMemcpyHostToDevice));
+      h2d(e->d_dual, m->dual_data, (size_t)n_dual * sizeof(double), e->stream);
     }
     if (!p.tab_data.empty()) {
       HIP_CHECK(hipMalloc((void**)&e->d_tabs, p.tab_data.size() * sizeof(int32_t)));
-      HIP_CHECK(hipMemcpy(e->d_tabs, p.tab_data.data(), p.tab_data.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      h2d(e->d_tabs, p.tab_data.data(), p.tab_data.size() * sizeof(int32_t), e->stream);
     }
     // lower-bound records, in factor order, and runs of factors the streaming dense kernel can take
     std::vector<LbRecHost> lb(p.nf);
@@ -611,7 +621,7 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
       if (e->lb_runs.empty() || e->lb_runs.back().cls != c) e->lb_runs.push_back({c, f, 1}); else e->lb_runs.back().count++;
     }
     HIP_CHECK(hipMalloc((void**)&e->d_lbrecs, (size_t)p.nf * sizeof(LbRecHost)));
-    HIP_CHECK(hipMemcpy(e->d_lbrecs, lb.data(), (size_t)p.nf * sizeof(LbRecHost), hipMemcpyHostToDevice));
+    h2d(e->d_lbrecs, lb.data(), (size_t)p.nf * sizeof(LbRecHost), e->stream);
     HIP_CHECK(hipMalloc((void**)&e->d_lb, (size_t)p.nf * sizeof(double)));
     HIP_CHECK(hipMalloc((void**)&e->d_part, 1024 * sizeof(double)));
     HIP_CHECK(hipHostMalloc((void**)&e->h_part, 1024 * sizeof(double), hipHostMallocDefault));
@@ -729,17 +739,17 @@ static void ensure_primal(lpmp_engine* e) {
   HIP_CHECK(hipHostMalloc((void**)&e->h_pbad, sizeof(int)));
   if (!prop.empty()) {
     HIP_CHECK(hipMalloc((void**)&e->d_plinks, prop.size() * sizeof(PrimalLink)));
-    HIP_CHECK(hipMemcpy(e->d_plinks, prop.data(), prop.size() * sizeof(PrimalLink), hipMemcpyHostToDevice));
+    h2d(e->d_plinks, prop.data(), prop.size() * sizeof(PrimalLink), e->stream);
   }
   // every factor starts unset (init_primal), then only the touched ones are ever re-initialised
   if (p.nf > 0) {
     std::vector<int32_t> h(2 * (size_t)p.nf);
     for (int64_t f = 0; f < p.nf; ++f) { h[2 * f] = all[f].a; h[2 * f + 1] = all[f].b; }
-    HIP_CHECK(hipMemcpy(e->d_primal, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    h2d(e->d_primal, h.data(), h.size() * sizeof(int32_t), e->stream);
   }
   if (!init.empty()) {
     HIP_CHECK(hipMalloc((void**)&e->d_pinit, init.size() * sizeof(PrimalInit)));
-    HIP_CHECK(hipMemcpy(e->d_pinit, init.data(), init.size() * sizeof(PrimalInit), hipMemcpyHostToDevice));
+    h2d(e->d_pinit, init.data(), init.size() * sizeof(PrimalInit), e->stream);
   }
   e->primal_t = 0;
   e->have_primal = true;
@@ -842,7 +852,7 @@ int lpmp_compute_pass_custom(lpmp_engine* e, int64_t n, const int32_t* factors, 
     check_generic_limits(e->plan->p, s);
     DevSchedule d;
     try {
-      upload_schedule(s, d);
+      upload_schedule(s, d, e->stream);
       const bool g = e->use_graph; e->use_graph = false;
       run_schedule(e, d);
       e->use_graph = g;
@@ -870,7 +880,7 @@ int lpmp_schedule_create_fused(lpmp_engine* e, int64_t n, const int32_t* factors
                              fuse != 0 && e->use_fused, s);
     check_generic_limits(e->plan->p, s);
     auto d = std::make_unique<DevSchedule>();
-    try { upload_schedule(s, *d); } catch (...) { d->release(); throw; }
+    try { upload_schedule(s, *d, e->stream); } catch (...) { d->release(); throw; }
     e->custom.push_back(std::move(d));
     *id_out = (int)e->custom.size() - 1;
   });

@@ -592,12 +592,23 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
         if constexpr (VAR) {
           const int R = uni<G>(o.pd0), C = uni<G>(o.pd1);
           roff[j] = side[j] == 0 ? 0 : R;
+          if (((uni<G>(o.info) >> 8) & 15) == LPMP_F_PAIRWISE_POTTS) {
+            // a Potts neighbour among dense ones: its table diff * [a != b] is made up in registers
+            const double diff = T[0];
 #pragma unroll
-          for (int i = 0; i < NL; ++i) {
-            const int row = i * RPL + rl;
-            const double* Tr = T + (int64_t)row * C + 2 * c2;
-            t[j][i].x = (row < R && 2 * c2 < C) ? ld_stream<NT>(Tr) : LPMP_INF;
-            t[j][i].y = (row < R && 2 * c2 + 1 < C) ? ld_stream<NT>(Tr + 1) : LPMP_INF;
+            for (int i = 0; i < NL; ++i) {
+              const int row = i * RPL + rl;
+              t[j][i].x = (row < R && 2 * c2 < C) ? (row == 2 * c2 ? 0.0 : diff) : LPMP_INF;
+              t[j][i].y = (row < R && 2 * c2 + 1 < C) ? (row == 2 * c2 + 1 ? 0.0 : diff) : LPMP_INF;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+              const int row = i * RPL + rl;
+              const double* Tr = T + (int64_t)row * C + 2 * c2;
+              t[j][i].x = (row < R && 2 * c2 < C) ? ld_stream<NT>(Tr) : LPMP_INF;
+              t[j][i].y = (row < R && 2 * c2 + 1 < C) ? ld_stream<NT>(Tr + 1) : LPMP_INF;
+            }
           }
           if (g < Lr) msv[j] = ld_stream<NT>(dual + pdual[j] + roff[j] + g);
           if (g < (side[j] == 0 ? C : R)) mov[j] = ld_stream<NT>(dual + pdual[j] + (side[j] == 0 ? R : 0) + g);

@@ -504,7 +504,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     const int slot = w <= 4 ? 0 : w <= 8 ? 1 : w <= 16 ? 2 : 3;
     if (var_dense[u]) return KC_DENSE_V4 + slot;
     if (var_potts[u]) return KC_POTTS_V4 + slot;
-    if (up_any[u]) return KC_DENSE_BIG;                      // unaries with both dense and Potts edges
+    if (up_any[u]) return KC_DENSE_V4 + slot;               // unaries with both dense and Potts edges: Potts tables made up in registers
     return small_ok[u] ? KC_SMALL : KC_GENERIC;
   };
   // a COMPUTE_PRIMAL factor is updated even without any active message (FactorUpdated, reference

@@ -170,7 +170,7 @@ def test_mixed_dense_and_potts_edges(eng):
         b.add_relations(p, u[var[bb[k]]])
     _check(eng, b.finish(), M.REPAM_ANISOTROPIC, 3)
     cls = eng.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC)
-    assert "generic" not in cls and cls.get("dense_big", 0) > 0       # unaries with both kinds of edges: streaming class
+    assert set(cls) <= {"dense_v8", "dense8", "potts8"} and cls.get("dense_v8", 0) > 0   # both kinds of edges: packed run-time-dims class
     _check(eng, b.finish(), M.REPAM_DAMPED_UNIFORM, 3)
 
 
