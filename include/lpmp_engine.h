@@ -99,7 +99,9 @@ int lpmp_set_stream(lpmp_engine* e, void* hip_stream);
 
 /* add_factor / add_message / AddFactorRelation, flattened (include/LP_MP.h:239-285, :698-702), plus the
  * packed duals as serialize_dual lists them (include/factors_messages.hxx:3196-3223).
- * const_mem / dual_mem say where m->const_data / m->dual_data live.
+ * const_mem / dual_mem say where m->const_data / m->dual_data live.  Device buffers (LPMP_MEM_DEVICE) are borrowed,
+ * not copied: whatever fills them must have completed, or be ordered on the engine's stream (lpmp_set_stream), before
+ * the next engine call — the engine's own stream is non-blocking and not ordered with the null stream.
  * Size limits of the device kernels (checked when the schedules are built, LPMP_ERR_UNSUPPORTED): a factor that is
  * updated by the wave-per-factor kernels may hold at most 512 doubles of duals and its messages at most 512 entries
  * (unaries with pairwise neighbours: 512 labels; everything else the generic kernel runs: 512 doubles); factors that
