@@ -67,12 +67,14 @@ struct DevSchedule {
   int64_t n_levels = 0, n_recv = 0, n_send = 0, alg_bytes = 0;
   hipGraphExec_t graph = nullptr;
   hipGraphExec_t graph_primal = nullptr;   // the same launches with the SWEEP_PRIMAL flag
+  size_t recs_cap = 0, ops_cap = 0, packets_cap = 0;   // allocated elements (a scratch schedule is refilled in place)
   void release() {
     if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
     if (graph_primal) { (void)hipGraphExecDestroy(graph_primal); graph_primal = nullptr; }
     if (recs) { (void)hipFree(recs); recs = nullptr; }
     if (ops) { (void)hipFree(ops); ops = nullptr; }
     if (packets) { (void)hipFree(packets); packets = nullptr; }
+    recs_cap = ops_cap = packets_cap = 0;
     launches.clear();
   }
 };
@@ -195,6 +197,7 @@ struct lpmp_engine {
   bool use_fused = true;
   bool use_rotation = true;
   std::vector<std::unique_ptr<DevSchedule>> custom;   // prepared iterator-range passes
+  DevSchedule scratch;                                 // the one-off schedule of lpmp_compute_pass_custom
   int mode = -1;
   int rtype = 0;   // reparametrization_type: 0 shared, 1 residual (kernel flag SWEEP_RESIDUAL)
   bool use_graph = true;
@@ -219,6 +222,7 @@ struct lpmp_engine {
     for (int m = 0; m < LPMP_REPAM_COUNT; ++m) { have_sched[m] = false; sched_pass[m].release(); sched_bf[m].release(); have_pass[m] = false; rotation_ok[m] = false; }
     for (auto& c : custom) if (c) c->release();
     custom.clear();
+    scratch.release();
     if (own_dual && d_dual) (void)hipFree(d_dual);
     if (own_const && d_const) (void)hipFree(d_const);
     d_dual = nullptr; d_const = nullptr; own_dual = own_const = false;
@@ -264,21 +268,25 @@ void h2d(void* dst, const void* src, size_t bytes, hipStream_t stream) {
   HIP_CHECK(hipStreamSynchronize(stream));
 }
 
-void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream) {
-  d.release();
+template <class T>
+void fill_device(T*& dst, size_t& cap, const std::vector<T>& src, hipStream_t stream) {
+  if (src.size() > cap) {
+    if (dst) { HIP_CHECK(hipFree(dst)); dst = nullptr; cap = 0; }
+    const size_t n = src.size() + src.size() / 4 + 16;
+    HIP_CHECK(hipMalloc((void**)&dst, n * sizeof(T)));
+    cap = n;
+  }
+  h2d(dst, src.data(), src.size() * sizeof(T), stream);
+}
+
+// keep: refill d's buffers in place where they are large enough (the scratch schedule of lpmp_compute_pass_custom)
+void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream, bool keep = false) {
+  if (keep) { if (d.graph) { (void)hipGraphExecDestroy(d.graph); d.graph = nullptr; } if (d.graph_primal) { (void)hipGraphExecDestroy(d.graph_primal); d.graph_primal = nullptr; } }
+  else d.release();
   d.launches = s.launches; d.n_levels = s.n_levels; d.n_recv = s.n_recv; d.n_send = s.n_send; d.alg_bytes = s.alg_bytes;
-  if (!s.recs.empty()) {
-    HIP_CHECK(hipMalloc((void**)&d.recs, s.recs.size() * sizeof(UpdRec)));
-    h2d(d.recs, s.recs.data(), s.recs.size() * sizeof(UpdRec), stream);
-  }
-  if (!s.ops.empty()) {
-    HIP_CHECK(hipMalloc((void**)&d.ops, s.ops.size() * sizeof(Op)));
-    h2d(d.ops, s.ops.data(), s.ops.size() * sizeof(Op), stream);
-  }
-  if (!s.packets.empty()) {
-    HIP_CHECK(hipMalloc((void**)&d.packets, s.packets.size() * sizeof(Op)));
-    h2d(d.packets, s.packets.data(), s.packets.size() * sizeof(Op), stream);
-  }
+  fill_device(d.recs, d.recs_cap, s.recs, stream);
+  fill_device(d.ops, d.ops_cap, s.ops, stream);
+  fill_device(d.packets, d.packets_cap, s.packets, stream);
 }
 
 void check_generic_limits(const Plan& p, const Schedule& s) {
@@ -850,15 +858,13 @@ int lpmp_compute_pass_custom(lpmp_engine* e, int64_t n, const int32_t* factors, 
     static const double dz = 0; static const uint8_t uz = 0;
     e->plan->p.make_schedule(factors, n, om_off, om ? om : &dz, mk_off, mk ? mk : &uz, s);
     check_generic_limits(e->plan->p, s);
-    DevSchedule d;
-    try {
-      upload_schedule(s, d, e->stream);
-      const bool g = e->use_graph; e->use_graph = false;
-      run_schedule(e, d);
-      e->use_graph = g;
-      HIP_CHECK(hipStreamSynchronize(e->stream));
-    } catch (...) { d.release(); throw; }
-    d.release();
+    // the schedule lives in a scratch buffer of the engine that is refilled in place: no allocation per call
+    DevSchedule& d = e->scratch;
+    upload_schedule(s, d, e->stream, true);
+    const bool g = e->use_graph; e->use_graph = false;
+    try { run_schedule(e, d); } catch (...) { e->use_graph = g; throw; }
+    e->use_graph = g;
+    HIP_CHECK(hipStreamSynchronize(e->stream));
   });
 }
 
