@@ -214,7 +214,7 @@ struct lpmp_engine {
     if (d_plinks) { (void)hipFree(d_plinks); d_plinks = nullptr; }
     if (d_pcost) { (void)hipFree(d_pcost); d_pcost = nullptr; }
     if (d_pbad) { (void)hipFree(d_pbad); d_pbad = nullptr; }
-    if (h_pbad) { (void)hipHostFree(h_pbad); h_pbad = nullptr; }
+    h_pbad = nullptr;
     have_primal = false; primal_t = 0; n_pinit = n_plinks = n_pprop = 0;
   }
   void release_model() {
@@ -230,11 +230,11 @@ struct lpmp_engine {
     if (d_lbrecs) { (void)hipFree(d_lbrecs); d_lbrecs = nullptr; }
     if (d_lb) { (void)hipFree(d_lb); d_lb = nullptr; }
     if (d_part) { (void)hipFree(d_part); d_part = nullptr; }
-    if (h_part) { (void)hipHostFree(h_part); h_part = nullptr; }
+    h_part = nullptr;
     release_primal();
     if (d_stale) { (void)hipFree(d_stale); d_stale = nullptr; }
     if (d_stale_n) { (void)hipFree(d_stale_n); d_stale_n = nullptr; }
-    if (h_stale_n) { (void)hipHostFree(h_stale_n); h_stale_n = nullptr; }
+    h_stale_n = nullptr;
     lb_all_stale = true;
     lb_runs.clear();
     plan.reset();
@@ -258,14 +258,65 @@ struct lpmp_engine {
 
 namespace {
 
-// Host -> device copies go through the engine's own stream and are waited for: the stream is non-blocking (no implicit
-// ordering with the null stream), and a synchronous hipMemcpy from pageable memory may return once the bytes are
-// staged, before they have landed — a kernel launched right after on the engine's stream could still read the old
-// contents.
+// Copies between caller memory (pageable) and the device go through a pinned staging buffer that this code owns:
+// plain memcpy on the calling thread on the host side, hipMemcpyAsync between the pinned buffer and the device on the
+// engine's stream, waited for.  Nothing in the HIP runtime then reads or writes caller memory — an asynchronous copy
+// straight to / from pageable memory is staged by the runtime on its own, and a handful of runs in ~300 000 randomised
+// test runs showed host heap corruption next to freshly freed download buffers.  The engine's stream is
+// non-blocking, so the null stream (plain hipMemcpy) would not be ordered with its kernels either.
+struct Staging {
+  void* p = nullptr; size_t bytes = 0;
+  void* get(size_t want) {
+    if (want > bytes) {
+      if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+      HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+      bytes = want;
+    }
+    return p;
+  }
+  // (never freed: it lives as long as the thread, and at thread exit the HIP runtime may already be gone)
+};
+// small device-written host words (partial sums, counters, flags): one pinned block per thread, allocated once and
+// never freed — no pinned allocation / free per uploaded model
+char* pinned_words() {
+  static thread_local char* p = nullptr;
+  if (!p) HIP_CHECK(hipHostMalloc((void**)&p, 8 * 1024 + 128, hipHostMallocDefault));
+  return p;
+}
+// streams are pooled per thread and device and never destroyed: a long-lived process that creates and destroys
+// thousands of engines does not churn HIP streams (each is a hardware queue with its own signals)
+struct StreamPool {
+  std::vector<std::pair<int, hipStream_t>> free_streams;
+  hipStream_t take(int device) {
+    for (size_t i = 0; i < free_streams.size(); ++i)
+      if (free_streams[i].first == device) { hipStream_t s = free_streams[i].second; free_streams.erase(free_streams.begin() + i); return s; }
+    hipStream_t s = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+  }
+  void give(int device, hipStream_t s) { if (s) free_streams.emplace_back(device, s); }
+};
+StreamPool& stream_pool() { static thread_local StreamPool p; return p; }
+constexpr size_t STAGE_CHUNK = (size_t)32 << 20;
+Staging& staging() { static thread_local Staging s; return s; }
+
 void h2d(void* dst, const void* src, size_t bytes, hipStream_t stream) {
-  if (bytes == 0) return;
-  HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
-  HIP_CHECK(hipStreamSynchronize(stream));
+  for (size_t off = 0; off < bytes; off += STAGE_CHUNK) {
+    const size_t n = std::min(STAGE_CHUNK, bytes - off);
+    void* st = staging().get(std::min(bytes, STAGE_CHUNK));
+    std::memcpy(st, (const char*)src + off, n);
+    HIP_CHECK(hipMemcpyAsync((char*)dst + off, st, n, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+}
+void d2h(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  for (size_t off = 0; off < bytes; off += STAGE_CHUNK) {
+    const size_t n = std::min(STAGE_CHUNK, bytes - off);
+    void* st = staging().get(std::min(bytes, STAGE_CHUNK));
+    HIP_CHECK(hipMemcpyAsync(st, (const char*)src + off, n, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    std::memcpy((char*)dst + off, st, n);
+  }
 }
 
 template <class T>
@@ -361,7 +412,7 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
     hipGraphExec_t& exec = e->primal_pass ? s.graph_primal : s.graph;
     if (!exec) {
       hipGraph_t g = nullptr;
-      if (!e->capture_stream) HIP_CHECK(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
+      if (!e->capture_stream) e->capture_stream = stream_pool().take(e->device);
       HIP_CHECK(hipStreamBeginCapture(e->capture_stream, hipStreamCaptureModeThreadLocal));
       try { issue_launches(e, s, false, e->capture_stream); }
       catch (...) { (void)hipStreamEndCapture(e->capture_stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
@@ -539,7 +590,7 @@ int lpmp_create(int device, lpmp_engine** out) {
     HIP_CHECK(hipSetDevice(device));
     auto e = std::make_unique<lpmp_engine>();
     e->device = device;
-    HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->stream = stream_pool().take(device);
     e->own_stream = true;
     const char* ng = std::getenv("LPMP_NO_GRAPH");
     e->use_graph = !(ng && ng[0] == '1');
@@ -562,8 +613,8 @@ void lpmp_destroy(lpmp_engine* e) {
   for (auto& p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
   e->release_model();
-  if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
-  if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
+  if (e->own_stream && e->stream) stream_pool().give(e->device, e->stream);
+  if (e->capture_stream) { (void)hipStreamSynchronize(e->capture_stream); stream_pool().give(e->device, e->capture_stream); }
   delete e;
 }
 
@@ -575,7 +626,7 @@ int lpmp_set_stream(lpmp_engine* e, void* s) {
       if (e->sched[d][m].graph) { (void)hipGraphExecDestroy(e->sched[d][m].graph); e->sched[d][m].graph = nullptr; }
     for (int m = 0; m < LPMP_REPAM_COUNT; ++m)
       if (e->sched_pass[m].graph) { (void)hipGraphExecDestroy(e->sched_pass[m].graph); e->sched_pass[m].graph = nullptr; }
-    if (e->own_stream && e->stream) { HIP_CHECK(hipStreamDestroy(e->stream)); }
+    if (e->own_stream && e->stream) stream_pool().give(e->device, e->stream);
     e->stream = (hipStream_t)s; e->own_stream = false;
   });
 }
@@ -632,10 +683,10 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
     h2d(e->d_lbrecs, lb.data(), (size_t)p.nf * sizeof(LbRecHost), e->stream);
     HIP_CHECK(hipMalloc((void**)&e->d_lb, (size_t)p.nf * sizeof(double)));
     HIP_CHECK(hipMalloc((void**)&e->d_part, 1024 * sizeof(double)));
-    HIP_CHECK(hipHostMalloc((void**)&e->h_part, 1024 * sizeof(double), hipHostMallocDefault));
+    e->h_part = (double*)pinned_words();                       // [0, 1024) doubles: partial sums
     HIP_CHECK(hipMalloc((void**)&e->d_stale, (size_t)p.nf * sizeof(int32_t)));
     HIP_CHECK(hipMalloc((void**)&e->d_stale_n, sizeof(unsigned long long)));
-    HIP_CHECK(hipHostMalloc((void**)&e->h_stale_n, sizeof(unsigned long long), hipHostMallocDefault));
+    e->h_stale_n = (unsigned long long*)(pinned_words() + 8 * 1024);   // one counter
     HIP_CHECK(hipMemsetAsync(e->d_lb, 0xFF, (size_t)p.nf * sizeof(double), e->stream));   // all NaN: nothing tracked yet
     HIP_CHECK(hipStreamSynchronize(e->stream));
     e->lb_all_stale = true;
@@ -744,7 +795,7 @@ static void ensure_primal(lpmp_engine* e) {
   HIP_CHECK(hipMalloc((void**)&e->d_primal, std::max<size_t>(1, 2 * (size_t)p.nf) * sizeof(int32_t)));
   HIP_CHECK(hipMalloc((void**)&e->d_pcost, std::max<size_t>(1, (size_t)p.nf) * sizeof(double)));
   HIP_CHECK(hipMalloc((void**)&e->d_pbad, sizeof(int)));
-  HIP_CHECK(hipHostMalloc((void**)&e->h_pbad, sizeof(int)));
+  e->h_pbad = (int*)(pinned_words() + 8 * 1024 + 64);          // one flag
   if (!prop.empty()) {
     HIP_CHECK(hipMalloc((void**)&e->d_plinks, prop.size() * sizeof(PrimalLink)));
     h2d(e->d_plinks, prop.data(), prop.size() * sizeof(PrimalLink), e->stream);
@@ -833,8 +884,7 @@ int lpmp_download_primal(lpmp_engine* e, int32_t* out) {
     if (!out) throw std::runtime_error("null argument");
     HIP_CHECK(hipSetDevice(e->device));
     ensure_primal(e);
-    HIP_CHECK(hipMemcpyAsync(out, e->d_primal, 2 * (size_t)e->plan->p.nf * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-    HIP_CHECK(hipStreamSynchronize(e->stream));
+    d2h(out, e->d_primal, 2 * (size_t)e->plan->p.nf * sizeof(int32_t), e->stream);
   });
 }
 int lpmp_upload_primal(lpmp_engine* e, const int32_t* in) {
@@ -843,8 +893,7 @@ int lpmp_upload_primal(lpmp_engine* e, const int32_t* in) {
     if (!in) throw std::runtime_error("null argument");
     HIP_CHECK(hipSetDevice(e->device));
     ensure_primal(e);
-    HIP_CHECK(hipMemcpyAsync(e->d_primal, in, 2 * (size_t)e->plan->p.nf * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-    HIP_CHECK(hipStreamSynchronize(e->stream));
+    h2d(e->d_primal, in, 2 * (size_t)e->plan->p.nf * sizeof(int32_t), e->stream);
   });
 }
 
@@ -967,8 +1016,7 @@ int lpmp_factor_lower_bounds(lpmp_engine* e, double* out) {
     if (!out) throw std::runtime_error("null argument");
     HIP_CHECK(hipSetDevice(e->device));
     compute_factor_lbs(e);
-    HIP_CHECK(hipMemcpyAsync(out, e->d_lb, (size_t)e->plan->p.nf * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIP_CHECK(hipStreamSynchronize(e->stream));
+    d2h(out, e->d_lb, (size_t)e->plan->p.nf * sizeof(double), e->stream);
   });
 }
 
@@ -985,8 +1033,7 @@ int lpmp_download_duals(lpmp_engine* e, double* out) {
     require_model(e);
     if (!out) throw std::runtime_error("null argument");
     HIP_CHECK(hipSetDevice(e->device));
-    HIP_CHECK(hipMemcpyAsync(out, e->d_dual, (size_t)lpmp_dual_size(e) * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIP_CHECK(hipStreamSynchronize(e->stream));
+    d2h(out, e->d_dual, (size_t)lpmp_dual_size(e) * sizeof(double), e->stream);
   });
 }
 int lpmp_upload_duals(lpmp_engine* e, const double* in) {
@@ -994,8 +1041,7 @@ int lpmp_upload_duals(lpmp_engine* e, const double* in) {
     require_model(e);
     if (!in) throw std::runtime_error("null argument");
     HIP_CHECK(hipSetDevice(e->device));
-    HIP_CHECK(hipMemcpyAsync(e->d_dual, in, (size_t)lpmp_dual_size(e) * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    HIP_CHECK(hipStreamSynchronize(e->stream));
+    h2d(e->d_dual, in, (size_t)lpmp_dual_size(e) * sizeof(double), e->stream);
     e->lb_all_stale = true;
   });
 }

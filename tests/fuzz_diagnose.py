@@ -14,7 +14,7 @@ first, count = int(sys.argv[1]), int(sys.argv[2])
 events = 0
 
 
-def step(eng, o, m, name, gfn, ofn, ctx, retry=True):
+def step(eng, o, m, name, gfn, ofn, ctx, retry=True, fresh=None):
     global events
     before = eng.download_duals()
     gfn(); ofn()
@@ -33,6 +33,17 @@ def step(eng, o, m, name, gfn, ofn, ctx, retry=True):
         d2 = eng.download_duals()
         print("   repeat from the same state:", "agrees with the oracle" if np.array_equal(d2, r) else
               ("same wrong result" if np.array_equal(d2, d) else "a third result"), flush=True)
+        # which side is off?  a FRESH oracle instance, same start state, same step
+        if fresh is not None:
+            o2 = Oracle(m); o2.set_reparametrization(ctx[2]); o2.set_duals(before)
+            fresh(o2)
+            r2 = o2.duals()
+            print("   fresh oracle instance:", "agrees with the GPU" if np.array_equal(r2, d) else
+                  ("agrees with the old oracle instance" if np.array_equal(r2, r) else "a third result"),
+                  "| message lists of the old instance intact:", all(np.array_equal(a, b) for a, b in zip(o.msg_lists(), o2.msg_lists())),
+                  "| weights intact:", all(np.array_equal(a, b) for dd in (0, 1) for a, b in zip(o.omega(dd, ctx[2]), o2.omega(dd, ctx[2]))), flush=True)
+            if np.array_equal(r2, d):
+                o.set_duals(r2); r = r2
     eng.upload_duals(r)
 
 
@@ -47,13 +58,13 @@ for seed in range(first, first + count):
             o = Oracle(m); o.set_reparametrization(mode)
             eng.upload(m); eng.set_reparametrization(mode)
             ctx = ("mixed", seed, mode)
-            step(eng, o, m, "compute_pass(2)", lambda: eng.compute_pass(2), lambda: o.ComputePass(2), ctx)
-            step(eng, o, m, "forward", lambda: eng.forward_pass(), lambda: o.ComputeForwardPass(), ctx)
+            step(eng, o, m, "compute_pass(2)", lambda: eng.compute_pass(2), lambda: o.ComputePass(2), ctx, fresh=lambda q: q.ComputePass(2))
+            step(eng, o, m, "forward", lambda: eng.forward_pass(), lambda: o.ComputeForwardPass(), ctx, fresh=lambda q: q.ComputeForwardPass())
             for k in range(2):
                 rows = T.random_rows(rng, None, o, m)
-                step(eng, o, m, "custom%d" % k, lambda: eng.compute_pass_custom(*rows), lambda: o.compute_pass_custom(*rows), ctx)
-            step(eng, o, m, "backward", lambda: eng.backward_pass(), lambda: o.ComputeBackwardPass(), ctx)
-            step(eng, o, m, "compute_pass(1)", lambda: eng.compute_pass(1), lambda: o.ComputePass(1), ctx)
+                step(eng, o, m, "custom%d" % k, lambda: eng.compute_pass_custom(*rows), lambda: o.compute_pass_custom(*rows), ctx, fresh=lambda q: q.compute_pass_custom(*rows))
+            step(eng, o, m, "backward", lambda: eng.backward_pass(), lambda: o.ComputeBackwardPass(), ctx, fresh=lambda q: q.ComputeBackwardPass())
+            step(eng, o, m, "compute_pass(1)", lambda: eng.compute_pass(1), lambda: o.ComputePass(1), ctx, fresh=lambda q: q.ComputePass(1))
     finally:
         eng.close()
     # family 2: MRFs with custom rows and passes (primal passes left out: their state cannot be restored here)
@@ -67,8 +78,8 @@ for seed in range(first, first + count):
             ctx = ("mrf", seed, mode)
             for s in range(4):
                 rows = T.random_rows(rng, None, o, m)
-                step(eng, o, m, "custom", lambda: eng.compute_pass_custom(*rows), lambda: o.compute_pass_custom(*rows), ctx)
-                step(eng, o, m, "compute_pass(1)", lambda: eng.compute_pass(1), lambda: o.ComputePass(1), ctx)
+                step(eng, o, m, "custom", lambda: eng.compute_pass_custom(*rows), lambda: o.compute_pass_custom(*rows), ctx, fresh=lambda q: q.compute_pass_custom(*rows))
+                step(eng, o, m, "compute_pass(1)", lambda: eng.compute_pass(1), lambda: o.ComputePass(1), ctx, fresh=lambda q: q.ComputePass(1))
     finally:
         eng.close()
 print("done", count, "seeds,", events, "events, %.0f s" % (time.time() - t0))
