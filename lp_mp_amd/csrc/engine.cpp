@@ -182,6 +182,7 @@ struct lpmp_engine {
   PrimalInit* d_pinit = nullptr; int64_t n_pinit = 0;
   PrimalLink* d_plinks = nullptr; int64_t n_plinks = 0, n_pprop = 0;   // all messages; the first n_pprop propagate labels
   double* d_pcost = nullptr; int* d_pbad = nullptr; int* h_pbad = nullptr;
+  char* pinned = nullptr;         // this engine's block of device-written host words (from the pool)
   uint64_t primal_t = 0;          // primal_access_ of every factor a primal pass touches (they move together)
   bool have_primal = false;
   bool primal_pass = false;       // the launches being issued belong to an ...AndPrimal pass
@@ -276,13 +277,20 @@ struct Staging {
   }
   // (never freed: it lives as long as the thread, and at thread exit the HIP runtime may already be gone)
 };
-// small device-written host words (partial sums, counters, flags): one pinned block per thread, allocated once and
-// never freed — no pinned allocation / free per uploaded model
-char* pinned_words() {
-  static thread_local char* p = nullptr;
-  if (!p) HIP_CHECK(hipHostMalloc((void**)&p, 8 * 1024 + 128, hipHostMallocDefault));
-  return p;
-}
+// small device-written host words (partial sums, counters, flags): one pinned block per engine, taken from a pool
+// and given back at destroy, never freed — no pinned allocation / free per uploaded model or per engine
+constexpr size_t PINNED_WORDS_BYTES = 8 * 1024 + 128;
+struct PinnedPool {
+  std::vector<char*> free_blocks;
+  char* take() {
+    if (!free_blocks.empty()) { char* p = free_blocks.back(); free_blocks.pop_back(); return p; }
+    char* p = nullptr;
+    HIP_CHECK(hipHostMalloc((void**)&p, PINNED_WORDS_BYTES, hipHostMallocDefault));
+    return p;
+  }
+  void give(char* p) { if (p) free_blocks.push_back(p); }
+};
+PinnedPool& pinned_pool() { static thread_local PinnedPool p; return p; }
 // streams are pooled per thread and device and never destroyed: a long-lived process that creates and destroys
 // thousands of engines does not churn HIP streams (each is a hardware queue with its own signals)
 struct StreamPool {
@@ -615,6 +623,7 @@ void lpmp_destroy(lpmp_engine* e) {
   e->release_model();
   if (e->own_stream && e->stream) stream_pool().give(e->device, e->stream);
   if (e->capture_stream) { (void)hipStreamSynchronize(e->capture_stream); stream_pool().give(e->device, e->capture_stream); }
+  pinned_pool().give(e->pinned);
   delete e;
 }
 
@@ -683,10 +692,11 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
     h2d(e->d_lbrecs, lb.data(), (size_t)p.nf * sizeof(LbRecHost), e->stream);
     HIP_CHECK(hipMalloc((void**)&e->d_lb, (size_t)p.nf * sizeof(double)));
     HIP_CHECK(hipMalloc((void**)&e->d_part, 1024 * sizeof(double)));
-    e->h_part = (double*)pinned_words();                       // [0, 1024) doubles: partial sums
+    if (!e->pinned) e->pinned = pinned_pool().take();
+    e->h_part = (double*)e->pinned;                            // [0, 1024) doubles: partial sums
     HIP_CHECK(hipMalloc((void**)&e->d_stale, (size_t)p.nf * sizeof(int32_t)));
     HIP_CHECK(hipMalloc((void**)&e->d_stale_n, sizeof(unsigned long long)));
-    e->h_stale_n = (unsigned long long*)(pinned_words() + 8 * 1024);   // one counter
+    e->h_stale_n = (unsigned long long*)(e->pinned + 8 * 1024);   // one counter
     HIP_CHECK(hipMemsetAsync(e->d_lb, 0xFF, (size_t)p.nf * sizeof(double), e->stream));   // all NaN: nothing tracked yet
     HIP_CHECK(hipStreamSynchronize(e->stream));
     e->lb_all_stale = true;
@@ -795,7 +805,7 @@ static void ensure_primal(lpmp_engine* e) {
   HIP_CHECK(hipMalloc((void**)&e->d_primal, std::max<size_t>(1, 2 * (size_t)p.nf) * sizeof(int32_t)));
   HIP_CHECK(hipMalloc((void**)&e->d_pcost, std::max<size_t>(1, (size_t)p.nf) * sizeof(double)));
   HIP_CHECK(hipMalloc((void**)&e->d_pbad, sizeof(int)));
-  e->h_pbad = (int*)(pinned_words() + 8 * 1024 + 64);          // one flag
+  e->h_pbad = (int*)(e->pinned + 8 * 1024 + 64);               // one flag (the block exists: a model is uploaded)
   if (!prop.empty()) {
     HIP_CHECK(hipMalloc((void**)&e->d_plinks, prop.size() * sizeof(PrimalLink)));
     h2d(e->d_plinks, prop.data(), prop.size() * sizeof(PrimalLink), e->stream);
