@@ -287,3 +287,24 @@ def test_counter_rng_matches_numpy_restatement():
     assert np.array_equal(synth_u01(1000, 42, 7), S.u01(1000, 42, 7))
     x = S.u01(100000, 1)
     assert 0.0 <= x.min() and x.max() < 1.0 and abs(x.mean() - 0.5) < 0.01
+
+
+def test_oracle_behaviour_is_frozen(golden_dir):
+    """regression vectors of the oracle itself (tests/golden/oracle_regression.npz, produced by
+    make_oracle_regression.py — NOT reference outputs): bounds, dual checksums and rounded labels must not move when
+    the oracle is edited"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(golden_dir, "make_oracle_regression.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    want = np.load(os.path.join(golden_dir, "oracle_regression.npz"))
+    n = 0
+    for name, m in mk.cases():
+        for k, v in mk.run(m, primal=m.ftype_computes_primal.any()).items():
+            ref = want[f"{name}/{k}"]
+            if v.dtype.kind == "f":
+                assert np.allclose(v, ref, rtol=1e-13, atol=1e-13), (name, k)
+            else:
+                assert np.array_equal(v, ref), (name, k)
+            n += 1
+    assert n == len(want.files)
