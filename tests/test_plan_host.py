@@ -267,3 +267,23 @@ def test_custom_pass_schedules_on_random_rows(block):
         cat = _cat_rows(*seq)
         info = p.custom_schedule_info(*cat, fuse=True)
         assert info["n_receives"] == int(cat[4].sum()) and info["n_sends"] == int((cat[2] != 0).sum())
+
+
+def test_baseline_configs_run_on_the_fast_kernel_classes():
+    """BASELINE.json configs[0..4] (at reduced size: the class depends on the shape, not the size): none of them needs
+    the generic wave-per-factor kernel"""
+    from lp_mp_amd import engine as E
+    shapes = {
+        "C1 chain, 4-label Potts": (S.chain_model(100, 4), {"potts4"}),
+        "C2 grid, 8-label Potts": (S.grid_model(16, 16, 8, pairwise="potts", order="colour_major", seed=2), {"potts8"}),
+        "C3 grid, 32-label dense": (S.grid_model(12, 12, 32, order="colour_major", seed=3), {"dense32"}),
+        "C4 random sparse graph, 16-label dense": (S.random_graph_model(300, 1500, 16, seed=4), {"dense16"}),
+        "C5 grid + labeling-list factors": (S.c5_model(8, 8, 8, 60, 30, 12, seed=5), {"potts8", "small"}),
+    }
+    for name, (m, want) in shapes.items():
+        p = E.Plan(m)
+        got = set()
+        for d in (M.FORWARD, M.BACKWARD):
+            for mode in MODES:
+                got |= set(p.schedule_classes(d, mode))
+        assert got == want, (name, got)
