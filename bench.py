@@ -153,15 +153,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     from lp_mp_amd import build as B
-    if not os.path.exists(B.SO):              # clean checkout: rank 0 compiles the extension, the others wait for it
-        if rank == 0:
-            B.build()
-        else:
-            for _ in range(1200):
-                if os.path.exists(B.SO):
-                    break
-                time.sleep(0.5)
-            time.sleep(2.0)
+    B.build_on_rank0(rank)                    # rebuilds when the sources changed; the other ranks wait for rank 0
     from lp_mp_amd import engine as E, model as M, synthetic as S
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -12,7 +12,10 @@
  *
  * Conventions (mirroring how the reference is used):
  *   - single caller thread per handle (the reference's Solve loop is single-threaded and its static
- *     arenas are not thread-safe, include/factors_messages.hxx:3369-3370);
+ *     arenas are not thread-safe, include/factors_messages.hxx:3369-3370).  THREAD AFFINITY: an engine is created,
+ *     used and destroyed on ONE thread.  Its streams, its block of pinned words and the staging buffer of its host
+ *     copies come from (bounded) per-thread pools and go back to the pool of the thread that calls lpmp_destroy;
+ *     different engines may live on different threads;
  *   - host arrays passed in are borrowed for the duration of the call; device arrays passed to
  *     lpmp_upload_model with LPMP_MEM_DEVICE are borrowed until lpmp_destroy / the next upload;
  *   - any structural change on the host side (everything that calls set_flags_dirty in the reference,
@@ -89,6 +92,11 @@ int lpmp_plan_get_update_levels(lpmp_plan* p, int direction, int mode, int32_t* 
  * of one factor across the two sweeps are folded into one record) */
 int lpmp_plan_pass_schedule_info(lpmp_plan* p, int mode, int64_t* n_levels, int64_t* n_launches,
                                  int64_t* n_receives, int64_t* n_sends, int64_t* algorithmic_bytes);
+
+/* 1 when lpmp_compute_pass(n >= 2) joins the tail of a pass with the head of the next one for this mode (2-colour
+ * orders: n passes = H, W, (K, W) x (n-1), T) — decided by an op-by-op comparison of the fused
+ * schedules; 0 when consecutive passes run one after the other; negative lpmp_status on error */
+int lpmp_plan_pass_rotates(lpmp_plan* p, int mode);
 
 /* ---- device engine --------------------------------------------------------------------------- */
 /* LP<FMC>::LP(cmd) (include/LP_MP.h:589-593).  device = HIP device ordinal. */

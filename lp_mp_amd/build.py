@@ -1,13 +1,21 @@
-"""Builds lp_mp_amd/csrc/liblpmp_engine.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+"""Builds lp_mp_amd/csrc/liblpmp_engine.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+``build()`` is cheap to call every time: the library carries a stamp (``liblpmp_engine.so.stamp``) with the hash of
+the sources, headers and flags it was compiled from, and is rebuilt whenever that hash differs — so tests, bench and
+smoke never run a binary that is older than the sources next to it (file times do not survive a copy to another box;
+the stamp travels with the library)."""
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
+import time
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO = os.path.join(CSRC, "liblpmp_engine.so")
-SOURCES = ["kernels.hip", "engine.cpp", "plan.cpp"]
+STAMP = SO + ".stamp"
+SOURCES = ["kernels.hip", "engine.cpp", "plan.cpp", "boundary.hip"]
 HEADERS = ["plan.hpp", os.path.join("..", "..", "include", "lpmp_engine.h"), os.path.join("..", "..", "include", "lpmp_model.h")]
 # -ffp-contract=off: the sweep's duals must equal the sequential CPU semantics bit for bit
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-strict-aliasing", "-Wall",
@@ -21,17 +29,46 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def sources() -> list:
+    return [f for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+
+
+def source_hash() -> str:
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sources() + HEADERS:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(SO):
+    if not (os.path.exists(SO) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(SO)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force: bool = False) -> str:
     if force or needs_build():
+        want = source_hash()
         tmp = SO + ".tmp%d" % os.getpid()          # appear atomically: other ranks may be waiting for the file
-        cmd = [hipcc()] + FLAGS + ["-o", tmp] + SOURCES
+        cmd = [hipcc()] + FLAGS + ["-o", tmp] + sources()
         subprocess.check_call(cmd, cwd=CSRC)
         os.replace(tmp, SO)
+        with open(STAMP + ".tmp%d" % os.getpid(), "w") as fh:
+            fh.write(want)
+        os.replace(STAMP + ".tmp%d" % os.getpid(), STAMP)
+    return SO
+
+
+def build_on_rank0(rank: int, timeout_s: float = 900.0) -> str:
+    """multi-process launch (bench.py under torchrun): rank 0 compiles, the others wait for a matching stamp"""
+    if rank == 0:
+        return build()
+    t0 = time.time()
+    while needs_build():
+        if time.time() - t0 > timeout_s:
+            raise RuntimeError("timed out waiting for rank 0 to build the HIP extension")
+        time.sleep(0.5)
     return SO

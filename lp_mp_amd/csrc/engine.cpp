@@ -116,21 +116,37 @@ static void plan_schedule(lpmp_plan* pl, int d, int mode) {
 
 // Seam between two consecutive passes.  If forward+backward fuses into exactly three steps
 //   [H: head of the forward sweep] [W] [T: tail of the backward sweep]
-// and backward+forward fuses into [H'] [K] [T'] where K updates exactly the factors of T and H (their
-// receives, then their sends) and H', T' together are W's factors, then n passes are
+// and backward+forward fuses into [H'] [K] [T'] where K's records are exactly T's receives followed by H's sends
+// (same peers, sides, weights, order — checked op by op) and W's are T's' receives followed by H's' sends, then n
+// passes are
 //   H, W, (K, W) x (n-1), T
 // — every record is the same sequence of receives and sends the unfused sweeps execute (plan.cpp, fusion).
 // 2-colour orders of bipartite graphs (checkerboard grids) have this shape.
-static std::vector<int32_t> level_factors(const Schedule& s, int level) {
-  std::vector<int32_t> f;
-  for (const auto& lr : s.launches) if (lr.level == level) for (int64_t i = lr.begin; i < lr.end; ++i) f.push_back(s.recs[i].factor);
-  std::sort(f.begin(), f.end());
+// records of one level keyed by factor
+static std::vector<std::pair<int32_t, const UpdRec*>> level_records(const Schedule& s, int level) {
+  std::vector<std::pair<int32_t, const UpdRec*>> f;
+  for (const auto& lr : s.launches) if (lr.level == level) for (int64_t i = lr.begin; i < lr.end; ++i) f.emplace_back(s.recs[i].factor, &s.recs[i]);
+  std::sort(f.begin(), f.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
   return f;
 }
-static int64_t level_ops(const Schedule& s, int level, bool recv) {
-  int64_t n = 0;
-  for (const auto& lr : s.launches) if (lr.level == level) n += recv ? lr.n_recv : lr.n_send;
-  return n;
+static bool same_op(const Op& a, const Op& b) {   // everything but the forwarding hint (pad), which is per schedule
+  return a.peer_dual == b.peer_dual && a.peer_const == b.peer_const && a.omega == b.omega && a.info == b.info &&
+         a.pd0 == b.pd0 && a.pd1 == b.pd1 && a.peer == b.peer && a.len == b.len;
+}
+// does every record of `joined` (level lj of schedule sj) hold exactly the receives of the same factor's record in
+// (sr, lr) followed by the sends of its record in (ss, ls) — same peers, sides, weights, order?
+static bool level_is_join(const Schedule& sj, int lj, const Schedule& sr, int lr, const Schedule& ss, int ls) {
+  const auto j = level_records(sj, lj), r = level_records(sr, lr), t = level_records(ss, ls);
+  if (j.size() != r.size() || j.size() != t.size()) return false;
+  for (size_t i = 0; i < j.size(); ++i) {
+    if (j[i].first != r[i].first || j[i].first != t[i].first) return false;
+    if (i > 0 && j[i].first == j[i - 1].first) return false;   // one record per factor and level
+    const UpdRec& a = *j[i].second; const UpdRec& b = *r[i].second; const UpdRec& c = *t[i].second;
+    if (b.n_send != 0 || c.n_recv != 0 || a.n_recv != b.n_recv || a.n_send != c.n_send) return false;
+    for (int k = 0; k < a.n_recv; ++k) if (!same_op(sj.ops[a.op_begin + k], sr.ops[b.op_begin + k])) return false;
+    for (int k = 0; k < a.n_send; ++k) if (!same_op(sj.ops[a.op_begin + a.n_recv + k], ss.ops[c.op_begin + k])) return false;
+  }
+  return true;
 }
 static void plan_rotation(lpmp_plan* pl, int mode) {
   if (pl->have_bf[mode]) return;
@@ -146,17 +162,10 @@ static void plan_rotation(lpmp_plan* pl, int mode) {
   }
   Schedule& bf = pl->bf_cache[mode];
   pl->p.make_schedule(segs, true, bf);
-  bool ok = bf.n_levels == 3;
-  if (ok) {
-    const auto h = level_factors(fb, 1), w = level_factors(fb, 2), t = level_factors(fb, 3);
-    const auto h2 = level_factors(bf, 1), k = level_factors(bf, 2), t2 = level_factors(bf, 3);
-    ok = h == t && k == h && h2 == t2 && h2 == w;
-    // K = receives of T then sends of H; W = receives of T' then sends of H'
-    ok = ok && level_ops(bf, 2, true) == level_ops(fb, 3, true) && level_ops(bf, 2, false) == level_ops(fb, 1, false) &&
-         level_ops(fb, 1, true) == 0 && level_ops(fb, 3, false) == 0 &&
-         level_ops(fb, 2, true) == level_ops(bf, 3, true) && level_ops(fb, 2, false) == level_ops(bf, 1, false) &&
-         level_ops(bf, 1, true) == 0 && level_ops(bf, 3, false) == 0;
-  }
+  // K (middle step of backward+forward) must be exactly "receives of T, then sends of H" factor by factor, and W
+  // (middle step of forward+backward) exactly "receives of T', then sends of H'": then H, W, (K, W)^(n-1), T executes
+  // the same receives and sends as n unfused passes, in an order that differs only between independent updates
+  const bool ok = bf.n_levels == 3 && level_is_join(bf, 2, fb, 3, fb, 1) && level_is_join(fb, 2, bf, 3, bf, 1);
   pl->rotation_ok[mode] = ok;
   if (!ok) bf = Schedule();
 }
@@ -265,34 +274,61 @@ namespace {
 // straight to / from pageable memory is staged by the runtime on its own, and a handful of runs in ~300 000 randomised
 // test runs showed host heap corruption next to freshly freed download buffers.  The engine's stream is
 // non-blocking, so the null stream (plain hipMemcpy) would not be ordered with its kernels either.
+// Guard regions.  Every host buffer the device or the HIP runtime writes into on the engine's behalf (the staging
+// buffer of h2d / d2h, the block of device-written words) sits between two GUARD_BYTES regions holding a fixed
+// pattern; the pattern is verified after every staged copy, in lpmp_synchronize and in lpmp_destroy.  A DMA or a
+// runtime-side write that runs past its buffer is reported instead of silently landing in a neighbour allocation
+// (the host-heap corruption hunt).
+constexpr size_t GUARD_BYTES = 4096;
+constexpr uint64_t GUARD_WORD = 0xA5C3E1F00F1E3C5AULL;
+void guard_fill(void* p) { uint64_t* w = (uint64_t*)p; for (size_t i = 0; i < GUARD_BYTES / 8; ++i) w[i] = GUARD_WORD ^ (uint64_t)i; }
+bool guard_ok(const void* p) {
+  const uint64_t* w = (const uint64_t*)p;
+  for (size_t i = 0; i < GUARD_BYTES / 8; ++i) if (w[i] != (GUARD_WORD ^ (uint64_t)i)) return false;
+  return true;
+}
+// pinned allocation of `bytes` usable bytes with a guard region on either side; returns the usable pointer
+char* guarded_host_alloc(size_t bytes) {
+  char* raw = nullptr;
+  HIP_CHECK(hipHostMalloc((void**)&raw, bytes + 2 * GUARD_BYTES, hipHostMallocDefault));
+  guard_fill(raw); guard_fill(raw + GUARD_BYTES + bytes);
+  return raw + GUARD_BYTES;
+}
+void guarded_host_free(char* p) { if (p) (void)hipHostFree(p - GUARD_BYTES); }
+bool guarded_ok(const char* p, size_t bytes) { return !p || (guard_ok(p - GUARD_BYTES) && guard_ok(p + bytes)); }
+
 struct Staging {
-  void* p = nullptr; size_t bytes = 0;
+  char* p = nullptr; size_t bytes = 0;
   void* get(size_t want) {
     if (want > bytes) {
-      if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
-      HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+      if (p) { check(); guarded_host_free(p); p = nullptr; bytes = 0; }
+      p = guarded_host_alloc(want);
       bytes = want;
     }
     return p;
   }
-  // (never freed: it lives as long as the thread, and at thread exit the HIP runtime may already be gone)
+  void check() const { if (!guarded_ok(p, bytes)) throw DeviceError("guard region of the pinned staging buffer was overwritten"); }
+  // (freed only when it grows: it lives as long as the thread, and at thread exit the HIP runtime may already be gone)
 };
 // small device-written host words (partial sums, counters, flags): one pinned block per engine, taken from a pool
-// and given back at destroy, never freed — no pinned allocation / free per uploaded model or per engine
+// and given back at destroy — no pinned allocation / free per uploaded model or per engine.  The pools are per thread
+// and bounded: beyond POOL_MAX idle entries a returned block is freed / a returned stream destroyed.
 constexpr size_t PINNED_WORDS_BYTES = 8 * 1024 + 128;
+constexpr size_t POOL_MAX = 8;
 struct PinnedPool {
   std::vector<char*> free_blocks;
   char* take() {
     if (!free_blocks.empty()) { char* p = free_blocks.back(); free_blocks.pop_back(); return p; }
-    char* p = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&p, PINNED_WORDS_BYTES, hipHostMallocDefault));
-    return p;
+    return guarded_host_alloc(PINNED_WORDS_BYTES);
   }
-  void give(char* p) { if (p) free_blocks.push_back(p); }
+  void give(char* p) {
+    if (!p) return;
+    if (free_blocks.size() < POOL_MAX) free_blocks.push_back(p); else guarded_host_free(p);
+  }
 };
 PinnedPool& pinned_pool() { static thread_local PinnedPool p; return p; }
-// streams are pooled per thread and device and never destroyed: a long-lived process that creates and destroys
-// thousands of engines does not churn HIP streams (each is a hardware queue with its own signals)
+// streams are pooled per thread and device: a long-lived process that creates and destroys thousands of engines does
+// not churn HIP streams (each is a hardware queue with its own signals)
 struct StreamPool {
   std::vector<std::pair<int, hipStream_t>> free_streams;
   hipStream_t take(int device) {
@@ -302,7 +338,13 @@ struct StreamPool {
     HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
   }
-  void give(int device, hipStream_t s) { if (s) free_streams.emplace_back(device, s); }
+  void give(int device, hipStream_t s) {
+    if (!s) return;
+    // LPMP_STREAM_POOL=0: destroy instead of pooling — the round-1 behaviour, kept as the A/B switch of the host-heap
+    // corruption hunt (tests/fuzz_split.py)
+    static const bool pooling = [] { const char* v = std::getenv("LPMP_STREAM_POOL"); return !(v && v[0] == '0'); }();
+    if (pooling && free_streams.size() < POOL_MAX) free_streams.emplace_back(device, s); else (void)hipStreamDestroy(s);
+  }
 };
 StreamPool& stream_pool() { static thread_local StreamPool p; return p; }
 constexpr size_t STAGE_CHUNK = (size_t)32 << 20;
@@ -316,6 +358,7 @@ void h2d(void* dst, const void* src, size_t bytes, hipStream_t stream) {
     HIP_CHECK(hipMemcpyAsync((char*)dst + off, st, n, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
   }
+  staging().check();
 }
 void d2h(void* dst, const void* src, size_t bytes, hipStream_t stream) {
   for (size_t off = 0; off < bytes; off += STAGE_CHUNK) {
@@ -323,6 +366,7 @@ void d2h(void* dst, const void* src, size_t bytes, hipStream_t stream) {
     void* st = staging().get(std::min(bytes, STAGE_CHUNK));
     HIP_CHECK(hipMemcpyAsync(st, (const char*)src + off, n, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    staging().check();
     std::memcpy((char*)dst + off, st, n);
   }
 }
@@ -432,6 +476,17 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
     return;
   }
   issue_launches(e, s, false, e->stream);
+}
+
+// weight / receive-mask rows of an iterator-range pass as they come over the C ABI: offsets start at 0 and do not
+// decrease, and a row with entries needs the array it indexes
+void check_rows(int64_t n, const int64_t* om_off, const double* om, const int64_t* mk_off, const uint8_t* mk) {
+  if (n <= 0) return;
+  if (om_off[0] != 0 || mk_off[0] != 0) throw std::runtime_error("omega / receive-mask offsets must start at 0");
+  for (int64_t i = 0; i < n; ++i)
+    if (om_off[i + 1] < om_off[i] || mk_off[i + 1] < mk_off[i]) throw std::runtime_error("omega / receive-mask offsets must not decrease");
+  if (!om && om_off[n] > 0) throw std::runtime_error("omega array missing");
+  if (!mk && mk_off[n] > 0) throw std::runtime_error("receive-mask array missing");
 }
 
 void require_model(const lpmp_engine* e) { if (!e || !e->plan) throw StateError("no model uploaded"); }
@@ -549,6 +604,7 @@ int lpmp_plan_custom_schedule_info(lpmp_plan* p, int64_t n, const int32_t* facto
                                    int64_t* n_recv, int64_t* n_send, int64_t* alg_bytes) {
   return guarded([&] {
     if (!p || n < 0 || (n > 0 && (!factors || !om_off || !mk_off))) throw std::runtime_error("bad argument");
+    check_rows(n, om_off, om, mk_off, mk);
     Schedule s;
     static const double dz = 0; static const uint8_t uz = 0;
     static const int64_t zero_off[1] = {0};
@@ -588,6 +644,16 @@ int lpmp_plan_pass_schedule_info(lpmp_plan* p, int mode, int64_t* n_levels, int6
   });
 }
 
+int lpmp_plan_pass_rotates(lpmp_plan* p, int mode) {
+  int r = 0;
+  const int rc = guarded([&] {
+    if (!p || mode < 0 || mode >= LPMP_REPAM_COUNT) throw std::runtime_error("bad argument");
+    if (!p->have_bf[mode]) { plan_pass_schedule(p, mode); if (p->pass_cache[mode].recs.empty() && !p->pass_cache[mode].launches.empty()) throw StateError("pass schedule already handed to the device"); plan_rotation(p, mode); }
+    r = p->rotation_ok[mode] ? 1 : 0;
+  });
+  return rc == LPMP_OK ? r : rc;
+}
+
 // ---- engine ---------------------------------------------------------------------------------------
 int lpmp_create(int device, lpmp_engine** out) {
   return guarded([&] {
@@ -623,7 +689,10 @@ void lpmp_destroy(lpmp_engine* e) {
   e->release_model();
   if (e->own_stream && e->stream) stream_pool().give(e->device, e->stream);
   if (e->capture_stream) { (void)hipStreamSynchronize(e->capture_stream); stream_pool().give(e->device, e->capture_stream); }
-  pinned_pool().give(e->pinned);
+  if (!guarded_ok(e->pinned, PINNED_WORDS_BYTES)) {   // a damaged block is reported and never reused
+    std::fprintf(stderr, "lpmp_destroy: guard region of the engine's pinned words was overwritten\n");
+    g_error = "guard region of the engine's pinned words was overwritten";
+  } else pinned_pool().give(e->pinned);
   delete e;
 }
 
@@ -912,6 +981,7 @@ int lpmp_compute_pass_custom(lpmp_engine* e, int64_t n, const int32_t* factors, 
   return guarded([&] {
     require_model(e);
     if (n < 0 || (n > 0 && (!factors || !om_off || !mk_off))) throw std::runtime_error("bad argument");
+    check_rows(n, om_off, om, mk_off, mk);
     HIP_CHECK(hipSetDevice(e->device));
     Schedule s;
     static const double dz = 0; static const uint8_t uz = 0;
@@ -936,6 +1006,7 @@ int lpmp_schedule_create_fused(lpmp_engine* e, int64_t n, const int32_t* factors
   return guarded([&] {
     require_model(e);
     if (!id_out || n < 0 || (n > 0 && (!factors || !om_off || !mk_off))) throw std::runtime_error("bad argument");
+    check_rows(n, om_off, om, mk_off, mk);
     HIP_CHECK(hipSetDevice(e->device));
     Schedule s;
     static const double dz = 0; static const uint8_t uz = 0;
@@ -1031,7 +1102,14 @@ int lpmp_factor_lower_bounds(lpmp_engine* e, double* out) {
 }
 
 int lpmp_synchronize(lpmp_engine* e) {
-  return guarded([&] { if (!e) throw std::runtime_error("null engine"); HIP_CHECK(hipSetDevice(e->device)); HIP_CHECK(hipStreamSynchronize(e->stream)); if (e->timing) e->drain_timing(); });
+  return guarded([&] {
+    if (!e) throw std::runtime_error("null engine");
+    HIP_CHECK(hipSetDevice(e->device));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    if (e->timing) e->drain_timing();
+    if (!guarded_ok(e->pinned, PINNED_WORDS_BYTES)) throw DeviceError("guard region of the engine's pinned words was overwritten");
+    staging().check();
+  });
 }
 
 int lpmp_streaming_access(const lpmp_engine* e) { return e && e->plan ? (e->nt_flag ? 1 : 0) : -1; }

@@ -88,10 +88,20 @@ void Plan::build(const lpmp_model& m) {
   ftype_primal.assign(n_ftypes, 0);
   if (m.ftype_computes_primal) ftype_primal.assign(m.ftype_computes_primal, m.ftype_computes_primal + n_ftypes);
   mtypes.assign(m.mtypes, m.mtypes + n_mtypes);
+  if (n_tables < 0) fail("negative table count");
   if (n_tables > 0) {
+    if (!m.tab_off || !m.tab_data || !m.tab_nleft) fail("labeling tables missing");
     tab_off.assign(m.tab_off, m.tab_off + n_tables + 1);
     tab_data.assign(m.tab_data, m.tab_data + tab_off[n_tables]);
     tab_nleft.assign(m.tab_nleft, m.tab_nleft + n_tables);
+    // an entry indexes the left factor's labelings (tab_nleft = "no matching left labeling"): anything else would be
+    // an out-of-bounds access in the labeling receive / send kernels
+    if (tab_off[0] != 0) fail("labeling tables: tab_off must start at 0");
+    for (int t = 0; t < n_tables; ++t) {
+      if (tab_off[t + 1] < tab_off[t] || tab_nleft[t] <= 0) fail("labeling table " + std::to_string(t) + ": bad offsets / left labeling count");
+      for (int64_t j = tab_off[t]; j < tab_off[t + 1]; ++j)
+        if (tab_data[j] < 0 || tab_data[j] > tab_nleft[t]) fail("labeling table " + std::to_string(t) + ": entry out of range");
+    }
   }
   nf = m.n_factors; nm = m.n_messages; constant = m.constant;
   f_type.assign(m.f_type, m.f_type + nf);

@@ -26,12 +26,12 @@ KCLASS_NAMES = ["generic", "dense4", "dense8", "dense16", "dense32", "potts4", "
 # are prefixes
 KERNEL_NAMES = ["sweep_generic_kernel<64>", "sweep_dense_pk_kernel<4, 4, false", "sweep_dense_pk_kernel<8, 4, false",
                 "sweep_dense_pk_kernel<16, 2, false", "sweep_dense_pk_kernel<32, 2, false",
-                "sweep_potts_pk_kernel<4, false>", "sweep_potts_pk_kernel<8, false>", "sweep_potts_pk_kernel<16, false>",
-                "sweep_potts_pk_kernel<32, false>",
+                "sweep_potts_pk_kernel<4, false", "sweep_potts_pk_kernel<8, false", "sweep_potts_pk_kernel<16, false",
+                "sweep_potts_pk_kernel<32, false",
                 "sweep_dense_pk_kernel<4, 4, true, false>", "sweep_dense_pk_kernel<8, 4, true, false>",
                 "sweep_dense_pk_kernel<16, 2, true, false>", "sweep_dense_pk_kernel<32, 2, true, false>",
-                "sweep_potts_pk_kernel<4, true>", "sweep_potts_pk_kernel<8, true>", "sweep_potts_pk_kernel<16, true>",
-                "sweep_potts_pk_kernel<32, true>", "sweep_dense_big_kernel", "sweep_generic_kernel<1>",
+                "sweep_potts_pk_kernel<4, true, false>", "sweep_potts_pk_kernel<8, true, false>",
+                "sweep_potts_pk_kernel<16, true, false>", "sweep_potts_pk_kernel<32, true, false>", "sweep_dense_big_kernel", "sweep_generic_kernel<1>",
                 "sweep_pairwise_pk_kernel<4>", "sweep_pairwise_pk_kernel<8>", "sweep_pairwise_pk_kernel<16>",
                 "sweep_pairwise_pk_kernel<32>"]
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -40,7 +40,7 @@ EXPORTS = [
     "lpmp_last_error", "lpmp_version", "lpmp_plan_create", "lpmp_plan_destroy", "lpmp_plan_n_factors",
     "lpmp_plan_n_updated", "lpmp_plan_get_order", "lpmp_plan_get_update_order", "lpmp_plan_omega_nnz",
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
-    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_custom_schedule_info", "lpmp_plan_schedule_classes", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
+    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_custom_schedule_info", "lpmp_plan_schedule_classes", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_plan_pass_rotates", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
     "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_set_reparametrization_type", "lpmp_compute_pass", "lpmp_compute_forward_pass",
     "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_create_fused", "lpmp_schedule_run",
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
@@ -90,6 +90,7 @@ def lib():
         L.lpmp_plan_anisotropic_weights.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8
         L.lpmp_plan_schedule_info.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.lpmp_plan_pass_schedule_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.lpmp_plan_pass_rotates.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_plan_get_update_levels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.lpmp_plan_schedule_classes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.lpmp_plan_custom_schedule_info.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 5
@@ -252,6 +253,17 @@ def _pass_info(self, mode: int) -> dict:
 
 
 Plan.pass_schedule_info = _pass_info
+
+
+def _pass_rotates(self, mode: int) -> bool:
+    """does lpmp_compute_pass(n >= 2) join consecutive passes at their seam for this mode?"""
+    r = self.L.lpmp_plan_pass_rotates(self.h, mode)
+    if r < 0:
+        _chk(r)
+    return bool(r)
+
+
+Plan.pass_rotates = _pass_rotates
 
 
 class Engine:

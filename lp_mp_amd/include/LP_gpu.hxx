@@ -612,7 +612,10 @@ class StandardVisitor {
     if (remainingIter_ == 0) { ret.end = true; return ret; }
     if (primalBound <= lowerBound + eps) { ret.end = true; return ret; }
     if (timeout_ != std::numeric_limits<INDEX>::max() && timeElapsed / 1000 >= timeout_) remainingIter_ = std::min(INDEX(1), remainingIter_);
-    if (c.computeLowerBound && curIter_ >= minDualImprovementInterval_ && minDualImprovementSet_) {
+    // (the reference compares as soon as curIter_ >= interval, standard_visitor.hxx:163-165, and on the first such visit
+    // indexes lowerBound_[size - 1 - interval] with size == interval: out of bounds, covered there only by a debug
+    // assert.  Deliberate deviation: start comparing one visit later, when that entry exists.)
+    if (c.computeLowerBound && lowerBound_.size() > minDualImprovementInterval_ && minDualImprovementSet_) {
       const REAL prev = lowerBound_[lowerBound_.size() - 1 - minDualImprovementInterval_];
       if (minDualImprovement_ > 0 && lowerBound - prev < minDualImprovement_) remainingIter_ = std::min(INDEX(1), remainingIter_);
     }

@@ -401,7 +401,8 @@ class StandardVisitor:
             return ret
         if self.timeout is not None and elapsed >= self.timeout:
             self.remainingIter = min(1, self.remainingIter)
-        if (c.computeLowerBound and self.curIter >= self.minDualImprovementInterval and self.minDualImprovement is not None):
+        # (reference standard_visitor.hxx:163-165 starts one visit earlier and then indexes out of bounds; see LP_gpu.hxx)
+        if (c.computeLowerBound and len(self.lowerBound_) > self.minDualImprovementInterval and self.minDualImprovement is not None):
             prev = self.lowerBound_[len(self.lowerBound_) - 1 - self.minDualImprovementInterval]
             if self.minDualImprovement > 0 and lowerBound - prev < self.minDualImprovement:
                 self.remainingIter = min(1, self.remainingIter)

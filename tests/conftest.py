@@ -13,12 +13,12 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """a clean checkout has no built extension: compile it once (hipcc cross-compiles without a GPU).  Building is
-    not a fallback — without hipcc the engine tests fail loudly."""
+    """(re)compile the extension whenever its sources changed (hipcc cross-compiles without a GPU; build() compares
+    a source hash stored next to the library and returns at once when nothing changed).  Building is not a
+    fallback — without hipcc the engine tests fail loudly."""
     try:
         from lp_mp_amd import build as B
-        if not os.path.exists(B.SO):
-            B.build()
+        B.build()
     except Exception as e:                                   # reported by the tests that need the library
         print(f"conftest: could not build the HIP extension: {e}", file=sys.stderr)
 

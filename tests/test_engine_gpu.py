@@ -50,6 +50,104 @@ def _check(eng, m, mode, passes, exact=True):
     return prev
 
 
+# ---- the non-temporal (streamed-once) kernel instantiations ------------------------------------
+# bench.py's C3 model is HBM-sized, so the engine picks the NT = true instantiations of the exact dense / Potts /
+# streaming kernels (engine.cpp: tables + duals > 1 GiB; kernel names end in ", true>" in BENCH_r*.json).  LPMP_NT
+# forces the choice for a model of any size, so the SAME instantiations are compared with the oracle here, bit for bit.
+@pytest.fixture(params=[0, 1], ids=["nt0", "nt1"])
+def nt_eng(request, monkeypatch):
+    monkeypatch.setenv("LPMP_NT", str(request.param))
+    e = E.Engine(0)
+    e.want_nt = request.param
+
+    def upload_checked(m, *a, _up=e.upload, **k):
+        _up(m, *a, **k)
+        assert e.L.lpmp_streaming_access(e.h) == e.want_nt
+    e.upload = upload_checked
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("L", [4, 8, 16, 32])
+@pytest.mark.parametrize("order", ["row_major", "colour_major"])
+def test_dense_fast_path_both_access_policies(nt_eng, L, order):
+    m = S.grid_model(13, 11, L, order=order, seed=L)
+    for mode in MODES:
+        _check(nt_eng, m, mode, 3)
+    assert list(nt_eng.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC)) == ["dense%d" % L]
+
+
+@pytest.mark.parametrize("L", [4, 8, 16, 32])
+@pytest.mark.parametrize("order", ["row_major", "colour_major"])
+def test_potts_fast_path_both_access_policies(nt_eng, L, order):
+    m = S.grid_model(12, 15, L, pairwise="potts", order=order, seed=10 + L)
+    for mode in MODES:
+        _check(nt_eng, m, mode, 3)
+    assert list(nt_eng.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC)) == ["potts%d" % L]
+
+
+@pytest.mark.parametrize("L", [33, 64, 130])
+def test_streaming_dense_kernel_both_access_policies(nt_eng, L):
+    m = S.grid_model(5, 6, L, order="colour_major", seed=200 + L)
+    for mode in (M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM):
+        _check(nt_eng, m, mode, 2)
+    assert list(nt_eng.plan.schedule_classes(M.FORWARD, M.REPAM_UNIFORM)) == ["dense_big"]
+
+
+@pytest.mark.parametrize("pairwise,L", [("dense", 32), ("dense", 16), ("potts", 8)])
+def test_multi_pass_rotated_schedule_both_access_policies(nt_eng, pairwise, L):
+    """the launch sequence bench.py times: lpmp_compute_pass(n) on a colour-major grid = H, W, (K, W)^(n-1), T"""
+    m = S.grid_model(14, 10, L, pairwise=pairwise, order="colour_major", seed=31)
+    o = Oracle(m)
+    o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    nt_eng.upload(m)
+    nt_eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    nt_eng.compute_pass(3); o.ComputePass(3)
+    nt_eng.compute_pass(20); o.ComputePass(20)
+    assert np.array_equal(nt_eng.download_duals(), o.duals())
+    assert abs(nt_eng.lower_bound() - o.LowerBound()) <= LB_RTOL * max(1.0, abs(o.LowerBound()))
+    nt_eng.enable_kernel_timing(True)
+    nt_eng.compute_pass(2); o.ComputePass(2)
+    kt = nt_eng.kernel_timing()
+    nt_eng.enable_kernel_timing(False)
+    assert np.array_equal(nt_eng.download_duals(), o.duals())
+    (name,) = [v["kernel"] for v in kt.values()]
+    assert name.endswith(", true>" if nt_eng.want_nt else ", false>"), name     # the instantiation BENCH names
+
+
+def test_hbm_sized_model_against_the_oracle():
+    """A model above the engine's 1 GiB streaming threshold (384 x 384, 32 labels, dense: 2.4 GB of tables), without
+    any override: the engine itself selects the NT = true kernels, exactly as for bench.py's C3, and the duals after
+    two passes equal the oracle's bit for bit (checksums over the IEEE bit patterns + a sampled direct comparison)."""
+    import torch
+    H = W = 384; L = 32
+    m = S.grid_model(H, W, L, order="colour_major", seed=5)
+    o = Oracle(m)
+    o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    e = E.Engine(0)
+    try:
+        e.upload(m)
+        assert e.L.lpmp_streaming_access(e.h) == 1
+        e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        e.enable_kernel_timing(True)
+        e.compute_pass(2); o.ComputePass(2)
+        kt = e.kernel_timing()
+        e.enable_kernel_timing(False)
+        assert [v["kernel"] for v in kt.values()] == ["sweep_dense_pk_kernel<32, 2, false, true>"]
+        assert np.array_equal(e.download_duals(), o.duals())
+        lb, lbo = e.lower_bound(), o.LowerBound()
+        assert abs(lb - lbo) <= LB_RTOL * abs(lbo)
+    finally:
+        e.close()
+
+
+def _device_dual_checksums(torch, dual):
+    """wrapping sums over the IEEE bit patterns of the packed duals, as tests/golden/make_c3_full.py computes them"""
+    b = dual.view(torch.int64)
+    w = torch.arange(b.numel(), dtype=torch.int64, device=b.device) * 2 + 1
+    return int(b.sum().item()) & (2**64 - 1), int((b * w).sum().item()) & (2**64 - 1)
+
+
 # ---- every kernel class x every weight mode ---------------------------------------------------
 @pytest.mark.parametrize("L", [4, 8, 16, 32])
 @pytest.mark.parametrize("order", ["row_major", "colour_major"])

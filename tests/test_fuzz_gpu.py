@@ -276,3 +276,53 @@ def test_random_mrfs_primal_rounding(seed):
                 assert (c == co) if np.isinf(co) else abs(c - co) <= 1e-9 * max(1.0, abs(co))
     finally:
         eng.close()
+
+
+def random_bipartite_mrf(rng):
+    """2-colourable non-grid graphs in colour-major order (all of side A, then all of side B) with irregular degrees,
+    mixed dense / Potts edges, occasional duplicate messages and a random subset of the relations: the shapes for which
+    lpmp_compute_pass(n >= 2) may join consecutive passes at their seam (engine.cpp, plan_rotation)"""
+    from lp_mp_amd import synthetic as S
+    L = int(rng.choice([4, 8, 16, 32]))
+    na, nb = int(rng.integers(3, 20)), int(rng.integers(3, 20))
+    kind = rng.choice(["dense", "potts", "mixed"])
+    b = M.ModelBuilder(2, S.mrf_mtypes() if rng.uniform() < 0.7 else
+                       [M.MsgType(0, 1, M.SCHED_LEFT, 0, 0, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, M.SCHED_LEFT, 0, 0, M.M_UNARY_PAIRWISE, 1)])
+    u = b.add_vector_factors(0, rng.uniform(0, 1, (na + nb, L)))
+    rel = []
+    seen = set()
+    for _ in range(int(rng.integers(max(na, nb), 3 * (na + nb)))):
+        i, j = int(rng.integers(na)), na + int(rng.integers(nb))
+        if (i, j) in seen and rng.uniform() < 0.7:
+            continue
+        seen.add((i, j))
+        dense = kind == "dense" or (kind == "mixed" and rng.uniform() < 0.5)
+        p = b.add_dense_pairwise(1, rng.uniform(0, 1, (1, L, L)))[0] if dense else b.add_potts_pairwise(1, L, [rng.uniform(-0.5, 1)])[0]
+        b.add_messages(0, u[i], p); b.add_messages(1, u[j], p)
+        if rng.uniform() < 0.05:
+            b.add_messages(1, u[j], p)                      # duplicate message into the same vector
+        rel += [(u[i], p), (p, u[j])]
+    keep = rng.uniform(size=len(rel)) < rng.choice([1.0, 1.0, 0.9, 0.5])
+    r = np.array([x for x, k in zip(rel, keep) if k], np.int32).reshape(-1, 2)
+    if r.shape[0]:
+        b.add_relations(r[:, 0], r[:, 1])
+    return b.finish()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_bipartite_graphs_multi_pass_calls_equal_single_passes(seed):
+    """compute_pass(n >= 2) — fused, and joined across passes where the op-by-op check allows it — against n
+    sequential reference passes, on non-grid 2-colourable graphs"""
+    rng = np.random.default_rng(17000 + seed)
+    m = random_bipartite_mrf(rng)
+    eng = E.Engine(0)
+    try:
+        for mode in MODES:
+            o = Oracle(m); o.set_reparametrization(mode)
+            eng.upload(m); eng.set_reparametrization(mode)
+            for n in (2, 5, 1, 3):
+                eng.compute_pass(n); o.ComputePass(n)
+                assert np.array_equal(eng.download_duals(), o.duals()), (seed, mode, n, eng.plan.pass_rotates(mode))
+            assert abs(eng.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+    finally:
+        eng.close()

@@ -118,6 +118,31 @@ def test_invalid_models_are_rejected():
     p = E.Plan(m)
     with pytest.raises(E.EngineError):
         p.omega(0, M.REPAM_MIXED)
+    # labeling match tables index the left factor's labelings: an entry outside [0, n_left] would be an out-of-bounds
+    # access in the labeling kernels
+    for v in (-1, 2):
+        bad = S.multicut_triangle_model(8, 4, seed=1)
+        bad.tab_data[1] = v
+        with pytest.raises(E.EngineError) as ei:
+            E.Plan(bad)
+        assert "out of range" in str(ei.value)
+    # iterator-range passes: rows with entries need their arrays, offsets start at 0 and do not decrease
+    upd = p.update_order(0)
+    om_off, om = p.omega(0, M.REPAM_UNIFORM)
+    mk_off, mk = p.mask(0, M.REPAM_UNIFORM)
+    assert p.custom_schedule_info(upd, om_off, om, mk_off, mk)["n_sends"] == om.shape[0]
+    L = E.lib()
+    five = [C.c_int64() for _ in range(5)]
+
+    def info(om_off_, om_ptr, mk_off_, mk_ptr):
+        return L.lpmp_plan_custom_schedule_info(p.h, upd.shape[0], upd.ctypes.data, om_off_.ctypes.data, om_ptr, mk_off_.ctypes.data,
+                                                mk_ptr, 0, *[C.addressof(x) for x in five])
+    assert info(om_off, om.ctypes.data, mk_off, mk.ctypes.data) == 0
+    assert info(om_off, None, mk_off, mk.ctypes.data) == -1 and b"omega array missing" in L.lpmp_last_error()
+    assert info(om_off, om.ctypes.data, mk_off, None) == -1 and b"receive-mask array missing" in L.lpmp_last_error()
+    assert info(om_off + 1, om.ctypes.data, mk_off, mk.ctypes.data) == -1
+    dec = om_off.copy(); dec[1], dec[2] = dec[2], dec[1] - 1
+    assert info(dec, om.ctypes.data, mk_off, mk.ctypes.data) == -1
 
 
 def test_c_abi_exports_every_declared_symbol():
@@ -287,3 +312,30 @@ def test_baseline_configs_run_on_the_fast_kernel_classes():
             for mode in MODES:
                 got |= set(p.schedule_classes(d, mode))
         assert got == want, (name, got)
+
+
+def test_pass_rotation_is_decided_op_by_op():
+    """n passes as H, W, (K, W)^(n-1), T need K = (receives of T, sends of H) and W = (receives of T', sends of H')
+    record by record (engine.cpp, plan_rotation): checkerboard grids in colour-major order qualify under anisotropic
+    weights, row-major orders and the uniform modes (every message both ways in each sweep) do not"""
+    for pw in ("dense", "potts"):
+        p = E.Plan(S.grid_model(6, 7, 8, pairwise=pw, order="colour_major"))
+        assert p.pass_rotates(M.REPAM_ANISOTROPIC) and p.pass_schedule_info(M.REPAM_ANISOTROPIC)["n_levels"] == 3
+        assert not p.pass_rotates(M.REPAM_UNIFORM)
+        assert not E.Plan(S.grid_model(6, 7, 8, pairwise=pw, order="row_major")).pass_rotates(M.REPAM_ANISOTROPIC)
+    # random bipartite graphs, colour-major: whatever is decided, a joined schedule must consist of the unfused ops
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_fuzz_gpu import random_bipartite_mrf
+    n_rot = 0
+    for seed in range(60):
+        m = random_bipartite_mrf(np.random.default_rng(17000 + seed))
+        p = E.Plan(m)
+        for mode in (M.REPAM_ANISOTROPIC, M.REPAM_ANISOTROPIC2):
+            if p.pass_rotates(mode):
+                n_rot += 1
+                fb = p.pass_schedule_info(mode)
+                one = [p.schedule_info(d, mode) for d in (0, 1)]
+                assert fb["n_receives"] == one[0]["n_receives"] + one[1]["n_receives"]
+                assert fb["n_sends"] == one[0]["n_sends"] + one[1]["n_sends"]
+    assert n_rot > 0
