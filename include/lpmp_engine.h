@@ -118,14 +118,27 @@ int lpmp_set_stream(lpmp_engine* e, void* hip_stream);
 int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int dual_mem);
 
 int lpmp_set_reparametrization(lpmp_engine* e, int mode);   /* LP::set_reparametrization, LP_MP.h:330 */
-/* --reparametrizationType parsed by LP::Begin (LP_MP.h:589-593, :710-722) and switched on in the hot loop
- * (:988-1004).  shared (default) and residual (update_factor_residual, factors_messages.hxx:2270-2279,
- * :2960-3007) run on the device; partition / overlapping_partition / adaptive return LPMP_ERR_UNSUPPORTED. */
+/* --reparametrizationType parsed by LP::Begin (LP_MP.h:589-593, :710-722) and switched on in the hot loop (:869-887,
+ * :988-1004).  All five run on the device:
+ *   shared                 UpdateFactor (factors_messages.hxx:2256-2261)
+ *   residual               update_factor_residual (:2270-2279, :2960-3007)
+ *   partition              compute_partition_pass over the components of the put_in_same_partition graph
+ *                          (lpmp_model.part_pairs; LP_MP.h:1717-1822, :1932-1963), lpmp_set_inner_iterations passes each
+ *   overlapping_partition  compute_overlapping_partition_pass (:1824-1843, :1966-2051), then the plain sweeps
+ *   adaptive               update_factor_adaptive (:2263-2268, :2860-2926) with the improvement op of
+ *                          lpmp_msg_flags; message types without it contribute improvement 0, as in the reference's
+ *                          release build, so their factors send nothing
+ * LPMP_ERR_UNSUPPORTED: residual / adaptive with batch-capable message ops; adaptive when an updated factor has a
+ * message it does not send through (the reference indexes past its weight row there). */
 enum lpmp_reparametrization_type {
   LPMP_RTYPE_SHARED = 0, LPMP_RTYPE_RESIDUAL = 1, LPMP_RTYPE_PARTITION = 2, LPMP_RTYPE_OVERLAPPING_PARTITION = 3,
   LPMP_RTYPE_ADAPTIVE = 4
 };
 int lpmp_set_reparametrization_type(lpmp_engine* e, int rtype);
+int lpmp_set_inner_iterations(lpmp_engine* e, int n);       /* --innerIteration, default 5 (LP_MP.h:590) */
+/* LP::construct_factor_partition (LP_MP.h:1717-1822): number of partitions; with off != NULL also their factor lists
+ * (updated factors only, CSR: off[n_partitions + 1], factors[n_updated]) */
+int lpmp_plan_get_partitions(lpmp_plan* p, int64_t* n_partitions, int64_t* off, int32_t* factors);
 int lpmp_compute_pass(lpmp_engine* e, int n_passes);        /* LP::ComputePass, LP_MP.h:869-887 ('shared') */
 int lpmp_compute_forward_pass(lpmp_engine* e);              /* LP::ComputeForwardPass, LP_MP.h:889-900 */
 int lpmp_compute_backward_pass(lpmp_engine* e);             /* LP::ComputeBackwardPass, LP_MP.h:902-911 */

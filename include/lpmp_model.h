@@ -67,6 +67,25 @@ enum lpmp_msg_kind {
   LPMP_M_MINNORM = 2
 };
 
+/* Optional members of a message op, detected at compile time in the reference (LP_MP_FUNCTION_EXISTENCE_CLASS,
+ * include/factors_messages.hxx:46-81) and declared here per message type.  None of the ops in the reference tree has
+ * them; they are hooks for richer factor families, so the device ops behind them are this engine's own definitions:
+ *   IMPROVEMENT   send_message_to_left_improvement / send_message_to_right_improvement (:734-747, :795-808), used by
+ *                 --reparametrizationType adaptive (:2860-2926).  Device op: the exact change of LowerBound(left) +
+ *                 LowerBound(right) a weight-1 send of this message would cause, computed from the current duals.
+ *                 Without the flag the reference's release build gets 0 from the container (assert(false); return 0)
+ *                 and adaptive updates send nothing; the engine does the same.
+ *   BATCH_TO_RIGHT / BATCH_TO_LEFT   static SendMessagesToRight / SendMessagesToLeft(factor, msg_begin, msg_end, omega)
+ *                 (:1070-1078, :1180-1188): CallSendMessages hands all active messages of the type to ONE call with
+ *                 the sum of their weights when more than one is active (:2709-2720).  Device op: every active message
+ *                 gets (omega / number of active messages) times the plain message, all computed from the factor as
+ *                 it is on entry. */
+enum lpmp_msg_flags {
+  LPMP_MF_IMPROVEMENT = 1,
+  LPMP_MF_BATCH_TO_RIGHT = 2,
+  LPMP_MF_BATCH_TO_LEFT = 4
+};
+
 /* message_passing_schedule, same numbering as include/config.hxx:43-49 */
 enum lpmp_schedule {
   LPMP_SCHED_LEFT = 0,
@@ -97,7 +116,7 @@ typedef struct lpmp_msg_type {
   int32_t n_right;     /* NO_OF_RIGHT_FACTORS */
   int32_t kind;        /* enum lpmp_msg_kind */
   int32_t param;       /* side (UNARY_PAIRWISE) or table index (LABELING) */
-  int32_t reserved;
+  int32_t flags;       /* enum lpmp_msg_flags: which OPTIONAL members the message op defines */
 } lpmp_msg_type;
 
 /* The whole model. Every pointer is borrowed for the duration of the call it is passed to. */
@@ -141,6 +160,11 @@ typedef struct lpmp_model {
   const int32_t* rel_bwd;           /* [n_rel_bwd][2] */
 
   double constant;                  /* LP::add_to_constant (LP_MP.h:462) */
+
+  /* --- LP::put_in_same_partition(f1, f2) calls, in call order (LP_MP.h:465): the partition graph of
+   * --reparametrizationType partition / overlapping_partition (LP_MP.h:1717-1822) --- */
+  int64_t n_part_pairs;
+  const int32_t* part_pairs;        /* [n_part_pairs][2] */
 } lpmp_model;
 
 /* sizes implied by kind/dims */

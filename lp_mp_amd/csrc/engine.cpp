@@ -32,6 +32,7 @@ bool launch_dense_lb(int L, const void* recs, const double* dual, const double* 
 void launch_sum_stage(const double* in, double* out, int64_t n, int64_t per_block, int64_t n_blocks, hipStream_t s);
 void launch_synth_fill(double* out, int64_t n, uint64_t seed, uint64_t first, hipStream_t s);
 int generic_max_dual();
+int generic_max_adaptive_sends();
 struct LbRecHost { int64_t dual_off; int64_t const_off; int32_t d0, d1; int32_t kind_flags; int32_t pad; };
 }  // namespace lpmp
 
@@ -67,6 +68,7 @@ struct DevSchedule {
   int64_t n_levels = 0, n_recv = 0, n_send = 0, alg_bytes = 0;
   hipGraphExec_t graph = nullptr;
   hipGraphExec_t graph_primal = nullptr;   // the same launches with the SWEEP_PRIMAL flag
+  bool adaptive_built = false;             // built with every update on the generic kernels (adaptive send rule)
   size_t recs_cap = 0, ops_cap = 0, packets_cap = 0;   // allocated elements (a scratch schedule is refilled in place)
   void release() {
     if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
@@ -89,6 +91,12 @@ struct lpmp_plan {
   Schedule pass_cache[LPMP_REPAM_COUNT]; bool have_pass[LPMP_REPAM_COUNT] = {false};   // forward+backward as one fused sequence
   Schedule bf_cache[LPMP_REPAM_COUNT]; bool have_bf[LPMP_REPAM_COUNT] = {false};       // backward+forward (the seam between two passes)
   bool rotation_ok[LPMP_REPAM_COUNT] = {false};
+  void drop_caches() {   // the kernel classes of every schedule change with Plan::force_generic
+    for (int m = 0; m < LPMP_REPAM_COUNT; ++m) {
+      for (int d = 0; d < 2; ++d) { sched_cache[d][m] = Schedule(); have_sched[d][m] = false; }
+      pass_cache[m] = Schedule(); have_pass[m] = false; bf_cache[m] = Schedule(); have_bf[m] = false; rotation_ok[m] = false;
+    }
+  }
 };
 
 static void plan_pass_schedule(lpmp_plan* pl, int mode) {
@@ -202,6 +210,8 @@ struct lpmp_engine {
   bool have_sched[LPMP_REPAM_COUNT] = {false, false, false, false};
   DevSchedule sched_pass[LPMP_REPAM_COUNT];            // fused forward+backward (ComputePass)
   DevSchedule sched_bf[LPMP_REPAM_COUNT];              // fused backward+forward: its middle step joins two passes
+  DevSchedule sched_part[2]; bool have_part[2] = {false, false};   // compute_partition_pass / compute_overlapping_partition_pass as ONE sequence
+  int inner_iterations = 5;                            // --innerIteration (reference LP_MP.h:590)
   bool rotation_ok[LPMP_REPAM_COUNT] = {false, false, false, false};
   bool have_pass[LPMP_REPAM_COUNT] = {false, false, false, false};
   bool use_fused = true;
@@ -209,7 +219,7 @@ struct lpmp_engine {
   std::vector<std::unique_ptr<DevSchedule>> custom;   // prepared iterator-range passes
   DevSchedule scratch;                                 // the one-off schedule of lpmp_compute_pass_custom
   int mode = -1;
-  int rtype = 0;   // reparametrization_type: 0 shared, 1 residual (kernel flag SWEEP_RESIDUAL)
+  int rtype = 0;   // enum lpmp_reparametrization_type
   bool use_graph = true;
   bool use_packed = true;
   bool timing = false;
@@ -227,9 +237,14 @@ struct lpmp_engine {
     h_pbad = nullptr;
     have_primal = false; primal_t = 0; n_pinit = n_plinks = n_pprop = 0;
   }
-  void release_model() {
+  // the built-in schedules (everything but the caller's prepared iterator-range passes)
+  void release_schedules() {
     for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m) sched[d][m].release();
     for (int m = 0; m < LPMP_REPAM_COUNT; ++m) { have_sched[m] = false; sched_pass[m].release(); sched_bf[m].release(); have_pass[m] = false; rotation_ok[m] = false; }
+    for (int k = 0; k < 2; ++k) { sched_part[k].release(); have_part[k] = false; }
+  }
+  void release_model() {
+    release_schedules();
     for (auto& c : custom) if (c) c->release();
     custom.clear();
     scratch.release();
@@ -383,10 +398,11 @@ void fill_device(T*& dst, size_t& cap, const std::vector<T>& src, hipStream_t st
 }
 
 // keep: refill d's buffers in place where they are large enough (the scratch schedule of lpmp_compute_pass_custom)
-void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream, bool keep = false) {
+void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream, bool keep = false, bool adaptive_built = false) {
   if (keep) { if (d.graph) { (void)hipGraphExecDestroy(d.graph); d.graph = nullptr; } if (d.graph_primal) { (void)hipGraphExecDestroy(d.graph_primal); d.graph_primal = nullptr; } }
   else d.release();
   d.launches = s.launches; d.n_levels = s.n_levels; d.n_recv = s.n_recv; d.n_send = s.n_send; d.alg_bytes = s.alg_bytes;
+  d.adaptive_built = adaptive_built;
   fill_device(d.recs, d.recs_cap, s.recs, stream);
   fill_device(d.ops, d.ops_cap, s.ops, stream);
   fill_device(d.packets, d.packets_cap, s.packets, stream);
@@ -399,12 +415,13 @@ void check_generic_limits(const Plan& p, const Schedule& s) {
     for (int64_t i = lr.begin; i < lr.end; ++i) {
       const UpdRec& r = s.recs[i];
       const int own = (r.kind_flags & 15) == LPMP_F_VECTOR ? r.d0 : r.d0 + r.d1;
+      if (p.force_generic && r.n_send > generic_max_adaptive_sends())
+        throw UnsupportedError("adaptive sends: factor " + std::to_string(r.factor) + " has more active sends than the device kernel keeps improvements for");
       if (own > lim) throw UnsupportedError("factor " + std::to_string(r.factor) + ": dual size " + std::to_string(own) + " exceeds the device limit " + std::to_string(lim));
       for (int k = 0; k < r.n_recv + r.n_send; ++k)
         if (s.ops[r.op_begin + k].len > lim) throw UnsupportedError("message too long for the device kernels");
     }
   }
-  (void)p;
 }
 
 void ensure_device_schedules(lpmp_engine* e, int mode) {
@@ -440,7 +457,8 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
     hipEvent_t a = nullptr, b = nullptr;
     if (timed) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, stream)); }
     // UpdateFactorPrimal always sends 'shared' (reference factors_messages.hxx:2357-2359), whatever the send rule
-    const int flags = (e->primal_pass ? SWEEP_PRIMAL : e->rtype) | e->nt_flag;
+    const int rule = e->rtype == LPMP_RTYPE_RESIDUAL ? SWEEP_RESIDUAL : e->rtype == LPMP_RTYPE_ADAPTIVE ? SWEEP_ADAPTIVE : 0;
+    const int flags = (e->primal_pass ? SWEEP_PRIMAL : rule) | e->nt_flag;
     if (!(e->use_packed && lr.stride != 0 &&
           launch_sweep_packed(lr.kclass, lr.stride > 0 ? s.packets + lr.pk_begin : nullptr, s.recs + lr.begin, s.ops, lr.stride, e->d_dual,
                               e->d_const, e->d_lb, e->d_primal, lr.end - lr.begin, flags, stream)))
@@ -644,6 +662,19 @@ int lpmp_plan_pass_schedule_info(lpmp_plan* p, int mode, int64_t* n_levels, int6
   });
 }
 
+int lpmp_plan_get_partitions(lpmp_plan* p, int64_t* n_partitions, int64_t* off, int32_t* factors) {
+  return guarded([&] {
+    if (!p || !n_partitions) throw std::runtime_error("bad argument");
+    p->p.ensure_partition();
+    const auto& pt = p->p.part;
+    *n_partitions = (int64_t)pt.off.size() - 1;
+    if (off && factors) {
+      std::memcpy(off, pt.off.data(), pt.off.size() * sizeof(int64_t));
+      if (!pt.f.empty()) std::memcpy(factors, pt.f.data(), pt.f.size() * sizeof(int32_t));
+    }
+  });
+}
+
 int lpmp_plan_pass_rotates(lpmp_plan* p, int mode) {
   int r = 0;
   const int rc = guarded([&] {
@@ -709,6 +740,7 @@ int lpmp_set_stream(lpmp_engine* e, void* s) {
   });
 }
 
+static void check_rtype(const lpmp_engine* e, int rtype);
 int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int dual_mem) {
   return guarded([&] {
     if (!e || !m) throw std::runtime_error("null argument");
@@ -770,6 +802,8 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
     HIP_CHECK(hipStreamSynchronize(e->stream));
     e->lb_all_stale = true;
     e->plan = std::move(pl);
+    e->plan->p.force_generic = e->rtype == LPMP_RTYPE_ADAPTIVE;
+    try { check_rtype(e, e->rtype); } catch (...) { e->release_model(); throw; }
   });
 }
 
@@ -784,22 +818,71 @@ int lpmp_set_reparametrization(lpmp_engine* e, int mode) {
   });
 }
 
+// what keeps the uploaded model from running under a send rule (also checked at upload: the rule may be set first,
+// as the reference parses --reparametrizationType in LP::Begin)
+static void check_rtype(const lpmp_engine* e, int rtype) {
+  if (!e->plan) return;
+  const Plan& p = e->plan->p;
+  if (rtype == LPMP_RTYPE_RESIDUAL && p.any_batch)
+    throw UnsupportedError("residual sends with batch-capable message ops are not built (send_messages_residual's batch branch, factors_messages.hxx:2980-2991)");
+  if (rtype == LPMP_RTYPE_ADAPTIVE) { const std::string why = p.adaptive_obstacle(); if (!why.empty()) throw UnsupportedError(why); }
+}
+static void apply_rtype(lpmp_engine* e, int rtype) {
+  const bool generic = rtype == LPMP_RTYPE_ADAPTIVE;
+  if (e->plan && e->plan->p.force_generic != generic) {   // other kernel classes: every built-in schedule is rebuilt
+    e->release_schedules();
+    e->plan->drop_caches();
+    e->plan->p.force_generic = generic;
+    e->mode = -1;
+  }
+  e->rtype = rtype;
+}
+
 int lpmp_set_reparametrization_type(lpmp_engine* e, int rtype) {
   return guarded([&] {
     if (!e) throw std::runtime_error("null engine");
-    if (rtype == LPMP_RTYPE_PARTITION || rtype == LPMP_RTYPE_OVERLAPPING_PARTITION || rtype == LPMP_RTYPE_ADAPTIVE)
-      throw UnsupportedError("reparametrization type not executable on the device (DESIGN.md 2)");
-    if (rtype != LPMP_RTYPE_SHARED && rtype != LPMP_RTYPE_RESIDUAL) throw std::runtime_error("unknown reparametrization type");
+    if (rtype < LPMP_RTYPE_SHARED || rtype > LPMP_RTYPE_ADAPTIVE) throw std::runtime_error("unknown reparametrization type");
+    check_rtype(e, rtype);
     if (rtype != e->rtype) {   // captured graphs bake the kernel flag in
       HIP_CHECK(hipStreamSynchronize(e->stream));
       for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m)
         if (e->sched[d][m].graph) { (void)hipGraphExecDestroy(e->sched[d][m].graph); e->sched[d][m].graph = nullptr; }
       for (int m = 0; m < LPMP_REPAM_COUNT; ++m)
         if (e->sched_pass[m].graph) { (void)hipGraphExecDestroy(e->sched_pass[m].graph); e->sched_pass[m].graph = nullptr; }
+      for (int k = 0; k < 2; ++k) if (e->sched_part[k].graph) { (void)hipGraphExecDestroy(e->sched_part[k].graph); e->sched_part[k].graph = nullptr; }
       for (auto& c : e->custom) if (c && c->graph) { (void)hipGraphExecDestroy(c->graph); c->graph = nullptr; }
     }
-    e->rtype = rtype;
+    const int mode = e->mode;
+    apply_rtype(e, rtype);
+    if (e->mode < 0 && mode >= 0) { ensure_device_schedules(e, mode); e->mode = mode; }   // the mode survives the rebuild
   });
+}
+
+int lpmp_set_inner_iterations(lpmp_engine* e, int n) {
+  return guarded([&] {
+    if (!e) throw std::runtime_error("null engine");
+    if (n < 1) throw std::runtime_error("innerIteration must be positive");
+    if (n != e->inner_iterations) {
+      HIP_CHECK(hipStreamSynchronize(e->stream));
+      for (int k = 0; k < 2; ++k) { e->sched_part[k].release(); e->have_part[k] = false; }
+    }
+    e->inner_iterations = n;
+  });
+}
+
+// compute_partition_pass / compute_overlapping_partition_pass (reference LP_MP.h:1932-2051): a fixed sequence of
+// iterator-range passes over the partitions' factor lists with their own anisotropic weights.  The whole sequence is
+// level-scheduled as ONE schedule: inner iterations of partitions that touch no common factor run side by side.
+static void ensure_partition_schedule(lpmp_engine* e, int rtype) {
+  const int k = rtype - LPMP_RTYPE_PARTITION;
+  if (e->have_part[k]) return;
+  std::vector<Plan::Segment> segs;
+  e->plan->p.partition_pass_segments(rtype, e->inner_iterations, segs);
+  Schedule s;
+  e->plan->p.make_schedule(segs, e->use_fused, s);
+  check_generic_limits(e->plan->p, s);
+  upload_schedule(s, e->sched_part[k], e->stream);
+  e->have_part[k] = true;
 }
 
 int lpmp_compute_forward_pass(lpmp_engine* e) {
@@ -808,26 +891,37 @@ int lpmp_compute_forward_pass(lpmp_engine* e) {
 int lpmp_compute_backward_pass(lpmp_engine* e) {
   return guarded([&] { require_mode(e); HIP_CHECK(hipSetDevice(e->device)); run_schedule(e, e->sched[1][e->mode]); });
 }
-int lpmp_compute_pass(lpmp_engine* e, int n) {
+static void compute_plain_passes(lpmp_engine* e, int n) {   // ComputeForwardPass(); ComputeBackwardPass(); n times
+  if (e->use_fused) {
+    ensure_pass_schedule(e, e->mode);
+    if (n >= 2 && e->rotation_ok[e->mode] && e->use_rotation) {
+      const DevSchedule& fb = e->sched_pass[e->mode];
+      const DevSchedule& bf = e->sched_bf[e->mode];
+      const bool timed = e->timing;
+      issue_launches(e, fb, timed, e->stream, 1);
+      issue_launches(e, fb, timed, e->stream, 2);
+      for (int i = 1; i < n; ++i) { issue_launches(e, bf, timed, e->stream, 2); issue_launches(e, fb, timed, e->stream, 2); }
+      issue_launches(e, fb, timed, e->stream, 3);
+      if (timed && e->pending.size() > 4096) e->drain_timing();
+    } else {
+      for (int i = 0; i < n; ++i) run_schedule(e, e->sched_pass[e->mode]);
+    }
+  } else {
+    for (int i = 0; i < n; ++i) { run_schedule(e, e->sched[0][e->mode]); run_schedule(e, e->sched[1][e->mode]); }
+  }
+}
+int lpmp_compute_pass(lpmp_engine* e, int n) {   // LP::ComputePass, LP_MP.h:869-887
   return guarded([&] {
     require_mode(e);
     HIP_CHECK(hipSetDevice(e->device));
-    if (e->use_fused) {
-      ensure_pass_schedule(e, e->mode);
-      if (n >= 2 && e->rotation_ok[e->mode] && e->use_rotation) {
-        const DevSchedule& fb = e->sched_pass[e->mode];
-        const DevSchedule& bf = e->sched_bf[e->mode];
-        const bool timed = e->timing;
-        issue_launches(e, fb, timed, e->stream, 1);
-        issue_launches(e, fb, timed, e->stream, 2);
-        for (int i = 1; i < n; ++i) { issue_launches(e, bf, timed, e->stream, 2); issue_launches(e, fb, timed, e->stream, 2); }
-        issue_launches(e, fb, timed, e->stream, 3);
-        if (timed && e->pending.size() > 4096) e->drain_timing();
-      } else {
-        for (int i = 0; i < n; ++i) run_schedule(e, e->sched_pass[e->mode]);
-      }
+    if (e->rtype == LPMP_RTYPE_PARTITION) {
+      ensure_partition_schedule(e, e->rtype);
+      for (int i = 0; i < n; ++i) run_schedule(e, e->sched_part[0]);
+    } else if (e->rtype == LPMP_RTYPE_OVERLAPPING_PARTITION) {
+      ensure_partition_schedule(e, e->rtype);
+      for (int i = 0; i < n; ++i) { run_schedule(e, e->sched_part[1]); compute_plain_passes(e, 1); }
     } else {
-      for (int i = 0; i < n; ++i) { run_schedule(e, e->sched[0][e->mode]); run_schedule(e, e->sched[1][e->mode]); }
+      compute_plain_passes(e, n);
     }
   });
 }
@@ -989,7 +1083,7 @@ int lpmp_compute_pass_custom(lpmp_engine* e, int64_t n, const int32_t* factors, 
     check_generic_limits(e->plan->p, s);
     // the schedule lives in a scratch buffer of the engine that is refilled in place: no allocation per call
     DevSchedule& d = e->scratch;
-    upload_schedule(s, d, e->stream, true);
+    upload_schedule(s, d, e->stream, true, e->plan->p.force_generic);
     const bool g = e->use_graph; e->use_graph = false;
     try { run_schedule(e, d); } catch (...) { e->use_graph = g; throw; }
     e->use_graph = g;
@@ -1016,7 +1110,7 @@ int lpmp_schedule_create_fused(lpmp_engine* e, int64_t n, const int32_t* factors
                              fuse != 0 && e->use_fused, s);
     check_generic_limits(e->plan->p, s);
     auto d = std::make_unique<DevSchedule>();
-    try { upload_schedule(s, *d, e->stream); } catch (...) { d->release(); throw; }
+    try { upload_schedule(s, *d, e->stream, false, e->plan->p.force_generic); } catch (...) { d->release(); throw; }
     e->custom.push_back(std::move(d));
     *id_out = (int)e->custom.size() - 1;
   });
@@ -1027,7 +1121,13 @@ static DevSchedule& custom_schedule(lpmp_engine* e, int id) {
   return *e->custom[id];
 }
 int lpmp_schedule_run(lpmp_engine* e, int id) {
-  return guarded([&] { DevSchedule& d = custom_schedule(e, id); HIP_CHECK(hipSetDevice(e->device)); run_schedule(e, d); });
+  return guarded([&] {
+    DevSchedule& d = custom_schedule(e, id);
+    if (d.adaptive_built != (e->rtype == LPMP_RTYPE_ADAPTIVE))
+      throw StateError("this schedule was prepared under another send rule (adaptive sends run on other kernels): create it again");
+    HIP_CHECK(hipSetDevice(e->device));
+    run_schedule(e, d);
+  });
 }
 int lpmp_schedule_info(lpmp_engine* e, int id, int64_t* n_levels, int64_t* n_launches, int64_t* n_recv, int64_t* n_send,
                        int64_t* alg_bytes) {

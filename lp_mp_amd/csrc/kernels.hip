@@ -25,6 +25,7 @@ namespace lpmp {
 #define LPMP_INF (__builtin_inf())
 constexpr int GEN_MAXD = 512;       // generic kernel: max dual size / message length held in LDS per wave
 constexpr int GEN_WAVES = 4;
+constexpr int GEN_ADAPTIVE_SENDS = 64;   // adaptive send rule: sends per updated factor whose improvements a wave keeps
 
 // Tracked lower bounds.  lb[f] holds FactorContainer::LowerBound of factor f, or NaN when it has to be
 // recomputed.  A sweep kernel knows the bound of every factor it touches for free:
@@ -121,8 +122,10 @@ constexpr int SMALL_WAVES = 1;
 template <int G> struct GenCtx;
 template <> struct GenCtx<64> {
   static constexpr int STRIDE = 64, FPB = GEN_WAVES, THREADS = 64 * GEN_WAVES;
-  struct Lds { double own[GEN_MAXD]; double snap[GEN_MAXD]; double dl[GEN_MAXD]; };
+  static constexpr int MAX_ADAPTIVE_SENDS = GEN_ADAPTIVE_SENDS;
+  struct Lds { double own[GEN_MAXD]; double snap[GEN_MAXD]; double dl[GEN_MAXD]; double imp[GEN_ADAPTIVE_SENDS]; };
   Lds& s; const int lane;
+  __device__ __forceinline__ double& imp(int i) const { return s.imp[i]; }
   __device__ __forceinline__ double& own(int i) const { return s.own[i]; }
   __device__ __forceinline__ double& snap(int i) const { return s.snap[i]; }
   __device__ __forceinline__ double& dl(int i) const { return s.dl[i]; }
@@ -138,8 +141,10 @@ template <> struct GenCtx<64> {
 };
 template <> struct GenCtx<1> {
   static constexpr int STRIDE = 1, FPB = 64 * SMALL_WAVES, THREADS = 64 * SMALL_WAVES;
-  struct Lds { double own[SMALL_MAXD][64]; double snap[SMALL_MAXD][64]; double dl[SMALL_MAXD][64]; };
+  static constexpr int MAX_ADAPTIVE_SENDS = SMALL_MAXD;
+  struct Lds { double own[SMALL_MAXD][64]; double snap[SMALL_MAXD][64]; double dl[SMALL_MAXD][64]; double imp[SMALL_MAXD][64]; };
   Lds& s; const int lane;
+  __device__ __forceinline__ double& imp(int i) const { return s.imp[i][lane]; }
   __device__ __forceinline__ double& own(int i) const { return s.own[i][lane]; }
   __device__ __forceinline__ double& snap(int i) const { return s.snap[i][lane]; }
   __device__ __forceinline__ double& dl(int i) const { return s.dl[i][lane]; }
@@ -201,6 +206,28 @@ __device__ __forceinline__ void minnorm_delta(const C& c, Src src, int n, double
   C::sync();
 }
 
+// FactorContainer::LowerBound of a factor seen through an accessor (its duals as they would be after a send):
+// vector factor min_i d(i), clamped at 0 with an implicit origin; pairwise min_a ( m(a) + min_b (T[a][b] + m(d0 + b)) )
+template <class C, class Acc>
+__device__ __forceinline__ double vec_lb_through(const C& c, int n, Acc d, int implicit_origin) {
+  double v = LPMP_INF;
+  for (int i = c.first(); i < n; i += C::STRIDE) v = fmin(v, d(i));
+  v = C::gmin(v);
+  if (implicit_origin && 0.0 < v) v = 0.0;
+  return v;
+}
+template <class C, class Acc>
+__device__ __forceinline__ double pw_lb_through(const C& c, const double* __restrict__ cdata, int64_t coff, int kind, int d0, int d1, Acc m) {
+  double best = LPMP_INF;
+  for (int a = 0; a < d0; ++a) {
+    double v = LPMP_INF;
+    for (int b = c.first(); b < d1; b += C::STRIDE) v = fmin(v, pw_cost(cdata, coff, kind, d1, a, b) + m(d0 + b));
+    v = C::gmin(v);
+    best = fmin(best, m(a) + v);
+  }
+  return best;
+}
+
 template <int G>
 __global__ void __launch_bounds__(GenCtx<G>::THREADS)
 sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
@@ -220,16 +247,44 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
   C::sync();
 
   const int n_ops = rec.n_recv + rec.n_send;
-  // one receive or send: compute delta from the peer (receive) or from the snapshot / live own state (send),
-  // then +delta to the side that did not compute it and -delta to the side that did
-  auto run_op = [&](const Op& op, const bool recv, const bool live_src, const double omega) {
-    if (c.leader()) lb[op.peer] = LPMP_NAN;
+  // delta of one message into c.dl: computed from the peer (receive) or from the snapshot / live own state (send)
+  auto compute_delta = [&](const Op& op, const bool recv, const bool live_src, const double omega) {
     const int code = op.info & 15, role = (op.info >> 4) & 1, side = (op.info >> 5) & 1, imp = (op.info >> 6) & 1;
     const int pkind = (op.info >> 8) & 15;
-    double* peer = dual + op.peer_dual;
+    const double* peer = dual + op.peer_dual;
     const int len = op.len;
     auto from_peer = [&](int i) { return peer[i]; };
     auto from_own = [&](int i) { return live_src ? c.own(i) : c.snap(i); };
+    const bool by_right = recv ? (role == 0) : (role == 1);
+    if (code == OP_UP) {
+      if (by_right) {   // min-marginal of the pairwise (right) factor
+        if (recv) pw_min_marginal(c, cdata, op.peer_const, pkind, op.pd0, op.pd1, from_peer, side, omega);
+        else pw_min_marginal(c, cdata, rec.const_off, okind, rec.d0, rec.d1, from_own, side, omega);
+      } else {          // omega * theta of the unary (left) factor
+        for (int i = c.first(); i < len; i += C::STRIDE) c.dl(i) = omega * (recv ? peer[i] : from_own(i));
+        C::sync();
+      }
+    } else if (code == OP_LABELING) {
+      const int32_t* tab = tabs + op.peer_const;
+      if (by_right) {
+        if (recv) labeling_to_left(c, from_peer, op.pd0, tab, op.pd1, imp, omega);
+        else labeling_to_left(c, from_own, rec.d0, tab, op.pd1, imp, omega);
+      } else {
+        for (int i = c.first(); i < len; i += C::STRIDE) c.dl(i) = omega * (recv ? peer[i] : from_own(i));
+        C::sync();
+      }
+    } else {            // OP_MINNORM
+      if (recv) minnorm_delta(c, from_peer, len, omega);
+      else minnorm_delta(c, from_own, len, omega);
+    }
+  };
+  // one receive or send: compute delta, then +delta to the side that did not compute it and -delta to the side that did
+  auto run_op = [&](const Op& op, const bool recv, const bool live_src, const double omega) {
+    if (c.leader()) lb[op.peer] = LPMP_NAN;
+    const int code = op.info & 15, role = (op.info >> 4) & 1, side = (op.info >> 5) & 1, imp = (op.info >> 6) & 1;
+    double* peer = dual + op.peer_dual;
+    const int len = op.len;
+    [[maybe_unused]] auto from_own = [&](int i) { return live_src ? c.own(i) : c.snap(i); };
     // the message is computed by the peer for a receive and by the updated factor for a send
     const bool by_right = recv ? (role == 0) : (role == 1);
     if constexpr (G == 1) {
@@ -266,27 +321,7 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
         return;
       }
     }
-    if (code == OP_UP) {
-      if (by_right) {   // min-marginal of the pairwise (right) factor
-        if (recv) pw_min_marginal(c, cdata, op.peer_const, pkind, op.pd0, op.pd1, from_peer, side, omega);
-        else pw_min_marginal(c, cdata, rec.const_off, okind, rec.d0, rec.d1, from_own, side, omega);
-      } else {          // omega * theta of the unary (left) factor
-        for (int i = c.first(); i < len; i += C::STRIDE) c.dl(i) = omega * (recv ? peer[i] : from_own(i));
-        C::sync();
-      }
-    } else if (code == OP_LABELING) {
-      const int32_t* tab = tabs + op.peer_const;
-      if (by_right) {
-        if (recv) labeling_to_left(c, from_peer, op.pd0, tab, op.pd1, imp, omega);
-        else labeling_to_left(c, from_own, rec.d0, tab, op.pd1, imp, omega);
-      } else {
-        for (int i = c.first(); i < len; i += C::STRIDE) c.dl(i) = omega * (recv ? peer[i] : from_own(i));
-        C::sync();
-      }
-    } else {            // OP_MINNORM
-      if (recv) minnorm_delta(c, from_peer, len, omega);
-      else minnorm_delta(c, from_own, len, omega);
-    }
+    compute_delta(op, recv, live_src, omega);
     // (reference MessageContainerView::operator-=, factors_messages.hxx:495-508)
     const bool own_is_left = role == 0;
     const double s_left = by_right ? +1.0 : -1.0, s_right = -s_left;
@@ -306,6 +341,56 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
     }
     C::sync();
   };
+  // The device op behind LPMP_MF_IMPROVEMENT (send_message_to_{left,right}_improvement of the message op, reference
+  // factors_messages.hxx:734-747, :795-808): the exact change of LowerBound(left) + LowerBound(right) a weight-1 send
+  // of this message from the factor's state after its receives would cause.  Nothing is written.
+  auto improvement = [&](const Op& op) -> double {
+    const int code = op.info & 15, role = (op.info >> 4) & 1, side = (op.info >> 5) & 1, pkind = (op.info >> 8) & 15;
+    const double* peer = dual + op.peer_dual;
+    const int len = op.len;
+    const bool by_right = role == 1, own_is_left = role == 0;
+    const double s_left = by_right ? +1.0 : -1.0, s_right = -s_left;
+    compute_delta(op, false, true, 1.0);
+    const int32_t* tab = code == OP_LABELING ? tabs + op.peer_const : nullptr;
+    const int nl = op.pd1;
+    const int own_io = (rec.kind_flags >> 4) & LPMP_FF_IMPLICIT_ORIGIN, peer_io = (op.info >> 7) & 1;
+    double before, after;
+    if (own_is_left) {          // left = this factor (vector), right = peer
+      const double lb_l = vec_lb_through(c, on, [&](int i) { return c.own(i); }, own_io);
+      const double la_l = vec_lb_through(c, on, [&](int i) { return i < len ? c.own(i) + s_left * c.dl(i) : c.own(i); }, own_io);
+      double lb_r, la_r;
+      if (code == OP_UP) {
+        const int o = side == 0 ? 0 : op.pd0;
+        lb_r = pw_lb_through(c, cdata, op.peer_const, pkind, op.pd0, op.pd1, [&](int j) { return peer[j]; });
+        la_r = pw_lb_through(c, cdata, op.peer_const, pkind, op.pd0, op.pd1, [&](int j) { return (j >= o && j < o + len) ? peer[j] + s_right * c.dl(j - o) : peer[j]; });
+      } else if (code == OP_LABELING) {
+        lb_r = vec_lb_through(c, op.pd0, [&](int j) { return peer[j]; }, peer_io);
+        la_r = vec_lb_through(c, op.pd0, [&](int j) { return tab[j] < nl ? peer[j] + s_right * c.dl(tab[j]) : peer[j]; }, peer_io);
+      } else {
+        lb_r = vec_lb_through(c, op.pd0, [&](int j) { return peer[j]; }, peer_io);
+        la_r = vec_lb_through(c, op.pd0, [&](int j) { return peer[j] + s_right * c.dl(j); }, peer_io);
+      }
+      before = lb_l + lb_r; after = la_l + la_r;
+    } else {                    // left = peer (vector), right = this factor
+      const double lb_l = vec_lb_through(c, op.pd0, [&](int i) { return peer[i]; }, peer_io);
+      const double la_l = vec_lb_through(c, op.pd0, [&](int i) { return i < len ? peer[i] + s_left * c.dl(i) : peer[i]; }, peer_io);
+      double lb_r, la_r;
+      if (code == OP_UP) {
+        const int o = side == 0 ? 0 : rec.d0;
+        lb_r = pw_lb_through(c, cdata, rec.const_off, okind, rec.d0, rec.d1, [&](int j) { return c.own(j); });
+        la_r = pw_lb_through(c, cdata, rec.const_off, okind, rec.d0, rec.d1, [&](int j) { return (j >= o && j < o + len) ? c.own(j) + s_right * c.dl(j - o) : c.own(j); });
+      } else if (code == OP_LABELING) {
+        lb_r = vec_lb_through(c, on, [&](int j) { return c.own(j); }, own_io);
+        la_r = vec_lb_through(c, on, [&](int j) { return tab[j] < nl ? c.own(j) + s_right * c.dl(tab[j]) : c.own(j); }, own_io);
+      } else {
+        lb_r = vec_lb_through(c, on, [&](int j) { return c.own(j); }, own_io);
+        la_r = vec_lb_through(c, on, [&](int j) { return c.own(j) + s_right * c.dl(j); }, own_io);
+      }
+      before = lb_l + lb_r; after = la_l + la_r;
+    }
+    C::sync();
+    return fabs(after - before);
+  };
   // MaximizePotentialAndComputePrimal between the receives and the sends (vector factors of a COMPUTE_PRIMAL type)
   auto round_label = [&]() {
     if (!((flags & SWEEP_PRIMAL) && (rec.kind_flags & UPD_PRIMAL) && okind == LPMP_F_VECTOR)) return;
@@ -323,11 +408,34 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
       for (int i = c.first(); i < on; i += C::STRIDE) c.snap(i) = c.own(i);
       C::sync();
     }
+    if (k == rec.n_recv && (flags & SWEEP_ADAPTIVE)) break;   // the sends of the adaptive rule follow below
     const Op op = nxt;
     if (k + 1 < n_ops) nxt = ops[rec.op_begin + k + 1];   // requested before this op's dependent chain starts
     run_op(op, k < rec.n_recv, false, op.omega);
   }
   if (rec.n_recv == n_ops) round_label();
+  if ((flags & SWEEP_ADAPTIVE) && rec.n_send > 0) {
+    // send_messages_with_adaptive_weights (reference factors_messages.hxx:2860-2926, non-batch branch): the dual
+    // improvement of every active message for weight 1, then adaptive_weight_rescaling (:2846-2857):
+    // w = omega / 2 + omega_sum / 2 * improvement / improvement_sum if that sum is positive, else the improvements
+    // themselves (all 0: nothing is sent); then SendMessages(w) from the state after the receives.
+    // (inactive entries have weight and improvement 0: they change neither sum)
+    for (int k = 0; k < rec.n_send; ++k) {
+      const Op op = ops[rec.op_begin + rec.n_recv + k];
+      const double v = (op.info & OP_HAS_IMPROVEMENT) ? improvement(op) : 0.0;
+      if (c.leader()) c.imp(k) = v;
+    }
+    C::sync();
+    double isum = 0.0, osum = 0.0;
+    for (int k = 0; k < rec.n_send; ++k) { isum += c.imp(k); osum += ops[rec.op_begin + rec.n_recv + k].omega; }
+    if (isum > 0) {
+      for (int k = 0; k < rec.n_send; ++k) {
+        const Op op = ops[rec.op_begin + rec.n_recv + k];
+        const double w = 0.5 * op.omega + 0.5 * osum * c.imp(k) / isum;
+        if (w != 0.0) run_op(op, false, false, w);
+      }
+    }
+  }
   if (flags & SWEEP_RESIDUAL) {   // reference send_messages_residual, factors_messages.hxx:2960-3007
     double residual = 0.0;
     for (int k = rec.n_recv; k < n_ops; ++k) {
@@ -1607,5 +1715,6 @@ void launch_synth_fill(double* out, int64_t n, uint64_t seed, uint64_t first, hi
 }
 
 int generic_max_dual() { return GEN_MAXD; }
+int generic_max_adaptive_sends() { return GEN_ADAPTIVE_SENDS; }
 
 }  // namespace lpmp

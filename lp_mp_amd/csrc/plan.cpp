@@ -122,11 +122,18 @@ void Plan::build(const lpmp_model& m) {
     f_doff[f + 1] = f_doff[f] + ds;
     max_dual = std::max<int64_t>(max_dual, ds);
   }
+  if (m.n_part_pairs < 0 || (m.n_part_pairs > 0 && !m.part_pairs)) fail("partition pairs missing");
+  part_pairs.assign(m.part_pairs, m.part_pairs + 2 * m.n_part_pairs);
+  for (int32_t x : part_pairs) if (x < 0 || x >= nf) fail("put_in_same_partition: factor out of range");
+  part = Partition();
   m_type.assign(m.m_type, m.m_type + nm);
   m_left.assign(m.m_left, m.m_left + nm);
   m_right.assign(m.m_right, m.m_right + nm);
+  any_batch = false;
   for (int t = 0; t < n_mtypes; ++t) {
     const auto& mt = mtypes[t];
+    if (mt.flags & ~(LPMP_MF_IMPROVEMENT | LPMP_MF_BATCH_TO_RIGHT | LPMP_MF_BATCH_TO_LEFT)) fail("message type " + std::to_string(t) + ": unknown flags");
+    any_batch = any_batch || (mt.flags & (LPMP_MF_BATCH_TO_RIGHT | LPMP_MF_BATCH_TO_LEFT)) != 0;
     if (mt.left_ftype < 0 || mt.left_ftype >= n_ftypes || mt.right_ftype < 0 || mt.right_ftype >= n_ftypes)
       fail("message type " + std::to_string(t) + ": factor type out of range");
     if (mt.schedule < 0 || mt.schedule > LPMP_SCHED_NONE) fail("message type " + std::to_string(t) + ": bad schedule");
@@ -364,6 +371,21 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       }
   }
   if (N > std::numeric_limits<int32_t>::max()) fail("too many updates for one schedule");
+  // batch-capable message ops: the weights the individual sends end up with (CallSendMessages' batch rule)
+  std::vector<double> eff_store;
+  if (any_batch) {
+    size_t total = 0;
+    for (int64_t u = 0; u < N; ++u) total += (size_t)row_sends(uf[u]);
+    eff_store.resize(total + 1);
+    size_t at = 0;
+    for (int64_t u = 0; u < N; ++u) {
+      const int64_t ns = row_sends(uf[u]);
+      for (int64_t k = 0; k < ns; ++k) if (uom[u][k] < 0) fail("negative send weight");
+      effective_send_weights(uf[u], uom[u], eff_store.data() + at);
+      uom[u] = eff_store.data() + at;
+      at += (size_t)ns;
+    }
+  }
   std::vector<int32_t> last_level(nf, 0), last_toucher(nf, -1), last_update_of(nf, -1);
   int32_t max_level = 0;
   std::vector<int32_t> touched;
@@ -457,7 +479,8 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
           imp = (f_flags[right] & LPMP_FF_IMPLICIT_ORIGIN) ? 1 : 0;
         }
       }
-      op.info = mt.kind | (e.role << 4) | (side << 5) | (imp << 6) | (f_kind[peer] << 8);
+      op.info = mt.kind | (e.role << 4) | (side << 5) | (imp << 6) | ((f_flags[peer] & LPMP_FF_IMPLICIT_ORIGIN) ? 1 << 7 : 0) | (f_kind[peer] << 8) |
+                ((mt.flags & LPMP_MF_IMPROVEMENT) ? OP_HAS_IMPROVEMENT : 0);
       if (std::max(op.len, std::max(op.pd0, op.pd1)) > SMALL_MAXD || f_doff[f + 1] - f_doff[f] > SMALL_MAXD) small_ok[o] = 0;
       if (!(mt.kind == LPMP_M_UNARY_PAIRWISE && e.role == 1 && f_kind[f] != LPMP_F_VECTOR && f_kind[peer] == LPMP_F_VECTOR &&
             f_dim1[f] > 0 && op.len == (side == 0 ? f_dim0[f] : f_dim1[f]))) pw_right[o] = 0;
@@ -498,6 +521,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   std::vector<int32_t> kclass(N, KC_GENERIC);
   auto cls_of = [&](int64_t u) -> int32_t {
     const int d0 = f_dim0[uf[u]];
+    if (force_generic) return small_ok[u] && n_send_of[u] <= SMALL_MAXD ? KC_SMALL : KC_GENERIC;
     if (f_kind[uf[u]] != LPMP_F_VECTOR) {                  // updated pairwise factors
       if (small_ok[u]) return KC_SMALL;
       const int w = std::max(f_dim0[uf[u]], f_dim1[uf[u]]);
@@ -653,6 +677,133 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       const UpdRec& r = out.recs[i];
       std::memcpy(slot, &r, sizeof(Op));
       for (int k = 0; k < r.n_recv + r.n_send; ++k) slot[1 + k] = out.ops[r.op_begin + k];
+    }
+  }
+}
+
+// reference factors_messages.hxx:2699-2744.  A dispatcher = the run of list entries with one message type and role; a
+// batch-capable one (MessageDispatcher::CanCallSendMessages: SendMessagesToRight for left-role entries, ...ToLeft for
+// right-role ones) with MORE THAN ONE active message (omega > 0) makes one call with the sum of the run's weights;
+// the device batch op (lpmp_msg_flags) gives each active message sum / n_active times the plain message.
+void Plan::effective_send_weights(int32_t f, const double* omega, double* w) const {
+  int64_t k = 0;
+  for (int64_t j = fm_off[f]; j < fm_off[f + 1];) {
+    int64_t j2 = j;
+    while (j2 < fm_off[f + 1] && m_type[fm[j2].msg] == m_type[fm[j].msg] && fm[j2].role == fm[j].role) ++j2;
+    if (!fm[j].sends) { j = j2; continue; }
+    const int64_t n = j2 - j;
+    const int fl = mtypes[m_type[fm[j].msg]].flags;
+    const bool batch = fm[j].role == 0 ? (fl & LPMP_MF_BATCH_TO_RIGHT) != 0 : (fl & LPMP_MF_BATCH_TO_LEFT) != 0;
+    if (batch) {
+      int64_t n_active = 0; double sum = 0.0;
+      for (int64_t i = 0; i < n; ++i) { if (omega[k + i] > 0.0) ++n_active; sum += omega[k + i]; }
+      const double each = n_active > 1 ? sum / double(n_active) : 0.0;
+      for (int64_t i = 0; i < n; ++i) w[k + i] = omega[k + i] > 0.0 ? (n_active > 1 ? each : omega[k + i]) : 0.0;
+    } else {
+      for (int64_t i = 0; i < n; ++i) w[k + i] = omega[k + i];
+    }
+    k += n; j = j2;
+  }
+}
+
+// send_messages_with_adaptive_weights (reference factors_messages.hxx:2860-2926) walks ALL dispatchers of the factor
+// with the iterator over the SENDING weights: defined only when every message of an updated factor sends; its batch
+// branch (and send_messages_residual's) calls op members no device op is defined for
+std::string Plan::adaptive_obstacle() const {
+  if (any_batch) return "adaptive sends with batch-capable message ops are not built";
+  for (int64_t f = 0; f < nf; ++f) {
+    if (!updated[f]) continue;
+    bool any = false, all = true;
+    for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) { any = any || fm[j].sends; all = all && fm[j].sends; }
+    if (any && !all) return "adaptive sends: factor " + std::to_string(f) + " has messages it does not send through (undefined in the reference)";
+  }
+  return "";
+}
+
+// ---- partition sweeps (reference LP_MP.h:1717-1843).  union_find.hxx:5-93: union by size, the first argument's root
+// wins ties, contiguous ids in increasing root index; partitions without updated factors are dropped (:1736-1745).
+// Intra-partition order: the reference sorts by position in forwardOrdering_ with a comparator that is false for every
+// pair (`std::get<0>(a) < std::get<0>(a)`, :1775), so the result depends on the standard library's sort; the engine
+// keeps the order the partition was populated in (insertion order of the updated factors, :1755-1760) — what a stable
+// sort returns for that comparator, and what libstdc++'s std::sort leaves for partitions of up to 16 factors.
+void Plan::ensure_partition() {
+  if (part.valid) return;
+  part = Partition();
+  std::vector<int64_t> id(nf), sz(nf, 1);
+  std::iota(id.begin(), id.end(), 0);
+  auto find = [&](int64_t p) {
+    int64_t root = p;
+    while (root != id[root]) root = id[root];
+    while (p != root) { const int64_t nx = id[p]; id[p] = root; p = nx; }
+    return root;
+  };
+  for (size_t k = 0; k + 1 < part_pairs.size(); k += 2) {
+    const int64_t i = find(part_pairs[k]), j = find(part_pairs[k + 1]);
+    if (i == j) continue;
+    if (sz[i] < sz[j]) { id[i] = j; sz[j] += sz[i]; } else { id[j] = i; sz[i] += sz[j]; }
+  }
+  std::vector<int64_t> root_id(nf, -1), count;
+  for (int64_t i = 0; i < nf; ++i) root_id[find(i)] = 1;
+  int64_t next = 0;
+  for (int64_t d = 0; d < nf; ++d) if (root_id[d] == 1) root_id[d] = next++;
+  count.assign(next, 0);
+  for (int64_t i = 0; i < nf; ++i) if (updated[i]) count[root_id[find(i)]]++;
+  std::vector<int64_t> part_of(next, -1);
+  int64_t P = 0;
+  for (int64_t c = 0; c < next; ++c) if (count[c] > 0) part_of[c] = P++;
+  if (P == 0) fail("partition sweeps: the model has no updated factor");
+  part.off.assign(P + 1, 0);
+  for (int64_t c = 0; c < next; ++c) if (part_of[c] >= 0) part.off[part_of[c] + 1] = count[c];
+  std::partial_sum(part.off.begin(), part.off.end(), part.off.begin());
+  part.f.resize(part.off[P]);
+  {
+    std::vector<int64_t> cur(part.off.begin(), part.off.end() - 1);
+    for (int64_t i = 0; i < nf; ++i) if (updated[i]) part.f[cur[part_of[root_id[find(i)]]]++] = (int32_t)i;
+  }
+  auto seg = [&](int64_t a, bool rev_a, int64_t b, bool rev_b) {
+    SegList s;
+    auto push = [&](int64_t p, bool rev) {
+      if (p < 0) return;
+      const int32_t* x = part.f.data() + part.off[p]; const int64_t n = part.off[p + 1] - part.off[p];
+      for (int64_t i = 0; i < n; ++i) s.f.push_back(rev ? x[n - 1 - i] : x[i]);
+    };
+    push(a, rev_a); push(b, rev_b);
+    anisotropic_weights(s.f.data(), (int64_t)s.f.size(), s.om, s.mk);
+    return s;
+  };
+  for (int64_t i = 0; i < P; ++i) { part.fwd.push_back(seg(i, false, -1, false)); part.bwd.push_back(seg(i, true, -1, false)); }
+  for (int64_t i = 0; i + 1 < P; ++i) {
+    part.push_fwd.push_back(seg(i, false, i + 1, true));      // :1806-1811
+    part.ov_fwd.push_back(seg(i, false, i + 1, true));        // :1835-1836
+    part.ov_bwd.push_back(seg(i + 1, false, i, true));        // :1838-1839
+  }
+  for (int64_t ri = 0; ri + 1 < P; ++ri) { const int64_t i = P - ri - 1; part.push_bwd.push_back(seg(i, false, i - 1, true)); }   // :1813-1820
+  part.valid = true;
+}
+
+void Plan::partition_pass_segments(int rtype, int inner, std::vector<Segment>& out) {
+  ensure_partition();
+  const int64_t P = (int64_t)part.fwd.size();
+  auto add = [&](const SegList& s) { out.push_back({s.f.data(), (int64_t)s.f.size(), s.om.off.data(), s.om.data.data(), s.mk.off.data(), s.mk.data.data()}); };
+  if (rtype == 2) {            // compute_partition_pass, LP_MP.h:1932-1963
+    for (int64_t i = 0; i < P; ++i) {
+      for (int it = 0; it < inner; ++it) { add(part.fwd[i]); add(part.bwd[i]); }
+      if (i < P - 1) add(part.push_fwd[i]);
+    }
+    for (int64_t ri = 0; ri < P; ++ri) {
+      const int64_t i = P - ri - 1;
+      for (int it = 0; it < inner; ++it) { add(part.fwd[i]); add(part.bwd[i]); }
+      if (i != 0) add(part.push_bwd[ri]);
+    }
+  } else {                     // compute_overlapping_partition_pass, LP_MP.h:2024-2050
+    for (int64_t i = 0; i + 1 < P; ++i) {
+      for (int it = 0; it < inner; ++it) { add(part.ov_fwd[i]); add(part.ov_bwd[i]); }
+      add(part.ov_fwd[i]);
+    }
+    for (int64_t ri = 1; ri < P; ++ri) {
+      const int64_t i = P - ri - 1;
+      for (int it = 0; it < inner; ++it) { add(part.ov_bwd[i]); add(part.ov_fwd[i]); }
+      add(part.ov_bwd[i]);
     }
   }
 }

@@ -33,6 +33,7 @@ struct Csr {
 
 // Device-side records (plain structs shared with kernels.hip) -----------------------------------
 enum OpCode : int32_t { OP_UP = 0, OP_LABELING = 1, OP_MINNORM = 2 };
+constexpr int32_t OP_HAS_IMPROVEMENT = 1 << 12;   // Op::info: the message op defines send_message_to_*_improvement
 
 struct alignas(16) UpdRec {   // one updated factor
   int64_t dual_off;   // own dual start
@@ -49,7 +50,7 @@ struct alignas(16) Op {       // one active receive or send
   int64_t peer_dual;  // peer dual start
   int64_t peer_const; // peer const start (pairwise peer), or offset of the match table in tab_data (labeling)
   double omega;       // send weight (receives: 1.0)
-  int32_t info;       // opcode | role<<4 | side<<5 | peer_implicit_origin<<6 | peer_kind<<8
+  int32_t info;       // opcode | role<<4 | side<<5 | right_implicit_origin<<6 | peer_implicit_origin<<7 | peer_kind<<8 | has_improvement<<12
   int32_t pd0;        // peer dim0
   int32_t pd1;        // peer dim1 (dense pairwise peer) / n_left of the table (labeling)
   int32_t peer;       // peer factor index (slot of its tracked lower bound)
@@ -106,6 +107,7 @@ constexpr int32_t UPD_PRIMAL = 1 << 17;       // UpdRec::kind_flags: the factor 
 // kernel flags of the sweep kernels
 constexpr int SWEEP_RESIDUAL = 1;   // --reparametrizationType residual
 constexpr int SWEEP_NT = 4;         // host-side selector: the model is far larger than the caches -> non-temporal variants
+constexpr int SWEEP_ADAPTIVE = 8;   // --reparametrizationType adaptive (generic kernels only)
 constexpr int SWEEP_PRIMAL = 2;     // UpdateFactorPrimal (reference factors_messages.hxx:2332-2373): factors of a
                                     // COMPUTE_PRIMAL type round their label from the state after the receives
 
@@ -145,6 +147,16 @@ struct Plan {
   Csr<uint8_t> mask[2][LPMP_REPAM_COUNT];
   bool have[LPMP_REPAM_COUNT] = {false, false, false, false};
   int max_dual = 1;
+  // LP::put_in_same_partition pairs (call order) and what construct_factor_partition derives from them
+  std::vector<int32_t> part_pairs;
+  struct SegList { std::vector<int32_t> f; Csr<double> om; Csr<uint8_t> mk; };   // a factor list with the weights of a pass over it
+  struct Partition {
+    bool valid = false;
+    std::vector<int64_t> off; std::vector<int32_t> f;          // partitions (updated factors only), CSR
+    std::vector<SegList> fwd, bwd, push_fwd, push_bwd, ov_fwd, ov_bwd;
+  } part;
+  bool any_batch = false;        // some message op has a static batch send (lpmp_msg_flags)
+  bool force_generic = false;    // schedule every update on the generic kernels (adaptive sends)
 
   // throws std::runtime_error on invalid input (the reference throws too, LP_MP.h:458)
   void build(const lpmp_model& m);
@@ -158,6 +170,15 @@ struct Plan {
                      const int64_t* mk_off, const uint8_t* mk, Schedule& out) const;
   int64_t row_sends(int32_t f) const;
   int64_t row_receives(int32_t f) const;
+  // LP::construct_factor_partition / construct_overlapping_factor_partition (reference LP_MP.h:1717-1843)
+  void ensure_partition();
+  // the iterator-range passes of compute_partition_pass (rtype 2, LP_MP.h:1932-1963) or
+  // compute_overlapping_partition_pass (rtype 3, :1966-2051; without the plain sweeps that follow it), in order
+  void partition_pass_segments(int rtype, int inner_iterations, std::vector<Segment>& out);
+  // CallSendMessages' batch rule (reference factors_messages.hxx:2709-2726) as the weights the individual sends get
+  void effective_send_weights(int32_t f, const double* omega, double* w) const;
+  // why the adaptive send rule cannot run this model ("" if it can)
+  std::string adaptive_obstacle() const;
 };
 
 }  // namespace lpmp

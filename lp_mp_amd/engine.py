@@ -41,7 +41,7 @@ EXPORTS = [
     "lpmp_plan_n_updated", "lpmp_plan_get_order", "lpmp_plan_get_update_order", "lpmp_plan_omega_nnz",
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
     "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_custom_schedule_info", "lpmp_plan_schedule_classes", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_plan_pass_rotates", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
-    "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_set_reparametrization_type", "lpmp_compute_pass", "lpmp_compute_forward_pass",
+    "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_set_reparametrization_type", "lpmp_set_inner_iterations", "lpmp_plan_get_partitions", "lpmp_compute_pass", "lpmp_compute_forward_pass",
     "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_create_fused", "lpmp_schedule_run",
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
     "lpmp_invalidate_lower_bounds", "lpmp_synchronize", "lpmp_dual_size", "lpmp_download_duals", "lpmp_upload_duals", "lpmp_device_duals",
@@ -100,6 +100,8 @@ def lib():
         L.lpmp_upload_model.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.lpmp_set_reparametrization.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_set_reparametrization_type.argtypes = [C.c_void_p, C.c_int]
+        L.lpmp_set_inner_iterations.argtypes = [C.c_void_p, C.c_int]
+        L.lpmp_plan_get_partitions.argtypes = [C.c_void_p] * 4
         L.lpmp_compute_pass.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_compute_forward_pass.argtypes = [C.c_void_p]
         L.lpmp_compute_backward_pass.argtypes = [C.c_void_p]
@@ -266,6 +268,20 @@ def _pass_rotates(self, mode: int) -> bool:
 Plan.pass_rotates = _pass_rotates
 
 
+def _partitions(self):
+    """LP::construct_factor_partition (reference LP_MP.h:1717-1822): the components of the put_in_same_partition
+    graph as arrays of (updated) factor indices"""
+    n = C.c_int64()
+    _chk(self.L.lpmp_plan_get_partitions(self.h, C.addressof(n), None, None))
+    off = np.empty(n.value + 1, np.int64)
+    f = np.empty(max(1, self.L.lpmp_plan_n_updated(self.h, 0)), np.int32)
+    _chk(self.L.lpmp_plan_get_partitions(self.h, C.addressof(n), off.ctypes.data, f.ctypes.data))
+    return [f[off[i]:off[i + 1]].copy() for i in range(n.value)]
+
+
+Plan.partitions = _partitions
+
+
 class Engine:
     """Device engine. ``const_dev`` / ``dual_dev``: optional device pointers (ints) of caller-owned HBM
     buffers holding the packed pairwise tables / duals (zero-copy; the caller keeps them alive)."""
@@ -307,8 +323,12 @@ class Engine:
         _chk(self.L.lpmp_set_reparametrization(self.h, int(mode)))
 
     def set_reparametrization_type(self, rtype: int):
-        """0 shared, 1 residual (reference --reparametrizationType)."""
+        """reference --reparametrizationType: 0 shared, 1 residual, 2 partition, 3 overlapping_partition, 4 adaptive"""
         _chk(self.L.lpmp_set_reparametrization_type(self.h, int(rtype)))
+
+    def set_inner_iterations(self, n: int):
+        """reference --innerIteration: passes per partition in the partition sweeps (default 5)"""
+        _chk(self.L.lpmp_set_inner_iterations(self.h, int(n)))
 
     def compute_pass(self, n: int = 1):
         _chk(self.L.lpmp_compute_pass(self.h, int(n)))

@@ -95,6 +95,7 @@ class UnaryPairwiseMessage:
     """UnaryPairwiseMessage<Chirality> (reference test/simplex_marginalization.cpp:19-20); side 0 = left variable."""
     side: int
     kind: int = M.M_UNARY_PAIRWISE
+    flags: int = 0      # M.MF_*: optional members of the op (improvement for adaptive sends, static batch sends)
 
 
 @dataclass(frozen=True)
@@ -166,9 +167,9 @@ class LP:
 
     REPARAMETRIZATION_TYPES = {"shared": 0, "residual": 1, "partition": 2, "overlapping_partition": 3, "adaptive": 4}
 
-    def __init__(self, fmc: FMC, device: int = 0, reparametrizationType: str = "shared"):
-        """reparametrizationType: the reference's --reparametrizationType (LP_MP.h:589-593); shared and residual
-        run on the device, the others raise when Begin() hands them to the engine."""
+    def __init__(self, fmc: FMC, device: int = 0, reparametrizationType: str = "shared", innerIteration: int = 5):
+        """reparametrizationType / innerIteration: the reference's --reparametrizationType and --innerIteration
+        (LP_MP.h:589-593); all five types run on the device."""
         if reparametrizationType not in self.REPARAMETRIZATION_TYPES:
             raise RuntimeError("reparametrization type " + reparametrizationType + " unknown")
         self._rtype = self.REPARAMETRIZATION_TYPES[reparametrizationType]
@@ -177,6 +178,8 @@ class LP:
         self._factors = []       # (container, op)
         self._messages = []      # (container, left, right)
         self._rel_fwd, self._rel_bwd = [], []
+        self._partition_graph = []
+        self._inner = int(innerIteration)
         self._tables = {}
         self._constant = 0.0
         self._repam = LPReparametrizationMode.Undefined
@@ -211,6 +214,10 @@ class LP:
 
     def BackwardPassFactorRelation(self, f1: int, f2: int):
         self._rel_bwd.append((f1, f2)); self._dirty = True
+
+    def put_in_same_partition(self, f1: int, f2: int):
+        """reference LP_MP.h:465"""
+        self._partition_graph.append((f1, f2)); self._dirty = True
 
     def GetNumberOfFactors(self) -> int:
         return len(self._factors)
@@ -247,7 +254,7 @@ class LP:
             op = mc.message_type
             param = op.side if op.kind == M.M_UNARY_PAIRWISE else (self._table_id(op) if op.kind == M.M_LABELING else 0)
             mtypes.append(M.MsgType(mc.left_factor_no, mc.right_factor_no, mc.schedule, mc.no_left_factors,
-                                    mc.no_right_factors, op.kind, param))
+                                    mc.no_right_factors, op.kind, param, getattr(op, "flags", 0)))
         b = M.ModelBuilder(len(fmc.FactorList), mtypes, [int(f.compute_primal) for f in fmc.FactorList])
         for key, _ in sorted(self._tables.items(), key=lambda kv: kv[1]):
             b.add_labeling_table(*key)
@@ -264,6 +271,8 @@ class LP:
             a = np.asarray(self._rel_fwd, np.int32); b.add_forward_relations(a[:, 0], a[:, 1])
         if self._rel_bwd:
             a = np.asarray(self._rel_bwd, np.int32); b.add_backward_relations(a[:, 0], a[:, 1])
+        if self._partition_graph:
+            a = np.asarray(self._partition_graph, np.int32); b.put_in_same_partition(a[:, 0], a[:, 1])
         b.constant = self._constant
         m = b.finish()
         if self._duals_host is not None:     # duals of factors that existed before a structural change
@@ -284,6 +293,7 @@ class LP:
             self._model = self.flat_model()
             self._engine.upload(self._model)
             self._dirty = False
+        self._engine.set_inner_iterations(self._inner)
         self._engine.set_reparametrization_type(self._rtype)
         return self._engine
 

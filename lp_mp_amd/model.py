@@ -25,6 +25,11 @@ SCHED_LEFT, SCHED_RIGHT, SCHED_FULL, SCHED_ONLY_SEND, SCHED_NONE = 0, 1, 2, 3, 4
 REPAM_ANISOTROPIC, REPAM_ANISOTROPIC2, REPAM_UNIFORM, REPAM_DAMPED_UNIFORM, REPAM_MIXED = 0, 1, 2, 3, 4
 REPAM_NAMES = {"anisotropic": 0, "anisotropic2": 1, "uniform": 2, "damped_uniform": 3, "mixed": 4}
 FORWARD, BACKWARD = 0, 1
+# enum lpmp_msg_flags
+MF_IMPROVEMENT, MF_BATCH_TO_RIGHT, MF_BATCH_TO_LEFT = 1, 2, 4
+# enum lpmp_reparametrization_type (reference --reparametrizationType, LP_MP.h:710-722)
+RTYPE_SHARED, RTYPE_RESIDUAL, RTYPE_PARTITION, RTYPE_OVERLAPPING_PARTITION, RTYPE_ADAPTIVE = 0, 1, 2, 3, 4
+RTYPE_NAMES = {"shared": 0, "residual": 1, "partition": 2, "overlapping_partition": 3, "adaptive": 4}
 # NO_OF_LEFT/RIGHT_FACTORS shorthands (reference include/config.hxx:60-66)
 variableMessageNumber = 0
 atMostOneMessage, atMostTwoMessages = -1, -2
@@ -32,7 +37,7 @@ atMostOneMessage, atMostTwoMessages = -1, -2
 
 class c_msg_type(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("left_ftype", "right_ftype", "schedule", "n_left", "n_right", "kind", "param", "reserved")]
+                ("left_ftype", "right_ftype", "schedule", "n_left", "n_right", "kind", "param", "flags")]
 
 
 class c_model(C.Structure):
@@ -45,6 +50,7 @@ class c_model(C.Structure):
         ("n_messages", C.c_int64), ("m_type", C.c_void_p), ("m_left", C.c_void_p), ("m_right", C.c_void_p),
         ("n_rel_fwd", C.c_int64), ("rel_fwd", C.c_void_p), ("n_rel_bwd", C.c_int64), ("rel_bwd", C.c_void_p),
         ("constant", C.c_double),
+        ("n_part_pairs", C.c_int64), ("part_pairs", C.c_void_p),
     ]
 
 
@@ -58,6 +64,7 @@ class MsgType:
     n_right: int = 1
     kind: int = M_UNARY_PAIRWISE
     param: int = 0
+    flags: int = 0          # MF_* : optional members of the message op (include/lpmp_model.h, enum lpmp_msg_flags)
 
 
 def _ptr(a: Optional[np.ndarray]):
@@ -85,7 +92,13 @@ class FlatModel:
     rel_fwd: np.ndarray                # [n,2] int32
     rel_bwd: np.ndarray
     constant: float = 0.0
+    part_pairs: Optional[np.ndarray] = None   # [n,2] int32: put_in_same_partition(f1, f2) calls in call order
     _keep: list = field(default_factory=list, repr=False)
+
+    def __getstate__(self):          # the ctypes views of c_struct() are per process and rebuilt on demand
+        d = dict(self.__dict__)
+        d["_keep"] = []
+        return d
 
     @property
     def n_factors(self) -> int:
@@ -115,7 +128,7 @@ class FlatModel:
         """ctypes view; arrays stay owned by ``self`` (borrowed for the duration of a call)."""
         mt = (c_msg_type * max(1, len(self.mtypes)))()
         for i, t in enumerate(self.mtypes):
-            mt[i] = c_msg_type(t.left_ftype, t.right_ftype, t.schedule, t.n_left, t.n_right, t.kind, t.param, 0)
+            mt[i] = c_msg_type(t.left_ftype, t.right_ftype, t.schedule, t.n_left, t.n_right, t.kind, t.param, t.flags)
         self._keep = [mt]
         m = c_model()
         m.n_ftypes = self.n_ftypes
@@ -133,6 +146,11 @@ class FlatModel:
         m.n_rel_fwd, m.rel_fwd = int(self.rel_fwd.shape[0]), _ptr(self.rel_fwd)
         m.n_rel_bwd, m.rel_bwd = int(self.rel_bwd.shape[0]), _ptr(self.rel_bwd)
         m.constant = float(self.constant)
+        if self.part_pairs is not None and len(self.part_pairs):
+            self.part_pairs = np.ascontiguousarray(self.part_pairs, np.int32).reshape(-1, 2)
+            m.n_part_pairs, m.part_pairs = int(self.part_pairs.shape[0]), _ptr(self.part_pairs)
+        else:
+            m.n_part_pairs, m.part_pairs = 0, None
         return m
 
 
@@ -154,6 +172,7 @@ class ModelBuilder:
         self._nm = 0
         self._rel_fwd = []
         self._rel_bwd = []
+        self._part = []
         self.constant = 0.0
         self.skip_const = False  # True: const tables live only on the device (see Engine.upload)
 
@@ -234,6 +253,10 @@ class ModelBuilder:
         self._rel_fwd.append(np.stack([f1, f2], 1))
         self._rel_bwd.append(np.stack([f2, f1], 1))
 
+    def put_in_same_partition(self, f1, f2):
+        """LP::put_in_same_partition(f1, f2) (reference LP_MP.h:465)"""
+        self._part.append(np.stack([np.atleast_1d(np.asarray(f1, np.int32)), np.atleast_1d(np.asarray(f2, np.int32))], 1))
+
     def add_forward_relations(self, f1, f2):
         self._rel_fwd.append(np.stack([np.atleast_1d(np.asarray(f1, np.int32)), np.atleast_1d(np.asarray(f2, np.int32))], 1))
 
@@ -256,4 +279,5 @@ class ModelBuilder:
             m_right=cat([c[2] for c in self._m], np.int32),
             rel_fwd=cat(self._rel_fwd, np.int32, (0, 2)).astype(np.int32).reshape(-1, 2),
             rel_bwd=cat(self._rel_bwd, np.int32, (0, 2)).astype(np.int32).reshape(-1, 2),
-            constant=self.constant)
+            constant=self.constant,
+            part_pairs=cat(self._part, np.int32, (0, 2)).astype(np.int32).reshape(-1, 2) if self._part else None)

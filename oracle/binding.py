@@ -42,6 +42,10 @@ def lib():
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_set_mode.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_reparametrization_type.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_inner_iterations.argtypes = [C.c_void_p, C.c_int]
+        L.orc_n_partitions.restype = C.c_int64
+        L.orc_n_partitions.argtypes = [C.c_void_p]
+        L.orc_get_partitions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_compute_pass.argtypes = [C.c_void_p, C.c_int]
         L.orc_forward_pass.argtypes = [C.c_void_p]
         L.orc_backward_pass.argtypes = [C.c_void_p]
@@ -94,6 +98,20 @@ class Oracle:
 
     def set_reparametrization_type(self, rtype: int):
         self._chk(self.L.orc_set_reparametrization_type(self.h, int(rtype)))
+
+    def set_inner_iterations(self, n: int):
+        """--innerIteration of the partition sweeps (reference LP_MP.h:590)"""
+        self._chk(self.L.orc_set_inner_iterations(self.h, int(n)))
+
+    def partitions(self):
+        """LP::construct_factor_partition: list of factor-index arrays (updated factors only)"""
+        n = self.L.orc_n_partitions(self.h)
+        if n < 0:
+            self._chk(-1)
+        off = np.empty(n + 1, np.int64)
+        f = np.empty(max(self.L.orc_n_updated(self.h, 0), 1), np.int32)
+        self._chk(self.L.orc_get_partitions(self.h, off.ctypes.data, f.ctypes.data))
+        return [f[off[i]:off[i + 1]].copy() for i in range(n)]
 
     def ComputePass(self, n: int = 1):
         self._chk(self.L.orc_compute_pass(self.h, int(n)))

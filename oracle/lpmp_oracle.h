@@ -27,7 +27,11 @@ void orc_destroy(orc_t* o);
 const char* orc_last_error(void);
 
 int orc_set_mode(orc_t* o, int repam_mode);             /* LP::set_reparametrization */
-int orc_set_reparametrization_type(orc_t* o, int rtype); /* --reparametrizationType: 0 shared, 1 residual (LP_MP.h:710-722) */
+int orc_set_reparametrization_type(orc_t* o, int rtype); /* --reparametrizationType, enum lpmp_reparametrization_type numbering: 0 shared, 1 residual, 2 partition, 3 overlapping_partition, 4 adaptive (LP_MP.h:710-722) */
+int orc_set_inner_iterations(orc_t* o, int n);           /* --innerIteration (LP_MP.h:590), default 5 */
+/* LP::construct_factor_partition (LP_MP.h:1717-1822): the partitions of the put_in_same_partition graph */
+int64_t orc_n_partitions(orc_t* o);
+int orc_get_partitions(orc_t* o, int64_t* off /*[n_partitions+1]*/, int32_t* factors /*[n_updated]*/);
 int orc_compute_pass(orc_t* o, int n_passes);           /* LP::ComputePass, default 'shared' type */
 int orc_forward_pass(orc_t* o);                         /* LP::ComputeForwardPass */
 int orc_backward_pass(orc_t* o);                        /* LP::ComputeBackwardPass */

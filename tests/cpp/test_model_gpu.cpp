@@ -9,7 +9,7 @@
 #include <iostream>
 #include <stdexcept>
 
-#include "LP_gpu.hxx"
+#include "LP_gpu_solver.hxx"   // LP_gpu.hxx (containers, LP) + Solver / StandardVisitor
 
 using namespace LP_MP;
 

@@ -143,6 +143,51 @@ class Canaries:
             self.blocks[k] = (q, size, tag)
 
 
+class _DryRunEngine:
+    """--dry-run: stands in for the HIP engine with an in-process oracle so that the harness itself (server, proxy,
+    pickling, canaries) can be exercised on a machine without a GPU.  Never used for a parity claim."""
+
+    def __init__(self, device=0):
+        self.o = None
+        self.rtype = 0
+
+    def upload(self, m):
+        from oracle.binding import Oracle
+        self.m = m
+        self.o = Oracle(m)
+        self.o.set_reparametrization_type(self.rtype)
+
+    def set_reparametrization_type(self, r):
+        self.rtype = r
+        if self.o is not None:
+            self.o.set_reparametrization_type(r)
+
+    def set_reparametrization(self, mode): self.o.set_reparametrization(mode)
+    def compute_pass(self, n=1): self.o.ComputePass(n)
+    def forward_pass(self): self.o.ComputeForwardPass()
+    def backward_pass(self): self.o.ComputeBackwardPass()
+    def lower_bound(self): return self.o.LowerBound()
+    def download_duals(self): return self.o.duals()
+    def compute_pass_custom(self, *rows): self.o.compute_pass_custom(*rows)
+    def factor_lower_bounds(self):
+        import numpy as np
+        return np.array([self.o.factor_lower_bound(f) for f in range(self.m.n_factors)])
+
+    def schedule_create(self, *rows, fuse=False):
+        self.rows = rows
+        return 0
+
+    def schedule_run(self, sid): self.o.compute_pass_custom(*self.rows)
+    def schedule_destroy(self, sid): pass
+    def forward_pass_and_primal(self, it): self.o.ComputeForwardPassAndPrimal(it)
+    def backward_pass_and_primal(self, it): self.o.ComputeBackwardPassAndPrimal(it)
+    def compute_pass_and_primal(self, it): self.o.ComputePassAndPrimal(it)
+    def download_primal(self): return self.o.primal()
+    def check_primal_consistency(self): return self.o.CheckPrimalConsistency()
+    def evaluate_primal(self): return self.o.EvaluatePrimal()
+    def close(self): pass
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
@@ -152,6 +197,7 @@ def main():
     ap.add_argument("--canaries", type=int, default=4000)
     ap.add_argument("--families", default="0123")
     ap.add_argument("--in-process-oracle", action="store_true", help="control run: the round-1 arrangement")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the harness with a stand-in engine")
     args = ap.parse_args()
 
     # the server starts BEFORE this process loads HIP: a child created later would be forked from a GPU process
@@ -167,6 +213,8 @@ def main():
     import test_fuzz_gpu as T
     if srv is not None:
         T.Oracle = RemoteOracle
+    if args.dry_run:
+        T.E.Engine = _DryRunEngine
     fams = [T.test_random_models_all_modes_and_custom_passes, T.test_random_mrfs_fast_kernels_multi_pass_calls_and_fused_custom_schedules,
             T.test_random_mrfs_any_label_count_runtime_dims_kernels, T.test_random_mrfs_primal_rounding]
     fams = [fams[int(c)] for c in args.families]

@@ -1,32 +1,54 @@
-"""The C++ host-side mirror (lp_mp_amd/include/LP_gpu.hxx): compile the reference-style test program with
-g++ against the C ABI library; run its host-only part here and the full program on the GPU."""
+"""The C++ side of the drop-in boundary, compiled with g++ against the C ABI library:
+
+  test_model_gpu     the standalone mirror (lp_mp_amd/include/LP_gpu.hxx + LP_gpu_solver.hxx) running the reference's
+                     own test programs (test/test_model.cpp, test/graphical_model.cpp, test/multicut.cpp)
+  test_offload_mock  lp_mp_amd/include/lpmp_offload.hxx taking a reference-SHAPED LP<FMC> (tests/cpp/mock_reference_lp.hxx:
+                     the reference's member names and container surface, its own sweep absent) to the device through
+                     serialize_dual, with kinds registered outside the ops; in the same translation unit as LP_gpu.hxx
+
+Host-only parts run here, the full programs on the GPU."""
 import os
 import subprocess
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROGRAMS = ["test_model_gpu", "test_offload_mock"]
 
 
-def _build(tmp_path):
+def _build(tmp_path, name):
     from lp_mp_amd import build as B
     B.build()
-    exe = str(tmp_path / "test_model_gpu")
+    exe = str(tmp_path / name)
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror",
-                           "-I", os.path.join(ROOT, "lp_mp_amd", "include"),
-                           "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_model_gpu.cpp"),
+                           "-I", os.path.join(ROOT, "lp_mp_amd", "include"), "-I", os.path.join(ROOT, "tests", "cpp"),
+                           "-o", exe, os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
                            "-L", B.CSRC, "-llpmp_engine", "-Wl,-rpath," + B.CSRC])
     return exe
 
 
-def test_cpp_mirror_compiles_and_host_part_passes(tmp_path):
-    exe = _build(tmp_path)
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_cpp_program_compiles_and_host_part_passes(tmp_path, name):
+    exe = _build(tmp_path, name)
     out = subprocess.check_output([exe, "--host-only"], text=True)
     assert "all tests passed" in out
 
 
+def test_offload_header_defines_no_reference_names():
+    """lpmp_offload.hxx must be includable next to the reference's headers: it may not open namespace LP_MP"""
+    import re
+    src = open(os.path.join(ROOT, "lp_mp_amd", "include", "lpmp_offload.hxx")).read()
+    code = re.sub(r"//[^\n]*", "", src)
+    assert not re.search(r"namespace\s+LP_MP\b", code)
+    for hdr in ("LP_gpu.hxx", "LP_gpu_solver.hxx"):
+        code = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "lp_mp_amd", "include", hdr)).read())
+        opened = re.findall(r"namespace\s+(LP_MP\w*)\s*\{", code)
+        assert opened and set(opened) <= {"LP_MP_gpu"}, opened      # LP_MP only ever appears as an alias, guarded
+
+
 @pytest.mark.gpu
-def test_cpp_mirror_full_run_on_device(tmp_path):
-    exe = _build(tmp_path)
+@pytest.mark.parametrize("name", PROGRAMS)
+def test_cpp_program_full_run_on_device(tmp_path, name):
+    exe = _build(tmp_path, name)
     out = subprocess.check_output([exe], text=True, timeout=600)
     assert "all tests passed" in out

@@ -339,3 +339,70 @@ def test_pass_rotation_is_decided_op_by_op():
                 assert fb["n_receives"] == one[0]["n_receives"] + one[1]["n_receives"]
                 assert fb["n_sends"] == one[0]["n_sends"] + one[1]["n_sends"]
     assert n_rot > 0
+
+
+def test_partitions_and_batch_weights_match_oracle():
+    """construct_factor_partition (reference LP_MP.h:1717-1760: union-find components in root order, updated factors
+    only, insertion order inside) — engine host analysis against the oracle's restatement on random models"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_fuzz_gpu import random_model
+    for seed in range(40):
+        rng = np.random.default_rng(21000 + seed)
+        m = random_model(rng)
+        n = m.n_factors
+        m.part_pairs = rng.integers(0, n, size=(int(rng.integers(0, 2 * n)), 2)).astype(np.int32)
+        pe, po = E.Plan(m).partitions(), Oracle(m).partitions()
+        assert len(pe) == len(po) and all(np.array_equal(a, b) for a, b in zip(pe, po))
+        upd = set(Oracle(m).update_order(0).tolist())
+        assert sorted(np.concatenate(pe).tolist()) == sorted(upd)
+    bad = S.grid_model(3, 3, 2)
+    bad.part_pairs = np.array([[0, 99]], np.int32)
+    with pytest.raises(E.EngineError):
+        E.Plan(bad)
+    bad = S.grid_model(3, 3, 2)
+    bad.mtypes[0].flags = 64
+    with pytest.raises(E.EngineError):
+        E.Plan(bad)
+
+
+def test_oracle_partition_and_adaptive_rules_are_dual_ascent():
+    """properties of the oracle's restatement that need no reference value: every rule only reparametrises (the energy
+    of a fixed labeling is unchanged) and never lowers the bound; the improvement op is non-negative and zero for a
+    message whose sender has nothing to give"""
+    H, W, L = 5, 6, 4
+    mts = S.mrf_mtypes()
+    for t in mts:
+        t.flags = M.MF_IMPROVEMENT
+    var = S.grid_variable_order(H, W, "row_major").reshape(-1)
+    a, bb = S.grid_edges(H, W)
+    b = M.ModelBuilder(2, mts)
+    un = S.u01(H * W * L, 7).reshape(-1, L)
+    tb = S.u01(len(a) * L * L, 8).reshape(-1, L, L)
+    u = b.add_vector_factors(0, un)
+    p = b.add_dense_pairwise(1, tb)
+    b.add_interleaved_messages(np.tile(np.array([0, 1], np.int32), len(a)), np.stack([u[a], u[bb]], 1).reshape(-1), np.repeat(p, 2))
+    b.add_relations(np.stack([u[a], p], 1).reshape(-1), np.stack([p, u[bb]], 1).reshape(-1))
+    for k in range(len(a)):
+        if (a[k] % W) // 3 == (bb[k] % W) // 3:
+            b.put_in_same_partition(u[a[k]], u[bb[k]])
+    m = b.finish()
+    x = np.random.default_rng(0).integers(0, L, H * W)
+
+    def energy(d):
+        th = d[: H * W * L].reshape(-1, L)
+        pw = d[H * W * L:].reshape(-1, 2 * L)
+        e = th[np.arange(H * W), x].sum()
+        for k in range(len(a)):
+            e += tb[k, x[a[k]], x[bb[k]]] + pw[k, x[a[k]]] + pw[k, L + x[bb[k]]]
+        return e
+    for rtype in (M.RTYPE_PARTITION, M.RTYPE_OVERLAPPING_PARTITION, M.RTYPE_ADAPTIVE):
+        o = Oracle(m)
+        o.set_reparametrization_type(rtype); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+        e0, lb = energy(o.duals()), o.LowerBound()
+        for _ in range(4):
+            o.ComputePass(1)
+            assert o.LowerBound() >= lb - 1e-9
+            lb = o.LowerBound()
+            assert abs(energy(o.duals()) - e0) <= 1e-9
+        assert lb <= e0 + 1e-9 and lb > 0
