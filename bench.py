@@ -32,6 +32,13 @@ def parse():
     ap.add_argument("--pairwise", default="dense", choices=["dense", "potts"])
     ap.add_argument("--order", default="colour_major", choices=["colour_major", "row_major"])
     ap.add_argument("--mode", default="anisotropic")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
+                    help="c3: the headline grid (BASELINE.json configs[2], --grid/--labels/--pairwise/--order); c4: the random "
+                         "sparse graph of configs[3] (--c4-nodes/--c4-edges/--c4-labels), partitioned across the ranks, every "
+                         "rank generating only its own part in HBM")
+    ap.add_argument("--c4-nodes", type=int, default=2_000_000)
+    ap.add_argument("--c4-edges", type=int, default=10_000_000)
+    ap.add_argument("--c4-labels", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-grid", type=int, default=256)
     ap.add_argument("--also-row-major", action="store_true", help="also time the row-major ordering (extra key)")
@@ -96,6 +103,28 @@ def pmc_traffic(kernel_name, args):
     return d["hbm_bytes_per_launch_avg"], os.path.relpath(files[-1], ROOT)
 
 
+def dual_bound_gap_c4(torch, dist, args, mode, world, rank):
+    """the same for the C4 workload: a 20 000-node / 100 000-edge graph of the same generator, partitioned like the big
+    one (same partitioner, same boundary schedule) against its unpartitioned sweep on rank 0"""
+    from lp_mp_amd import engine as E, multi_gpu as MG, synthetic as S
+    n, m, L, passes = 20000, 100000, args.c4_labels, args.steps
+    sw = MG.GraphSweep(torch, dist, n, m, L, mode, seed=1)
+    sw.compute_pass(passes)
+    lb_part = sw.lower_bound()
+    out = None
+    if rank == 0:
+        e = E.Engine(torch.cuda.current_device())
+        e.upload(S.counter_graph_model(n, m, L, 1))
+        e.set_reparametrization(mode)
+        e.compute_pass(passes)
+        lb_ref = e.lower_bound()
+        e.close()
+        out = {"dual_bound_gap": (lb_ref - lb_part) / abs(lb_ref), "gap_config": f"G({n}, {m}), {L} labels in {world} parts, {passes} passes, "
+               f"boundary step every {sw.boundary_every}", "cut_fraction": sw.global_cut_fraction, "lb_partitioned": lb_part, "lb_unpartitioned": lb_ref}
+    sw.engine.close()
+    return out
+
+
 def dual_bound_gap(torch, dist, args, mode, world, rank):
     """Second half of BASELINE.json's metric.  Same partition schedule, same RCCL exchange, on strips small enough
     that rank 0 can also run the UNPARTITIONED (world*g) x g grid: gap = (LB_unpartitioned - LB_partitioned) /
@@ -147,8 +176,14 @@ def cpu_baseline(args, synthetic, M):
     """The oracle (single-threaded C restatement of the reference sweep; the reference sweep is
     single-threaded too) on a bounded sample of the same workload."""
     from oracle.binding import Oracle
-    g = min(args.cpu_sample_grid, args.grid)
-    m = synthetic.grid_model(g, g, args.labels, pairwise=args.pairwise, order=args.order, seed=1)
+    if getattr(args, "workload", "c3") == "c4":
+        n, e = min(args.c4_nodes, 40000), min(args.c4_edges, 200000)
+        m = synthetic.counter_graph_model(n, e, args.c4_labels, 1)
+        what = f"G({n}, {e}), {args.c4_labels} labels, dense pairwise"
+    else:
+        g = min(args.cpu_sample_grid, args.grid)
+        m = synthetic.grid_model(g, g, args.labels, pairwise=args.pairwise, order=args.order, seed=1)
+        what = f"{g}x{g} grid, {args.labels} labels, {args.pairwise} pairwise, {args.order}"
     o = Oracle(m)
     o.set_reparametrization(M.REPAM_NAMES[args.mode])
     o.ComputePass(1)
@@ -163,8 +198,7 @@ def cpu_baseline(args, synthetic, M):
             break
     r1, s1 = o.counters()
     return {"value": (r1 - r0 + s1 - s0) / dt, "unit": "msg-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{g}x{g} grid, {args.labels} labels, {args.pairwise} pairwise, {args.order}, {passes} passes, "
-                      f"oracle/lpmp_oracle.c single thread"}
+            "sample": f"{what}, {passes} passes, oracle/lpmp_oracle.c single thread"}
 
 
 def main():
@@ -193,7 +227,18 @@ def main():
     L = args.labels
     stream_ptr = torch.cuda.current_stream().cuda_stream
 
-    if world == 1:
+    dual = None
+    if args.workload == "c4":
+        from lp_mp_amd import multi_gpu as MG
+        L = args.c4_labels
+        runner = MG.GraphSweep(torch, dist if world > 1 else None, args.c4_nodes, args.c4_edges, L, mode, seed=1)
+        updates_per_pass = runner.global_updates_per_pass
+        bytes_per_pass = runner.global_bytes_per_pass
+        levels = runner.levels
+        eng = runner.engine
+        parallelism = (f"{world} parts (reverse Cuthill-McKee + balanced KL refinement), {100 * runner.global_cut_fraction:.1f} % of the edges cut, "
+                       f"boundary step every {runner.boundary_every}") if world > 1 else "1 GPU"
+    elif world == 1:
         m, const, dual = build_device_grid(torch, H, W, L, args.pairwise, args.order, 1, E, S, stream_ptr)
         eng = E.Engine(torch.cuda.current_device())
         eng.set_stream(stream_ptr)
@@ -225,7 +270,7 @@ def main():
     # (tests/golden/make_c3_full.py, seed 1); its lower bound and the checksums of its packed duals after the same
     # number of passes are compared with the state the timed passes left in HBM
     oracle_check = None
-    if world == 1:
+    if world == 1 and args.workload == "c3":
         oracle_check = golden_check(torch, args, dual, lb1)
 
     # roofline leg: the same passes again with every launch bracketed by HIP events on the engine's stream
@@ -239,7 +284,7 @@ def main():
     # outside the timed region: one pass with primal rounding (what MpRoundingSolver runs every 5th iteration,
     # reference solver.hxx:387-397) and LP::EvaluatePrimal
     rounding = None
-    if world == 1:
+    if world == 1 and args.workload == "c3":
         eng.compute_pass_and_primal(args.steps + args.warmup)      # first call builds the label-propagation lists
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -250,7 +295,7 @@ def main():
         rounding = {"ms_pass_and_primal": (t1 - t0) * 1e3, "ms_evaluate_primal": (time.perf_counter() - t1) * 1e3,
                     "primal_cost": cost, "lower_bound": eng.lower_bound()}
 
-    gap = dual_bound_gap(torch, dist, args, mode, world, rank) if world > 1 else \
+    gap = (dual_bound_gap_c4 if args.workload == "c4" else dual_bound_gap)(torch, dist, args, mode, world, rank) if world > 1 else \
         {"dual_bound_gap": 0.0, "gap_config": "1 GPU: the unpartitioned sweep itself"}
     out = None
     if rank == 0:
@@ -266,13 +311,16 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_launch_ms": avg_ms,
                     "launches": k["launches"], "algorithmic_bytes_per_launch": k["bytes"] / k["launches"]}
         out = {
-            "metric": "message updates/sec + dual-bound gap, 32-label grid MRF @1/2/4/8 GPUs" if L == 32 and args.pairwise == "dense"
-                      else "message updates/sec + dual-bound gap, grid MRF",
+            "metric": "message updates/sec + dual-bound gap, 32-label grid MRF @1/2/4/8 GPUs" if L == 32 and args.pairwise == "dense" and args.workload == "c3"
+                      else "message updates/sec + dual-bound gap, " + ("random sparse graph MRF" if args.workload == "c4" else "grid MRF"),
+            "scaling_note": None if args.workload == "c3" else "strong scaling: the graph is fixed, the ranks share it",
             "value": value, "unit": "msg-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.workload == "c3" else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{H}x{W} grid per GPU, {L} labels, {args.pairwise} pairwise, {args.mode} weights, "
-                                   f"{args.order} order", "parallelism": parallelism,
+            "config": {"workload": (f"random sparse graph G({args.c4_nodes}, {args.c4_edges}), {L} labels, dense pairwise, {args.mode} weights, "
+                                    "index order" if args.workload == "c4" else
+                                    f"{H}x{W} grid per GPU, {L} labels, {args.pairwise} pairwise, {args.mode} weights, {args.order} order"),
+                       "parallelism": parallelism,
                        "levels_per_direction": levels, "msg_updates_per_pass": updates_per_pass,
                        "algorithmic_bytes_per_pass": bytes_per_pass},
             "pass_algorithmic_GBps": bytes_per_pass * args.steps / dt / 1e9,
@@ -285,7 +333,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, S, M)
-    if world == 1 and args.also_row_major and args.order != "row_major":
+    if world == 1 and args.workload == "c3" and args.also_row_major and args.order != "row_major":
         del eng, runner
         m, const, dual = build_device_grid(torch, H, W, L, args.pairwise, "row_major", 1, E, S, stream_ptr)
         e2 = E.Engine(torch.cuda.current_device())

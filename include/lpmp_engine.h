@@ -205,8 +205,37 @@ int lpmp_get_kernel_timing(lpmp_engine* e, int n_classes, double* ms /*[n]*/, in
                            int64_t* factors /*[n]*/, int64_t* receives /*[n]*/, int64_t* bytes /*[n]*/);
 int lpmp_reset_kernel_timing(lpmp_engine* e);
 
+/* ---- boundary step of the partitioned (multi-GPU) sweep, DESIGN.md 7 -------------------------------------------------
+ * One process per GPU owns one part of the factor graph (lp_mp_amd/multi_gpu.py builds the parts; a C++ host can do
+ * the same from lpmp_model arrays).  Cut messages travel as flat runs of doubles between DEVICE buffers the caller
+ * owns: the caller posts the exchange itself (RCCL ncclSend / ncclRecv or all-to-all-v on lpmp_engine_stream, or
+ * torch.distributed) between these calls.  Every step is the reference's UpdateFactor of a non-owner endpoint restricted
+ * to its cut messages (include/factors_messages.hxx:2256-2261), so the whole schedule replays on the unpartitioned
+ * model with LP::ComputePass(factorIt, ...) (include/LP_MP.h:981-1005).
+ *   out_*   the cut messages this part OWNS (ghost vectors), in exchange order (by peer, then key)
+ *   in_*    the cut messages owned elsewhere that end in a variable of this part, in exchange order; in_omega their send
+ *           weights (a row sums to <= 1, LP_MP.h:1008-1014); in_order = indices into in_* grouped by variable and, inside
+ *           a variable, in the order its message list holds them (receives and sends happen in that order) */
+typedef struct lpmp_boundary lpmp_boundary;
+int lpmp_boundary_create(lpmp_engine* e, int64_t n_out, const int64_t* out_dual_off, const int32_t* out_len, int64_t n_in,
+                         const int64_t* in_dual_off, const int32_t* in_len, const double* in_omega, const int64_t* in_order,
+                         lpmp_boundary** out);
+void lpmp_boundary_destroy(lpmp_boundary* b);
+int64_t lpmp_boundary_out_doubles(const lpmp_boundary* b);   /* size of the send buffer of pack / the buffer of fold */
+int64_t lpmp_boundary_in_doubles(const lpmp_boundary* b);    /* size of the receive buffer / the reply buffer */
+/* owner: send[...] = ghost vectors (after the ghost receive schedule ran), ghosts zeroed */
+int lpmp_boundary_pack(lpmp_engine* e, lpmp_boundary* b, double* send_dev);
+/* non-owner: theta += received (list order); reply = omega * theta after all receives; theta -= reply (list order) */
+int lpmp_boundary_reply(lpmp_engine* e, lpmp_boundary* b, const double* recv_dev, double* reply_dev);
+/* owner: ghost vectors = reply (then run the ghost send schedule) */
+int lpmp_boundary_fold(lpmp_engine* e, lpmp_boundary* b, const double* back_dev);
+void* lpmp_engine_stream(lpmp_engine* e);                    /* the hipStream_t all engine work is issued on */
+
 /* synthetic workloads: out[i] = u01(splitmix64(seed + (first+i+1)*GOLDEN)) written on the device */
 int lpmp_synth_fill(void* device_ptr, int64_t n, uint64_t seed, uint64_t first, void* hip_stream);
+/* the same for n_blocks blocks of block_len values each, block b continuing the stream at first_dev[b] (device array):
+ * a rank's scattered share of a global cost stream */
+int lpmp_synth_fill_blocks(void* device_ptr, int64_t n_blocks, int64_t block_len, uint64_t seed, const int64_t* first_dev, void* hip_stream);
 
 #ifdef __cplusplus
 }

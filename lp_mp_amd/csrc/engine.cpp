@@ -21,6 +21,8 @@ void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, c
                   double* lb, int32_t* primal, int64_t first, int64_t count, int flags, hipStream_t s);
 bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, const Op* ops, int stride, double* dual, const double* cdata,
                          double* lb, int32_t* primal, int64_t count, int flags, hipStream_t s);
+bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, const Op* packets, const UpdRec* recs,
+                  const Op* ops, double* dual, const double* cdata, double* lb, hipStream_t s);
 void launch_primal_init(const PrimalInit* list, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_propagate(const PrimalLink* links, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_check(const PrimalLink* links, int64_t n, const int32_t* primal, int* bad, hipStream_t s);
@@ -40,6 +42,7 @@ using namespace lpmp;
 
 static thread_local std::string g_error;
 const char* lpmp_last_error(void) { return g_error.c_str(); }
+extern "C" int lpmp_set_last_error(const char* msg) { g_error = msg ? msg : ""; return 0; }   // for the other translation units of the library
 const char* lpmp_version(void) { return "lp_mp_amd 0.1 (gfx950)"; }
 
 namespace {
@@ -69,6 +72,13 @@ struct DevSchedule {
   hipGraphExec_t graph = nullptr;
   hipGraphExec_t graph_primal = nullptr;   // the same launches with the SWEEP_PRIMAL flag
   bool adaptive_built = false;             // built with every update on the generic kernels (adaptive send rule)
+  // chain executor (deep single-class schedules): device copies of the ChainPlan
+  bool chain = false; int32_t chain_class = 0, chain_tickets = 0, chain_epoch = 0;
+  ChainLaunchHost* c_launches = nullptr; int32_t *c_tk_launch = nullptr, *c_dep_off = nullptr, *c_dep = nullptr, *c_done = nullptr, *c_next = nullptr;
+  void release_chain() {
+    for (void* p : {(void*)c_launches, (void*)c_tk_launch, (void*)c_dep_off, (void*)c_dep, (void*)c_done, (void*)c_next}) if (p) (void)hipFree(p);
+    c_launches = nullptr; c_tk_launch = c_dep_off = c_dep = c_done = c_next = nullptr; chain = false; chain_tickets = 0;
+  }
   size_t recs_cap = 0, ops_cap = 0, packets_cap = 0;   // allocated elements (a scratch schedule is refilled in place)
   void release() {
     if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
@@ -76,10 +86,18 @@ struct DevSchedule {
     if (recs) { (void)hipFree(recs); recs = nullptr; }
     if (ops) { (void)hipFree(ops); ops = nullptr; }
     if (packets) { (void)hipFree(packets); packets = nullptr; }
+    release_chain();
     recs_cap = ops_cap = packets_cap = 0;
     launches.clear();
   }
 };
+
+// device-side description of a chain plan (layouts shared with kernels.hip: ChainArgs, ChainLaunch)
+struct ChainArgsHost {
+  const int32_t* dep_off; const int32_t* dep; int32_t* done; int32_t* next; int32_t* abort_flag; const int32_t* tk_launch;
+  int32_t n_tickets; int32_t epoch;
+};
+static_assert(sizeof(ChainLaunchHost) == 32, "ChainLaunch layout");
 
 struct ClassTiming { double ms = 0; int64_t launches = 0, factors = 0, receives = 0, bytes = 0; };
 
@@ -222,6 +240,8 @@ struct lpmp_engine {
   int rtype = 0;   // enum lpmp_reparametrization_type
   bool use_graph = true;
   bool use_packed = true;
+  bool use_chain = true;          // deep single-class schedules as one persistent launch (LPMP_NO_CHAIN=1: graph replay)
+  int32_t* d_chain_abort = nullptr; bool chain_ran = false;
   bool timing = false;
   ClassTiming ct[KC_COUNT];
   struct Pending { hipEvent_t a, b; int cls; int64_t factors, receives, bytes; };
@@ -406,6 +426,22 @@ void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream, bool
   fill_device(d.recs, d.recs_cap, s.recs, stream);
   fill_device(d.ops, d.ops_cap, s.ops, stream);
   fill_device(d.packets, d.packets_cap, s.packets, stream);
+  d.release_chain();
+  if (s.chain.valid && !adaptive_built) {
+    const ChainPlan& c = s.chain;
+    auto up = [&](auto*& dst, const auto& v) {
+      using T = std::remove_reference_t<decltype(*dst)>;
+      HIP_CHECK(hipMalloc((void**)&dst, std::max<size_t>(1, v.size()) * sizeof(T)));
+      if (!v.empty()) h2d(dst, v.data(), v.size() * sizeof(T), stream);
+    };
+    up(d.c_launches, c.launches); up(d.c_tk_launch, c.tk_launch); up(d.c_dep_off, c.dep_off); up(d.c_dep, c.dep);
+    d.chain_tickets = (int32_t)c.tk_launch.size();
+    HIP_CHECK(hipMalloc((void**)&d.c_done, (size_t)d.chain_tickets * sizeof(int32_t)));
+    HIP_CHECK(hipMalloc((void**)&d.c_next, sizeof(int32_t)));
+    HIP_CHECK(hipMemsetAsync(d.c_done, 0, (size_t)d.chain_tickets * sizeof(int32_t), stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    d.chain_class = c.kclass; d.chain_epoch = 0; d.chain = true;
+  }
 }
 
 void check_generic_limits(const Plan& p, const Schedule& s) {
@@ -476,6 +512,17 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
 void run_schedule(lpmp_engine* e, DevSchedule& s) {
   if (s.launches.empty()) return;
   if (e->timing) { issue_launches(e, s, true, e->stream); if (e->pending.size() > 4096) e->drain_timing(); return; }
+  if (s.chain && e->use_chain && !e->primal_pass) {
+    if (!e->d_chain_abort) { HIP_CHECK(hipMalloc((void**)&e->d_chain_abort, sizeof(int32_t))); HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, sizeof(int32_t), e->stream)); }
+    HIP_CHECK(hipMemsetAsync(s.c_next, 0, sizeof(int32_t), e->stream));
+    const ChainArgsHost ca{s.c_dep_off, s.c_dep, s.c_done, s.c_next, e->d_chain_abort, s.c_tk_launch, s.chain_tickets, ++s.chain_epoch};
+    const int rule = e->rtype == LPMP_RTYPE_RESIDUAL ? SWEEP_RESIDUAL : 0;
+    if (launch_chain(s.chain_class, rule | e->nt_flag, &ca, s.c_launches, s.packets, s.recs, s.ops, e->d_dual, e->d_const, e->d_lb, e->stream)) {
+      HIP_CHECK(hipGetLastError());
+      e->chain_ran = true;
+      return;
+    }
+  }
   // (graphs of up to ~20 k kernel nodes were exercised — C5; beyond 200 k the nodes are issued one by
   // one instead of instantiating a graph of that size)
   if (e->use_graph && s.launches.size() > 8 && s.launches.size() <= 200000) {
@@ -707,6 +754,8 @@ int lpmp_create(int device, lpmp_engine** out) {
     e->use_lb_tracking = !(nt && nt[0] == '1');
     const char* np = std::getenv("LPMP_NO_PACKED");
     e->use_packed = !(np && np[0] == '1');
+    const char* nc = std::getenv("LPMP_NO_CHAIN");
+    e->use_chain = !(nc && nc[0] == '1');
     *out = e.release();
   });
 }
@@ -718,6 +767,7 @@ void lpmp_destroy(lpmp_engine* e) {
   for (auto& p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
   e->release_model();
+  if (e->d_chain_abort) { (void)hipFree(e->d_chain_abort); e->d_chain_abort = nullptr; }
   if (e->own_stream && e->stream) stream_pool().give(e->device, e->stream);
   if (e->capture_stream) { (void)hipStreamSynchronize(e->capture_stream); stream_pool().give(e->device, e->capture_stream); }
   if (!guarded_ok(e->pinned, PINNED_WORDS_BYTES)) {   // a damaged block is reported and never reused
@@ -1149,7 +1199,21 @@ int lpmp_schedule_destroy(lpmp_engine* e, int id) {
   });
 }
 
+// the chain executor bounds every wait; a run that gave up leaves the duals half updated and must not pass silently
+static void check_chain(lpmp_engine* e) {
+  if (!e->chain_ran || !e->d_chain_abort) return;
+  int32_t* h = (int32_t*)(e->pinned + 8 * 1024 + 96);
+  HIP_CHECK(hipMemcpyAsync(h, e->d_chain_abort, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+  e->chain_ran = false;
+  if (*h != 0) {
+    HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, sizeof(int32_t), e->stream));
+    throw DeviceError("chain executor: a dependency wait timed out; the duals are in an undefined state (LPMP_NO_CHAIN=1 selects graph replay)");
+  }
+}
+
 static void compute_factor_lbs(lpmp_engine* e) {
+  check_chain(e);
   if (e->use_lb_tracking && !e->lb_all_stale) {
     // the sweep kernels kept d_lb current except for the entries they marked NaN: recompute only those
     const int64_t nf = e->plan->p.nf;
@@ -1207,6 +1271,7 @@ int lpmp_synchronize(lpmp_engine* e) {
     HIP_CHECK(hipSetDevice(e->device));
     HIP_CHECK(hipStreamSynchronize(e->stream));
     if (e->timing) e->drain_timing();
+    check_chain(e);
     if (!guarded_ok(e->pinned, PINNED_WORDS_BYTES)) throw DeviceError("guard region of the engine's pinned words was overwritten");
     staging().check();
   });
@@ -1221,6 +1286,7 @@ int lpmp_download_duals(lpmp_engine* e, double* out) {
     require_model(e);
     if (!out) throw std::runtime_error("null argument");
     HIP_CHECK(hipSetDevice(e->device));
+    check_chain(e);
     d2h(out, e->d_dual, (size_t)lpmp_dual_size(e) * sizeof(double), e->stream);
   });
 }
@@ -1237,6 +1303,7 @@ int lpmp_invalidate_lower_bounds(lpmp_engine* e) {
   return guarded([&] { require_model(e); e->lb_all_stale = true; });
 }
 void* lpmp_device_duals(lpmp_engine* e) { return e ? e->d_dual : nullptr; }
+void* lpmp_engine_stream(lpmp_engine* e) { return e ? (void*)e->stream : nullptr; }
 const lpmp_plan* lpmp_engine_plan(const lpmp_engine* e) { return e ? e->plan.get() : nullptr; }
 lpmp_plan* lpmp_engine_plan_mut(lpmp_engine* e) { return e ? e->plan.get() : nullptr; }
 

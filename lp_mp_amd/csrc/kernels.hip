@@ -46,6 +46,79 @@ template <bool NT, class T> __device__ __forceinline__ T ld_stream(const T* p) {
 template <bool NT, class T> __device__ __forceinline__ void st_stream(T* p, T v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
 }
+// Access policy of the DUALS (theta, message vectors).  ACC_PLAIN / ACC_NT: one launch per level, the launch boundary
+// makes other workgroups' stores visible.  ACC_COH: the chain executor below — updates of different levels run inside
+// ONE launch and hand their results over through flags, so every dual load / store is an agent-scope access
+// (global_load / global_store ... sc1: write-through stores, loads that do not hit a stale line of this CU's L1; the
+// XCDs' L2s are not coherent with each other, MI355X_MICROARCH.md "inter-workgroup visibility").  The pairwise tables
+// are constants and keep the streaming policy in every mode.
+enum Access : int { ACC_PLAIN = 0, ACC_NT = 1, ACC_COH = 2 };
+template <int A> __device__ __forceinline__ double ld_dual(const double* p) {
+  if constexpr (A == ACC_COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if constexpr (A == ACC_NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int A> __device__ __forceinline__ void st_dual(double* p, double v) {
+  if constexpr (A == ACC_COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if constexpr (A == ACC_NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+// tracked lower bounds: several updates of ONE launch may write the same slot in the chain executor (a factor is
+// touched at several levels); plain stores from different XCDs would reach memory in no particular order
+template <int A> __device__ __forceinline__ void st_lb(double* p, double v) {
+  if constexpr (A == ACC_COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+
+// ---- chain executor: dependent levels inside one persistent launch -------------------------------------------------
+// A deep schedule (row-major grids: one level per anti-diagonal; chains of tiny factors) is latency-bound when every
+// level is its own launch.  Here the workgroups of ONE launch take "tickets" — blocks of records, numbered in level
+// order — from a global counter.  A ticket names the tickets that hold its records' predecessors (the last earlier
+// update of every factor it touches, from the host's level analysis); the workgroup requests everything constant
+// (packet, pairwise tables) first, THEN waits for those tickets' completion flags, then loads the duals.  A ticket
+// only ever waits for lower tickets, and those are held by workgroups that are already running, so the scheme needs
+// no assumption about residency or dispatch order.  Every wait is bounded: on a timeout the launch sets an abort word
+// and drains, and the host reports an error instead of hanging the device.
+struct ChainArgs {
+  const int32_t* dep_off;    // [n_tickets + 1]
+  const int32_t* dep;        // predecessor tickets
+  int32_t* done;             // [n_tickets]: epoch of the run that completed the ticket
+  int32_t* next;             // ticket counter (zeroed before the launch)
+  int32_t* abort_flag;
+  const int32_t* tk_launch;  // [n_tickets]: launch (level x class range) the ticket belongs to
+  int32_t n_tickets;
+  int32_t epoch;
+};
+struct ChainLaunch { int64_t rec_begin, count, pk_begin; int32_t stride, ticket0; };
+constexpr int CHAIN_SPIN_LIMIT = 1 << 22;   // polls of one dependency before giving up (seconds)
+
+// all threads of the workgroup; returns false when the run was aborted
+__device__ __forceinline__ bool chain_wait(const ChainArgs& ca, int ticket) {
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  const int b = ca.dep_off[ticket], e = ca.dep_off[ticket + 1];
+  for (int i = b + (int)threadIdx.x; i < e; i += (int)blockDim.x) {
+    const int32_t* flag = ca.done + ca.dep[i];
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ca.epoch) {
+      __builtin_amdgcn_s_sleep(1);
+      if (((++spins) & 1023) == 0 && (spins >= CHAIN_SPIN_LIMIT || __hip_atomic_load(ca.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        __hip_atomic_store(ca.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_bad = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  return s_bad == 0;
+}
+// all threads: every wave drains its stores, then one lane publishes the ticket
+__device__ __forceinline__ void chain_publish(const ChainArgs& ca, int ticket) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(ca.done + ticket, ca.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 
 __device__ __forceinline__ void wave_sync() {
@@ -634,11 +707,13 @@ __device__ __forceinline__ void load_packet(double2_t* slab, const Op* __restric
 
 // VAR: L is the padded width; the label count of the factor (<= L) and the dims of each peer table (d0 x d1, both
 // <= L, the own side's equal to the label count) are read at run time, lanes beyond them carry +inf / 0
-template <int L, int KMAX, bool VAR, bool NT>
-__global__ void __launch_bounds__(256)
-sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
-                      double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
-                      int32_t* __restrict__ primal, int64_t count, int stride, int flags) {
+// NT: streaming policy of the table loads.  A: access policy of the duals.  CHAIN: called from the chain executor with a
+// ticket: everything constant is requested first, then the ticket's predecessors are awaited, then the duals are read.
+template <int L, int KMAX, bool VAR, bool NT, int A, bool CHAIN>
+__device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
+                                              double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
+                                              int32_t* __restrict__ primal, int64_t count, int stride, int flags, int64_t block,
+                                              const ChainArgs* ca, int ticket) {
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
   constexpr int KS = 4;                          // sends whose target vectors are prefetched / forwarded
@@ -648,7 +723,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
   __shared__ double lds_mo[GPB][L];
   __shared__ double lds_q[GPB][L];
   const int grp = threadIdx.x / G, g = threadIdx.x % G;
-  const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
+  const int64_t idx = block * GPB + grp;
   const bool live = idx < count;
   const int c2 = g % CL, rl = g / CL;
   load_packet<G>(lds_pk[grp], packets, recs, ops, idx, stride, live, g);
@@ -660,17 +735,21 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
   double* own_g = dual + (live ? uni64<G>(hdr->dual_off) : 0);
   const int Lr = VAR ? (live ? uni<G>(hdr->d0) : 0) : L;      // label count of this factor
   const bool vl = live && g < Lr;
-  double theta = vl ? own_g[g] : 0.0;
-  // target vectors of the first KS sends
-  double sm[KS];
+  double theta = 0.0;
+  double sm[KS];                                 // target vectors of the first KS sends
 #pragma unroll
-  for (int k = 0; k < KS; ++k) {
-    sm[k] = 0.0;
-    if (preload_ok && k < n_send && g < Lr) {
-      const Op& o = lop[n_recv + k];
-      sm[k] = ld_stream<NT>(dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0) + g);
+  for (int k = 0; k < KS; ++k) sm[k] = 0.0;
+  auto load_own_and_targets = [&]() {
+    theta = vl ? ld_dual<A>(own_g + g) : 0.0;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (preload_ok && k < n_send && g < Lr) {
+        const Op& o = lop[n_recv + k];
+        sm[k] = ld_dual<A>(dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0) + g);
+      }
     }
-  }
+  };
+  if constexpr (!CHAIN) load_own_and_targets();
   double mnew[NFW];                              // results of receives whose store is deferred to a send
 #pragma unroll
   for (int k = 0; k < NFW; ++k) mnew[k] = 0.0;
@@ -679,18 +758,22 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
 #pragma unroll
     for (int m = 32; m >= G; m >>= 1) max_recv = max(max_recv, __shfl_xor(max_recv, m, 64));
   }
+  bool aborted = false;
 
-  // one chunk of up to KMAX receives starting at c; FW: c is a compile-time constant and results may be forwarded
-  auto chunk = [&](const int c, auto fw_tag) {
+  // one chunk of up to KMAX receives starting at c; FW: c is a compile-time constant and results may be forwarded;
+  // FIRST (chain executor): the tables (constants) are requested, then the predecessors awaited, then the duals read
+  auto chunk = [&](const int c, auto fw_tag, auto first_tag) {
     constexpr bool FW = decltype(fw_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
     double2_t t[KMAX][NL];
     double msv[KMAX], mov[KMAX];
     int64_t pdual[KMAX];
     int side[KMAX], defer[KMAX], roff[KMAX];     // roff: offset of the own-side message vector in the peer's dual
+    int dR[KMAX], dC[KMAX];
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {             // request everything first
+    for (int j = 0; j < KMAX; ++j) {             // request everything constant first
       const bool act = c + j < n_recv;
-      pdual[j] = 0; side[j] = 0; defer[j] = 0; roff[j] = 0; msv[j] = 0.0; mov[j] = 0.0;
+      pdual[j] = 0; side[j] = 0; defer[j] = 0; roff[j] = 0; msv[j] = 0.0; mov[j] = 0.0; dR[j] = L; dC[j] = L;
       if (act) {
         const Op& o = lop[c + j];
         pdual[j] = uni64<G>(o.peer_dual);
@@ -699,6 +782,7 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
         const double* T = cdata + uni64<G>(o.peer_const);
         if constexpr (VAR) {
           const int R = uni<G>(o.pd0), C = uni<G>(o.pd1);
+          dR[j] = R; dC[j] = C;
           roff[j] = side[j] == 0 ? 0 : R;
           if (((uni<G>(o.info) >> 8) & 15) == LPMP_F_PAIRWISE_POTTS) {
             // a Potts neighbour among dense ones: its table diff * [a != b] is made up in registers
@@ -718,20 +802,30 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
               t[j][i].y = (row < R && 2 * c2 + 1 < C) ? ld_stream<NT>(Tr + 1) : LPMP_INF;
             }
           }
-          if (g < Lr) msv[j] = ld_stream<NT>(dual + pdual[j] + roff[j] + g);
-          if (g < (side[j] == 0 ? C : R)) mov[j] = ld_stream<NT>(dual + pdual[j] + (side[j] == 0 ? R : 0) + g);
         } else {
           roff[j] = side[j] == 0 ? 0 : L;
 #pragma unroll
           for (int i = 0; i < NL; ++i) t[j][i] = ld_stream<NT>(reinterpret_cast<const double2_t*>(T + (int64_t)i * 2 * G + 2 * g));
-          if (g < L) {
-            msv[j] = ld_stream<NT>(dual + pdual[j] + (side[j] == 0 ? 0 : L) + g);
-            mov[j] = ld_stream<NT>(dual + pdual[j] + (side[j] == 0 ? L : 0) + g);
-          }
         }
       } else {
 #pragma unroll
         for (int i = 0; i < NL; ++i) t[j][i] = double2_t{0.0, 0.0};
+      }
+    }
+    if constexpr (CHAIN && FIRST) {              // the tables are in flight while the predecessors finish
+      aborted = !chain_wait(*ca, ticket);
+      load_own_and_targets();
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {             // then the message vectors of these receives
+      if (c + j < n_recv) {
+        if constexpr (VAR) {
+          if (g < Lr) msv[j] = ld_dual<A>(dual + pdual[j] + roff[j] + g);
+          if (g < (side[j] == 0 ? dC[j] : dR[j])) mov[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? dR[j] : 0) + g);
+        } else if (g < L) {
+          msv[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? 0 : L) + g);
+          mov[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? L : 0) + g);
+        }
       }
     }
 #pragma unroll
@@ -780,28 +874,32 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
             stored = true;
           }
         }
-        if (!stored) st_stream<NT>(dual + pdual[j] + roff[j] + g, mn);
+        if (!stored) st_dual<A>(dual + pdual[j] + roff[j] + g, mn);
       }
 #ifndef LPMP_ABLATE_LB_TRACK
       if (!(FW && defer[j])) {                    // a deferred receive is followed by a send that dirties the peer
         pb = vec_min<G, L>(pb);
-        if (act && g == 0) lb[uni<G>(lop[c + j].peer)] = pb;
+        if (act && g == 0) st_lb<A>(lb + uni<G>(lop[c + j].peer), pb);
       }
 #endif
       wave_sync();
     }
   };
   // the first chunks are unrolled with constant indices so that forwarded results stay in registers
-  if (max_recv > 0) chunk(0, std::true_type{});
-  if constexpr (KMAX < NFW) { if (max_recv > KMAX) chunk(KMAX, std::true_type{}); }
-  if constexpr (2 * KMAX < NFW) { if (max_recv > 2 * KMAX) chunk(2 * KMAX, std::true_type{}); if (max_recv > 3 * KMAX) chunk(3 * KMAX, std::true_type{}); }
-  for (int c = (KMAX >= NFW ? KMAX : NFW); c < max_recv; c += KMAX) chunk(c, std::false_type{});
+  if constexpr (CHAIN) {
+    chunk(0, std::true_type{}, std::true_type{});   // also waits when the workgroup's factors receive nothing
+  } else {
+    if (max_recv > 0) chunk(0, std::true_type{}, std::false_type{});
+  }
+  if constexpr (KMAX < NFW) { if (max_recv > KMAX) chunk(KMAX, std::true_type{}, std::false_type{}); }
+  if constexpr (2 * KMAX < NFW) { if (max_recv > 2 * KMAX) chunk(2 * KMAX, std::true_type{}, std::false_type{}); if (max_recv > 3 * KMAX) chunk(3 * KMAX, std::true_type{}, std::false_type{}); }
+  for (int c = (KMAX >= NFW ? KMAX : NFW); c < max_recv; c += KMAX) chunk(c, std::false_type{}, std::false_type{});
 
   if (flags & SWEEP_PRIMAL) {
     const int lab = group_argmin<G, L>(theta, vl, g);
     if (live && g == 0 && (uni<G>(hdr->kind_flags) & UPD_PRIMAL)) store_label(primal, uni<G>(hdr->factor), Lr, lab);
   }
-  if (vl) {
+  if (vl && !aborted) {
     const double snap = theta;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
@@ -811,12 +909,12 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
         const int fw = uni<G>(o.pad);
         double cur;
         if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
-        else cur = preload_ok ? sm[k] : ms[g];
+        else cur = preload_ok ? sm[k] : ld_dual<A>(ms + g);
         const double delta = o.omega * snap;
-        st_stream<NT>(ms + g, cur + delta);
+        st_dual<A>(ms + g, cur + delta);
         theta -= delta;
 #ifndef LPMP_ABLATE_LB_TRACK
-        if (g == 0) lb[uni<G>(o.peer)] = LPMP_NAN;
+        if (g == 0) st_lb<A>(lb + uni<G>(o.peer), LPMP_NAN);
 #endif
       }
     }
@@ -824,9 +922,9 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
       const Op& o = lop[n_recv + k];
       double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? (VAR ? o.pd0 : L) : 0);
       const double delta = o.omega * snap;
-      ms[g] += delta;
+      st_dual<A>(ms + g, ld_dual<A>(ms + g) + delta);
       theta -= delta;
-      if (g == 0) lb[o.peer] = LPMP_NAN;
+      if (g == 0) st_lb<A>(lb + o.peer, LPMP_NAN);
     }
     if (flags & SWEEP_RESIDUAL) {
       double residual = 0.0;
@@ -835,15 +933,52 @@ sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
         double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? (VAR ? o.pd0 : L) : 0);
         residual += o.omega;
         const double delta = residual * theta;
-        ms[g] += delta;
+        st_dual<A>(ms + g, ld_dual<A>(ms + g) + delta);
         theta -= delta;
       }
     }
-    own_g[g] = theta;
+    st_dual<A>(own_g + g, theta);
   }
 #ifndef LPMP_ABLATE_LB_TRACK
-  { const double ob = vec_min<G, L>(vl ? theta : LPMP_INF); if (live && g == 0) lb[uni<G>(hdr->factor)] = ob; }
+  { const double ob = vec_min<G, L>(vl ? theta : LPMP_INF); if (live && g == 0) st_lb<A>(lb + uni<G>(hdr->factor), ob); }
 #endif
+}
+
+template <int L, int KMAX, bool VAR, bool NT>
+__global__ void __launch_bounds__(256)
+sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
+                      double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
+                      int32_t* __restrict__ primal, int64_t count, int stride, int flags) {
+  dense_pk_body<L, KMAX, VAR, NT, NT ? ACC_NT : ACC_PLAIN, false>(packets, recs, ops, dual, cdata, lb, primal, count, stride, flags,
+                                                                   (int64_t)blockIdx.x, nullptr, 0);
+}
+
+// The chain executor's launch: workgroups take tickets until none is left (kernel classes of one BODY per launch).
+// The next ticket is drawn while the current one is processed, so the counter's latency is off the critical path.
+template <class Body>
+__device__ __forceinline__ void chain_loop(const ChainArgs& ca, const ChainLaunch* __restrict__ launches, Body body) {
+  __shared__ int s_ticket[2];
+  if (threadIdx.x == 0) s_ticket[0] = atomicAdd(ca.next, 1);
+  __syncthreads();
+  for (int it = 0;; ++it) {
+    const int ticket = s_ticket[it & 1];
+    if (ticket >= ca.n_tickets) break;
+    if (threadIdx.x == 0) s_ticket[(it + 1) & 1] = atomicAdd(ca.next, 1);
+    const ChainLaunch ln = launches[ca.tk_launch[ticket]];
+    body(ln, (int64_t)(ticket - ln.ticket0), ticket);
+    chain_publish(ca, ticket);
+    __syncthreads();                               // s_ticket[(it + 1) & 1] is written, the LDS of the body is free again
+  }
+}
+template <int L, int KMAX, bool VAR, bool NT>
+__global__ void __launch_bounds__(256)
+chain_dense_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, const Op* __restrict__ packets,
+                      const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+                      const double* __restrict__ cdata, double* __restrict__ lb, int flags) {
+  chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
+    dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.stride > 0 ? packets + ln.pk_begin : nullptr, recs + ln.rec_begin, ops, dual, cdata, lb,
+                                                    nullptr, ln.count, ln.stride, flags, block, &ca, ticket);
+  });
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -957,17 +1092,18 @@ __device__ __forceinline__ void two_min_merge(double& a1, double& a2) {   // two
 }
 
 // VAR: L is the padded width, the label count (<= L) is read at run time; lanes beyond it carry +inf
-template <int L, bool VAR, bool NT>
-__global__ void __launch_bounds__(256)
-sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
-                      double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
-                      int32_t* __restrict__ primal, int64_t count, int stride, int flags) {
+// A: access policy of the duals; CHAIN: called from the chain executor (see dense_pk_body)
+template <int L, bool VAR, int A, bool CHAIN>
+__device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
+                                              double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
+                                              int32_t* __restrict__ primal, int64_t count, int stride, int flags, int64_t block,
+                                              const ChainArgs* ca, int ticket) {
   constexpr int GPB = 256 / L;
   constexpr int KR = 4, KS = 4;
   constexpr int PIECES = 3 * (1 + pk_indirect_cap(L));
   __shared__ double2_t lds_pk[GPB][PIECES];
   const int grp = threadIdx.x / L, g = threadIdx.x % L;
-  const int64_t idx = (int64_t)blockIdx.x * GPB + grp;
+  const int64_t idx = block * GPB + grp;
   const bool live = idx < count;
   load_packet<L>(lds_pk[grp], packets, recs, ops, idx, stride, live, g);
   const UpdRec* hdr = reinterpret_cast<const UpdRec*>(&lds_pk[grp][0]);
@@ -978,14 +1114,16 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
   double* own_g = dual + (live ? hdr->dual_off : 0);
   const int Lr = VAR ? (live ? (int)hdr->d0 : 0) : L;
   const bool vl = live && g < Lr;
-  double theta = vl ? own_g[g] : 0.0;
+  bool aborted = false;
+  if constexpr (CHAIN) aborted = !chain_wait(*ca, ticket);   // a Potts neighbour has no table to request ahead: only the coupling
+  double theta = vl ? ld_dual<A>(own_g + g) : 0.0;
   double sm[KS];
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
     sm[k] = 0.0;
     if (preload_ok && k < n_send && vl) {
       const Op& o = lop[n_recv + k];
-      sm[k] = dual[o.peer_dual + (((o.info >> 5) & 1) ? Lr : 0) + g];
+      sm[k] = ld_dual<A>(dual + o.peer_dual + (((o.info >> 5) & 1) ? Lr : 0) + g);
     }
   }
   double mnew[KR];
@@ -1010,8 +1148,8 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
         const int side = (o.info >> 5) & 1;
         msoff[j] = o.peer_dual + (side == 0 ? 0 : Lr) + g;
         if (vl) {
-          msv[j] = ld_stream<NT>(dual + msoff[j]);
-          mov[j] = ld_stream<NT>(dual + o.peer_dual + (side == 0 ? Lr : 0) + g);
+          msv[j] = ld_dual<A>(dual + msoff[j]);
+          mov[j] = ld_dual<A>(dual + o.peer_dual + (side == 0 ? Lr : 0) + g);
         }
         diff[j] = cdata[o.peer_const];
         defer[j] = FW ? o.pad : 0;
@@ -1042,11 +1180,11 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
             stored = true;
           }
         }
-        if (!stored) st_stream<NT>(dual + msoff[j], mn);
+        if (!stored) st_dual<A>(dual + msoff[j], mn);
       }
       if (!(FW && defer[j])) {
         pb = vec_min<L, L>(pb);
-        if (c + j < n_recv && g == 0) lb[lop[c + j].peer] = pb;
+        if (c + j < n_recv && g == 0) st_lb<A>(lb + lop[c + j].peer, pb);
       }
     }
   };
@@ -1057,7 +1195,7 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
     const int lab = group_argmin<L, L>(theta, vl, g);
     if (live && g == 0 && (hdr->kind_flags & UPD_PRIMAL)) store_label(primal, hdr->factor, Lr, lab);
   }
-  if (vl) {
+  if (vl && !aborted) {
     const double snap = theta;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
@@ -1067,20 +1205,20 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
         const int fw = o.pad;
         double cur;
         if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
-        else cur = preload_ok ? sm[k] : ms[g];
+        else cur = preload_ok ? sm[k] : ld_dual<A>(ms + g);
         const double delta = o.omega * snap;
-        st_stream<NT>(ms + g, cur + delta);
+        st_dual<A>(ms + g, cur + delta);
         theta -= delta;
-        if (g == 0) lb[o.peer] = LPMP_NAN;
+        if (g == 0) st_lb<A>(lb + o.peer, LPMP_NAN);
       }
     }
     for (int k = KS; k < n_send; ++k) {
       const Op& o = lop[n_recv + k];
       double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? Lr : 0);
       const double delta = o.omega * snap;
-      ms[g] += delta;
+      st_dual<A>(ms + g, ld_dual<A>(ms + g) + delta);
       theta -= delta;
-      if (g == 0) lb[o.peer] = LPMP_NAN;
+      if (g == 0) st_lb<A>(lb + o.peer, LPMP_NAN);
     }
     if (flags & SWEEP_RESIDUAL) {
       double residual = 0.0;
@@ -1089,13 +1227,31 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
         double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? Lr : 0);
         residual += o.omega;
         const double delta = residual * theta;
-        ms[g] += delta;
+        st_dual<A>(ms + g, ld_dual<A>(ms + g) + delta);
         theta -= delta;
       }
     }
-    own_g[g] = theta;
+    st_dual<A>(own_g + g, theta);
   }
-  { const double ob = vec_min<L, L>(vl ? theta : LPMP_INF); if (live && g == 0) lb[hdr->factor] = ob; }
+  { const double ob = vec_min<L, L>(vl ? theta : LPMP_INF); if (live && g == 0) st_lb<A>(lb + hdr->factor, ob); }
+}
+
+template <int L, bool VAR, bool NT>
+__global__ void __launch_bounds__(256)
+sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
+                      double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
+                      int32_t* __restrict__ primal, int64_t count, int stride, int flags) {
+  potts_pk_body<L, VAR, NT ? ACC_NT : ACC_PLAIN, false>(packets, recs, ops, dual, cdata, lb, primal, count, stride, flags, (int64_t)blockIdx.x, nullptr, 0);
+}
+template <int L, bool VAR>
+__global__ void __launch_bounds__(256)
+chain_potts_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, const Op* __restrict__ packets,
+                      const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+                      const double* __restrict__ cdata, double* __restrict__ lb, int flags) {
+  chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
+    potts_pk_body<L, VAR, ACC_COH, true>(ln.stride > 0 ? packets + ln.pk_begin : nullptr, recs + ln.rec_begin, ops, dual, cdata, lb,
+                                         nullptr, ln.count, ln.stride, flags, block, &ca, ticket);
+  });
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1661,6 +1817,51 @@ bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, cons
   }
 #undef PK_LAUNCH
 #undef PK_LAUNCH1
+}
+
+// chain executor: one persistent launch for a deep single-class schedule; grid = what is resident at once (more
+// workgroups would only queue behind the running ones).  Returns false for a class without a chain kernel.
+template <class K>
+static unsigned chain_grid(K kernel, int n_tickets) {
+  static int n_cu = 0;
+  if (n_cu == 0) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  const long cap = (long)n_cu * per_cu;
+  return (unsigned)(n_tickets < cap ? n_tickets : cap);
+}
+bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, const Op* packets, const UpdRec* recs,
+                  const Op* ops, double* dual, const double* cdata, double* lb, hipStream_t s) {
+  const ChainArgs ca = *static_cast<const ChainArgs*>(chain_args);
+  const ChainLaunch* ln = static_cast<const ChainLaunch*>(launches);
+  const bool nt = (flags & SWEEP_NT) != 0;
+#define CHAIN_LAUNCH1(LL, KK, VV, NTT) do { auto k = chain_dense_pk_kernel<LL, KK, VV, NTT>; \
+    hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, packets, recs, ops, dual, cdata, lb, flags); } while (0)
+#define CHAIN_LAUNCH(LL, KK) do { if (nt) CHAIN_LAUNCH1(LL, KK, false, true); else CHAIN_LAUNCH1(LL, KK, false, false); } while (0)
+  switch (kclass) {
+    case KC_DENSE_32: CHAIN_LAUNCH(32, 2); return true;
+    case KC_DENSE_16: CHAIN_LAUNCH(16, 2); return true;
+    case KC_DENSE_8: CHAIN_LAUNCH(8, 4); return true;
+    case KC_DENSE_4: CHAIN_LAUNCH(4, 4); return true;
+    case KC_DENSE_V32: CHAIN_LAUNCH1(32, 2, true, false); return true;
+    case KC_DENSE_V16: CHAIN_LAUNCH1(16, 2, true, false); return true;
+    case KC_DENSE_V8: CHAIN_LAUNCH1(8, 4, true, false); return true;
+    case KC_DENSE_V4: CHAIN_LAUNCH1(4, 4, true, false); return true;
+#define CHAIN_POTTS(LL, VV) do { auto k = chain_potts_pk_kernel<LL, VV>; \
+    hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, packets, recs, ops, dual, cdata, lb, flags); } while (0)
+    case KC_POTTS_32: CHAIN_POTTS(32, false); return true;
+    case KC_POTTS_16: CHAIN_POTTS(16, false); return true;
+    case KC_POTTS_8: CHAIN_POTTS(8, false); return true;
+    case KC_POTTS_4: CHAIN_POTTS(4, false); return true;
+    case KC_POTTS_V32: CHAIN_POTTS(32, true); return true;
+    case KC_POTTS_V16: CHAIN_POTTS(16, true); return true;
+    case KC_POTTS_V8: CHAIN_POTTS(8, true); return true;
+    case KC_POTTS_V4: CHAIN_POTTS(4, true); return true;
+#undef CHAIN_POTTS
+    default: return false;
+  }
+#undef CHAIN_LAUNCH
+#undef CHAIN_LAUNCH1
 }
 
 void launch_factor_lb(const void* recs, const double* dual, const double* cdata, double* out, int64_t count, hipStream_t s) {

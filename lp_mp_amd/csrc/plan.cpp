@@ -3,6 +3,7 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -572,6 +573,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   }
   std::partial_sum(key_count.begin(), key_count.end(), key_count.begin());
   out.recs.resize(key_count[n_keys]);
+  std::vector<int32_t> rec_upd(key_count[n_keys]);   // update (position in the sequence) each record stands for
   {
     std::vector<int64_t> cur(key_count.begin(), key_count.end() - 1);
     for (int64_t u = 0; u < N; ++u) {
@@ -585,6 +587,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       r.n_recv = (int16_t)n_recv_of[u]; r.n_send = (int16_t)n_send_of[u];
       r.factor = f;
       r.kind_flags = f_kind[f] | (f_flags[f] << 4) | (ftype_primal[f_type[f]] ? UPD_PRIMAL : 0);
+      rec_upd[cur[key(u)]] = (int32_t)u;
       out.recs[cur[key(u)]++] = r;
     }
   }
@@ -599,10 +602,18 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   // inside a launch the order of the records is free (they are independent): sub-wave kernels run several
   // factors per wavefront, so neighbours in the list should have similar amounts of work
   for (const auto& lr : out.launches)
-    if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32 && lr.kclass != KC_DENSE_V32 && lr.kclass != KC_DENSE_BIG && lr.kclass != KC_PW_32)   // incl. KC_SMALL
-      std::stable_sort(out.recs.begin() + lr.begin, out.recs.begin() + lr.end, [](const UpdRec& a, const UpdRec& b) {
+    if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32 && lr.kclass != KC_DENSE_V32 && lr.kclass != KC_DENSE_BIG && lr.kclass != KC_PW_32) {   // incl. KC_SMALL
+      std::vector<int64_t> perm(lr.end - lr.begin);
+      std::iota(perm.begin(), perm.end(), lr.begin);
+      std::stable_sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) {
+        const UpdRec& a = out.recs[x]; const UpdRec& b = out.recs[y];
         return a.n_recv != b.n_recv ? a.n_recv > b.n_recv : a.n_send > b.n_send;
       });
+      std::vector<UpdRec> tr(perm.size()); std::vector<int32_t> tu(perm.size());
+      for (size_t i = 0; i < perm.size(); ++i) { tr[i] = out.recs[perm[i]]; tu[i] = rec_upd[perm[i]]; }
+      std::copy(tr.begin(), tr.end(), out.recs.begin() + lr.begin);
+      std::copy(tu.begin(), tu.end(), rec_upd.begin() + lr.begin);
+    }
   // flags of the fast-class records, kept in recs / ops themselves (packets are plain copies)
   static_assert(sizeof(UpdRec) == sizeof(Op), "a packet slot holds either record");
   for (auto& lr : out.launches) {
@@ -677,6 +688,65 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       const UpdRec& r = out.recs[i];
       std::memcpy(slot, &r, sizeof(Op));
       for (int k = 0; k < r.n_recv + r.n_send; ++k) slot[1 + k] = out.ops[r.op_begin + k];
+    }
+  }
+
+  // ---- chain plan: a deep schedule whose launches all run one packed kernel class becomes ONE persistent launch
+  // (kernels.hip, chain executor).  Dependencies: update u must see the results of the last earlier update that touched
+  // u's factor or a factor u touches — the same relation the levels were computed from.
+  // (LPMP_CHAIN_MIN: experiments — the smallest number of launches that makes a schedule a chain)
+  static const int64_t chain_min = [] { const char* v = std::getenv("LPMP_CHAIN_MIN"); return v ? (int64_t)std::atoll(v) : CHAIN_MIN_LAUNCHES; }();
+  if ((int64_t)out.launches.size() >= chain_min && !out.launches.empty()) {
+    bool ok = kc_chain_capable(out.launches[0].kclass);
+    for (const auto& lr : out.launches) ok = ok && lr.kclass == out.launches[0].kclass && lr.stride != 0;
+    int64_t n_tickets = 0;
+    const int gpb = ok ? kc_block_records(out.launches[0].kclass) : 1;
+    for (const auto& lr : out.launches) n_tickets += (lr.end - lr.begin + gpb - 1) / gpb;
+    ok = ok && n_tickets < std::numeric_limits<int32_t>::max();
+    if (ok) {
+      ChainPlan& cp = out.chain;
+      cp.kclass = out.launches[0].kclass;
+      std::vector<int32_t> ticket_of_update(N, -1);
+      int32_t t0 = 0;
+      for (size_t li = 0; li < out.launches.size(); ++li) {
+        const auto& lr = out.launches[li];
+        cp.launches.push_back({lr.begin, lr.end - lr.begin, lr.pk_begin, lr.stride, t0});
+        const int32_t nb = (int32_t)((lr.end - lr.begin + gpb - 1) / gpb);
+        for (int32_t b = 0; b < nb; ++b) cp.tk_launch.push_back((int32_t)li);
+        for (int64_t i = lr.begin; i < lr.end; ++i) ticket_of_update[rec_upd[i]] = t0 + (int32_t)((i - lr.begin) / gpb);
+        t0 += nb;
+      }
+      // replay the sequence: who touched each factor last
+      std::vector<int32_t> toucher(nf, -1);
+      std::vector<std::pair<int32_t, int32_t>> edges;     // (ticket, predecessor ticket)
+      for (int64_t u = 0; u < N; ++u) {
+        const int32_t o = owner[u];
+        const int32_t tk = ticket_of_update[o];
+        if (tk < 0) continue;                             // dropped update (no active message)
+        const int32_t f = uf[u];
+        auto visit = [&](int32_t g) {
+          const int32_t w = toucher[g];
+          if (w >= 0 && w != o) { const int32_t tw = ticket_of_update[w]; if (tw != tk) edges.emplace_back(tk, tw); }
+          toucher[g] = o;
+        };
+        visit(f);
+        int64_t ks = 0, kr = 0;
+        for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
+          const MsgEntry& e = fm[j];
+          bool active = false;
+          if (e.receives && umk[u][kr++]) active = true;
+          if (e.sends && uom[u][ks++] != 0.0) active = true;
+          if (active) visit(e.adjacent);
+        }
+      }
+      std::sort(edges.begin(), edges.end());
+      edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+      cp.dep_off.assign((size_t)n_tickets + 1, 0);
+      for (const auto& e : edges) { if (e.second >= e.first) fail("chain plan: dependency on a later ticket"); cp.dep_off[e.first + 1]++; }
+      std::partial_sum(cp.dep_off.begin(), cp.dep_off.end(), cp.dep_off.begin());
+      cp.dep.resize(edges.size());
+      for (size_t i = 0; i < edges.size(); ++i) cp.dep[i] = edges[i].second;   // sorted by ticket: already in CSR order
+      cp.valid = true;
     }
   }
 }

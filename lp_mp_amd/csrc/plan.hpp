@@ -115,6 +115,27 @@ constexpr int SWEEP_PRIMAL = 2;     // UpdateFactorPrimal (reference factors_mes
 struct PrimalLink { int32_t u, p, side, dim; };   // left (vector) factor, right (pairwise) factor, side, label count of u
 struct PrimalInit { int32_t f, a, b, pad; };      // primal_ of factor f when unset: (a, b)
 
+// Chain executor (kernels.hip): the launches of a deep schedule as ONE persistent launch.  A ticket = one workgroup's
+// block of records of one launch; dep = the tickets holding the predecessors of its records (the last earlier update
+// of every factor a record touches).  Tickets are numbered in level order, so a dependency always has a lower number.
+struct ChainLaunchHost { int64_t rec_begin, count, pk_begin; int32_t stride, ticket0; };
+struct ChainPlan {
+  bool valid = false;
+  int32_t kclass = 0;                       // the one kernel class of the schedule
+  std::vector<ChainLaunchHost> launches;    // parallel to Schedule::launches
+  std::vector<int32_t> tk_launch;           // [n_tickets]
+  std::vector<int32_t> dep_off, dep;        // CSR over tickets
+};
+// records one workgroup of the packed kernels takes (256 threads / lanes per record)
+constexpr int kc_block_records(int kclass) {
+  const int w = kc_width(kclass);
+  if (w == 0) return 0;
+  const bool dense = (kclass >= KC_DENSE_4 && kclass <= KC_DENSE_32) || (kclass >= KC_DENSE_V4 && kclass <= KC_DENSE_V32);
+  return dense ? (w == 32 ? 4 : 256 / w) : 256 / w;   // dense: G = 64 lanes at 32 labels, else one lane per label
+}
+constexpr bool kc_chain_capable(int kclass) { return kclass >= KC_DENSE_4 && kclass <= KC_POTTS_V32; }
+constexpr int64_t CHAIN_MIN_LAUNCHES = 9;   // shorter schedules run as plain launches
+
 struct Schedule {             // executable form of one (factor list, omega, mask) sweep
   std::vector<UpdRec> recs;   // sorted by (level, kclass)
   std::vector<Op> ops;
@@ -123,6 +144,7 @@ struct Schedule {             // executable form of one (factor list, omega, mas
   int64_t n_levels = 0;
   int64_t n_recv = 0, n_send = 0;     // active receives / sends = message updates per sweep
   int64_t alg_bytes = 0;              // algorithmic HBM bytes per sweep (DESIGN.md accounting)
+  ChainPlan chain;                    // filled for deep single-class schedules of the packed kernels
 };
 
 struct Plan {

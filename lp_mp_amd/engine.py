@@ -49,6 +49,8 @@ EXPORTS = [
     "lpmp_reset_kernel_timing", "lpmp_synth_fill", "lpmp_compute_forward_pass_and_primal",
     "lpmp_compute_backward_pass_and_primal", "lpmp_compute_pass_and_primal", "lpmp_check_primal_consistency",
     "lpmp_evaluate_primal", "lpmp_download_primal", "lpmp_upload_primal", "lpmp_streaming_access",
+    "lpmp_boundary_create", "lpmp_boundary_destroy", "lpmp_boundary_out_doubles", "lpmp_boundary_in_doubles", "lpmp_boundary_pack",
+    "lpmp_boundary_reply", "lpmp_boundary_fold", "lpmp_engine_stream", "lpmp_synth_fill_blocks",
 ]
 
 
@@ -132,6 +134,17 @@ def lib():
         L.lpmp_get_kernel_timing.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.lpmp_reset_kernel_timing.argtypes = [C.c_void_p]
         L.lpmp_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.lpmp_synth_fill_blocks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.lpmp_boundary_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+        L.lpmp_boundary_destroy.argtypes = [C.c_void_p]
+        for n in ("lpmp_boundary_out_doubles", "lpmp_boundary_in_doubles"):
+            getattr(L, n).restype = C.c_int64
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.lpmp_boundary_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lpmp_boundary_reply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lpmp_boundary_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lpmp_engine_stream.restype = C.c_void_p
+        L.lpmp_engine_stream.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -434,6 +447,31 @@ class Engine:
     def device_duals_ptr(self) -> int:
         return self.L.lpmp_device_duals(self.h)
 
+    # ---- boundary step of the partitioned sweep (include/lpmp_engine.h, csrc/boundary.hip) ----
+    def boundary_create(self, out_dual_off, out_len, in_dual_off, in_len, in_omega, in_order) -> int:
+        a = [np.ascontiguousarray(out_dual_off, np.int64), np.ascontiguousarray(out_len, np.int32),
+             np.ascontiguousarray(in_dual_off, np.int64), np.ascontiguousarray(in_len, np.int32),
+             np.ascontiguousarray(in_omega, np.float64), np.ascontiguousarray(in_order, np.int64)]
+        h = C.c_void_p()
+        _chk(self.L.lpmp_boundary_create(self.h, a[0].shape[0], a[0].ctypes.data, a[1].ctypes.data, a[2].shape[0],
+                                         a[2].ctypes.data, a[3].ctypes.data, a[4].ctypes.data, a[5].ctypes.data, C.addressof(h)))
+        return h.value
+
+    def boundary_destroy(self, b: int):
+        self.L.lpmp_boundary_destroy(b)
+
+    def boundary_sizes(self, b: int):
+        return self.L.lpmp_boundary_out_doubles(b), self.L.lpmp_boundary_in_doubles(b)
+
+    def boundary_pack(self, b: int, send_ptr: int):
+        _chk(self.L.lpmp_boundary_pack(self.h, b, C.c_void_p(send_ptr)))
+
+    def boundary_reply(self, b: int, recv_ptr: int, reply_ptr: int):
+        _chk(self.L.lpmp_boundary_reply(self.h, b, C.c_void_p(recv_ptr), C.c_void_p(reply_ptr)))
+
+    def boundary_fold(self, b: int, back_ptr: int):
+        _chk(self.L.lpmp_boundary_fold(self.h, b, C.c_void_p(back_ptr)))
+
     def enable_kernel_timing(self, on: bool):
         _chk(self.L.lpmp_enable_kernel_timing(self.h, 1 if on else 0))
 
@@ -455,6 +493,11 @@ class Engine:
                 out[KCLASS_NAMES[c]] = dict(kernel=name, ms=float(ms[c]), launches=int(arrs[0][c]),
                                             factors=int(arrs[1][c]), receives=int(arrs[2][c]), bytes=int(arrs[3][c]))
         return out
+
+
+def synth_fill_blocks(device_ptr: int, n_blocks: int, block_len: int, seed: int, first_dev_ptr: int, stream_ptr: int = 0):
+    """block b of ``block_len`` values continues the global u01 stream at first[b] (int64 device array)"""
+    _chk(lib().lpmp_synth_fill_blocks(C.c_void_p(device_ptr), n_blocks, block_len, C.c_uint64(seed), C.c_void_p(first_dev_ptr), C.c_void_p(stream_ptr)))
 
 
 def synth_fill(device_ptr: int, n: int, seed: int, first: int = 0, stream_ptr: int = 0):

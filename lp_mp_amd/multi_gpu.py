@@ -64,18 +64,24 @@ def _sorted_by_peer_key(peer, *cols, key):
 
 
 def partition_mrf(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, part: np.ndarray, world: int,
-                  unaries: np.ndarray, tables: Optional[np.ndarray] = None, potts: Optional[np.ndarray] = None
-                  ) -> List[LocalPart]:
+                  unaries: Optional[np.ndarray] = None, tables: Optional[np.ndarray] = None, potts: Optional[np.ndarray] = None,
+                  only: Optional[int] = None, stream_seed: Optional[int] = None) -> List[LocalPart]:
     """General partitioner for an MRF given as in synthetic.mrf_model (edge e between variables
-    edge_i[e] < edge_j[e]); ``part[v]`` = owning rank of variable v."""
+    edge_i[e] < edge_j[e]); ``part[v]`` = owning rank of variable v.
+    ``only``: build this rank's part alone (what a rank of a multi-process run needs).
+    ``stream_seed``: the costs are not given as host arrays but live in the counter-based stream of
+    synthetic.counter_graph_model (unaries at [0, n L), the table of edge e at [n L + e L^2, ...)): the part's model
+    is built without cost arrays and carries block-fill descriptors (``const_fill`` / ``dual_fill`` =
+    ("blocks", block_len, seed, first[])) for lpmp_synth_fill_blocks — no rank ever holds the global costs."""
     edge_i = np.asarray(edge_i, np.int64)
     edge_j = np.asarray(edge_j, np.int64)
     part = np.asarray(part, np.int64)
-    unaries = np.asarray(unaries, np.float64).reshape(n_vars, L)
+    if stream_seed is None:
+        unaries = np.asarray(unaries, np.float64).reshape(n_vars, L)
     n_edges = edge_i.shape[0]
     owner = part[edge_i]
     parts = []
-    for k in range(world):
+    for k in (range(world) if only is None else [only]):
         lv = np.nonzero(part == k)[0]
         gmap = np.full(n_vars, -1, np.int64)
         gmap[lv] = np.arange(lv.shape[0])
@@ -85,13 +91,19 @@ def partition_mrf(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, p
         li = gmap[edge_i[le]]
         lj = gmap[edge_j[le]].copy()
         lj[cut] = lv.shape[0] + np.arange(n_ghost)
-        un = np.concatenate([unaries[lv], np.zeros((n_ghost, L))])
-        kw = {}
-        if potts is not None:
-            kw["potts"] = np.asarray(potts, np.float64)[le]
+        const_fill = dual_fill = None
+        if stream_seed is not None:
+            m = S.mrf_model(lv.shape[0] + n_ghost, L, li, lj, np.zeros((lv.shape[0] + n_ghost) * L), device_const=True)
+            const_fill = [("blocks", L * L, stream_seed, (n_vars * L + le * (L * L)).astype(np.int64))]
+            dual_fill = [("blocks", L, stream_seed, (lv * L).astype(np.int64))]
         else:
-            kw["tables"] = np.asarray(tables, np.float64).reshape(n_edges, L, L)[le]
-        m = S.mrf_model(lv.shape[0] + n_ghost, L, li, lj, un, **kw)
+            un = np.concatenate([unaries[lv], np.zeros((n_ghost, L))])
+            kw = {}
+            if potts is not None:
+                kw["potts"] = np.asarray(potts, np.float64)[le]
+            else:
+                kw["tables"] = np.asarray(tables, np.float64).reshape(n_edges, L, L)[le]
+            m = S.mrf_model(lv.shape[0] + n_ghost, L, li, lj, un, **kw)
         n_vec = lv.shape[0] + n_ghost
         l2g = np.concatenate([lv, edge_j[le][cut], n_vars + le]).astype(np.int64)
         lm2g = np.stack([2 * le, 2 * le + 1], 1).reshape(-1).astype(np.int64)
@@ -100,8 +112,16 @@ def partition_mrf(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, p
         in_peer, in_unary, in_key = _sorted_by_peer_key(owner[ine], gmap[edge_j[ine]].astype(np.int32), key=ine)
         assert n_vec + le.shape[0] == m.n_factors
         parts.append(LocalPart(k, world, L, m, lv.shape[0], n_ghost, l2g, lm2g, out_peer, out_ghost, out_key,
-                               in_peer, in_unary, in_key))
+                               in_peer, in_unary, in_key, const_fill, dual_fill))
     return parts
+
+
+def graph_local_part(n: int, m: int, L: int, rank: int, world: int, seed: int = 1) -> LocalPart:
+    """this rank's part of the C4-style model synthetic.counter_graph_model(n, m, L, seed): structure from the counter
+    generator, partition by graph_partition (identical on every rank), costs generated in this rank's HBM"""
+    ei, ej = S.counter_graph_edges(n, m, seed)
+    part = graph_partition(n, ei, ej, world) if world > 1 else np.zeros(n, np.int64)
+    return partition_mrf(n, L, ei, ej, part, world, only=rank, stream_seed=seed)[0]
 
 
 def partition_model(gm: M.FlatModel, part: np.ndarray, world: int) -> List[LocalPart]:
@@ -205,18 +225,67 @@ def partition_model(gm: M.FlatModel, part: np.ndarray, world: int) -> List[Local
     return parts
 
 
-def graph_partition(n_vars: int, edge_i: np.ndarray, edge_j: np.ndarray, world: int) -> np.ndarray:
-    """k-way partition of a sparse variable graph without METIS (not in this image): reverse Cuthill-McKee order
-    (bandwidth reducing, scipy.sparse.csgraph) cut into ``world`` contiguous chunks of equal size.  Graphs with
-    locality get few cut edges; G(n, m) random graphs have none to exploit (any balanced partition cuts about
-    (world-1)/world of the edges)."""
+def graph_partition(n_vars: int, edge_i: np.ndarray, edge_j: np.ndarray, world: int, refine_rounds: int = 30,
+                    imbalance: float = 0.03, seed: int = 0) -> np.ndarray:
+    """k-way partition of a sparse variable graph without METIS (not in this image; SURVEY 8e allows a built-in
+    partitioner): a reverse Cuthill-McKee order (bandwidth reducing, scipy.sparse.csgraph) cut into ``world``
+    contiguous chunks, then refined by balanced Kernighan-Lin / label-propagation moves (``refine_partition``): every
+    round each variable looks at the part most of its neighbours live in and moves there if that cuts fewer edges and
+    the target stays within (1 + imbalance) of the mean size.  Graphs with locality get few cut edges; G(n, m) random
+    graphs have little to exploit (any balanced partition cuts most of the edges), the refinement recovers a few
+    percent there.  Deterministic: every rank computes the same partition from the same edge list."""
     from scipy.sparse import coo_matrix
     from scipy.sparse.csgraph import reverse_cuthill_mckee
-    a = coo_matrix((np.ones(edge_i.shape[0], np.int8), (edge_i, edge_j)), shape=(n_vars, n_vars)).tocsr()
-    a = a + a.T
+    edge_i = np.asarray(edge_i, np.int64); edge_j = np.asarray(edge_j, np.int64)
+    a = coo_matrix((np.ones(edge_i.shape[0], np.float32), (edge_i, edge_j)), shape=(n_vars, n_vars)).tocsr()
+    a = (a + a.T).tocsr()
     order = reverse_cuthill_mckee(a, symmetric_mode=True)
     part = np.empty(n_vars, np.int64)
     part[order] = (np.arange(n_vars) * world) // n_vars
+    if world > 1 and refine_rounds > 0:
+        part = refine_partition(a, part, world, refine_rounds, imbalance, seed)
+    return part
+
+
+def refine_partition(adj, part: np.ndarray, world: int, rounds: int = 30, imbalance: float = 0.03, seed: int = 0) -> np.ndarray:
+    """balanced label-propagation / Kernighan-Lin style refinement of a k-way partition (``adj``: symmetric scipy CSR
+    adjacency with edge multiplicities).  Per round: gain of moving v to the part holding most of its neighbours;
+    a pseudo-random half of the variables with positive gain is considered (neighbours moving at once could undo each
+    other), best gains first, as long as the target part has room."""
+    from scipy.sparse import csr_matrix
+    n = adj.shape[0]
+    part = part.copy()
+    cap = int(np.ceil(n / world * (1.0 + imbalance)))
+    idx = np.arange(n)
+    with np.errstate(over="ignore"):
+        coin = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)) >> np.uint64(40)
+    for r in range(rounds):
+        onehot = csr_matrix((np.ones(n, np.float32), (idx, part)), shape=(n, world))
+        cnt = np.asarray((adj @ onehot).todense())                       # neighbours of v in every part
+        cur = cnt[idx, part]
+        best = np.argmax(cnt, axis=1)
+        gain = cnt[idx, best] - cur
+        cand = np.nonzero((gain > 0) & (((coin >> np.uint64(r % 20)) & np.uint64(1)) == (r & 1)))[0]
+        if cand.size == 0:
+            if r > 2:
+                break
+            continue
+        size = np.bincount(part, minlength=world)
+        moved = 0
+        order = cand[np.argsort(-gain[cand], kind="stable")]
+        tgt = best[order]
+        for t in range(world):                                           # per target: the best moves that fit
+            sel = order[tgt == t]
+            room = cap - size[t]
+            if room <= 0 or sel.size == 0:
+                continue
+            sel = sel[:room]
+            np.subtract.at(size, part[sel], 1)
+            size[t] += sel.size
+            part[sel] = t
+            moved += sel.size
+        if moved == 0 and r > 2:
+            break
     return part
 
 
@@ -366,6 +435,9 @@ class LocalComm:
         self.box = {}
 
 
+BOUNDARY_SHARE = 0.375
+
+
 # ---- the sweep ---------------------------------------------------------------------------------------
 class PartitionedSweep:
     """One part of the partitioned sweep.  ``engine`` is an lp_mp_amd.engine.Engine (or, in CPU tests, an
@@ -382,10 +454,13 @@ class PartitionedSweep:
         assert boundary_every in ("pass", "sweep")
         self.boundary_every = boundary_every
         self.torch, self.part, self.engine, self.mode = torch, part, engine, mode
-        # send weight of the boundary update of a non-owner endpoint with k cut messages: 1/(k+1) each (the row must
-        # sum to <= 1, reference omega_valid LP_MP.h:1008-1014; one share stays in the factor) unless given
+        # send weight of the boundary update of a non-owner endpoint with k cut messages: BOUNDARY_SHARE / k each (the
+        # row must sum to <= 1, reference omega_valid LP_MP.h:1008-1014) unless given.  The share is a tuning knob of the
+        # partitioned schedule, not of the reference: on the C4-shaped graph (20 000 nodes, 2 parts, 31 % of the edges
+        # cut, 8 passes) the gap to the unpartitioned bound is 2.2 % with 1 / (k + 1) each, 1.5 % with 0.2 / k, 1.1 % with
+        # 0.35 ... 0.4 / k, 1.3 % with 0.5 / k, 2.7 % with 0.7 / k (what the variable keeps feeds its own next sweep)
         k_cut = np.bincount(part.in_unary, minlength=part.n_local + part.n_ghost)[part.in_unary] if part.in_unary.size else np.zeros(0)
-        self.in_omega = (1.0 / (k_cut + 1.0)) if omega_b is None else np.full(part.in_unary.shape[0], float(omega_b))
+        self.in_omega = (BOUNDARY_SHARE / np.maximum(k_cut, 1.0)) if omega_b is None else np.full(part.in_unary.shape[0], float(omega_b))
         if np.any(np.bincount(part.in_unary, weights=self.in_omega) > 1.0 + 1e-8) if part.in_unary.size else False:
             raise ValueError("boundary send weights of one unary sum to more than 1")
         p = part
@@ -480,6 +555,21 @@ class PartitionedSweep:
                 self.rounds.append((torch.from_numpy(tgt).to(dev), torch.from_numpy(src.astype(np.int64)).to(dev)))
             self.in_elems_t = torch.from_numpy(in_e).to(dev)
             self.in_omega_t = torch.from_numpy(np.repeat(self.in_omega, in_len)).to(dev)
+        # the boundary arithmetic as device kernels behind the C ABI (csrc/boundary.hip) when the engine is the HIP
+        # engine; the torch index ops below remain for engine stand-ins (CPU tests on the oracle)
+        self.bd = None
+        if hasattr(engine, "boundary_create") and dual_tensor.is_cuda:
+            in_order = np.zeros(0, np.int64)
+            if p.in_unary.shape[0]:
+                pos = p.in_pos if p.in_pos is not None else -p.in_key
+                in_order = np.lexsort((pos, p.in_unary))
+            self.bd = engine.boundary_create(doff[np.asarray(p.out_ghost, np.int64)], dim[np.asarray(p.out_ghost, np.int64)],
+                                             doff[np.asarray(p.in_unary, np.int64)], dim[np.asarray(p.in_unary, np.int64)],
+                                             self.in_omega, in_order)
+            n_out, n_in = engine.boundary_sizes(self.bd)
+            assert n_out == int(self.out_counts.sum()) and n_in == int(self.in_counts.sum())
+            self._send = dual_tensor.new_empty(max(n_out, 1))[:n_out]
+            self._reply = dual_tensor.new_empty(max(n_in, 1))[:n_in]
         self.info = [engine.schedule_info(s) for s in self.main]
         self.info_ghost = [engine.schedule_info(self.ghost_recv), engine.schedule_info(self.ghost_send)]
 
@@ -501,6 +591,9 @@ class PartitionedSweep:
         if self.part.n_ghost == 0:
             return self.dual.new_zeros((0,))
         self.engine.schedule_run(self.ghost_recv)
+        if self.bd is not None:
+            self.engine.boundary_pack(self.bd, self._send.data_ptr())
+            return self._send
         send = self.dual[self.out_elems_t]
         self.dual[self.out_elems_t] = 0.0
         return send
@@ -509,6 +602,10 @@ class PartitionedSweep:
         """non-owner: theta_j += delta (message-list order), delta' = omega_b * theta_j, theta_j -= delta'."""
         if not self.rounds:
             return recv.new_zeros((0,))
+        if self.bd is not None:
+            recv = recv.contiguous()
+            self.engine.boundary_reply(self.bd, recv.data_ptr(), self._reply.data_ptr())
+            return self._reply
         for tgt, src in self.rounds:
             self.dual[tgt] += recv[src]
         reply = self.in_omega_t * self.dual[self.in_elems_t]
@@ -520,7 +617,11 @@ class PartitionedSweep:
         """owner: ghost <- delta'; a weight-1 send folds it into the cut edge's pairwise factor."""
         if self.part.n_ghost == 0:
             return
-        self.dual[self.out_elems_t] = recv
+        if self.bd is not None:
+            recv = recv.contiguous()
+            self.engine.boundary_fold(self.bd, recv.data_ptr())
+        else:
+            self.dual[self.out_elems_t] = recv
         self.engine.schedule_run(self.ghost_send)
 
     # -- stand-alone driver over a DistComm -------------------------------------------------------------
@@ -634,11 +735,7 @@ class StripSweep:
         n_const = int(m.const_sizes().sum())
         self.const = torch.empty(max(n_const, 2), dtype=torch.float64, device=dev)
         self.dualt = torch.zeros(int(m.dual_sizes().sum()), dtype=torch.float64, device=dev)
-        for (off, cnt, sd, first) in part.const_fill:
-            E.synth_fill(self.const.data_ptr() + 8 * off, cnt, sd, first, stream)
-        for (off, cnt, sd, first) in part.dual_fill:
-            E.synth_fill(self.dualt.data_ptr() + 8 * off, cnt, sd, first, stream)
-        torch.cuda.synchronize()
+        fill_device_costs(torch, E, part, self.const, self.dualt, stream)
         self.engine = E.Engine(torch.cuda.current_device())
         self.engine.set_stream(stream)
         self.engine.upload(m, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt))
@@ -655,6 +752,76 @@ class StripSweep:
 
     def lower_bound(self):
         return self.comm.all_reduce_sum(self.sweep.local_lower_bound())
+
+
+def fill_device_costs(torch, E, part: LocalPart, const_t, dual_t, stream):
+    """run a part's fill descriptors: (offset, count, seed, first) contiguous runs, or ("blocks", block_len, seed,
+    first[]) scattered blocks of the global stream (rows of consecutive blocks in the buffer)"""
+    keep = []
+    for buf, fills in ((const_t, part.const_fill), (dual_t, part.dual_fill)):
+        for f in fills or []:
+            if f[0] == "blocks":
+                _, blen, sd, first = f
+                fd = torch.from_numpy(np.ascontiguousarray(first, np.int64)).to(buf.device)
+                keep.append(fd)
+                E.synth_fill_blocks(buf.data_ptr(), int(first.shape[0]), int(blen), sd, fd.data_ptr(), stream)
+            else:
+                off, cnt, sd, first = f
+                E.synth_fill(buf.data_ptr() + 8 * off, cnt, sd, first, stream)
+    torch.cuda.synchronize()
+    return keep
+
+
+class GraphSweep:
+    """bench.py driver for C4 (BASELINE.json configs[3]): this rank's part of the random sparse graph on its own GPU.
+    The global model is never materialised: structure from the counter generator, costs generated in HBM.  Random
+    graphs cut most of their edges under any balanced partition, so the boundary step runs after every directional
+    sweep (boundary_every="sweep")."""
+
+    def __init__(self, torch, dist, n, m, L, mode, seed=1, omega_b=None, boundary_every=None):
+        from . import engine as E
+        self.torch, self.dist = torch, dist
+        self.comm = DistComm(dist, torch) if dist is not None and dist.is_initialized() else None
+        rank, world = (self.comm.rank, self.comm.world) if self.comm else (0, 1)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if self.comm:
+            self.comm._dev = dev
+        part = graph_local_part(n, m, L, rank, world, seed)
+        self.part = part
+        mdl = part.model
+        stream = torch.cuda.current_stream().cuda_stream
+        self.const = torch.empty(max(int(mdl.const_sizes().sum()), 2), dtype=torch.float64, device=dev)
+        self.dualt = torch.zeros(int(mdl.dual_sizes().sum()), dtype=torch.float64, device=dev)
+        fill_device_costs(torch, E, part, self.const, self.dualt, stream)
+        self.engine = E.Engine(torch.cuda.current_device())
+        self.engine.set_stream(stream)
+        self.engine.upload(mdl, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt))
+        n_cut = int(part.out_ghost.shape[0] + part.in_unary.shape[0])
+        self.cut_fraction = n_cut / max(1, int(mdl.n_messages) // 2 + int(part.in_unary.shape[0]))
+        if boundary_every is None:                       # few cut edges: once per pass (fused sweeps); many: every sweep
+            boundary_every = "sweep" if self.cut_fraction > 0.10 else "pass"
+        self.boundary_every = boundary_every
+        self.engine.set_reparametrization(mode)
+        self.sweep = PartitionedSweep(torch, part, self.engine, self.dualt, mode, omega_b, boundary_every)
+        vals = [self.sweep.updates_per_pass(), self.sweep.bytes_per_pass(), part.out_ghost.shape[0], m]
+        if self.comm:
+            t = torch.tensor(vals[:3], dtype=torch.float64, device="cpu" if self.comm.stage_cpu else dev)
+            dist.all_reduce(t)
+            vals[:3] = [float(x) for x in t]
+        self.global_updates_per_pass = int(vals[0])
+        self.global_bytes_per_pass = int(vals[1])
+        self.global_cut_fraction = vals[2] / m
+        self.levels = [i["n_levels"] for i in self.sweep.info]
+
+    def compute_pass(self, n=1):
+        if self.comm:
+            self.sweep.compute_pass(self.comm, n)
+        else:                                           # one part: no boundary, plain engine passes
+            self.engine.compute_pass(n)
+
+    def lower_bound(self):
+        lb = self.sweep.local_lower_bound()
+        return self.comm.all_reduce_sum(lb) if self.comm else lb
 
 
 class ModelSweep:

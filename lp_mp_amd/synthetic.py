@@ -27,6 +27,37 @@ def u01(n: int, seed: int, first: int = 0) -> np.ndarray:
     return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
+def u64(n: int, seed: int, first: int = 0) -> np.ndarray:
+    """the 64-bit words behind u01 (same counter-based stream)"""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (np.arange(first + 1, first + n + 1, dtype=np.uint64)) * _GOLD
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def counter_graph_edges(n: int, m: int, seed: int):
+    """C4 (BASELINE.json configs[3]) structure from the counter generator alone, so that every rank of a partitioned
+    run derives the same edge list without any communication: edge e joins a = h(2e) mod n and b = a + 1 + h(2e+1) mod
+    (n - 1) (never a self loop); returned as (min, max) in edge order.  Uniform random edges; the expected handful of
+    repeated pairs at m << n^2 / 2 are kept (two pairwise factors between the same variables are a valid model)."""
+    h = u64(2 * m, seed ^ 0x5DEECE66D, 0)
+    a = (h[0::2] % np.uint64(n)).astype(np.int64)
+    b = (a + 1 + (h[1::2] % np.uint64(n - 1)).astype(np.int64)) % n
+    return np.minimum(a, b), np.maximum(a, b)
+
+
+def counter_graph_model(n: int, m: int, L: int, seed: int = 1, device_const: bool = False) -> M.FlatModel:
+    """the unpartitioned C4-style model over counter_graph_edges: unaries u01 stream [0, n L), table of edge e at
+    [n L + e L^2, ...) — the layout the per-rank generator of multi_gpu.graph_local_part reproduces piecewise"""
+    i, j = counter_graph_edges(n, m, seed)
+    un = u01(n * L, seed, 0)
+    if device_const:
+        return mrf_model(n, L, i, j, un, device_const=True)
+    return mrf_model(n, L, i, j, un, tables=u01(m * L * L, seed, n * L))
+
+
 def mrf_mtypes():
     return [M.MsgType(0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, M.M_UNARY_PAIRWISE, 0),
             M.MsgType(0, 1, M.SCHED_LEFT, M.variableMessageNumber, 1, M.M_UNARY_PAIRWISE, 1)]

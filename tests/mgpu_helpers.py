@@ -116,3 +116,31 @@ def gather_global_duals(global_model, parts, local_duals):
 def attach_local_lists(parts):
     for p in parts:
         p._local_lists = E.Plan(p.model).msg_lists(p.model.n_messages)
+
+
+def materialise_fills(part):
+    """host copies of the costs a part would generate in HBM from its fill descriptors (multi_gpu.fill_device_costs):
+    lets the per-rank generator of the C4 workload run on the oracle-backed stand-in engine"""
+    from lp_mp_amd import synthetic as S
+    m = part.model
+    for name, fills, size in (("const_data", part.const_fill, int(m.const_sizes().sum())), ("dual_data", part.dual_fill, int(m.dual_sizes().sum()))):
+        buf = np.zeros(size)
+        for f in fills or []:
+            if f[0] == "blocks":
+                _, blen, sd, first = f
+                if len(first):
+                    w = np.arange(blen, dtype=np.int64)[None, :] + np.asarray(first, np.int64)[:, None]     # stream positions
+                    # u01(position) for scattered positions: the generator is a pure function of the counter
+                    flat = w.reshape(-1)
+                    vals = np.empty(flat.shape[0])
+                    order = np.argsort(flat, kind="stable")
+                    srt = flat[order]
+                    runs = np.nonzero(np.diff(srt) != 1)[0] + 1
+                    for a, b in zip(np.r_[0, runs], np.r_[runs, srt.shape[0]]):
+                        vals[order[a:b]] = S.u01(b - a, sd, int(srt[a]))
+                    buf[: flat.shape[0]] = vals
+            else:
+                off, cnt, sd, first = f
+                buf[off: off + cnt] = S.u01(cnt, sd, first)
+        setattr(m, name, buf)
+    return part

@@ -376,6 +376,70 @@ def test_many_levels_graph_replay(eng):
     _check(eng, m, M.REPAM_ANISOTROPIC, 4)
 
 
+@pytest.mark.parametrize("pairwise,L,H,W", [("dense", 32, 96, 80), ("dense", 8, 150, 170), ("dense", 21, 60, 70), ("potts", 8, 200, 150), ("potts", 5, 64, 90)])
+def test_chain_executor_deep_schedules(pairwise, L, H, W, monkeypatch):
+    """row-major grids: one level per anti-diagonal.  The chain executor runs a whole pass as ONE persistent launch whose
+    workgroups wait for their predecessors' completion flags (kernels.hip); it must equal the oracle bit for bit, and
+    the same passes as one launch per level (LPMP_NO_CHAIN=1)."""
+    m = S.grid_model(H, W, L, pairwise=pairwise, order="row_major", seed=L + H)
+    o = Oracle(m)
+    engines = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("LPMP_NO_CHAIN", env)
+        e = E.Engine(0); e.upload(m); engines.append(e)
+    try:
+        for mode in (M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM):
+            o.set_reparametrization(mode)
+            for e in engines:
+                e.set_reparametrization(mode)
+            for n in (1, 3):
+                o.ComputePass(n)
+                for e in engines:
+                    e.compute_pass(n)
+                    assert np.array_equal(e.download_duals(), o.duals()), (mode, n)
+                    assert abs(e.lower_bound() - o.LowerBound()) <= LB_RTOL * max(1.0, abs(o.LowerBound()))
+            o.ComputeForwardPass(); o.ComputeBackwardPass()
+            for e in engines:
+                e.forward_pass(); e.backward_pass()
+                assert np.array_equal(e.download_duals(), o.duals())
+        # residual sends run in the chain executor too
+        o.set_reparametrization_type(1)
+        for e in engines:
+            e.set_reparametrization_type(1)
+        o.ComputePass(2)
+        for e in engines:
+            e.compute_pass(2)
+            assert np.array_equal(e.download_duals(), o.duals())
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_chain_executor_repeated_runs_are_deterministic():
+    """the flags of a chain run carry the run's epoch: many runs back to back on one schedule, every result equal to
+    the one-launch-per-level path"""
+    import torch
+    H = W = 192; L = 32
+    res = {}
+    for env in ("0", "1"):
+        os.environ["LPMP_NO_CHAIN"] = env
+        try:
+            m, const, dual, n, n_e = _device_grid(torch, H, W, L, "row_major", 9)
+            e = E.Engine(0)
+            e.upload(m, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual))
+            e.set_reparametrization(M.REPAM_ANISOTROPIC)
+            sums = []
+            for _ in range(12):
+                e.compute_pass(1)
+                e.synchronize()
+                sums.append(_device_dual_checksums(torch, dual))
+            res[env] = sums
+            e.close()
+        finally:
+            os.environ.pop("LPMP_NO_CHAIN")
+    assert res["0"] == res["1"]
+
+
 def test_error_paths(eng):
     e2 = E.Engine(0)
     with pytest.raises(E.EngineError):

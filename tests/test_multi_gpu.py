@@ -177,10 +177,18 @@ def test_graph_partition_is_balanced_and_finds_locality():
     H = W = 40
     a, b = S.grid_edges(H, W)
     part = MG.graph_partition(H * W, a, b, 4)
-    assert np.bincount(part, minlength=4).max() - np.bincount(part, minlength=4).min() <= 1
+    sizes = np.bincount(part, minlength=4)
+    assert sizes.max() <= np.ceil(H * W / 4 * 1.03) and sizes.min() >= H * W / 4 * 0.9       # balanced within the refinement's slack
     cut = int((part[a] != part[b]).sum())
     rnd = np.random.default_rng(0).integers(0, 4, H * W)
     assert cut < 0.2 * int((rnd[a] != rnd[b]).sum())
+    # the refinement never cuts more than the chunked order it starts from, and recovers a good share of a random
+    # graph's edges (where the order finds nothing)
+    assert cut <= int((MG.graph_partition(H * W, a, b, 4, refine_rounds=0)[a] != MG.graph_partition(H * W, a, b, 4, refine_rounds=0)[b]).sum())
+    ei, ej = S.counter_graph_edges(5000, 25000, 3)
+    c0 = MG.graph_partition(5000, ei, ej, 8, refine_rounds=0); c1 = MG.graph_partition(5000, ei, ej, 8)
+    assert (c1[ei] != c1[ej]).mean() < 0.8 * (c0[ei] != c0[ej]).mean()
+    assert np.array_equal(c1, MG.graph_partition(5000, ei, ej, 8))                            # deterministic: every rank gets the same
 
 
 @pytest.mark.gpu
@@ -355,6 +363,56 @@ def test_two_process_gloo_run_of_a_general_model(tmp_path):
     assert abs(np.load(tmp_path / "glb.npy")[0] - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
 
 
+WORKER_C4 = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from lp_mp_amd import model as M, multi_gpu as MG
+from tests.mgpu_helpers import OracleEngine, materialise_fills
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+part = materialise_fills(MG.graph_local_part({n}, {m}, {L}, rank, world, seed=1))     # this rank's part only
+d = part.model.dual_data.copy()
+sw = MG.PartitionedSweep(torch, part, OracleEngine(part.model, d), torch.from_numpy(d), M.REPAM_ANISOTROPIC, None, "sweep")
+comm = MG.DistComm(dist, torch)
+sw.compute_pass(comm, {passes})
+lb = comm.all_reduce_sum(sw.local_lower_bound())
+np.save(os.path.join({out!r}, f"c4_duals_{{rank}}.npy"), d)
+if rank == 0:
+    np.save(os.path.join({out!r}, "c4_lb.npy"), np.array([lb]))
+dist.destroy_process_group()
+"""
+
+
+def test_two_process_gloo_run_of_the_c4_graph(tmp_path):
+    """BASELINE.json configs[3] in the shape bench.py --workload c4 runs it, at 20 000 nodes / 100 000 edges: every rank
+    builds ONLY its own part (counter-generated structure, partition by graph_partition, costs from fill descriptors),
+    cut messages travel over torch.distributed (gloo, world_size 2).  The result equals the in-process lock-step run
+    of the partition of the global model, which equals the oracle's replay of the schedule on the unpartitioned
+    model, bit for bit; the dual bound stays within a few percent of the unpartitioned sweep's."""
+    n, m, L, passes = 20000, 100000, 4, 2
+    script = tmp_path / "worker_c4.py"
+    script.write_text(WORKER_C4.format(root=ROOT, out=str(tmp_path), n=n, m=m, L=L, passes=passes))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29535", str(script)], env=env, cwd=ROOT, timeout=600)
+    gm = S.counter_graph_model(n, m, L, 1)
+    ei, ej = S.counter_graph_edges(n, m, 1)
+    part_of = MG.graph_partition(n, ei, ej, 2)
+    assert 0.2 < float((part_of[ei] != part_of[ej]).mean()) < 0.4 and abs(np.bincount(part_of)[0] / n - 0.5) < 0.02
+    parts = MG.partition_mrf(n, L, ei, ej, part_of, 2, gm.dual_data[: n * L], tables=gm.const_data)
+    attach_local_lists(parts)
+    sweeps, duals = _cpu_sweeps(parts, None, "sweep")
+    MG.run_lockstep(sweeps, passes)
+    for k in range(2):
+        assert np.array_equal(np.load(tmp_path / f"c4_duals_{k}.npy"), duals[k])
+    o = global_replay(gm, parts, sweeps, passes)
+    assert np.array_equal(gather_global_duals(gm, parts, duals), o.duals())
+    lb = np.load(tmp_path / "c4_lb.npy")[0]
+    assert abs(lb - o.LowerBound()) <= 1e-9 * abs(o.LowerBound())
+    ref = Oracle(gm); ref.set_reparametrization(M.REPAM_ANISOTROPIC); ref.ComputePass(passes)
+    assert 0 <= (ref.LowerBound() - lb) / abs(ref.LowerBound()) < 0.08
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,world,every", [("c5", 3, "pass"), ("multicut", 4, "sweep"), ("mixed_mrf", 2, "pass")])
 def test_general_partitioner_on_device(name, world, every):
@@ -393,7 +451,7 @@ def test_graph_partition_of_a_general_model_is_balanced_and_local():
     part = MG.graph_partition_model(gm, world)
     is_right = np.zeros(gm.n_factors, bool); is_right[gm.m_right] = True
     sizes = np.bincount(part[~is_right], minlength=world)
-    assert sizes.max() - sizes.min() <= 1
+    assert sizes.max() <= np.ceil(sizes.sum() / world * 1.03) and sizes.min() >= sizes.sum() / world * 0.85
     parts = MG.partition_model(gm, part, world)
     cut = sum(p.n_ghost for p in parts)
     rnd = np.random.default_rng(0).integers(0, world, gm.n_factors)
