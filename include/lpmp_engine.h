@@ -93,6 +93,12 @@ int lpmp_plan_get_update_levels(lpmp_plan* p, int direction, int mode, int32_t* 
 int lpmp_plan_pass_schedule_info(lpmp_plan* p, int mode, int64_t* n_levels, int64_t* n_launches,
                                  int64_t* n_receives, int64_t* n_sends, int64_t* algorithmic_bytes);
 
+/* chain executor: how a deep sweep (direction 0 / 1, or -1 for the fused forward+backward pass) is run —
+ * persistent launches (one per kernel class), their tickets and dependencies, and the launches that stay plain;
+ * all 0 when the sweep runs as ordinary launches / graph replay */
+int lpmp_plan_chain_info(lpmp_plan* p, int direction, int mode, int64_t* n_chains, int64_t* n_tickets, int64_t* n_dependencies,
+                         int64_t* n_plain_launches);
+
 /* 1 when lpmp_compute_pass(n >= 2) joins the tail of a pass with the head of the next one for this mode (2-colour
  * orders: n passes = H, W, (K, W) x (n-1), T) — decided by an op-by-op comparison of the fused
  * schedules; 0 when consecutive passes run one after the other; negative lpmp_status on error */

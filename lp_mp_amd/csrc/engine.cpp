@@ -22,7 +22,7 @@ void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, c
 bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, const Op* ops, int stride, double* dual, const double* cdata,
                          double* lb, int32_t* primal, int64_t count, int flags, hipStream_t s);
 bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, const Op* packets, const UpdRec* recs,
-                  const Op* ops, double* dual, const double* cdata, double* lb, hipStream_t s);
+                  const Op* ops, double* dual, const double* cdata, const int32_t* tabs, double* lb, hipStream_t s);
 void launch_primal_init(const PrimalInit* list, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_propagate(const PrimalLink* links, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_check(const PrimalLink* links, int64_t n, const int32_t* primal, int* bad, hipStream_t s);
@@ -72,14 +72,20 @@ struct DevSchedule {
   hipGraphExec_t graph = nullptr;
   hipGraphExec_t graph_primal = nullptr;   // the same launches with the SWEEP_PRIMAL flag
   bool adaptive_built = false;             // built with every update on the generic kernels (adaptive send rule)
-  // chain executor (deep single-class schedules): device copies of the ChainPlan
-  bool chain = false; int32_t chain_class = 0, chain_tickets = 0, chain_epoch = 0;
-  ChainLaunchHost* c_launches = nullptr; int32_t *c_tk_launch = nullptr, *c_dep_off = nullptr, *c_dep = nullptr, *c_done = nullptr, *c_next = nullptr;
-  void release_chain() {
-    for (void* p : {(void*)c_launches, (void*)c_tk_launch, (void*)c_dep_off, (void*)c_dep, (void*)c_done, (void*)c_next}) if (p) (void)hipFree(p);
-    c_launches = nullptr; c_tk_launch = c_dep_off = c_dep = c_done = c_next = nullptr; chain = false; chain_tickets = 0;
-  }
   size_t recs_cap = 0, ops_cap = 0, packets_cap = 0;   // allocated elements (a scratch schedule is refilled in place)
+  // chain executor (deep schedules): device copies of the ChainPlans, one per kernel class; the other launches stay plain
+  struct DevChain {
+    int32_t kclass = 0, tickets = 0, epoch = 0;
+    ChainLaunchHost* launches = nullptr; int32_t *tk_launch = nullptr, *tk_block = nullptr, *dep_off = nullptr, *dep = nullptr, *done = nullptr, *next = nullptr;
+  };
+  std::vector<DevChain> chains;
+  std::vector<LevelRange> plain;           // launches that do not belong to a chain
+  bool chain = false;
+  void release_chain() {
+    for (auto& c : chains)
+      for (void* p : {(void*)c.launches, (void*)c.tk_launch, (void*)c.tk_block, (void*)c.dep_off, (void*)c.dep, (void*)c.done, (void*)c.next}) if (p) (void)hipFree(p);
+    chains.clear(); plain.clear(); chain = false;
+  }
   void release() {
     if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
     if (graph_primal) { (void)hipGraphExecDestroy(graph_primal); graph_primal = nullptr; }
@@ -95,7 +101,7 @@ struct DevSchedule {
 // device-side description of a chain plan (layouts shared with kernels.hip: ChainArgs, ChainLaunch)
 struct ChainArgsHost {
   const int32_t* dep_off; const int32_t* dep; int32_t* done; int32_t* next; int32_t* abort_flag; const int32_t* tk_launch;
-  int32_t n_tickets; int32_t epoch;
+  const int32_t* tk_block; int32_t n_tickets; int32_t epoch;
 };
 static_assert(sizeof(ChainLaunchHost) == 32, "ChainLaunch layout");
 
@@ -385,7 +391,11 @@ StreamPool& stream_pool() { static thread_local StreamPool p; return p; }
 constexpr size_t STAGE_CHUNK = (size_t)32 << 20;
 Staging& staging() { static thread_local Staging s; return s; }
 
+// LPMP_DIRECT_COPIES=1: asynchronous copies straight to / from the caller's (pageable) memory followed by a stream
+// synchronise — the round-1 original, kept as an A/B switch of the host-heap corruption hunt
+bool direct_copies() { static const bool v = [] { const char* e = std::getenv("LPMP_DIRECT_COPIES"); return e && e[0] == '1'; }(); return v; }
 void h2d(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (direct_copies()) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); HIP_CHECK(hipStreamSynchronize(stream)); return; }
   for (size_t off = 0; off < bytes; off += STAGE_CHUNK) {
     const size_t n = std::min(STAGE_CHUNK, bytes - off);
     void* st = staging().get(std::min(bytes, STAGE_CHUNK));
@@ -396,6 +406,7 @@ void h2d(void* dst, const void* src, size_t bytes, hipStream_t stream) {
   staging().check();
 }
 void d2h(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  if (direct_copies()) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream)); HIP_CHECK(hipStreamSynchronize(stream)); return; }
   for (size_t off = 0; off < bytes; off += STAGE_CHUNK) {
     const size_t n = std::min(STAGE_CHUNK, bytes - off);
     void* st = staging().get(std::min(bytes, STAGE_CHUNK));
@@ -427,20 +438,25 @@ void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream, bool
   fill_device(d.ops, d.ops_cap, s.ops, stream);
   fill_device(d.packets, d.packets_cap, s.packets, stream);
   d.release_chain();
-  if (s.chain.valid && !adaptive_built) {
-    const ChainPlan& c = s.chain;
+  if (!s.chains.empty() && !adaptive_built) {
     auto up = [&](auto*& dst, const auto& v) {
       using T = std::remove_reference_t<decltype(*dst)>;
       HIP_CHECK(hipMalloc((void**)&dst, std::max<size_t>(1, v.size()) * sizeof(T)));
       if (!v.empty()) h2d(dst, v.data(), v.size() * sizeof(T), stream);
     };
-    up(d.c_launches, c.launches); up(d.c_tk_launch, c.tk_launch); up(d.c_dep_off, c.dep_off); up(d.c_dep, c.dep);
-    d.chain_tickets = (int32_t)c.tk_launch.size();
-    HIP_CHECK(hipMalloc((void**)&d.c_done, (size_t)d.chain_tickets * sizeof(int32_t)));
-    HIP_CHECK(hipMalloc((void**)&d.c_next, sizeof(int32_t)));
-    HIP_CHECK(hipMemsetAsync(d.c_done, 0, (size_t)d.chain_tickets * sizeof(int32_t), stream));
+    for (const ChainPlan& c : s.chains) {
+      DevSchedule::DevChain dc;
+      up(dc.launches, c.launches); up(dc.tk_launch, c.tk_launch); up(dc.tk_block, c.tk_block); up(dc.dep_off, c.dep_off); up(dc.dep, c.dep);
+      dc.tickets = (int32_t)c.tk_launch.size();
+      HIP_CHECK(hipMalloc((void**)&dc.done, std::max<size_t>(1, (size_t)dc.tickets) * sizeof(int32_t)));
+      HIP_CHECK(hipMalloc((void**)&dc.next, sizeof(int32_t)));
+      HIP_CHECK(hipMemsetAsync(dc.done, 0, std::max<size_t>(1, (size_t)dc.tickets) * sizeof(int32_t), stream));
+      dc.kclass = c.kclass;
+      d.chains.push_back(dc);
+    }
+    for (int32_t li : s.plain_launches) d.plain.push_back(s.launches[li]);
     HIP_CHECK(hipStreamSynchronize(stream));
-    d.chain_class = c.kclass; d.chain_epoch = 0; d.chain = true;
+    d.chain = true;
   }
 }
 
@@ -514,14 +530,23 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
   if (e->timing) { issue_launches(e, s, true, e->stream); if (e->pending.size() > 4096) e->drain_timing(); return; }
   if (s.chain && e->use_chain && !e->primal_pass) {
     if (!e->d_chain_abort) { HIP_CHECK(hipMalloc((void**)&e->d_chain_abort, sizeof(int32_t))); HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, sizeof(int32_t), e->stream)); }
-    HIP_CHECK(hipMemsetAsync(s.c_next, 0, sizeof(int32_t), e->stream));
-    const ChainArgsHost ca{s.c_dep_off, s.c_dep, s.c_done, s.c_next, e->d_chain_abort, s.c_tk_launch, s.chain_tickets, ++s.chain_epoch};
     const int rule = e->rtype == LPMP_RTYPE_RESIDUAL ? SWEEP_RESIDUAL : 0;
-    if (launch_chain(s.chain_class, rule | e->nt_flag, &ca, s.c_launches, s.packets, s.recs, s.ops, e->d_dual, e->d_const, e->d_lb, e->stream)) {
-      HIP_CHECK(hipGetLastError());
-      e->chain_ran = true;
-      return;
+    // classes are independent of each other (plan.cpp): the plain launches first, then one persistent launch per class
+    if (!s.plain.empty()) {
+      DevSchedule tmp;                       // a view: issue_launches only reads recs / ops / packets / launches
+      tmp.recs = s.recs; tmp.ops = s.ops; tmp.packets = s.packets; tmp.launches = s.plain;
+      try { issue_launches(e, tmp, false, e->stream); } catch (...) { tmp.recs = nullptr; tmp.ops = nullptr; tmp.packets = nullptr; throw; }
+      tmp.recs = nullptr; tmp.ops = nullptr; tmp.packets = nullptr;
     }
+    for (auto& c : s.chains) {
+      HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
+      const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch};
+      if (!launch_chain(c.kclass, rule | e->nt_flag, &ca, c.launches, s.packets, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream))
+        throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
+    }
+    HIP_CHECK(hipGetLastError());
+    e->chain_ran = true;
+    return;
   }
   // (graphs of up to ~20 k kernel nodes were exercised — C5; beyond 200 k the nodes are issued one by
   // one instead of instantiating a graph of that size)
@@ -706,6 +731,20 @@ int lpmp_plan_pass_schedule_info(lpmp_plan* p, int mode, int64_t* n_levels, int6
     if (n_recv) *n_recv = s.n_recv;
     if (n_send) *n_send = s.n_send;
     if (alg_bytes) *alg_bytes = s.alg_bytes;
+  });
+}
+
+int lpmp_plan_chain_info(lpmp_plan* p, int d, int mode, int64_t* n_chains, int64_t* n_tickets, int64_t* n_dependencies, int64_t* n_plain_launches) {
+  return guarded([&] {
+    if (!p || mode < 0 || mode >= LPMP_REPAM_COUNT || d < -1 || d > 1) throw std::runtime_error("bad argument");
+    const Schedule* s;
+    if (d < 0) { plan_pass_schedule(p, mode); s = &p->pass_cache[mode]; } else { plan_schedule(p, d, mode); s = &p->sched_cache[d][mode]; }
+    int64_t t = 0, e = 0;
+    for (const auto& c : s->chains) { t += (int64_t)c.tk_launch.size(); e += (int64_t)c.dep.size(); }
+    if (n_chains) *n_chains = (int64_t)s->chains.size();
+    if (n_tickets) *n_tickets = t;
+    if (n_dependencies) *n_dependencies = e;
+    if (n_plain_launches) *n_plain_launches = (int64_t)s->plain_launches.size();
   });
 }
 

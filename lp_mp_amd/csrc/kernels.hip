@@ -86,6 +86,7 @@ struct ChainArgs {
   int32_t* next;             // ticket counter (zeroed before the launch)
   int32_t* abort_flag;
   const int32_t* tk_launch;  // [n_tickets]: launch (level x class range) the ticket belongs to
+  const int32_t* tk_block;   // [n_tickets]: block of records inside that launch
   int32_t n_tickets;
   int32_t epoch;
 };
@@ -301,22 +302,22 @@ __device__ __forceinline__ double pw_lb_through(const C& c, const double* __rest
   return best;
 }
 
-template <int G>
-__global__ void __launch_bounds__(GenCtx<G>::THREADS)
-sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
-                     const double* __restrict__ cdata, const int32_t* __restrict__ tabs, double* __restrict__ lb,
-                     int32_t* __restrict__ primal, int64_t first, int64_t count, int flags) {
+// A: access policy of the duals (ACC_COH inside the chain executor)
+template <int G, int A>
+__device__ __forceinline__ void generic_body(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+                                             const double* __restrict__ cdata, const int32_t* __restrict__ tabs, double* __restrict__ lb,
+                                             int32_t* __restrict__ primal, int64_t first, int64_t count, int flags, int64_t block) {
   using C = GenCtx<G>;
   __shared__ typename C::Lds lds[G == 64 ? GEN_WAVES : SMALL_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t idx = (int64_t)blockIdx.x * C::FPB + (G == 64 ? wave : (int)threadIdx.x);
+  const int64_t idx = block * C::FPB + (G == 64 ? wave : (int)threadIdx.x);
   if (idx >= count) return;
   const C c{lds[wave], lane};
   const UpdRec rec = recs[first + idx];
   const int okind = rec.kind_flags & 15;
   const int on = okind == LPMP_F_VECTOR ? rec.d0 : rec.d0 + rec.d1;   // own dual size
   double* own_g = dual + rec.dual_off;
-  for (int i = c.first(); i < on; i += C::STRIDE) c.own(i) = own_g[i];
+  for (int i = c.first(); i < on; i += C::STRIDE) c.own(i) = ld_dual<A>(own_g + i);
   C::sync();
 
   const int n_ops = rec.n_recv + rec.n_send;
@@ -326,7 +327,7 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
     const int pkind = (op.info >> 8) & 15;
     const double* peer = dual + op.peer_dual;
     const int len = op.len;
-    auto from_peer = [&](int i) { return peer[i]; };
+    auto from_peer = [&](int i) { return ld_dual<A>(peer + i); };
     auto from_own = [&](int i) { return live_src ? c.own(i) : c.snap(i); };
     const bool by_right = recv ? (role == 0) : (role == 1);
     if (code == OP_UP) {
@@ -334,7 +335,7 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
         if (recv) pw_min_marginal(c, cdata, op.peer_const, pkind, op.pd0, op.pd1, from_peer, side, omega);
         else pw_min_marginal(c, cdata, rec.const_off, okind, rec.d0, rec.d1, from_own, side, omega);
       } else {          // omega * theta of the unary (left) factor
-        for (int i = c.first(); i < len; i += C::STRIDE) c.dl(i) = omega * (recv ? peer[i] : from_own(i));
+        for (int i = c.first(); i < len; i += C::STRIDE) c.dl(i) = omega * (recv ? ld_dual<A>(peer + i) : from_own(i));
         C::sync();
       }
     } else if (code == OP_LABELING) {
@@ -343,7 +344,7 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
         if (recv) labeling_to_left(c, from_peer, op.pd0, tab, op.pd1, imp, omega);
         else labeling_to_left(c, from_own, rec.d0, tab, op.pd1, imp, omega);
       } else {
-        for (int i = c.first(); i < len; i += C::STRIDE) c.dl(i) = omega * (recv ? peer[i] : from_own(i));
+        for (int i = c.first(); i < len; i += C::STRIDE) c.dl(i) = omega * (recv ? ld_dual<A>(peer + i) : from_own(i));
         C::sync();
       }
     } else {            // OP_MINNORM
@@ -353,7 +354,7 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
   };
   // one receive or send: compute delta, then +delta to the side that did not compute it and -delta to the side that did
   auto run_op = [&](const Op& op, const bool recv, const bool live_src, const double omega) {
-    if (c.leader()) lb[op.peer] = LPMP_NAN;
+    if (c.leader()) st_lb<A>(lb + op.peer, LPMP_NAN);
     const int code = op.info & 15, role = (op.info >> 4) & 1, side = (op.info >> 5) & 1, imp = (op.info >> 6) & 1;
     double* peer = dual + op.peer_dual;
     const int len = op.len;
@@ -371,7 +372,7 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
         const int nr = op.pd0, nl = op.pd1;
         int tv[SMALL_MAXD]; double Rv[SMALL_MAXD];
 #pragma unroll
-        for (int r = 0; r < SMALL_MAXD; ++r) { const bool in = r < nr; tv[r] = in ? tab[r] : nl; Rv[r] = in ? peer[r] : LPMP_INF; }
+        for (int r = 0; r < SMALL_MAXD; ++r) { const bool in = r < nr; tv[r] = in ? tab[r] : nl; Rv[r] = in ? ld_dual<A>(peer + r) : LPMP_INF; }
         if (recv) {
           double nt = imp ? 0.0 : LPMP_INF;
 #pragma unroll
@@ -384,12 +385,12 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
           }
           for (int i = 0; i < len; ++i) c.own(i) += +1.0 * c.dl(i);
 #pragma unroll
-          for (int r = 0; r < SMALL_MAXD; ++r) if (r < nr && tv[r] < nl) peer[r] = Rv[r] + -1.0 * c.dl(tv[r]);
+          for (int r = 0; r < SMALL_MAXD; ++r) if (r < nr && tv[r] < nl) st_dual<A>(peer + r, Rv[r] + -1.0 * c.dl(tv[r]));
         } else {
           for (int i = 0; i < len; ++i) c.dl(i) = omega * from_own(i);
           for (int i = 0; i < len; ++i) c.own(i) += -1.0 * c.dl(i);
 #pragma unroll
-          for (int r = 0; r < SMALL_MAXD; ++r) if (r < nr && tv[r] < nl) peer[r] = Rv[r] + +1.0 * c.dl(tv[r]);
+          for (int r = 0; r < SMALL_MAXD; ++r) if (r < nr && tv[r] < nl) st_dual<A>(peer + r, Rv[r] + +1.0 * c.dl(tv[r]));
         }
         return;
       }
@@ -399,17 +400,17 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
     const bool own_is_left = role == 0;
     const double s_left = by_right ? +1.0 : -1.0, s_right = -s_left;
     if (own_is_left) { for (int i = c.first(); i < len; i += C::STRIDE) c.own(i) += s_left * c.dl(i); }
-    else { for (int i = c.first(); i < len; i += C::STRIDE) peer[i] += s_left * c.dl(i); }
+    else { for (int i = c.first(); i < len; i += C::STRIDE) st_dual<A>(peer + i, ld_dual<A>(peer + i) + s_left * c.dl(i)); }
     if (code == OP_UP) {
-      if (own_is_left) { double* m = peer + (side == 0 ? 0 : op.pd0); for (int i = c.first(); i < len; i += C::STRIDE) m[i] += s_right * c.dl(i); }
+      if (own_is_left) { double* m = peer + (side == 0 ? 0 : op.pd0); for (int i = c.first(); i < len; i += C::STRIDE) st_dual<A>(m + i, ld_dual<A>(m + i) + s_right * c.dl(i)); }
       else { const int o = side == 0 ? 0 : rec.d0; for (int i = c.first(); i < len; i += C::STRIDE) c.own(o + i) += s_right * c.dl(i); }
     } else if (code == OP_LABELING) {
       const int32_t* tab = tabs + op.peer_const;
       const int nl = op.pd1;
-      if (own_is_left) { for (int r = c.first(); r < op.pd0; r += C::STRIDE) if (tab[r] < nl) peer[r] += s_right * c.dl(tab[r]); }
+      if (own_is_left) { for (int r = c.first(); r < op.pd0; r += C::STRIDE) if (tab[r] < nl) st_dual<A>(peer + r, ld_dual<A>(peer + r) + s_right * c.dl(tab[r])); }
       else { for (int r = c.first(); r < rec.d0; r += C::STRIDE) if (tab[r] < nl) c.own(r) += s_right * c.dl(tab[r]); }
     } else {
-      if (own_is_left) { for (int i = c.first(); i < len; i += C::STRIDE) peer[i] += s_right * c.dl(i); }
+      if (own_is_left) { for (int i = c.first(); i < len; i += C::STRIDE) st_dual<A>(peer + i, ld_dual<A>(peer + i) + s_right * c.dl(i)); }
       else { for (int i = c.first(); i < len; i += C::STRIDE) c.own(i) += s_right * c.dl(i); }
     }
     C::sync();
@@ -434,19 +435,19 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
       double lb_r, la_r;
       if (code == OP_UP) {
         const int o = side == 0 ? 0 : op.pd0;
-        lb_r = pw_lb_through(c, cdata, op.peer_const, pkind, op.pd0, op.pd1, [&](int j) { return peer[j]; });
-        la_r = pw_lb_through(c, cdata, op.peer_const, pkind, op.pd0, op.pd1, [&](int j) { return (j >= o && j < o + len) ? peer[j] + s_right * c.dl(j - o) : peer[j]; });
+        lb_r = pw_lb_through(c, cdata, op.peer_const, pkind, op.pd0, op.pd1, [&](int j) { return ld_dual<A>(peer + j); });
+        la_r = pw_lb_through(c, cdata, op.peer_const, pkind, op.pd0, op.pd1, [&](int j) { return (j >= o && j < o + len) ? ld_dual<A>(peer + j) + s_right * c.dl(j - o) : ld_dual<A>(peer + j); });
       } else if (code == OP_LABELING) {
-        lb_r = vec_lb_through(c, op.pd0, [&](int j) { return peer[j]; }, peer_io);
-        la_r = vec_lb_through(c, op.pd0, [&](int j) { return tab[j] < nl ? peer[j] + s_right * c.dl(tab[j]) : peer[j]; }, peer_io);
+        lb_r = vec_lb_through(c, op.pd0, [&](int j) { return ld_dual<A>(peer + j); }, peer_io);
+        la_r = vec_lb_through(c, op.pd0, [&](int j) { return tab[j] < nl ? ld_dual<A>(peer + j) + s_right * c.dl(tab[j]) : ld_dual<A>(peer + j); }, peer_io);
       } else {
-        lb_r = vec_lb_through(c, op.pd0, [&](int j) { return peer[j]; }, peer_io);
-        la_r = vec_lb_through(c, op.pd0, [&](int j) { return peer[j] + s_right * c.dl(j); }, peer_io);
+        lb_r = vec_lb_through(c, op.pd0, [&](int j) { return ld_dual<A>(peer + j); }, peer_io);
+        la_r = vec_lb_through(c, op.pd0, [&](int j) { return ld_dual<A>(peer + j) + s_right * c.dl(j); }, peer_io);
       }
       before = lb_l + lb_r; after = la_l + la_r;
     } else {                    // left = peer (vector), right = this factor
-      const double lb_l = vec_lb_through(c, op.pd0, [&](int i) { return peer[i]; }, peer_io);
-      const double la_l = vec_lb_through(c, op.pd0, [&](int i) { return i < len ? peer[i] + s_left * c.dl(i) : peer[i]; }, peer_io);
+      const double lb_l = vec_lb_through(c, op.pd0, [&](int i) { return ld_dual<A>(peer + i); }, peer_io);
+      const double la_l = vec_lb_through(c, op.pd0, [&](int i) { return i < len ? ld_dual<A>(peer + i) + s_left * c.dl(i) : ld_dual<A>(peer + i); }, peer_io);
       double lb_r, la_r;
       if (code == OP_UP) {
         const int o = side == 0 ? 0 : rec.d0;
@@ -517,8 +518,16 @@ sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops
       run_op(op, false, true, residual);
     }
   }
-  if (c.leader()) lb[rec.factor] = LPMP_NAN;
-  for (int i = c.first(); i < on; i += C::STRIDE) own_g[i] = c.own(i);
+  if (c.leader()) st_lb<A>(lb + rec.factor, LPMP_NAN);
+  for (int i = c.first(); i < on; i += C::STRIDE) st_dual<A>(own_g + i, c.own(i));
+}
+
+template <int G>
+__global__ void __launch_bounds__(GenCtx<G>::THREADS)
+sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+                     const double* __restrict__ cdata, const int32_t* __restrict__ tabs, double* __restrict__ lb,
+                     int32_t* __restrict__ primal, int64_t first, int64_t count, int flags) {
+  generic_body<G, ACC_PLAIN>(recs, ops, dual, cdata, tabs, lb, primal, first, count, flags, (int64_t)blockIdx.x);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -965,7 +974,7 @@ __device__ __forceinline__ void chain_loop(const ChainArgs& ca, const ChainLaunc
     if (ticket >= ca.n_tickets) break;
     if (threadIdx.x == 0) s_ticket[(it + 1) & 1] = atomicAdd(ca.next, 1);
     const ChainLaunch ln = launches[ca.tk_launch[ticket]];
-    body(ln, (int64_t)(ticket - ln.ticket0), ticket);
+    body(ln, (int64_t)ca.tk_block[ticket], ticket);
     chain_publish(ca, ticket);
     __syncthreads();                               // s_ticket[(it + 1) & 1] is written, the LDS of the body is free again
   }
@@ -978,6 +987,19 @@ chain_dense_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, co
   chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
     dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.stride > 0 ? packets + ln.pk_begin : nullptr, recs + ln.rec_begin, ops, dual, cdata, lb,
                                                     nullptr, ln.count, ln.stride, flags, block, &ca, ticket);
+  });
+}
+
+// the generic kernels inside the chain executor (chains of tiny factors: multicut / C5 labeling lists): nothing
+// constant worth requesting ahead, so the wait comes first
+static_assert(GEN_WAVES == GENERIC_BLOCK_RECORDS && 64 * SMALL_WAVES == SMALL_BLOCK_RECORDS, "plan.hpp: records per workgroup of the generic kernels");
+template <int G>
+__global__ void __launch_bounds__(GenCtx<G>::THREADS)
+chain_generic_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
+                     double* __restrict__ dual, const double* __restrict__ cdata, const int32_t* __restrict__ tabs,
+                     double* __restrict__ lb, int flags) {
+  chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
+    if (chain_wait(ca, ticket)) generic_body<G, ACC_COH>(recs, ops, dual, cdata, tabs, lb, nullptr, ln.rec_begin, ln.count, flags, block);
   });
 }
 
@@ -1822,16 +1844,16 @@ bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, cons
 // chain executor: one persistent launch for a deep single-class schedule; grid = what is resident at once (more
 // workgroups would only queue behind the running ones).  Returns false for a class without a chain kernel.
 template <class K>
-static unsigned chain_grid(K kernel, int n_tickets) {
+static unsigned chain_grid(K kernel, int n_tickets, int threads = 256) {
   static int n_cu = 0;
   if (n_cu == 0) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
   const long cap = (long)n_cu * per_cu;
   return (unsigned)(n_tickets < cap ? n_tickets : cap);
 }
 bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, const Op* packets, const UpdRec* recs,
-                  const Op* ops, double* dual, const double* cdata, double* lb, hipStream_t s) {
+                  const Op* ops, double* dual, const double* cdata, const int32_t* tabs, double* lb, hipStream_t s) {
   const ChainArgs ca = *static_cast<const ChainArgs*>(chain_args);
   const ChainLaunch* ln = static_cast<const ChainLaunch*>(launches);
   const bool nt = (flags & SWEEP_NT) != 0;
@@ -1839,6 +1861,8 @@ bool launch_chain(int kclass, int flags, const void* chain_args, const void* lau
     hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, packets, recs, ops, dual, cdata, lb, flags); } while (0)
 #define CHAIN_LAUNCH(LL, KK) do { if (nt) CHAIN_LAUNCH1(LL, KK, false, true); else CHAIN_LAUNCH1(LL, KK, false, false); } while (0)
   switch (kclass) {
+    case KC_GENERIC: { auto k = chain_generic_kernel<64>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<64>::THREADS)), dim3(GenCtx<64>::THREADS), 0, s, ca, ln, recs, ops, dual, cdata, tabs, lb, flags); return true; }
+    case KC_SMALL: { auto k = chain_generic_kernel<1>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<1>::THREADS)), dim3(GenCtx<1>::THREADS), 0, s, ca, ln, recs, ops, dual, cdata, tabs, lb, flags); return true; }
     case KC_DENSE_32: CHAIN_LAUNCH(32, 2); return true;
     case KC_DENSE_16: CHAIN_LAUNCH(16, 2); return true;
     case KC_DENSE_8: CHAIN_LAUNCH(8, 4); return true;

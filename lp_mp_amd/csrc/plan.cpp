@@ -691,42 +691,53 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     }
   }
 
-  // ---- chain plan: a deep schedule whose launches all run one packed kernel class becomes ONE persistent launch
-  // (kernels.hip, chain executor).  Dependencies: update u must see the results of the last earlier update that touched
-  // u's factor or a factor u touches — the same relation the levels were computed from.
-  // (LPMP_CHAIN_MIN: experiments — the smallest number of launches that makes a schedule a chain)
+  // ---- chain plans: a deep schedule becomes persistent launches (kernels.hip, chain executor), one per kernel class.
+  // Dependencies: update u must see the results of the last earlier update that touched u's factor or a factor u
+  // touches — the same relation the levels were computed from.  Classes are separate launches and cannot wait for each
+  // other, so a schedule qualifies only if no dependency runs between records of different classes (C5: the Potts grid
+  // and the labeling-list factors are separate components); classes with few launches stay plain launches.
+  // (LPMP_CHAIN_MIN: experiments — the smallest number of launches that makes a class a chain)
   static const int64_t chain_min = [] { const char* v = std::getenv("LPMP_CHAIN_MIN"); return v ? (int64_t)std::atoll(v) : CHAIN_MIN_LAUNCHES; }();
+  static const int bands = [] { const char* v = std::getenv("LPMP_CHAIN_BANDS"); return v ? std::atoi(v) : 0; }();
+  static const int lag = [] { const char* v = std::getenv("LPMP_CHAIN_LAG"); return v ? std::atoi(v) : 2; }();
   if ((int64_t)out.launches.size() >= chain_min && !out.launches.empty()) {
-    bool ok = kc_chain_capable(out.launches[0].kclass);
-    for (const auto& lr : out.launches) ok = ok && lr.kclass == out.launches[0].kclass && lr.stride != 0;
-    int64_t n_tickets = 0;
-    const int gpb = ok ? kc_block_records(out.launches[0].kclass) : 1;
-    for (const auto& lr : out.launches) n_tickets += (lr.end - lr.begin + gpb - 1) / gpb;
-    ok = ok && n_tickets < std::numeric_limits<int32_t>::max();
+    std::vector<int64_t> n_launches_of(KC_COUNT, 0);
+    bool ok = true;
+    for (const auto& lr : out.launches) {
+      n_launches_of[lr.kclass]++;
+      ok = ok && kc_chain_capable(lr.kclass) && (kc_width(lr.kclass) == 0 || lr.stride != 0);
+    }
     if (ok) {
-      ChainPlan& cp = out.chain;
-      cp.kclass = out.launches[0].kclass;
-      std::vector<int32_t> ticket_of_update(N, -1);
-      int32_t t0 = 0;
+      // tickets per class
+      std::vector<ChainPlan> cps(KC_COUNT);
+      std::vector<int32_t> ticket_of_update(N, -1), class_of_update(N, -1);
+      std::vector<int32_t> t0(KC_COUNT, 0);
       for (size_t li = 0; li < out.launches.size(); ++li) {
         const auto& lr = out.launches[li];
-        cp.launches.push_back({lr.begin, lr.end - lr.begin, lr.pk_begin, lr.stride, t0});
+        ChainPlan& cp = cps[lr.kclass];
+        cp.kclass = lr.kclass;
+        const int gpb = kc_block_records(lr.kclass);
         const int32_t nb = (int32_t)((lr.end - lr.begin + gpb - 1) / gpb);
-        for (int32_t b = 0; b < nb; ++b) cp.tk_launch.push_back((int32_t)li);
-        for (int64_t i = lr.begin; i < lr.end; ++i) ticket_of_update[rec_upd[i]] = t0 + (int32_t)((i - lr.begin) / gpb);
-        t0 += nb;
+        cp.launches.push_back({lr.begin, lr.end - lr.begin, lr.pk_begin, lr.stride, t0[lr.kclass]});
+        for (int32_t b = 0; b < nb; ++b) { cp.tk_launch.push_back((int32_t)cp.launches.size() - 1); cp.tk_block.push_back(b); }
+        for (int64_t i = lr.begin; i < lr.end; ++i) { ticket_of_update[rec_upd[i]] = t0[lr.kclass] + (int32_t)((i - lr.begin) / gpb); class_of_update[rec_upd[i]] = lr.kclass; }
+        t0[lr.kclass] += nb;
+        if ((int64_t)t0[lr.kclass] + nb > std::numeric_limits<int32_t>::max() / 2) ok = false;
       }
       // replay the sequence: who touched each factor last
       std::vector<int32_t> toucher(nf, -1);
-      std::vector<std::pair<int32_t, int32_t>> edges;     // (ticket, predecessor ticket)
-      for (int64_t u = 0; u < N; ++u) {
+      std::vector<std::vector<std::pair<int32_t, int32_t>>> edges(KC_COUNT);     // per class: (ticket, predecessor ticket)
+      for (int64_t u = 0; u < N && ok; ++u) {
         const int32_t o = owner[u];
         const int32_t tk = ticket_of_update[o];
         if (tk < 0) continue;                             // dropped update (no active message)
         const int32_t f = uf[u];
         auto visit = [&](int32_t g) {
           const int32_t w = toucher[g];
-          if (w >= 0 && w != o) { const int32_t tw = ticket_of_update[w]; if (tw != tk) edges.emplace_back(tk, tw); }
+          if (w >= 0 && w != o) {
+            if (class_of_update[w] != class_of_update[o]) ok = false;      // a dependency between classes
+            else if (ticket_of_update[w] != tk) edges[class_of_update[o]].emplace_back(tk, ticket_of_update[w]);
+          }
           toucher[g] = o;
         };
         visit(f);
@@ -739,17 +750,53 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
           if (active) visit(e.adjacent);
         }
       }
-      std::sort(edges.begin(), edges.end());
-      edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
-      cp.dep_off.assign((size_t)n_tickets + 1, 0);
-      for (const auto& e : edges) { if (e.second >= e.first) fail("chain plan: dependency on a later ticket"); cp.dep_off[e.first + 1]++; }
-      std::partial_sum(cp.dep_off.begin(), cp.dep_off.end(), cp.dep_off.begin());
-      cp.dep.resize(edges.size());
-      for (size_t i = 0; i < edges.size(); ++i) cp.dep[i] = edges[i].second;   // sorted by ticket: already in CSR order
-      cp.valid = true;
+      for (int c = 0; c < KC_COUNT && ok; ++c) {
+        if (n_launches_of[c] == 0) continue;
+        if (n_launches_of[c] < chain_min) {               // few launches: plain
+          for (size_t li = 0; li < out.launches.size(); ++li) if (out.launches[li].kclass == c) out.plain_launches.push_back((int32_t)li);
+          continue;
+        }
+        ChainPlan& cp = cps[c];
+        auto& ed = edges[c];
+        const int64_t n_tickets = (int64_t)cp.tk_launch.size();
+        // Temporal blocking (LPMP_CHAIN_BANDS=NB, experiments): tickets are not taken level by level but in a skewed
+        // order — band j of the l-th launch at time j + LAG * l — so that what a level reads (pairwise tables) is read
+        // again by the next level while it is still in the Infinity Cache.  Only an order: the dependency flags keep
+        // the result identical; an order that would put a dependency behind its dependent is refused.
+        if (bands > 1 && n_tickets > 0) {
+          std::vector<int64_t> key((size_t)n_tickets);
+          const int64_t nl = (int64_t)cp.launches.size();
+          for (int64_t t = 0; t < n_tickets; ++t) {
+            const int64_t l = cp.tk_launch[t];
+            const int gpb = kc_block_records(c);
+            const int64_t nb = (cp.launches[l].count + gpb - 1) / gpb;
+            key[t] = ((int64_t)cp.tk_block[t] * bands / nb + (int64_t)lag * l) * (nl + 1) + l;
+          }
+          std::vector<int32_t> order((size_t)n_tickets);
+          std::iota(order.begin(), order.end(), 0);
+          std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+          std::vector<int32_t> new_of((size_t)n_tickets);
+          for (int64_t i = 0; i < n_tickets; ++i) new_of[order[i]] = (int32_t)i;
+          for (auto& e : ed) { e.first = new_of[e.first]; e.second = new_of[e.second]; }
+          std::vector<int32_t> tl((size_t)n_tickets), tb((size_t)n_tickets);
+          for (int64_t i = 0; i < n_tickets; ++i) { tl[i] = cp.tk_launch[order[i]]; tb[i] = cp.tk_block[order[i]]; }
+          cp.tk_launch.swap(tl); cp.tk_block.swap(tb);
+        }
+        std::sort(ed.begin(), ed.end());
+        ed.erase(std::unique(ed.begin(), ed.end()), ed.end());
+        cp.dep_off.assign((size_t)n_tickets + 1, 0);
+        for (const auto& e : ed) { if (e.second >= e.first) fail("chain plan: dependency on a later ticket (LPMP_CHAIN_BANDS / LPMP_CHAIN_LAG?)"); cp.dep_off[e.first + 1]++; }
+        std::partial_sum(cp.dep_off.begin(), cp.dep_off.end(), cp.dep_off.begin());
+        cp.dep.resize(ed.size());
+        for (size_t i = 0; i < ed.size(); ++i) cp.dep[i] = ed[i].second;   // sorted by ticket: already in CSR order
+        cp.valid = true;
+        out.chains.push_back(std::move(cp));
+      }
+      if (!ok) { out.chains.clear(); out.plain_launches.clear(); }
     }
   }
 }
+
 
 // reference factors_messages.hxx:2699-2744.  A dispatcher = the run of list entries with one message type and role; a
 // batch-capable one (MessageDispatcher::CanCallSendMessages: SendMessagesToRight for left-role entries, ...ToLeft for

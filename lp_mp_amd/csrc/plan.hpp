@@ -124,16 +124,20 @@ struct ChainPlan {
   int32_t kclass = 0;                       // the one kernel class of the schedule
   std::vector<ChainLaunchHost> launches;    // parallel to Schedule::launches
   std::vector<int32_t> tk_launch;           // [n_tickets]
+  std::vector<int32_t> tk_block;            // [n_tickets]: block of records inside that launch
   std::vector<int32_t> dep_off, dep;        // CSR over tickets
 };
 // records one workgroup of the packed kernels takes (256 threads / lanes per record)
+constexpr int GENERIC_BLOCK_RECORDS = 4, SMALL_BLOCK_RECORDS = 64;   // sweep_generic_kernel<64> / <1> (kernels.hip asserts them)
 constexpr int kc_block_records(int kclass) {
+  if (kclass == KC_GENERIC) return GENERIC_BLOCK_RECORDS;
+  if (kclass == KC_SMALL) return SMALL_BLOCK_RECORDS;
   const int w = kc_width(kclass);
   if (w == 0) return 0;
   const bool dense = (kclass >= KC_DENSE_4 && kclass <= KC_DENSE_32) || (kclass >= KC_DENSE_V4 && kclass <= KC_DENSE_V32);
   return dense ? (w == 32 ? 4 : 256 / w) : 256 / w;   // dense: G = 64 lanes at 32 labels, else one lane per label
 }
-constexpr bool kc_chain_capable(int kclass) { return kclass >= KC_DENSE_4 && kclass <= KC_POTTS_V32; }
+constexpr bool kc_chain_capable(int kclass) { return (kclass >= KC_DENSE_4 && kclass <= KC_POTTS_V32) || kclass == KC_GENERIC || kclass == KC_SMALL; }
 constexpr int64_t CHAIN_MIN_LAUNCHES = 9;   // shorter schedules run as plain launches
 
 struct Schedule {             // executable form of one (factor list, omega, mask) sweep
@@ -144,7 +148,10 @@ struct Schedule {             // executable form of one (factor list, omega, mas
   int64_t n_levels = 0;
   int64_t n_recv = 0, n_send = 0;     // active receives / sends = message updates per sweep
   int64_t alg_bytes = 0;              // algorithmic HBM bytes per sweep (DESIGN.md accounting)
-  ChainPlan chain;                    // filled for deep single-class schedules of the packed kernels
+  // deep schedules: one chain plan per kernel class (classes between which no dependency runs are independent
+  // sequences), the launches of the remaining classes stay plain launches (indices into `launches`)
+  std::vector<ChainPlan> chains;
+  std::vector<int32_t> plain_launches;
 };
 
 struct Plan {

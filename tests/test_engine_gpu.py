@@ -772,6 +772,48 @@ def test_c4_shape_mid_size():
         e.close()
 
 
+def test_c4_full_size_properties():
+    """BASELINE.json configs[3] at FULL size on one GPU: random sparse graph, 2 M unaries / 10 M dense 16 x 16 pairwise
+    factors (20.5 GB of tables generated in HBM by the per-rank generator bench.py --workload c4 uses, here with one
+    part).  Too big for the oracle, so the size-independent properties: the bound never decreases, a sweep only
+    reparametrises (the energy of fixed labelings is unchanged), weak duality; and the generator equals the host
+    generator on a sample of tables."""
+    import torch
+    from lp_mp_amd import multi_gpu as MG
+    n, m, L = 2_000_000, 10_000_000, 16
+    torch.cuda.set_device(0)
+    sw = MG.GraphSweep(torch, None, n, m, L, M.REPAM_ANISOTROPIC, seed=1)
+    try:
+        dev = sw.dualt.device
+        ei, ej = S.counter_graph_edges(n, m, 1)
+        T = sw.const[: m * L * L].view(m, L, L)
+        for e in (0, 12345, m - 1):                                      # table of edge e = stream block at n L + e L^2
+            assert np.array_equal(T[e].cpu().numpy().reshape(-1), S.u01(L * L, 1, n * L + e * L * L))
+        ei_t, ej_t = torch.from_numpy(ei).to(dev), torch.from_numpy(ej).to(dev)
+        gen = torch.Generator(device="cpu").manual_seed(0)
+        xs = [torch.randint(0, L, (n,), generator=gen).to(dev), sw.dualt[: n * L].view(n, L).argmin(1)]
+
+        def energies():
+            th = sw.dualt[: n * L].view(n, L)
+            pw = sw.dualt[n * L:].view(m, 2 * L)
+            return [_energy(torch, th, pw, T, ei_t, ej_t, x) for x in xs]
+        e0 = energies()
+        lbs = [sw.lower_bound()]
+        for _ in range(3):
+            sw.compute_pass(1)
+            lbs.append(sw.lower_bound())
+        sw.engine.synchronize()
+        e1 = energies()
+        for a, b in zip(e0, e1):
+            assert abs(a - b) <= 1e-9 * abs(a)
+        assert all(b >= a - 1e-7 * abs(a) for a, b in zip(lbs, lbs[1:])) and lbs[-1] > lbs[0]
+        assert lbs[-1] <= min(e1) + 1e-6
+        cls = sw.engine.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC)
+        assert sum(cls.values()) > 0 and "generic" not in cls
+    finally:
+        sw.engine.close()
+
+
 def _scheduled_grid(H, W, L, sched, seed, order="colour_major", dims=None):
     """grid MRF whose unary-pairwise messages have the given schedule (right / full: the pairwise factors are updated)"""
     mt = [M.MsgType(0, 1, sched, 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, sched, 0, 1, M.M_UNARY_PAIRWISE, 1)]

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""tools/profile_collect.py TAG [kernel substring] [last_n skip_tail] — summaries of tools/profile_round.sh's runs
+(gpurun_out/prof_TAG/) written into profiles/:
+  TAG_bench_c3_default.json, TAG_bench_c3_under_rocprof.json   bench lines (plain / under the kernel trace)
+  TAG_bench_c3_kernel_stats.csv                                per-kernel calls / total / average of the kernel trace
+  TAG_pmc_{fetch,write}_counter_collection.csv                 the sweep kernels' PMC rows
+  TAG_pmc_c3_dense32.json                                      HBM bytes per launch, corrected as MI355X_MICROARCH.md prescribes
+  + a cross-check printed: in-bench HIP-event average against the profiler's average of the same launches"""
+import glob
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+kernel = sys.argv[2] if len(sys.argv) > 2 else "sweep_dense_pk_kernel<32"
+last_n, skip_tail = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (41, 8)
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+
+
+def bench_line(log, out):
+    for line in open(os.path.join(src, log)):
+        if line.startswith('{"metric"'):
+            open(os.path.join(dst, out), "w").write(line)
+            return json.loads(line)
+    raise SystemExit(f"no bench line in {log}")
+
+
+plain = bench_line("bench_plain.log", f"{tag}_bench_c3_default.json")
+prof = bench_line("bench_stats.log", f"{tag}_bench_c3_under_rocprof.json")
+db = lambda d: glob.glob(os.path.join(src, d, "*", "*.db"))[0]
+tool = os.path.join(ROOT, "tools", "rocpd_summary.py")
+subprocess.check_call([sys.executable, tool, "stats", db("stats"), os.path.join(dst, f"{tag}_bench_c3_kernel_stats.csv")])
+for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    subprocess.check_call([sys.executable, tool, "pmc", db("pmc_" + name), counter, os.path.join(dst, f"{tag}_pmc_{name}_counter_collection.csv")])
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(dst, f"{tag}_pmc_fetch_counter_collection.csv"),
+                       os.path.join(dst, f"{tag}_pmc_write_counter_collection.csv"), kernel, os.path.join(dst, f"{tag}_pmc_c3_dense32.json"),
+                       str(last_n), str(skip_tail)])
+c = sqlite3.connect(db("stats"))
+v = [r[0] for r in c.execute("select duration from kernels where name like ? order by start", ("%" + kernel + "%",))]
+leg = v[:len(v) - skip_tail][-last_n:]
+print(json.dumps({"plain_ms_per_step": plain["ms_per_step"], "plain_frac": plain["roofline"]["frac"], "oracle_check": plain.get("oracle_check"),
+                  "under_rocprof_in_bench_avg_launch_ms": prof["roofline"]["avg_launch_ms"],
+                  "rocprof_kernel_trace_avg_ms_same_launches": sum(leg) / len(leg) / 1e6, "launches": len(leg)}))
