@@ -146,6 +146,9 @@ int lpmp_set_inner_iterations(lpmp_engine* e, int n);       /* --innerIteration,
  * (updated factors only, CSR: off[n_partitions + 1], factors[n_updated]) */
 int lpmp_plan_get_partitions(lpmp_plan* p, int64_t* n_partitions, int64_t* off, int32_t* factors);
 int lpmp_compute_pass(lpmp_engine* e, int n_passes);        /* LP::ComputePass, LP_MP.h:869-887 ('shared') */
+/* optional: build ahead of time what lpmp_compute_pass(e, n_passes) needs that depends on n_passes (the ticket order of
+ * n joined passes for the chain executor), e.g. outside of a timed region */
+int lpmp_prepare_passes(lpmp_engine* e, int n_passes);
 int lpmp_compute_forward_pass(lpmp_engine* e);              /* LP::ComputeForwardPass, LP_MP.h:889-900 */
 int lpmp_compute_backward_pass(lpmp_engine* e);             /* LP::ComputeBackwardPass, LP_MP.h:902-911 */
 /* LP::ComputePass(factorIt, factorItEnd, omegaIt, receive_it), LP_MP.h:981-1005: any factor list with
@@ -210,6 +213,8 @@ int lpmp_enable_kernel_timing(lpmp_engine* e, int on);
 int lpmp_get_kernel_timing(lpmp_engine* e, int n_classes, double* ms /*[n]*/, int64_t* launches /*[n]*/,
                            int64_t* factors /*[n]*/, int64_t* receives /*[n]*/, int64_t* bytes /*[n]*/);
 int lpmp_reset_kernel_timing(lpmp_engine* e);
+/* of the launches reported per class: how many were persistent launches of the chain executor */
+int lpmp_get_chain_launches(lpmp_engine* e, int n_classes, int64_t* chain_launches /*[n]*/);
 
 /* ---- boundary step of the partitioned (multi-GPU) sweep, DESIGN.md 7 -------------------------------------------------
  * One process per GPU owns one part of the factor graph (lp_mp_amd/multi_gpu.py builds the parts; a C++ host can do

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -21,8 +22,8 @@ void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, c
                   double* lb, int32_t* primal, int64_t first, int64_t count, int flags, hipStream_t s);
 bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, const Op* ops, int stride, double* dual, const double* cdata,
                          double* lb, int32_t* primal, int64_t count, int flags, hipStream_t s);
-bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, const Op* packets, const UpdRec* recs,
-                  const Op* ops, double* dual, const double* cdata, const int32_t* tabs, double* lb, hipStream_t s);
+bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, double* dual, const double* cdata,
+                  const int32_t* tabs, double* lb, hipStream_t s);
 void launch_primal_init(const PrimalInit* list, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_propagate(const PrimalLink* links, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_check(const PrimalLink* links, int64_t n, const int32_t* primal, int* bad, hipStream_t s);
@@ -63,6 +64,10 @@ int guarded(F&& f) {
   catch (const std::exception& e) { g_error = e.what(); return LPMP_ERR_INVALID; }
 }
 
+// one launch as the chain kernels see it (layout shared with kernels.hip: ChainLaunch)
+struct ChainLaunchDev { const Op* packets; const UpdRec* recs; const Op* ops; int64_t count; int32_t stride, pad; };
+static_assert(sizeof(ChainLaunchDev) == 40, "ChainLaunch layout");
+
 struct DevSchedule {
   UpdRec* recs = nullptr;
   Op* ops = nullptr;
@@ -76,7 +81,7 @@ struct DevSchedule {
   // chain executor (deep schedules): device copies of the ChainPlans, one per kernel class; the other launches stay plain
   struct DevChain {
     int32_t kclass = 0, tickets = 0, epoch = 0;
-    ChainLaunchHost* launches = nullptr; int32_t *tk_launch = nullptr, *tk_block = nullptr, *dep_off = nullptr, *dep = nullptr, *done = nullptr, *next = nullptr;
+    ChainLaunchDev* launches = nullptr; int32_t *tk_launch = nullptr, *tk_block = nullptr, *dep_off = nullptr, *dep = nullptr, *done = nullptr, *next = nullptr;
   };
   std::vector<DevChain> chains;
   std::vector<LevelRange> plain;           // launches that do not belong to a chain
@@ -103,14 +108,27 @@ struct ChainArgsHost {
   const int32_t* dep_off; const int32_t* dep; int32_t* done; int32_t* next; int32_t* abort_flag; const int32_t* tk_launch;
   const int32_t* tk_block; int32_t n_tickets; int32_t epoch;
 };
-static_assert(sizeof(ChainLaunchHost) == 32, "ChainLaunch layout");
 
-struct ClassTiming { double ms = 0; int64_t launches = 0, factors = 0, receives = 0, bytes = 0; };
+struct ClassTiming { double ms = 0; int64_t launches = 0, factors = 0, receives = 0, bytes = 0, chain_launches = 0; };
 
 }  // namespace
 
+// Joined passes as ONE persistent launch (chain executor with a skewed ticket order): what the expansion
+// for n passes needs of the two fused schedules.  Templates: H, W, T = the three steps of forward+backward, K = the middle
+// step of backward+forward; n passes = H, W, (K, W)^(n-1), T.
+struct RotationInfo {
+  bool valid = false;
+  int kclass = 0, gpb = 1;
+  struct Tmpl { int sched; LevelRange lr; int32_t nb; int64_t factors, recv, bytes; };   // sched: 0 forward+backward, 1 backward+forward
+  Tmpl t[4];                                                   // H, W, K, T
+  // predecessors of a step's blocks: kind 0 W after [H]; 1 K after [W, H]; 2 W after [K, W]; 3 K after [W, K];
+  // 4 T after [W, K]; 5 T after [W, H].  (delta, block): the block of the step delta steps earlier
+  std::vector<int64_t> off[6]; std::vector<int8_t> delta[6]; std::vector<int32_t> block[6];
+};
+
 struct lpmp_plan {
   Plan p;
+  RotationInfo rot[LPMP_REPAM_COUNT];
   Schedule sched_cache[2][LPMP_REPAM_COUNT]; bool have_sched[2][LPMP_REPAM_COUNT] = {{false}};
   Schedule pass_cache[LPMP_REPAM_COUNT]; bool have_pass[LPMP_REPAM_COUNT] = {false};   // forward+backward as one fused sequence
   Schedule bf_cache[LPMP_REPAM_COUNT]; bool have_bf[LPMP_REPAM_COUNT] = {false};       // backward+forward (the seam between two passes)
@@ -203,6 +221,69 @@ static void plan_rotation(lpmp_plan* pl, int mode) {
 }
 
 
+// who touches what in one launch: the block (of gpb records) whose record updates factor g or reaches it through an op
+static std::vector<int32_t> launch_touchers(const Schedule& s, const LevelRange& lr, int gpb, int64_t nf) {
+  std::vector<int32_t> t((size_t)nf, -1);
+  for (int64_t i = lr.begin; i < lr.end; ++i) {
+    const UpdRec& r = s.recs[i];
+    const int32_t b = (int32_t)((i - lr.begin) / gpb);
+    t[r.factor] = b;
+    for (int k = 0; k < r.n_recv + r.n_send; ++k) t[s.ops[r.op_begin + k].peer] = b;
+  }
+  return t;
+}
+static void plan_rotation_chain(lpmp_plan* pl, int mode) {
+  RotationInfo& ri = pl->rot[mode];
+  ri = RotationInfo();
+  if (!pl->rotation_ok[mode]) return;
+  const Schedule& fb = pl->pass_cache[mode];
+  const Schedule& bf = pl->bf_cache[mode];
+  auto only_launch = [](const Schedule& s, int level, LevelRange& out) {
+    int n = 0;
+    for (const auto& lr : s.launches) if (lr.level == level) { out = lr; ++n; }
+    return n == 1;
+  };
+  LevelRange h, w, k, t;
+  if (!only_launch(fb, 1, h) || !only_launch(fb, 2, w) || !only_launch(fb, 3, t) || !only_launch(bf, 2, k)) return;
+  const int kc = w.kclass;
+  if (h.kclass != kc || k.kclass != kc || t.kclass != kc || !kc_chain_capable(kc) || kc_width(kc) == 0) return;
+  if (h.stride == 0 || w.stride == 0 || k.stride == 0 || t.stride == 0) return;
+  ri.kclass = kc; ri.gpb = kc_block_records(kc);
+  const LevelRange* lrs[4] = {&h, &w, &k, &t};
+  const Schedule* sch[4] = {&fb, &fb, &bf, &fb};
+  std::vector<int32_t> touch[4];
+  for (int i = 0; i < 4; ++i) {
+    const int64_t cnt = lrs[i]->end - lrs[i]->begin;
+    ri.t[i] = {i == 2 ? 1 : 0, *lrs[i], (int32_t)((cnt + ri.gpb - 1) / ri.gpb), cnt, lrs[i]->n_recv, lrs[i]->bytes};
+    touch[i] = launch_touchers(*sch[i], *lrs[i], ri.gpb, pl->p.nf);
+  }
+  // kind -> (X, Y1, Y2)
+  const int X[6] = {1, 2, 1, 2, 3, 3}, Y1[6] = {0, 1, 2, 1, 1, 1}, Y2[6] = {-1, 0, 1, 2, 2, 0};
+  for (int kind = 0; kind < 6; ++kind) {
+    const Schedule& s = *sch[X[kind]];
+    const LevelRange& lr = *lrs[X[kind]];
+    std::vector<std::vector<std::pair<int8_t, int32_t>>> per((size_t)ri.t[X[kind]].nb);
+    for (int64_t i = lr.begin; i < lr.end; ++i) {
+      const UpdRec& r = s.recs[i];
+      auto& dst = per[(size_t)((i - lr.begin) / ri.gpb)];
+      auto visit = [&](int32_t g) {
+        if (touch[Y1[kind]][g] >= 0) dst.emplace_back((int8_t)1, touch[Y1[kind]][g]);
+        else if (Y2[kind] >= 0 && touch[Y2[kind]][g] >= 0) dst.emplace_back((int8_t)2, touch[Y2[kind]][g]);
+      };
+      visit(r.factor);
+      for (int q = 0; q < r.n_recv + r.n_send; ++q) visit(s.ops[r.op_begin + q].peer);
+    }
+    ri.off[kind].assign(1, 0);
+    for (auto& v : per) {
+      std::sort(v.begin(), v.end());
+      v.erase(std::unique(v.begin(), v.end()), v.end());
+      for (const auto& d : v) { ri.delta[kind].push_back(d.first); ri.block[kind].push_back(d.second); }
+      ri.off[kind].push_back((int64_t)ri.block[kind].size());
+    }
+  }
+  ri.valid = true;
+}
+
 struct lpmp_engine {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -248,6 +329,20 @@ struct lpmp_engine {
   bool use_packed = true;
   bool use_chain = true;          // deep single-class schedules as one persistent launch (LPMP_NO_CHAIN=1: graph replay)
   int32_t* d_chain_abort = nullptr; bool chain_ran = false;
+  // joined passes as one persistent launch: expansions of RotationInfo, by mode and pass count
+  struct RotChain { DevSchedule::DevChain dc; int n_steps = 0; int64_t factors = 0, recv = 0, bytes = 0; };
+  std::map<int, RotChain> rot_chain[LPMP_REPAM_COUNT];
+  bool use_blocked_passes = true;     // LPMP_NO_BLOCKED_PASSES=1: the joined passes as one launch per step
+  int rot_bands = 0, rot_lag = 2, rot_depth = 4;   // skewed ticket order (0 bands: from the table bytes per step)
+  void release_rot_chains() {
+    for (auto& m : rot_chain) {
+      for (auto& kv : m) {
+        auto& c = kv.second.dc;
+        for (void* p : {(void*)c.launches, (void*)c.tk_launch, (void*)c.tk_block, (void*)c.dep_off, (void*)c.dep, (void*)c.done, (void*)c.next}) if (p) (void)hipFree(p);
+      }
+      m.clear();
+    }
+  }
   bool timing = false;
   ClassTiming ct[KC_COUNT];
   struct Pending { hipEvent_t a, b; int cls; int64_t factors, receives, bytes; };
@@ -268,6 +363,7 @@ struct lpmp_engine {
     for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m) sched[d][m].release();
     for (int m = 0; m < LPMP_REPAM_COUNT; ++m) { have_sched[m] = false; sched_pass[m].release(); sched_bf[m].release(); have_pass[m] = false; rotation_ok[m] = false; }
     for (int k = 0; k < 2; ++k) { sched_part[k].release(); have_part[k] = false; }
+    release_rot_chains();
   }
   void release_model() {
     release_schedules();
@@ -446,7 +542,9 @@ void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream, bool
     };
     for (const ChainPlan& c : s.chains) {
       DevSchedule::DevChain dc;
-      up(dc.launches, c.launches); up(dc.tk_launch, c.tk_launch); up(dc.tk_block, c.tk_block); up(dc.dep_off, c.dep_off); up(dc.dep, c.dep);
+      std::vector<ChainLaunchDev> lds;
+      for (const auto& l : c.launches) lds.push_back({l.stride > 0 ? d.packets + l.pk_begin : nullptr, d.recs + l.rec_begin, d.ops, l.count, l.stride, 0});
+      up(dc.launches, lds); up(dc.tk_launch, c.tk_launch); up(dc.tk_block, c.tk_block); up(dc.dep_off, c.dep_off); up(dc.dep, c.dep);
       dc.tickets = (int32_t)c.tk_launch.size();
       HIP_CHECK(hipMalloc((void**)&dc.done, std::max<size_t>(1, (size_t)dc.tickets) * sizeof(int32_t)));
       HIP_CHECK(hipMalloc((void**)&dc.next, sizeof(int32_t)));
@@ -495,6 +593,7 @@ void ensure_pass_schedule(lpmp_engine* e, int mode) {
   e->rotation_ok[mode] = e->plan->rotation_ok[mode];
   if (e->rotation_ok[mode]) {
     upload_schedule(e->plan->bf_cache[mode], e->sched_bf[mode], e->stream);
+    plan_rotation_chain(e->plan.get(), mode);
     e->plan->bf_cache[mode] = Schedule();
   }
   // the host copy is only needed for its summary
@@ -541,7 +640,7 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
     for (auto& c : s.chains) {
       HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
       const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch};
-      if (!launch_chain(c.kclass, rule | e->nt_flag, &ca, c.launches, s.packets, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream))
+      if (!launch_chain(c.kclass, rule | e->nt_flag, &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream))
         throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
     }
     HIP_CHECK(hipGetLastError());
@@ -577,6 +676,125 @@ void check_rows(int64_t n, const int64_t* om_off, const double* om, const int64_
     if (om_off[i + 1] < om_off[i] || mk_off[i + 1] < mk_off[i]) throw std::runtime_error("omega / receive-mask offsets must not decrease");
   if (!om && om_off[n] > 0) throw std::runtime_error("omega array missing");
   if (!mk && mk_off[n] > 0) throw std::runtime_error("receive-mask array missing");
+}
+
+// n joined passes (H, W, (K, W)^(n-1), T) as ONE persistent launch of the chain executor.  Tickets are not taken step by
+// step but in a skewed order: inside a group of `depth` consecutive steps, band j of the group's d-th step comes at time
+// j + lag * d, so that the pairwise tables a step reads are read again by the next step while they are still in the
+// 256 MiB Infinity Cache (every table is needed by both of its endpoints, i.e. by consecutive steps).  Only the order
+// changes: the dependency flags keep every result identical to the sequential sweeps.  Returns nullptr when the model
+// does not qualify (then the steps run as one launch each).
+lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
+  auto it = e->rot_chain[mode].find(n);
+  if (it != e->rot_chain[mode].end()) return it->second.n_steps > 0 ? &it->second : nullptr;
+  lpmp_engine::RotChain& rc = e->rot_chain[mode][n];           // n_steps == 0: tried, not possible
+  const RotationInfo& ri = e->plan->rot[mode];
+  if (!ri.valid) return nullptr;
+  const int n_steps = 2 * n + 1;
+  std::vector<int> tmpl(n_steps), kind(n_steps, -1);
+  tmpl[0] = 0;
+  for (int s = 1; s < n_steps - 1; ++s) tmpl[s] = (s & 1) ? 1 : 2;
+  tmpl[n_steps - 1] = 3;
+  for (int s = 1; s < n_steps; ++s) kind[s] = s == n_steps - 1 ? (n == 1 ? 5 : 4) : s == 1 ? 0 : s == 2 ? 1 : (s & 1) ? 2 : 3;
+  std::vector<int64_t> base(n_steps + 1, 0);
+  for (int s = 0; s < n_steps; ++s) base[s + 1] = base[s] + ri.t[tmpl[s]].nb;
+  const int64_t N = base[n_steps];
+  if (N > (int64_t)48 << 20) return nullptr;                   // too many tickets for one launch: the caller splits the passes
+  // a model whose tables fit the caches gains nothing from the order and is launch-bound: one launch per step then
+  if (e->rot_bands <= 0 && ri.t[1].bytes < ((int64_t)64 << 20)) return nullptr;
+  // bands: about 16 MiB of algorithmic bytes per band of a step
+  int bands = e->rot_bands;
+  if (bands <= 0) bands = (int)std::max<int64_t>(1, std::min<int64_t>(ri.t[1].nb, ri.t[1].bytes / ((int64_t)16 << 20)));
+  const int depth = std::max(1, e->rot_depth);
+  std::vector<int32_t> new_of((size_t)N), tk_launch((size_t)N), tk_block((size_t)N);
+  auto band_begin = [](int64_t b, int64_t nb, int64_t bands_) { return (b * nb + bands_ - 1) / bands_; };   // first block of band b
+  for (int lag = std::max(1, e->rot_lag); lag <= 16; lag *= 2) {
+    int64_t at = 0;
+    for (int s0 = 0; s0 < n_steps; s0 += depth) {
+      const int d = std::min(depth, n_steps - s0);
+      for (int64_t tau = 0; tau < bands + (int64_t)lag * (d - 1); ++tau)
+        for (int sd = 0; sd < d; ++sd) {
+          const int64_t b = tau - (int64_t)lag * sd;
+          if (b < 0 || b >= bands) continue;
+          const int s = s0 + sd;
+          const int64_t nb = ri.t[tmpl[s]].nb;
+          for (int64_t j = band_begin(b, nb, bands); j < band_begin(b + 1, nb, bands); ++j) {
+            new_of[base[s] + j] = (int32_t)at; tk_launch[at] = s; tk_block[at] = (int32_t)j; ++at;
+          }
+        }
+    }
+    if (at != N) throw std::runtime_error("rotation chain: ticket count");
+    // every predecessor must come earlier
+    bool ok = true;
+    for (int s = 1; s < n_steps && ok; ++s) {
+      const int kd = kind[s];
+      const auto& off = ri.off[kd];
+      for (int64_t j = 0; j < ri.t[tmpl[s]].nb && ok; ++j)
+        for (int64_t q = off[j]; q < off[j + 1]; ++q)
+          if (new_of[base[s - ri.delta[kd][q]] + ri.block[kd][q]] >= new_of[base[s] + j]) { ok = false; break; }
+    }
+    if (!ok) continue;
+    // dependencies in ticket order
+    std::vector<int32_t> dep_off((size_t)N + 1, 0);
+    for (int s = 1; s < n_steps; ++s) {
+      const auto& off = ri.off[kind[s]];
+      for (int64_t j = 0; j < ri.t[tmpl[s]].nb; ++j) dep_off[new_of[base[s] + j] + 1] = (int32_t)(off[j + 1] - off[j]);
+    }
+    for (int64_t i = 0; i < N; ++i) dep_off[i + 1] += dep_off[i];
+    std::vector<int32_t> dep((size_t)dep_off[N]);
+    for (int s = 1; s < n_steps; ++s) {
+      const int kd = kind[s];
+      const auto& off = ri.off[kd];
+      for (int64_t j = 0; j < ri.t[tmpl[s]].nb; ++j) {
+        int32_t* dst = dep.data() + dep_off[new_of[base[s] + j]];
+        for (int64_t q = off[j]; q < off[j + 1]; ++q) *dst++ = new_of[base[s - ri.delta[kd][q]] + ri.block[kd][q]];
+      }
+    }
+    std::vector<ChainLaunchDev> lds;
+    for (int s = 0; s < n_steps; ++s) {
+      const auto& t = ri.t[tmpl[s]];
+      const DevSchedule& ds = t.sched == 0 ? e->sched_pass[mode] : e->sched_bf[mode];
+      lds.push_back({t.lr.stride > 0 ? ds.packets + t.lr.pk_begin : nullptr, ds.recs + t.lr.begin, ds.ops, t.lr.end - t.lr.begin, t.lr.stride, 0});
+      rc.factors += t.factors; rc.recv += t.recv; rc.bytes += t.bytes;
+    }
+    auto up = [&](auto*& dst, const auto& v) {
+      using T = std::remove_reference_t<decltype(*dst)>;
+      HIP_CHECK(hipMalloc((void**)&dst, std::max<size_t>(1, v.size()) * sizeof(T)));
+      if (!v.empty()) h2d(dst, v.data(), v.size() * sizeof(T), e->stream);
+    };
+    auto& dc = rc.dc;
+    up(dc.launches, lds); up(dc.tk_launch, tk_launch); up(dc.tk_block, tk_block); up(dc.dep_off, dep_off); up(dc.dep, dep);
+    dc.tickets = (int32_t)N; dc.kclass = ri.kclass;
+    HIP_CHECK(hipMalloc((void**)&dc.done, (size_t)N * sizeof(int32_t)));
+    HIP_CHECK(hipMalloc((void**)&dc.next, sizeof(int32_t)));
+    HIP_CHECK(hipMemsetAsync(dc.done, 0, (size_t)N * sizeof(int32_t), e->stream));
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    rc.n_steps = n_steps;
+    return &rc;
+  }
+  return nullptr;
+}
+
+bool run_rotation_chain(lpmp_engine* e, int mode, int n) {
+  if (!e->use_chain || !e->use_blocked_passes || e->primal_pass || e->rtype != LPMP_RTYPE_SHARED) return false;
+  lpmp_engine::RotChain* rc = rotation_chain(e, mode, n);
+  if (!rc) return false;
+  if (!e->d_chain_abort) { HIP_CHECK(hipMalloc((void**)&e->d_chain_abort, sizeof(int32_t))); HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, sizeof(int32_t), e->stream)); }
+  auto& c = rc->dc;
+  HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
+  const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch};
+  hipEvent_t a = nullptr, b = nullptr;
+  if (e->timing) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, e->stream)); }
+  // (plain table loads, not the streaming policy: the second reader of a table is meant to find it in the Infinity Cache)
+  if (!launch_chain(c.kclass, 0, &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream)) throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
+  if (e->timing) {
+    HIP_CHECK(hipEventRecord(b, e->stream));
+    e->pending.push_back({a, b, c.kclass, rc->factors, rc->recv, rc->bytes});
+    e->ct[c.kclass].chain_launches++;
+  }
+  HIP_CHECK(hipGetLastError());
+  e->chain_ran = true;
+  return true;
 }
 
 void require_model(const lpmp_engine* e) { if (!e || !e->plan) throw StateError("no model uploaded"); }
@@ -795,6 +1013,11 @@ int lpmp_create(int device, lpmp_engine** out) {
     e->use_packed = !(np && np[0] == '1');
     const char* nc = std::getenv("LPMP_NO_CHAIN");
     e->use_chain = !(nc && nc[0] == '1');
+    const char* nb = std::getenv("LPMP_NO_BLOCKED_PASSES");
+    e->use_blocked_passes = !(nb && nb[0] == '1');
+    if (const char* v = std::getenv("LPMP_ROT_BANDS")) e->rot_bands = std::atoi(v);
+    if (const char* v = std::getenv("LPMP_ROT_LAG")) e->rot_lag = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("LPMP_ROT_DEPTH")) e->rot_depth = std::max(1, std::atoi(v));
     *out = e.release();
   });
 }
@@ -983,6 +1206,17 @@ int lpmp_compute_backward_pass(lpmp_engine* e) {
 static void compute_plain_passes(lpmp_engine* e, int n) {   // ComputeForwardPass(); ComputeBackwardPass(); n times
   if (e->use_fused) {
     ensure_pass_schedule(e, e->mode);
+    if (e->rotation_ok[e->mode] && e->use_rotation) {
+      // passes in slices of at most 32: each slice one persistent launch (memory of the ticket arrays stays bounded)
+      int done = 0;
+      while (done < n) {
+        const int m = std::min(n - done, 32);
+        if (!run_rotation_chain(e, e->mode, m)) break;
+        done += m;
+      }
+      if (done == n) return;
+      n -= done;
+    }
     if (n >= 2 && e->rotation_ok[e->mode] && e->use_rotation) {
       const DevSchedule& fb = e->sched_pass[e->mode];
       const DevSchedule& bf = e->sched_bf[e->mode];
@@ -998,6 +1232,19 @@ static void compute_plain_passes(lpmp_engine* e, int n) {   // ComputeForwardPas
   } else {
     for (int i = 0; i < n; ++i) { run_schedule(e, e->sched[0][e->mode]); run_schedule(e, e->sched[1][e->mode]); }
   }
+}
+// build whatever lpmp_compute_pass(e, n) needs that depends on n (the ticket order of n joined passes), outside of a
+// timed region; optional
+int lpmp_prepare_passes(lpmp_engine* e, int n) {
+  return guarded([&] {
+    require_mode(e);
+    if (n < 1) throw std::runtime_error("bad argument");
+    HIP_CHECK(hipSetDevice(e->device));
+    if (e->rtype != LPMP_RTYPE_SHARED || !e->use_fused) return;
+    ensure_pass_schedule(e, e->mode);
+    if (!(e->rotation_ok[e->mode] && e->use_rotation && e->use_chain && e->use_blocked_passes)) return;
+    for (int done = 0; done < n;) { const int m = std::min(n - done, 32); (void)rotation_chain(e, e->mode, m); done += m; }
+  });
 }
 int lpmp_compute_pass(lpmp_engine* e, int n) {   // LP::ComputePass, LP_MP.h:869-887
   return guarded([&] {
@@ -1366,6 +1613,15 @@ int lpmp_get_kernel_timing(lpmp_engine* e, int n, double* ms, int64_t* launches,
       if (receives) receives[c] = e->ct[c].receives;
       if (bytes) bytes[c] = e->ct[c].bytes;
     }
+  });
+}
+// of the launches lpmp_get_kernel_timing reports per class: how many were persistent chain-executor launches
+int lpmp_get_chain_launches(lpmp_engine* e, int n, int64_t* chain_launches) {
+  return guarded([&] {
+    if (!e || !chain_launches) throw std::runtime_error("null argument");
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->drain_timing();
+    for (int c = 0; c < n && c < KC_COUNT; ++c) chain_launches[c] = e->ct[c].chain_launches;
   });
 }
 int lpmp_reset_kernel_timing(lpmp_engine* e) {

@@ -90,7 +90,9 @@ struct ChainArgs {
   int32_t n_tickets;
   int32_t epoch;
 };
-struct ChainLaunch { int64_t rec_begin, count, pk_begin; int32_t stride, ticket0; };
+// one launch (a level x class range of records) as the chain kernels see it: absolute device pointers, so that tickets of
+// one persistent launch may come from several schedules (the joined passes of lpmp_compute_pass(n), engine.cpp)
+struct ChainLaunch { const Op* packets; const UpdRec* recs; const Op* ops; int64_t count; int32_t stride, pad; };
 constexpr int CHAIN_SPIN_LIMIT = 1 << 22;   // polls of one dependency before giving up (seconds)
 
 // all threads of the workgroup; returns false when the run was aborted
@@ -981,12 +983,10 @@ __device__ __forceinline__ void chain_loop(const ChainArgs& ca, const ChainLaunc
 }
 template <int L, int KMAX, bool VAR, bool NT>
 __global__ void __launch_bounds__(256)
-chain_dense_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, const Op* __restrict__ packets,
-                      const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+chain_dense_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, double* __restrict__ dual,
                       const double* __restrict__ cdata, double* __restrict__ lb, int flags) {
   chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
-    dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.stride > 0 ? packets + ln.pk_begin : nullptr, recs + ln.rec_begin, ops, dual, cdata, lb,
-                                                    nullptr, ln.count, ln.stride, flags, block, &ca, ticket);
+    dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, nullptr, ln.count, ln.stride, flags, block, &ca, ticket);
   });
 }
 
@@ -995,11 +995,10 @@ chain_dense_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, co
 static_assert(GEN_WAVES == GENERIC_BLOCK_RECORDS && 64 * SMALL_WAVES == SMALL_BLOCK_RECORDS, "plan.hpp: records per workgroup of the generic kernels");
 template <int G>
 __global__ void __launch_bounds__(GenCtx<G>::THREADS)
-chain_generic_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
-                     double* __restrict__ dual, const double* __restrict__ cdata, const int32_t* __restrict__ tabs,
-                     double* __restrict__ lb, int flags) {
+chain_generic_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, double* __restrict__ dual, const double* __restrict__ cdata,
+                     const int32_t* __restrict__ tabs, double* __restrict__ lb, int flags) {
   chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
-    if (chain_wait(ca, ticket)) generic_body<G, ACC_COH>(recs, ops, dual, cdata, tabs, lb, nullptr, ln.rec_begin, ln.count, flags, block);
+    if (chain_wait(ca, ticket)) generic_body<G, ACC_COH>(ln.recs, ln.ops, dual, cdata, tabs, lb, nullptr, 0, ln.count, flags, block);
   });
 }
 
@@ -1267,12 +1266,10 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
 }
 template <int L, bool VAR>
 __global__ void __launch_bounds__(256)
-chain_potts_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, const Op* __restrict__ packets,
-                      const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+chain_potts_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, double* __restrict__ dual,
                       const double* __restrict__ cdata, double* __restrict__ lb, int flags) {
   chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
-    potts_pk_body<L, VAR, ACC_COH, true>(ln.stride > 0 ? packets + ln.pk_begin : nullptr, recs + ln.rec_begin, ops, dual, cdata, lb,
-                                         nullptr, ln.count, ln.stride, flags, block, &ca, ticket);
+    potts_pk_body<L, VAR, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, nullptr, ln.count, ln.stride, flags, block, &ca, ticket);
   });
 }
 
@@ -1852,17 +1849,17 @@ static unsigned chain_grid(K kernel, int n_tickets, int threads = 256) {
   const long cap = (long)n_cu * per_cu;
   return (unsigned)(n_tickets < cap ? n_tickets : cap);
 }
-bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, const Op* packets, const UpdRec* recs,
-                  const Op* ops, double* dual, const double* cdata, const int32_t* tabs, double* lb, hipStream_t s) {
+bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, double* dual, const double* cdata,
+                  const int32_t* tabs, double* lb, hipStream_t s) {
   const ChainArgs ca = *static_cast<const ChainArgs*>(chain_args);
   const ChainLaunch* ln = static_cast<const ChainLaunch*>(launches);
   const bool nt = (flags & SWEEP_NT) != 0;
 #define CHAIN_LAUNCH1(LL, KK, VV, NTT) do { auto k = chain_dense_pk_kernel<LL, KK, VV, NTT>; \
-    hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, packets, recs, ops, dual, cdata, lb, flags); } while (0)
+    hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, dual, cdata, lb, flags); } while (0)
 #define CHAIN_LAUNCH(LL, KK) do { if (nt) CHAIN_LAUNCH1(LL, KK, false, true); else CHAIN_LAUNCH1(LL, KK, false, false); } while (0)
   switch (kclass) {
-    case KC_GENERIC: { auto k = chain_generic_kernel<64>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<64>::THREADS)), dim3(GenCtx<64>::THREADS), 0, s, ca, ln, recs, ops, dual, cdata, tabs, lb, flags); return true; }
-    case KC_SMALL: { auto k = chain_generic_kernel<1>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<1>::THREADS)), dim3(GenCtx<1>::THREADS), 0, s, ca, ln, recs, ops, dual, cdata, tabs, lb, flags); return true; }
+    case KC_GENERIC: { auto k = chain_generic_kernel<64>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<64>::THREADS)), dim3(GenCtx<64>::THREADS), 0, s, ca, ln, dual, cdata, tabs, lb, flags); return true; }
+    case KC_SMALL: { auto k = chain_generic_kernel<1>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<1>::THREADS)), dim3(GenCtx<1>::THREADS), 0, s, ca, ln, dual, cdata, tabs, lb, flags); return true; }
     case KC_DENSE_32: CHAIN_LAUNCH(32, 2); return true;
     case KC_DENSE_16: CHAIN_LAUNCH(16, 2); return true;
     case KC_DENSE_8: CHAIN_LAUNCH(8, 4); return true;
@@ -1872,7 +1869,7 @@ bool launch_chain(int kclass, int flags, const void* chain_args, const void* lau
     case KC_DENSE_V8: CHAIN_LAUNCH1(8, 4, true, false); return true;
     case KC_DENSE_V4: CHAIN_LAUNCH1(4, 4, true, false); return true;
 #define CHAIN_POTTS(LL, VV) do { auto k = chain_potts_pk_kernel<LL, VV>; \
-    hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, packets, recs, ops, dual, cdata, lb, flags); } while (0)
+    hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, dual, cdata, lb, flags); } while (0)
     case KC_POTTS_32: CHAIN_POTTS(32, false); return true;
     case KC_POTTS_16: CHAIN_POTTS(16, false); return true;
     case KC_POTTS_8: CHAIN_POTTS(8, false); return true;

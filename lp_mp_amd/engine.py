@@ -46,7 +46,7 @@ EXPORTS = [
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
     "lpmp_invalidate_lower_bounds", "lpmp_synchronize", "lpmp_dual_size", "lpmp_download_duals", "lpmp_upload_duals", "lpmp_device_duals",
     "lpmp_engine_plan", "lpmp_engine_plan_mut", "lpmp_enable_kernel_timing", "lpmp_get_kernel_timing",
-    "lpmp_reset_kernel_timing", "lpmp_synth_fill", "lpmp_compute_forward_pass_and_primal",
+    "lpmp_reset_kernel_timing", "lpmp_get_chain_launches", "lpmp_prepare_passes", "lpmp_synth_fill", "lpmp_compute_forward_pass_and_primal",
     "lpmp_compute_backward_pass_and_primal", "lpmp_compute_pass_and_primal", "lpmp_check_primal_consistency",
     "lpmp_evaluate_primal", "lpmp_download_primal", "lpmp_upload_primal", "lpmp_streaming_access",
     "lpmp_boundary_create", "lpmp_boundary_destroy", "lpmp_boundary_out_doubles", "lpmp_boundary_in_doubles", "lpmp_boundary_pack",
@@ -134,6 +134,8 @@ def lib():
         L.lpmp_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_get_kernel_timing.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.lpmp_reset_kernel_timing.argtypes = [C.c_void_p]
+        L.lpmp_get_chain_launches.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.lpmp_prepare_passes.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]
         L.lpmp_synth_fill_blocks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.lpmp_boundary_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 5
@@ -358,6 +360,10 @@ class Engine:
     def compute_pass(self, n: int = 1):
         _chk(self.L.lpmp_compute_pass(self.h, int(n)))
 
+    def prepare_passes(self, n: int):
+        """build ahead of time what compute_pass(n) needs that depends on n (outside of a timed region)"""
+        _chk(self.L.lpmp_prepare_passes(self.h, int(n)))
+
     def forward_pass(self):
         _chk(self.L.lpmp_compute_forward_pass(self.h))
 
@@ -494,10 +500,21 @@ class Engine:
         ms = np.zeros(N_KCLASS, np.float64)
         arrs = [np.zeros(N_KCLASS, np.int64) for _ in range(4)]
         _chk(self.L.lpmp_get_kernel_timing(self.h, N_KCLASS, ms.ctypes.data, *[a.ctypes.data for a in arrs]))
+        chain = np.zeros(N_KCLASS, np.int64)
+        _chk(self.L.lpmp_get_chain_launches(self.h, N_KCLASS, chain.ctypes.data))
         out = {}
         for c in range(N_KCLASS):
             if arrs[0][c] > 0:
                 name = KERNEL_NAMES[c]
+                if chain[c] > 0:             # joined passes as persistent launches: plain table loads, agent-scope dual accesses
+                    name = name.replace("sweep_", "chain_")
+                    if not name.endswith(">") and "dense" in name:
+                        name += ", false>"
+                    elif not name.endswith(">"):
+                        name += ">"
+                    out[KCLASS_NAMES[c]] = dict(kernel=name, ms=float(ms[c]), launches=int(arrs[0][c]), chain_launches=int(chain[c]),
+                                                factors=int(arrs[1][c]), receives=int(arrs[2][c]), bytes=int(arrs[3][c]))
+                    continue
                 if not name.endswith(">") and "<" in name:       # exact dense kernels: plain / non-temporal form
                     name += ", true>" if self.L.lpmp_streaming_access(self.h) == 1 else ", false>"
                 elif name == "sweep_dense_big_kernel":

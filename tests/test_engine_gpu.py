@@ -117,11 +117,14 @@ def test_multi_pass_rotated_schedule_both_access_policies(nt_eng, pairwise, L):
     assert name.endswith(", true>" if nt_eng.want_nt else ", false>"), name     # the instantiation BENCH names
 
 
-def test_hbm_sized_model_against_the_oracle():
+@pytest.mark.parametrize("blocked", [True, False], ids=["blocked_chain", "launch_per_step"])
+def test_hbm_sized_model_against_the_oracle(blocked, monkeypatch):
     """A model above the engine's 1 GiB streaming threshold (384 x 384, 32 labels, dense: 2.4 GB of tables), without
-    any override: the engine itself selects the NT = true kernels, exactly as for bench.py's C3, and the duals after
-    two passes equal the oracle's bit for bit (checksums over the IEEE bit patterns + a sampled direct comparison)."""
-    import torch
+    any kernel override: the engine itself selects what it selects for bench.py's C3 — joined passes as ONE persistent
+    chain launch with the Infinity-Cache ticket order (default), or (LPMP_NO_BLOCKED_PASSES=1) one launch per step
+    with the NT = true kernels — and the duals after two + three passes equal the oracle's bit for bit."""
+    if not blocked:
+        monkeypatch.setenv("LPMP_NO_BLOCKED_PASSES", "1")
     H = W = 384; L = 32
     m = S.grid_model(H, W, L, order="colour_major", seed=5)
     o = Oracle(m)
@@ -135,10 +138,41 @@ def test_hbm_sized_model_against_the_oracle():
         e.compute_pass(2); o.ComputePass(2)
         kt = e.kernel_timing()
         e.enable_kernel_timing(False)
-        assert [v["kernel"] for v in kt.values()] == ["sweep_dense_pk_kernel<32, 2, false, true>"]
+        want = "chain_dense_pk_kernel<32, 2, false, false>" if blocked else "sweep_dense_pk_kernel<32, 2, false, true>"
+        assert [v["kernel"] for v in kt.values()] == [want]
+        assert np.array_equal(e.download_duals(), o.duals())
+        e.compute_pass(3); o.ComputePass(3)
+        e.compute_pass(1); o.ComputePass(1)
         assert np.array_equal(e.download_duals(), o.duals())
         lb, lbo = e.lower_bound(), o.LowerBound()
         assert abs(lb - lbo) <= LB_RTOL * abs(lbo)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("pairwise,L,H,W", [("dense", 32, 40, 36), ("dense", 8, 60, 70), ("potts", 8, 64, 48), ("dense", 21, 30, 31)])
+@pytest.mark.parametrize("bands,lag,depth", [(8, 2, 4), (5, 1, 2), (16, 2, 3), (3, 4, 7)])
+def test_joined_passes_as_one_blocked_chain_launch(pairwise, L, H, W, bands, lag, depth, monkeypatch):
+    """lpmp_compute_pass(n) on a 2-colour order as ONE persistent launch whose tickets follow the skewed band order
+    (engine.cpp, rotation_chain): forced on small models here (LPMP_ROT_BANDS), every n, against the oracle bit for bit.
+    An order that would break a dependency is detected on the host and the lag widened."""
+    monkeypatch.setenv("LPMP_ROT_BANDS", str(bands)); monkeypatch.setenv("LPMP_ROT_LAG", str(lag)); monkeypatch.setenv("LPMP_ROT_DEPTH", str(depth))
+    m = S.grid_model(H, W, L, pairwise=pairwise, order="colour_major", seed=L + bands)
+    o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    e = E.Engine(0)
+    try:
+        e.upload(m); e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        assert e.plan.pass_rotates(M.REPAM_ANISOTROPIC)
+        e.prepare_passes(5)
+        for n in (1, 5, 2, 1, 9):
+            e.enable_kernel_timing(True)
+            e.compute_pass(n); o.ComputePass(n)
+            kt = e.kernel_timing(); e.reset_kernel_timing(); e.enable_kernel_timing(False)
+            assert all(v["kernel"].startswith("chain_") and v["chain_launches"] == 1 for v in kt.values()), kt
+            assert np.array_equal(e.download_duals(), o.duals()), (n,)
+            assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+        flb = e.factor_lower_bounds()
+        assert np.max(np.abs(flb - np.array([o.factor_lower_bound(f) for f in range(m.n_factors)]))) <= DUAL_ATOL
     finally:
         e.close()
 
@@ -494,11 +528,13 @@ def test_device_buffers_and_synth_fill_match_host(eng):
     e2.close()
 
 
-@pytest.mark.parametrize("cfg", ["C2_512x512_L8_potts", "C3_1024x1024_L32_dense"])
-def test_full_size_properties(cfg):
+@pytest.mark.parametrize("cfg", ["C2_512x512_L8_potts", "C3_1024x1024_L32_dense", "C3_1024x1024_L32_dense_launch_per_step"])
+def test_full_size_properties(cfg, monkeypatch):
     """BASELINE.json configs[1] and [2] at full size: dual ascent (LB non-decreasing), energy of fixed
     labelings invariant under the sweep, LB <= energy of any labeling, and the oracle where it is cheap."""
     import torch
+    if cfg.endswith("launch_per_step"):
+        monkeypatch.setenv("LPMP_NO_BLOCKED_PASSES", "1")
     e2 = E.Engine(0)
     dev = torch.device("cuda:0")
     if cfg.startswith("C2"):
@@ -535,7 +571,8 @@ def test_full_size_properties(cfg):
         e0 = energies()
         # the oracle ran ONCE on exactly this model in the build container (tests/golden/make_c3_full.py, seed 3): lower
         # bound after 0..3 passes and exact checksums of the packed duals.  This run uses the kernel instantiation
-        # BENCH names (tables + duals > 1 GiB: sweep_dense_pk_kernel<32, 2, false, true>).
+        # BENCH names: the joined passes as one persistent chain launch (chain_dense_pk_kernel<32, 2, false, false>) or,
+        # in the launch-per-step variant, sweep_dense_pk_kernel<32, 2, false, true> (tables + duals > 1 GiB).
         g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c3_full_lb.npz"))
         assert (int(g["H"]), int(g["W"]), int(g["L"])) == (H, W, L) and list(g["passes_seed3"]) == [0, 1, 2, 3]
         assert e2.L.lpmp_streaming_access(e2.h) == 1
@@ -553,7 +590,8 @@ def test_full_size_properties(cfg):
         e2.compute_pass(2)
         kt = e2.kernel_timing()
         e2.enable_kernel_timing(False)
-        assert [v["kernel"] for v in kt.values()] == ["sweep_dense_pk_kernel<32, 2, false, true>"]
+        assert [v["kernel"] for v in kt.values()] == ["sweep_dense_pk_kernel<32, 2, false, true>" if cfg.endswith("launch_per_step")
+                                                     else "chain_dense_pk_kernel<32, 2, false, false>"]
         e2.synchronize()
         e1 = energies()
         for x0, x1 in zip(e0, e1):
