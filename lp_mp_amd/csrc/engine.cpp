@@ -708,7 +708,7 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
   const int depth = std::max(1, e->rot_depth);
   std::vector<int32_t> new_of((size_t)N), tk_launch((size_t)N), tk_block((size_t)N);
   auto band_begin = [](int64_t b, int64_t nb, int64_t bands_) { return (b * nb + bands_ - 1) / bands_; };   // first block of band b
-  for (int lag = std::max(1, e->rot_lag); lag <= 16; lag *= 2) {
+  for (int lag = std::max(1, e->rot_lag); lag <= 16; ++lag) {
     int64_t at = 0;
     for (int s0 = 0; s0 < n_steps; s0 += depth) {
       const int d = std::min(depth, n_steps - s0);
@@ -770,6 +770,8 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
     HIP_CHECK(hipMemsetAsync(dc.done, 0, (size_t)N * sizeof(int32_t), e->stream));
     HIP_CHECK(hipStreamSynchronize(e->stream));
     rc.n_steps = n_steps;
+    if (std::getenv("LPMP_ROT_VERBOSE"))
+      std::fprintf(stderr, "lpmp: %d passes as one launch: %lld tickets, %d bands, lag %d, depth %d\n", n, (long long)N, bands, lag, depth);
     return &rc;
   }
   return nullptr;

@@ -700,12 +700,18 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   static const int64_t chain_min = [] { const char* v = std::getenv("LPMP_CHAIN_MIN"); return v ? (int64_t)std::atoll(v) : CHAIN_MIN_LAUNCHES; }();
   static const int bands = [] { const char* v = std::getenv("LPMP_CHAIN_BANDS"); return v ? std::atoi(v) : 0; }();
   static const int lag = [] { const char* v = std::getenv("LPMP_CHAIN_LAG"); return v ? std::atoi(v) : 2; }();
+  const char* chain_all_env = std::getenv("LPMP_CHAIN_ALL");
+  const bool chain_all = chain_all_env && std::atoi(chain_all_env) != 0;
   if ((int64_t)out.launches.size() >= chain_min && !out.launches.empty()) {
     std::vector<int64_t> n_launches_of(KC_COUNT, 0);
     bool ok = true;
     for (const auto& lr : out.launches) {
       n_launches_of[lr.kclass]++;
       ok = ok && kc_chain_capable(lr.kclass) && (kc_width(lr.kclass) == 0 || lr.stride != 0);
+      // lane-per-factor and generic records: every dual access of a chain kernel is a device-scope access that goes past
+      // the L2, and these bodies issue them one dependent access at a time — measured slower than replaying a hipGraph
+      // of plain launches (C5: 202 ms against 188 ms per pass).  The kernels stay available: LPMP_CHAIN_ALL=1
+      ok = ok && (kc_width(lr.kclass) != 0 || chain_all);
     }
     if (ok) {
       // tickets per class

@@ -49,4 +49,5 @@ def test_bench_json_line_contract():
     assert d["cpu_baseline"]["kind"] == "port"
     rd = d["rounding"]                                         # one pass with primal rounding, outside the timed region
     assert rd["primal_cost"] >= rd["lower_bound"] and rd["ms_pass_and_primal"] > 0
-    assert d["roofline"]["kernel"].startswith("sweep_dense_pk_kernel<32, 2, false")
+    # launch per step, or the whole pass as one chain launch (engine.cpp rotation_chain): same body either way
+    assert d["roofline"]["kernel"].startswith(("sweep_dense_pk_kernel<32, 2, false", "chain_dense_pk_kernel<32, 2, false"))

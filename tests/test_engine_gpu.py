@@ -449,6 +449,30 @@ def test_chain_executor_deep_schedules(pairwise, L, H, W, monkeypatch):
             e.close()
 
 
+def test_chain_executor_lane_per_factor_class_is_opt_in(monkeypatch):
+    """the chain kernels of the lane-per-factor and generic classes are not the default (slower than graph replay:
+    plan.cpp make_schedule) but stay a supported path: LPMP_CHAIN_ALL=1, against the oracle bit for bit"""
+    m = S.c5_model(24, 24, 8, 400, 300, 100, seed=5, window=16)      # backward sweep: 178 levels of labeling-list factors
+    o = Oracle(m)
+    e0 = E.Engine(0); e0.upload(m)
+    assert e0.plan.chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)["n_chains"] == 0
+    monkeypatch.setenv("LPMP_CHAIN_ALL", "1")
+    e1 = E.Engine(0); e1.upload(m)
+    try:
+        assert e1.plan.chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)["n_chains"] == 1
+        for mode in (M.REPAM_ANISOTROPIC, M.REPAM_UNIFORM):
+            o.set_reparametrization(mode)
+            for e in (e0, e1):
+                e.set_reparametrization(mode)
+            o.ComputePass(2)
+            for e in (e0, e1):
+                e.compute_pass(2)
+                assert np.array_equal(e.download_duals(), o.duals()), mode
+                assert abs(e.lower_bound() - o.LowerBound()) <= LB_RTOL * max(1.0, abs(o.LowerBound()))
+    finally:
+        e0.close(); e1.close()
+
+
 def test_chain_executor_repeated_runs_are_deterministic():
     """the flags of a chain run carry the run's epoch: many runs back to back on one schedule, every result equal to
     the one-launch-per-level path"""

@@ -314,6 +314,17 @@ def test_baseline_configs_run_on_the_fast_kernel_classes():
         assert got == want, (name, got)
 
 
+def test_chain_plans_default_to_the_packed_classes(monkeypatch):
+    """deep schedules of the packed dense / Potts classes become chain launches; the lane-per-factor class only on
+    request (LPMP_CHAIN_ALL=1: measured slower than graph replay, plan.cpp make_schedule)"""
+    assert E.Plan(S.grid_model(40, 30, 8, order="row_major")).chain_info(M.FORWARD, M.REPAM_ANISOTROPIC)["n_chains"] == 1
+    m = S.c5_model(24, 24, 8, 400, 300, 100, seed=5, window=16)
+    assert E.Plan(m).chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)["n_chains"] == 0
+    monkeypatch.setenv("LPMP_CHAIN_ALL", "1")
+    ci = E.Plan(m).chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)
+    assert ci["n_chains"] == 1 and ci["n_plain_launches"] == 2 and ci["n_dependencies"] >= ci["n_tickets"] - 1
+
+
 def test_pass_rotation_is_decided_op_by_op():
     """n passes as H, W, (K, W)^(n-1), T need K = (receives of T, sends of H) and W = (receives of T', sends of H')
     record by record (engine.cpp, plan_rotation): checkerboard grids in colour-major order qualify under anisotropic

@@ -32,7 +32,7 @@ e.synchronize(); torch.cuda.synchronize()
 print(json.dumps({{"ms_per_pass": dt / {passes} * 1e3, "ms_single_pass_calls": (time.perf_counter() - t1) / 5 * 1e3, "prepare_s": prep, "lb": e.lower_bound(), "dual_sum": int(b.sum().item())}}))
 """
 for c in cfgs:
-    env = dict(os.environ)
+    env = dict(os.environ, LPMP_ROT_VERBOSE="1")
     if c == "off":
         env["LPMP_NO_BLOCKED_PASSES"] = "1"
     else:
@@ -40,4 +40,5 @@ for c in cfgs:
         env.update(LPMP_ROT_BANDS=b, LPMP_ROT_LAG=l, LPMP_ROT_DEPTH=d)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     out = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": r.stderr[-400:]}
+    out["chain"] = [l[6:] for l in r.stderr.splitlines() if l.startswith("lpmp: ")]
     print(c, json.dumps(out), flush=True)
