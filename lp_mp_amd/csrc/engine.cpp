@@ -333,7 +333,7 @@ struct lpmp_engine {
   struct RotChain { DevSchedule::DevChain dc; int n_steps = 0; int64_t factors = 0, recv = 0, bytes = 0; };
   std::map<int, RotChain> rot_chain[LPMP_REPAM_COUNT];
   bool use_blocked_passes = true;     // LPMP_NO_BLOCKED_PASSES=1: the joined passes as one launch per step
-  int rot_bands = 0, rot_lag = 2, rot_depth = 4;   // skewed ticket order (0 bands: from the table bytes per step)
+  int rot_bands = 0, rot_lag = 3, rot_depth = 4;   // skewed ticket order (0 bands: from the table bytes per step); DESIGN.md 6 has the sweep
   void release_rot_chains() {
     for (auto& m : rot_chain) {
       for (auto& kv : m) {
@@ -702,7 +702,10 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
   if (N > (int64_t)48 << 20) return nullptr;                   // too many tickets for one launch: the caller splits the passes
   // a model whose tables fit the caches gains nothing from the order and is launch-bound: one launch per step then
   if (e->rot_bands <= 0 && ri.t[1].bytes < ((int64_t)64 << 20)) return nullptr;
-  // bands: about 16 MiB of algorithmic bytes per band of a step
+  // bands: about 16 MiB of algorithmic bytes per band of a step.  What a group keeps alive between two reads of a table is
+  // lag * depth bands (3 * 4 * 16 MiB = 192 MiB of the 256 MiB Infinity Cache); measured on C3: windows of 200-230 MB are
+  // the fastest whatever the split (1024:3:4 5.09, 2048:4:6 5.03, 1536:3:6 5.09 ms per pass), 290 MB and more lose the
+  // reuse (1024:3:5 5.67, 1024:3:6 6.37), lag 2 leaves the waiting workgroups less slack (1024:2:4 5.24)
   int bands = e->rot_bands;
   if (bands <= 0) bands = (int)std::max<int64_t>(1, std::min<int64_t>(ri.t[1].nb, ri.t[1].bytes / ((int64_t)16 << 20)));
   const int depth = std::max(1, e->rot_depth);
