@@ -99,10 +99,17 @@ def pmc_traffic(kernel_name, args):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_c3_dense32.json")))
     if not files:
         return None, None
-    d = json.load(open(files[-1]))
-    if d.get("kernel") not in kernel_name:
+    for f in reversed(files):                         # the latest summary taken on this kernel
+        d = json.load(open(f))
+        if d.get("kernel") in kernel_name:
+            files = [f]
+            break
+    else:
         return None, None
-    return d["hbm_bytes_per_launch_avg"], os.path.relpath(files[-1], ROOT)
+    b = d["hbm_bytes_per_launch_avg"]
+    if d.get("passes_per_launch"):                   # one chain launch = all passes of the call
+        b = b / d["passes_per_launch"] * args.steps
+    return b, os.path.relpath(files[-1], ROOT)
 
 
 def dual_bound_gap_c4(torch, dist, args, mode, world, rank):

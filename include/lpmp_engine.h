@@ -186,8 +186,12 @@ int lpmp_streaming_access(const lpmp_engine* e);
  * minimiser of its reparametrised costs as its label unless it already holds one of this time stamp
  * (conditionally_init_primal :3302-3309, MaximizePotentialAndComputePrimal :2382-2389), and the label is copied into
  * the adjacent pairwise factors (propagate_primal_through_messages :2391-2403, :1313-1328).  Built for unary /
- * pairwise models whose COMPUTE_PRIMAL types are vector factors on the left of unary-pairwise messages (LP_MP-MRF's
- * FMC_SRMP); anything else returns LPMP_ERR_UNSUPPORTED.  Time stamps as in the reference: 2*iteration+1 / +2. */
+ * pairwise models: COMPUTE_PRIMAL vector factors on the left of unary-pairwise messages (LP_MP-MRF's FMC_SRMP), and
+ * COMPUTE_PRIMAL pairwise factors (`right` / `full` schedules, MPLP-style): an updated one fills its free sides with
+ * the first minimiser in row-major order given the labels its unaries hold and labels those unaries
+ * (ComputeLeftFromRightPrimal :1330-1344, then the recursion into their other pairwise factors).  Other message
+ * kinds, or two unaries on one side of a pairwise factor, return LPMP_ERR_UNSUPPORTED.  Time stamps as in the
+ * reference: 2*iteration+1 / +2. */
 int lpmp_compute_forward_pass_and_primal(lpmp_engine* e, uint64_t iteration);   /* LP::ComputeForwardPassAndPrimal, LP_MP.h:914-923 */
 int lpmp_compute_backward_pass_and_primal(lpmp_engine* e, uint64_t iteration);  /* LP::ComputeBackwardPassAndPrimal, LP_MP.h:925-934 */
 int lpmp_compute_pass_and_primal(lpmp_engine* e, uint64_t iteration);           /* LP::ComputePassAndPrimal, LP_MP.h:936-940 */

@@ -19,7 +19,7 @@
 
 namespace lpmp {
 void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
-                  double* lb, int32_t* primal, int64_t first, int64_t count, int flags, hipStream_t s);
+                  double* lb, int32_t* primal, const int32_t* pw_unary, int64_t first, int64_t count, int flags, hipStream_t s);
 bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, const Op* ops, int stride, double* dual, const double* cdata,
                          double* lb, int32_t* primal, int64_t count, int flags, hipStream_t s);
 bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, double* dual, const double* cdata,
@@ -303,6 +303,7 @@ struct lpmp_engine {
   int32_t* d_primal = nullptr;
   PrimalInit* d_pinit = nullptr; int64_t n_pinit = 0;
   PrimalLink* d_plinks = nullptr; int64_t n_plinks = 0, n_pprop = 0;   // all messages; the first n_pprop propagate labels
+  int32_t* d_pw_unary = nullptr;  // [2 nf] the unary on each side of a pairwise factor; only with pairwise types that round themselves
   double* d_pcost = nullptr; int* d_pbad = nullptr; int* h_pbad = nullptr;
   char* pinned = nullptr;         // this engine's block of device-written host words (from the pool)
   uint64_t primal_t = 0;          // primal_access_ of every factor a primal pass touches (they move together)
@@ -353,6 +354,7 @@ struct lpmp_engine {
     if (d_primal) { (void)hipFree(d_primal); d_primal = nullptr; }
     if (d_pinit) { (void)hipFree(d_pinit); d_pinit = nullptr; }
     if (d_plinks) { (void)hipFree(d_plinks); d_plinks = nullptr; }
+    if (d_pw_unary) { (void)hipFree(d_pw_unary); d_pw_unary = nullptr; }
     if (d_pcost) { (void)hipFree(d_pcost); d_pcost = nullptr; }
     if (d_pbad) { (void)hipFree(d_pbad); d_pbad = nullptr; }
     h_pbad = nullptr;
@@ -610,10 +612,14 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
     // UpdateFactorPrimal always sends 'shared' (reference factors_messages.hxx:2357-2359), whatever the send rule
     const int rule = e->rtype == LPMP_RTYPE_RESIDUAL ? SWEEP_RESIDUAL : e->rtype == LPMP_RTYPE_ADAPTIVE ? SWEEP_ADAPTIVE : 0;
     const int flags = (e->primal_pass ? SWEEP_PRIMAL : rule) | e->nt_flag;
-    if (!(e->use_packed && lr.stride != 0 &&
+    // primal pass over pairwise factors that round themselves: those records take the generic kernels (ensure_primal)
+    const bool pw_rounds = e->primal_pass && e->d_pw_unary && kc_is_pw(lr.kclass);
+    if (pw_rounds)
+      launch_sweep(KC_GENERIC, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->d_primal, e->d_pw_unary, lr.begin, lr.end - lr.begin, flags, stream);
+    else if (!(e->use_packed && lr.stride != 0 &&
           launch_sweep_packed(lr.kclass, lr.stride > 0 ? s.packets + lr.pk_begin : nullptr, s.recs + lr.begin, s.ops, lr.stride, e->d_dual,
                               e->d_const, e->d_lb, e->d_primal, lr.end - lr.begin, flags, stream)))
-      launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->d_primal, lr.begin, lr.end - lr.begin, flags, stream);
+      launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->d_primal, e->d_pw_unary, lr.begin, lr.end - lr.begin, flags, stream);
     if (timed) {
       HIP_CHECK(hipEventRecord(b, stream));
       e->pending.push_back({a, b, lr.kclass, lr.end - lr.begin, lr.n_recv, lr.bytes});
@@ -1281,22 +1287,42 @@ static void ensure_primal(lpmp_engine* e) {
   for (const auto& mt : p.mtypes)
     if (mt.kind != LPMP_M_UNARY_PAIRWISE)
       throw UnsupportedError("primal rounding is built for unary / pairwise models (DESIGN.md 8)");
+  // Pairwise factor types with COMPUTE_PRIMAL_SOLUTION (MPLP-style `right` / `full` schedules): the recursion of
+  // propagate_primal_through_messages then runs pairwise -> its unaries -> their other pairwise factors and stops
+  // (a slot that is set always equals its unary's label, so nothing changes further out).  The device keeps the
+  // UNARY labels as the one source of truth inside a sweep: an updated pairwise factor of such a type reads its
+  // sides from its unaries' labels, fills the free ones (first minimiser in row-major order given the others) and
+  // labels those unaries; the pairwise slots are copies, made after the sweep as before.  Such records run on the
+  // generic kernels in primal passes (issue_launches) and depend on all their unaries (plan.cpp, make_schedule).
+  bool pw_computes = false;
+  for (int64_t f = 0; f < p.nf; ++f) if (p.f_kind[f] != LPMP_F_VECTOR && p.ftype_primal[p.f_type[f]] && p.updated[f]) pw_computes = true;
   std::vector<PrimalLink> prop, rest;
   std::vector<int32_t> writer(2 * (size_t)p.nf, -1);
-  std::vector<uint8_t> touched((size_t)p.nf, 0);
+  std::vector<uint8_t> touched((size_t)p.nf, 0), labelable((size_t)p.nf, 0);
+  for (int64_t m = 0; m < p.nm; ++m) {
+    const int32_t l = p.m_left[m], r = p.m_right[m];
+    if (p.f_kind[l] != LPMP_F_VECTOR || p.f_kind[r] == LPMP_F_VECTOR) throw UnsupportedError("primal rounding: unary-pairwise message between unexpected factor kinds");
+    if (p.ftype_primal[p.f_type[l]] || (p.ftype_primal[p.f_type[r]] && p.updated[r])) labelable[l] = 1;
+  }
   for (int64_t m = 0; m < p.nm; ++m) {
     const int32_t l = p.m_left[m], r = p.m_right[m];
     const int side = p.mtypes[p.m_type[m]].param;
-    if (p.f_kind[l] != LPMP_F_VECTOR || p.f_kind[r] == LPMP_F_VECTOR) throw UnsupportedError("primal rounding: unary-pairwise message between unexpected factor kinds");
-    if (p.ftype_primal[p.f_type[r]]) throw UnsupportedError("primal rounding: pairwise factor types with COMPUTE_PRIMAL_SOLUTION are not built");
     const PrimalLink k{l, r, side, p.f_dim0[l]};
-    if (p.ftype_primal[p.f_type[l]]) {
+    if (labelable[l]) {
       int32_t& w = writer[2 * (size_t)r + side];   // the copy into the pairwise factor is deferred: one writer per slot
       if (w >= 0 && w != l) throw UnsupportedError("primal rounding: two unaries on one side of a pairwise factor");
       w = l;
       prop.push_back(k);
       touched[r] = 1;
     } else rest.push_back(k);
+  }
+  if (pw_computes) {
+    // conditionally_init_primal reaches one step further: a pairwise factor whose slot changes initialises all its unaries
+    for (int64_t m = 0; m < p.nm; ++m) if (touched[p.m_right[m]]) touched[p.m_left[m]] = 2;
+    std::vector<int32_t> h(2 * (size_t)p.nf);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = writer[i];
+    HIP_CHECK(hipMalloc((void**)&e->d_pw_unary, std::max<size_t>(1, h.size()) * sizeof(int32_t)));
+    if (!h.empty()) h2d(e->d_pw_unary, h.data(), h.size() * sizeof(int32_t), e->stream);
   }
   for (int64_t f = 0; f < p.nf; ++f) if (p.updated[f]) touched[f] = 1;
   auto unset = [&](int64_t f) { return PrimalInit{(int32_t)f, p.f_dim0[f], p.f_kind[f] == LPMP_F_VECTOR ? 0 : p.f_dim1[f], 0}; };

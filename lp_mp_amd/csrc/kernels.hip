@@ -308,7 +308,8 @@ __device__ __forceinline__ double pw_lb_through(const C& c, const double* __rest
 template <int G, int A>
 __device__ __forceinline__ void generic_body(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
                                              const double* __restrict__ cdata, const int32_t* __restrict__ tabs, double* __restrict__ lb,
-                                             int32_t* __restrict__ primal, int64_t first, int64_t count, int flags, int64_t block) {
+                                             int32_t* __restrict__ primal, const int32_t* __restrict__ pw_unary, int64_t first, int64_t count,
+                                             int flags, int64_t block) {
   using C = GenCtx<G>;
   __shared__ typename C::Lds lds[G == 64 ? GEN_WAVES : SMALL_WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -469,7 +470,36 @@ __device__ __forceinline__ void generic_body(const UpdRec* __restrict__ recs, co
   };
   // MaximizePotentialAndComputePrimal between the receives and the sends (vector factors of a COMPUTE_PRIMAL type)
   auto round_label = [&]() {
-    if (!((flags & SWEEP_PRIMAL) && (rec.kind_flags & UPD_PRIMAL) && okind == LPMP_F_VECTOR)) return;
+    if (!((flags & SWEEP_PRIMAL) && (rec.kind_flags & UPD_PRIMAL))) return;
+    if (okind != LPMP_F_VECTOR) {
+      // a pairwise factor that rounds itself (engine.cpp, ensure_primal): a side is given when its unary holds a
+      // label (else when the factor's own slot does: a side without a unary), the free sides take the first minimiser
+      // of T[a][b] + m1[a] + m2[b] in row-major order; the unaries of the filled sides are labelled
+      if (!pw_unary) return;
+      const int d0 = rec.d0, d1 = rec.d1;
+      int32_t* pr = primal + 2 * (int64_t)rec.factor;
+      const int u0 = pw_unary[2 * (int64_t)rec.factor], u1 = pw_unary[2 * (int64_t)rec.factor + 1];
+      int x0 = u0 >= 0 ? primal[2 * (int64_t)u0] : pr[0], x1 = u1 >= 0 ? primal[2 * (int64_t)u1] : pr[1];
+      const bool free0 = x0 >= d0, free1 = x1 >= d1;
+      if (free0 || free1) {
+        const int a0 = free0 ? 0 : x0, na = free0 ? d0 : 1, b0 = free1 ? 0 : x1, nb = free1 ? d1 : 1;
+        double bv = LPMP_INF; int bi = 0x7fffffff;
+        for (int i = c.first(); i < na * nb; i += C::STRIDE) {
+          const int a = a0 + i / nb, b = b0 + i % nb;
+          const double v = pw_cost(cdata, rec.const_off, okind, d1, a, b) + c.own(a) + c.own(d0 + b);
+          if (bi == 0x7fffffff || v < bv) { bv = v; bi = i; }
+        }
+        const double mn = C::gmin(bv);
+        const int cand = C::gmin((bi != 0x7fffffff && bv == mn) ? bi : 0x7fffffff);
+        x0 = a0 + cand / nb; x1 = b0 + cand % nb;
+      }
+      if (c.leader()) {
+        pr[0] = x0; pr[1] = x1;
+        if (free0 && u0 >= 0) primal[2 * (int64_t)u0] = x0;
+        if (free1 && u1 >= 0) primal[2 * (int64_t)u1] = x1;
+      }
+      return;
+    }
     double bv = LPMP_INF; int bi = 0x7fffffff;
     for (int i = c.first(); i < on; i += C::STRIDE) { const double v = c.own(i); if (bi == 0x7fffffff || v < bv) { bv = v; bi = i; } }
     const double mn = C::gmin(bv);
@@ -528,8 +558,8 @@ template <int G>
 __global__ void __launch_bounds__(GenCtx<G>::THREADS)
 sweep_generic_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
                      const double* __restrict__ cdata, const int32_t* __restrict__ tabs, double* __restrict__ lb,
-                     int32_t* __restrict__ primal, int64_t first, int64_t count, int flags) {
-  generic_body<G, ACC_PLAIN>(recs, ops, dual, cdata, tabs, lb, primal, first, count, flags, (int64_t)blockIdx.x);
+                     int32_t* __restrict__ primal, const int32_t* __restrict__ pw_unary, int64_t first, int64_t count, int flags) {
+  generic_body<G, ACC_PLAIN>(recs, ops, dual, cdata, tabs, lb, primal, pw_unary, first, count, flags, (int64_t)blockIdx.x);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -998,7 +1028,7 @@ __global__ void __launch_bounds__(GenCtx<G>::THREADS)
 chain_generic_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, double* __restrict__ dual, const double* __restrict__ cdata,
                      const int32_t* __restrict__ tabs, double* __restrict__ lb, int flags) {
   chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
-    if (chain_wait(ca, ticket)) generic_body<G, ACC_COH>(ln.recs, ln.ops, dual, cdata, tabs, lb, nullptr, 0, ln.count, flags, block);
+    if (chain_wait(ca, ticket)) generic_body<G, ACC_COH>(ln.recs, ln.ops, dual, cdata, tabs, lb, nullptr, nullptr, 0, ln.count, flags, block);
   });
 }
 
@@ -1764,7 +1794,7 @@ __global__ void synth_fill_kernel(double* __restrict__ out, int64_t n, uint64_t 
 
 // ---- launch wrappers (called from engine.cpp) -----------------------------------------------------
 void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, const double* cdata, const int32_t* tabs,
-                  double* lb, int32_t* primal, int64_t first, int64_t count, int flags, hipStream_t s) {
+                  double* lb, int32_t* primal, const int32_t* pw_unary, int64_t first, int64_t count, int flags, hipStream_t s) {
   if (count <= 0) return;
   auto blocks = [&](int per_block) { return dim3((unsigned)((count + per_block - 1) / per_block)); };
   switch (kclass) {
@@ -1780,8 +1810,8 @@ void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, c
       if (flags & SWEEP_NT) hipLaunchKernelGGL(sweep_dense_big_kernel<true>, blocks(BIG_WAVES), dim3(64 * BIG_WAVES), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags);
       else hipLaunchKernelGGL(sweep_dense_big_kernel<false>, blocks(BIG_WAVES), dim3(64 * BIG_WAVES), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags);
       break;
-    case KC_SMALL: hipLaunchKernelGGL(sweep_generic_kernel<1>, blocks(GenCtx<1>::FPB), dim3(GenCtx<1>::THREADS), 0, s, recs, ops, dual, cdata, tabs, lb, primal, first, count, flags); break;
-    default: hipLaunchKernelGGL(sweep_generic_kernel<64>, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, lb, primal, first, count, flags); break;
+    case KC_SMALL: hipLaunchKernelGGL(sweep_generic_kernel<1>, blocks(GenCtx<1>::FPB), dim3(GenCtx<1>::THREADS), 0, s, recs, ops, dual, cdata, tabs, lb, primal, pw_unary, first, count, flags); break;
+    default: hipLaunchKernelGGL(sweep_generic_kernel<64>, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, lb, primal, pw_unary, first, count, flags); break;
   }
 }
 

@@ -402,7 +402,9 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         bool active = false;
         if (e.receives && umk[u][kr++]) { active = true; ++nr; }
         if (e.sends) { const double w = uom[u][ks++]; if (w < 0) fail("negative send weight"); if (w != 0.0) { active = true; ++ns; } }
-        if (active) touched.push_back(e.adjacent);
+        // a pairwise factor that rounds itself reads and writes the labels of ALL its unaries in a primal pass
+        // (engine.cpp, ensure_primal), whether or not the message is active in this sweep
+        if (active || (ftype_primal[f_type[f]] && f_kind[f] != LPMP_F_VECTOR)) touched.push_back(e.adjacent);
       }
     }
     int32_t lv = 0;

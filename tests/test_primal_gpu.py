@@ -147,10 +147,10 @@ def test_unsupported_models_are_refused(eng):
     with pytest.raises(E.EngineError) as ei:
         eng.forward_pass_and_primal(0)
     assert ei.value.code == -2                                 # LPMP_ERR_UNSUPPORTED
-    b = M.ModelBuilder(2, S.mrf_mtypes(), [1, 1])             # pairwise type that computes its own primal
+    b = M.ModelBuilder(2, S.mrf_mtypes(), [1, 1])             # two unaries on one side of a pairwise factor
     u = b.add_vector_factors(0, np.zeros((2, 3)))
     p = b.add_dense_pairwise(1, np.zeros((1, 3, 3)))[0]
-    b.add_messages(0, u[0], p); b.add_messages(1, u[1], p)
+    b.add_messages(0, u[0], p); b.add_messages(0, u[1], p)
     eng.upload(b.finish()); eng.set_reparametrization(M.REPAM_ANISOTROPIC)
     with pytest.raises(E.EngineError) as ei:
         eng.evaluate_primal()
@@ -211,3 +211,83 @@ def test_rounding_when_the_pairwise_factors_are_updated_too(eng, sched):
     m = b.finish()
     for mode in MODES:
         _run(eng, m, mode)
+
+
+def _mrf(sched, computes, L, edges, n, rng, pairwise="dense", relations="chain", dims=None):
+    """unaries 0..n-1, one pairwise factor per edge (i < j), messages of schedule `sched`; relations unary -> pairwise ->
+    unary in variable order"""
+    mt = [M.MsgType(0, 1, sched, 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, sched, 0, 1, M.M_UNARY_PAIRWISE, 1)]
+    b = M.ModelBuilder(2, mt, list(computes))
+    dims = dims if dims is not None else [L] * n
+    u = np.concatenate([b.add_vector_factors(0, rng.uniform(0, 1, (1, dims[k]))) for k in range(n)])
+    for (i, j) in edges:
+        if pairwise == "potts" and dims[i] == dims[j]:
+            p = b.add_potts_pairwise(1, dims[i], rng.uniform(0.1, 1, 1))[0]
+        else:
+            p = b.add_dense_pairwise(1, rng.uniform(0, 1, (1, dims[i], dims[j])))[0]
+        b.add_messages(0, u[i], p); b.add_messages(1, u[j], p)
+        b.add_relations(u[i], p); b.add_relations(p, u[j])
+    return b.finish()
+
+
+def _grid_edges_list(H, W):
+    a, bb = S.grid_edges(H, W)
+    return [(int(min(x, y)), int(max(x, y))) for x, y in zip(a, bb)]
+
+
+@pytest.mark.parametrize("sched", [M.SCHED_FULL, M.SCHED_RIGHT])
+@pytest.mark.parametrize("computes", [(0, 1), (1, 1)])
+@pytest.mark.parametrize("L,pairwise", [(3, "dense"), (6, "dense"), (32, "dense"), (40, "dense"), (5, "potts"), (16, "potts")])
+def test_pairwise_factors_that_round_themselves(eng, sched, computes, L, pairwise):
+    """MPLP-style models (reference factors_messages.hxx:2332-2373 with a COMPUTE_PRIMAL_SOLUTION pairwise type): the
+    updated pairwise factor fills its free sides given the labels its unaries already hold and labels them; the
+    recursion of propagate_primal_through_messages then reaches the unaries' other pairwise factors"""
+    rng = np.random.default_rng(L + 7 * sched + computes[0])
+    H, W = (5, 6) if L <= 16 else (3, 4)
+    m = _mrf(sched, computes, L, _grid_edges_list(H, W), H * W, rng, pairwise)
+    for mode in MODES:
+        best = _run(eng, m, mode, iterations=2)
+        assert np.isfinite(best)                                   # every factor ends up labelled, consistently
+
+
+def test_pairwise_rounding_trees_random_graphs_and_mixed_label_counts(eng):
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        n = int(rng.integers(2, 14))
+        dims = [int(x) for x in rng.integers(2, 9, n)]
+        if trial % 2 == 0:                                          # tree
+            edges = [(int(rng.integers(0, k)), k) for k in range(1, n)]
+        else:
+            pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+            pick = rng.choice(len(pairs), min(len(pairs), int(rng.integers(1, 3 * n))), replace=False)
+            edges = [pairs[k] for k in sorted(pick)]
+        for sched in (M.SCHED_FULL, M.SCHED_RIGHT, M.SCHED_LEFT):
+            for computes in ((0, 1), (1, 1)):
+                m = _mrf(sched, computes, 0, edges, n, rng, "potts" if trial % 3 == 0 else "dense", dims=dims)
+                for mode in (M.REPAM_ANISOTROPIC, M.REPAM_UNIFORM):
+                    _run(eng, m, mode, iterations=2)
+
+
+def test_pairwise_rounding_ties_and_sides_without_a_unary(eng):
+    """all-zero costs: every restricted minimiser is the first in row-major order; a pairwise factor with a message on
+    one side only keeps the label of the other side in its own slot"""
+    mt = [M.MsgType(0, 1, M.SCHED_FULL, 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, M.SCHED_FULL, 0, 1, M.M_UNARY_PAIRWISE, 1)]
+    b = M.ModelBuilder(2, mt, [0, 1])
+    u = b.add_vector_factors(0, np.zeros((3, 4)))
+    p = b.add_dense_pairwise(1, np.zeros((3, 4, 4)))
+    b.add_messages(0, u[0], p[0]); b.add_messages(1, u[1], p[0])
+    b.add_messages(0, u[1], p[1]); b.add_messages(1, u[2], p[1])
+    b.add_messages(1, u[2], p[2])                                   # p[2]: nothing on side 0
+    b.add_relations(u[0], p[0]); b.add_relations(p[0], u[1]); b.add_relations(u[1], p[1]); b.add_relations(p[1], u[2]); b.add_relations(u[2], p[2])
+    m = b.finish()
+    for mode in MODES:
+        _run(eng, m, mode, iterations=2)
+    rng = np.random.default_rng(3)                                   # and with costs: the free side of p[2] is a real argmin
+    b = M.ModelBuilder(2, mt, [0, 1])
+    u = b.add_vector_factors(0, rng.uniform(0, 1, (3, 4)))
+    p = b.add_dense_pairwise(1, rng.uniform(0, 1, (3, 4, 4)))
+    b.add_messages(0, u[0], p[0]); b.add_messages(1, u[1], p[0]); b.add_messages(0, u[1], p[1]); b.add_messages(1, u[2], p[1]); b.add_messages(1, u[2], p[2])
+    b.add_relations(u[0], p[0]); b.add_relations(p[0], u[1]); b.add_relations(u[1], p[1]); b.add_relations(p[1], u[2]); b.add_relations(u[2], p[2])
+    m = b.finish()
+    for mode in MODES:
+        _run(eng, m, mode, iterations=2)

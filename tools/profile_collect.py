@@ -39,6 +39,13 @@ for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(dst, f"{tag}_pmc_fetch_counter_collection.csv"),
                        os.path.join(dst, f"{tag}_pmc_write_counter_collection.csv"), kernel, os.path.join(dst, f"{tag}_pmc_c3_dense32.json"),
                        str(last_n), str(skip_tail)])
+# a chain launch covers as many passes as the call had: keep that with the byte count (bench.py scales by it)
+pj = os.path.join(dst, f"{tag}_pmc_c3_dense32.json")
+d = json.load(open(pj))
+d["passes_per_launch"] = plain["roofline"].get("passes_per_launch")
+d["note"] = ("FETCH_SIZE / WRITE_SIZE are the L2's fabric-side request counters: reads served by the 256 MiB Infinity Cache are "
+             "counted like reads served by HBM (MI355X_MICROARCH.md, HBM / rocprofv3 section)")
+json.dump(d, open(pj, "w"))
 c = sqlite3.connect(db("stats"))
 v = [r[0] for r in c.execute("select duration from kernels where name like ? order by start", ("%" + kernel + "%",))]
 leg = v[:len(v) - skip_tail][-last_n:]
