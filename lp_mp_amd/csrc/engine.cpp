@@ -106,7 +106,7 @@ struct DevSchedule {
 // device-side description of a chain plan (layouts shared with kernels.hip: ChainArgs, ChainLaunch)
 struct ChainArgsHost {
   const int32_t* dep_off; const int32_t* dep; int32_t* done; int32_t* next; int32_t* abort_flag; const int32_t* tk_launch;
-  const int32_t* tk_block; int32_t n_tickets; int32_t epoch;
+  const int32_t* tk_block; int32_t n_tickets; int32_t epoch; long long* trace;
 };
 
 struct ClassTiming { double ms = 0; int64_t launches = 0, factors = 0, receives = 0, bytes = 0, chain_launches = 0; };
@@ -628,6 +628,42 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
   HIP_CHECK(hipGetLastError());
 }
 
+// LPMP_CHAIN_TRACE=<file> (debugging): every chain run is followed by a synchronisation and its per-ticket time stamps
+// (ticket in hand, predecessors seen, body done, published; 100 MHz) are written to the file together with the ticket
+// -> launch map and the dependency lists: tools/chain_trace.py turns them into the latency budget of DESIGN.md 6
+struct ChainTrace {
+  long long* d = nullptr; int32_t n = 0;
+  static const char* path() { static const char* p = std::getenv("LPMP_CHAIN_TRACE"); return p; }
+  long long* begin(int32_t n_tickets, hipStream_t s) {
+    if (!path()) return nullptr;
+    n = n_tickets;
+    HIP_CHECK(hipMalloc((void**)&d, (size_t)8 * n * sizeof(long long)));
+    HIP_CHECK(hipMemsetAsync(d, 0, (size_t)8 * n * sizeof(long long), s));
+    return d;
+  }
+  template <class DC> void end(const DC& c, hipStream_t s) {
+    if (!d) return;
+    HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<long long> st((size_t)8 * n);
+    std::vector<int32_t> tl((size_t)n), off((size_t)n + 1);
+    HIP_CHECK(hipMemcpy(st.data(), d, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(tl.data(), c.tk_launch, tl.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(off.data(), c.dep_off, off.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> dep((size_t)off[n]);
+    if (!dep.empty()) HIP_CHECK(hipMemcpy(dep.data(), c.dep, dep.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    (void)hipFree(d); d = nullptr;
+    if (FILE* f = std::fopen(path(), "wb")) {
+      const int64_t hdr[2] = {n, off[n]};
+      std::fwrite(hdr, sizeof(hdr), 1, f);
+      std::fwrite(st.data(), sizeof(long long), st.size(), f);
+      std::fwrite(tl.data(), sizeof(int32_t), tl.size(), f);
+      std::fwrite(off.data(), sizeof(int32_t), off.size(), f);
+      std::fwrite(dep.data(), sizeof(int32_t), dep.size(), f);
+      std::fclose(f);
+    }
+  }
+};
+
 // one sweep over a device schedule; long launch chains (row-major grids: one launch per anti-diagonal)
 // are captured once into a hipGraph and replayed
 void run_schedule(lpmp_engine* e, DevSchedule& s) {
@@ -645,9 +681,11 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
     }
     for (auto& c : s.chains) {
       HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
-      const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch};
+      ChainTrace tr;
+      const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream)};
       if (!launch_chain(c.kclass, rule | e->nt_flag, &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream))
         throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
+      tr.end(c, e->stream);
     }
     HIP_CHECK(hipGetLastError());
     e->chain_ran = true;
@@ -793,11 +831,13 @@ bool run_rotation_chain(lpmp_engine* e, int mode, int n) {
   if (!e->d_chain_abort) { HIP_CHECK(hipMalloc((void**)&e->d_chain_abort, sizeof(int32_t))); HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, sizeof(int32_t), e->stream)); }
   auto& c = rc->dc;
   HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
-  const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch};
+  ChainTrace tr;
+  const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream)};
   hipEvent_t a = nullptr, b = nullptr;
   if (e->timing) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, e->stream)); }
   // (plain table loads, not the streaming policy: the second reader of a table is meant to find it in the Infinity Cache)
   if (!launch_chain(c.kclass, 0, &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream)) throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
+  tr.end(c, e->stream);
   if (e->timing) {
     HIP_CHECK(hipEventRecord(b, e->stream));
     e->pending.push_back({a, b, c.kclass, rc->factors, rc->recv, rc->bytes});

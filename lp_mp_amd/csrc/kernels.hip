@@ -89,7 +89,11 @@ struct ChainArgs {
   const int32_t* tk_block;   // [n_tickets]: block of records inside that launch
   int32_t n_tickets;
   int32_t epoch;
+  long long* trace;          // debugging (LPMP_CHAIN_TRACE): 8 slots of time stamps per ticket, 100 MHz; nullptr otherwise
 };
+__device__ __forceinline__ void chain_stamp(const ChainArgs& ca, int ticket, int k) {
+  if (ca.trace && threadIdx.x == 0) ca.trace[8 * (int64_t)ticket + k] = (long long)__builtin_amdgcn_s_memrealtime();
+}
 // one launch (a level x class range of records) as the chain kernels see it: absolute device pointers, so that tickets of
 // one persistent launch may come from several schedules (the joined passes of lpmp_compute_pass(n), engine.cpp)
 struct ChainLaunch { const Op* packets; const UpdRec* recs; const Op* ops; int64_t count; int32_t stride, pad; };
@@ -114,13 +118,16 @@ __device__ __forceinline__ bool chain_wait(const ChainArgs& ca, int ticket) {
     }
   }
   __syncthreads();
+  chain_stamp(ca, ticket, 1);                      // predecessors seen
   return s_bad == 0;
 }
 // all threads: every wave drains its stores, then one lane publishes the ticket
 __device__ __forceinline__ void chain_publish(const ChainArgs& ca, int ticket) {
+  chain_stamp(ca, ticket, 2);                      // body done, stores issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(ca.done + ticket, ca.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  chain_stamp(ca, ticket, 3);                      // published
 }
 
 
@@ -869,6 +876,18 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
         }
       }
     }
+    if constexpr (CHAIN && FIRST) {
+      // Loads and stores share one counter on this ISA and may complete out of order with respect to each other, so a
+      // wait for an older load that the compiler places after a store drains that store too — a round trip to memory
+      // for a write-through store, three or four times per record (measured: 4.3 us of body per dependent level,
+      // tools/chain_trace.py).  Every dual this record will read is therefore awaited HERE, before its first store.
+      asm volatile("" :: "v"(theta));
+#pragma unroll
+      for (int k = 0; k < KS; ++k) asm volatile("" :: "v"(sm[k]));
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) { asm volatile("" :: "v"(msv[j])); asm volatile("" :: "v"(mov[j])); }
+      chain_stamp(*ca, ticket, 4);               // duals landed
+    }
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {             // then reduce, in message order
       if (c + j >= max_recv) break;
@@ -929,6 +948,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
   // the first chunks are unrolled with constant indices so that forwarded results stay in registers
   if constexpr (CHAIN) {
     chunk(0, std::true_type{}, std::true_type{});   // also waits when the workgroup's factors receive nothing
+    chain_stamp(*ca, ticket, 5);                    // first receives done
   } else {
     if (max_recv > 0) chunk(0, std::true_type{}, std::false_type{});
   }
@@ -1005,6 +1025,7 @@ __device__ __forceinline__ void chain_loop(const ChainArgs& ca, const ChainLaunc
     const int ticket = s_ticket[it & 1];
     if (ticket >= ca.n_tickets) break;
     if (threadIdx.x == 0) s_ticket[(it + 1) & 1] = atomicAdd(ca.next, 1);
+    chain_stamp(ca, ticket, 0);                    // ticket in hand
     const ChainLaunch ln = launches[ca.tk_launch[ticket]];
     body(ln, (int64_t)ca.tk_block[ticket], ticket);
     chain_publish(ca, ticket);
@@ -1205,6 +1226,13 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
         diff[j] = cdata[o.peer_const];
         defer[j] = FW ? o.pad : 0;
       }
+    }
+    if constexpr (CHAIN) {                       // every dual awaited before the first store (see dense_pk_body)
+      asm volatile("" :: "v"(theta));
+#pragma unroll
+      for (int k = 0; k < KS; ++k) asm volatile("" :: "v"(sm[k]));
+#pragma unroll
+      for (int j = 0; j < KR; ++j) { asm volatile("" :: "v"(msv[j])); asm volatile("" :: "v"(mov[j])); asm volatile("" :: "v"(diff[j])); }
     }
 #pragma unroll
     for (int j = 0; j < KR; ++j) {

@@ -452,6 +452,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     const int32_t f = uf[u];
     const int32_t o = owner[u];
     const int32_t own_d0 = f_dim0[f];
+    if (f_doff[f + 1] - f_doff[f] > SMALL_MAXD) small_ok[o] = 0;   // also for a record without any op (COMPUTE_PRIMAL types)
     Op* base = ops.data() + op_start[o];
     auto fill = [&](const MsgEntry& e, double w) {
       const auto& mt = mtypes[m_type[e.msg]];

@@ -246,6 +246,10 @@ def test_random_mrfs_primal_rounding(seed):
     the primal cost against the oracle, interleaved with plain passes and random iterator-range passes"""
     rng = np.random.default_rng(13000 + seed)
     m = random_mrf(rng, primal=True) if seed % 2 else random_mrf_any_labels(rng, primal=True)
+    _primal_steps(m, rng, seed)
+
+
+def _primal_steps(m, rng, seed):
     eng = E.Engine(0)
     try:
         for mode in MODES:
@@ -276,6 +280,45 @@ def test_random_mrfs_primal_rounding(seed):
                 assert (c == co) if np.isinf(co) else abs(c - co) <= 1e-9 * max(1.0, abs(co))
     finally:
         eng.close()
+
+
+def random_mrf_rounding_pairwise(rng):
+    """unary / pairwise MRFs whose PAIRWISE type rounds itself (and, half of the time, the unary type too) under `full`,
+    `right` or `left` schedules: random graphs, one label count of a packed class or mixed small ones, dense / Potts,
+    odd orders, occasional duplicate messages"""
+    sched = int(rng.choice([M.SCHED_FULL, M.SCHED_RIGHT, M.SCHED_LEFT]))
+    mt = [M.MsgType(0, 1, sched, 0, 1, M.M_UNARY_PAIRWISE, 0), M.MsgType(0, 1, sched, 0, 1, M.M_UNARY_PAIRWISE, 1)]
+    b = M.ModelBuilder(2, mt, [int(rng.integers(2)), 1])
+    n = int(rng.integers(3, 30))
+    if rng.uniform() < 0.5:
+        dims = [int(rng.choice([4, 8, 16, 32]))] * n
+    else:
+        dims = [int(x) for x in rng.integers(2, 12, n)]
+    u = np.concatenate([b.add_vector_factors(0, rng.uniform(0, 1, (1, d))) for d in dims])
+    rel = []
+    for _ in range(int(rng.integers(max(1, n // 2), 3 * n))):
+        i, j = sorted(int(x) for x in rng.choice(n, 2, replace=False))
+        if dims[i] == dims[j] and rng.uniform() < 0.4:
+            p = b.add_potts_pairwise(1, dims[i], [rng.uniform(-0.5, 1)])[0]
+        else:
+            p = b.add_dense_pairwise(1, rng.uniform(0, 1, (1, dims[i], dims[j])))[0]
+        b.add_messages(0, u[i], p)
+        if rng.uniform() < 0.9:
+            b.add_messages(1, u[j], p)                      # else: a side without a unary
+        if rng.uniform() < 0.05:
+            b.add_messages(0, u[i], p)                      # duplicate message of the same unary
+        rel += [(u[i], p), (p, u[j])]
+    keep = rng.uniform(size=len(rel)) < rng.choice([1.0, 0.9, 0.5, 0.0])
+    r = np.array([x for x, k in zip(rel, keep) if k], np.int32).reshape(-1, 2)
+    if r.shape[0]:
+        b.add_relations(r[:, 0], r[:, 1])
+    return b.finish()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_mrfs_pairwise_factors_round_themselves(seed):
+    rng = np.random.default_rng(17000 + seed)
+    _primal_steps(random_mrf_rounding_pairwise(rng), rng, seed)
 
 
 def random_bipartite_mrf(rng):
