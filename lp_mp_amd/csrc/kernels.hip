@@ -962,6 +962,22 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
   }
   if (vl && !aborted) {
     const double snap = theta;
+    if constexpr (CHAIN) {
+      // targets that could not be requested up front (a receive of this record rewrites them): all of them now, one
+      // wait inside this branch — a load inside the send loop would put a wait at the loop's join that drains the
+      // write-through stores of the receives on EVERY path (measured: 1 us per record, tools/chain_trace.py)
+      if (!preload_ok) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          if (k < n_send) {
+            const Op& o = lop[n_recv + k];
+            if (uni<G>(o.pad) == 0) sm[k] = ld_dual<A>(dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0) + g);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k) asm volatile("" :: "v"(sm[k]));
+      }
+    }
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       if (k < n_send) {
@@ -970,6 +986,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
         const int fw = uni<G>(o.pad);
         double cur;
         if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
+        else if constexpr (CHAIN) cur = sm[k];
         else cur = preload_ok ? sm[k] : ld_dual<A>(ms + g);
         const double delta = o.omega * snap;
         st_dual<A>(ms + g, cur + delta);
@@ -1276,6 +1293,19 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
   }
   if (vl && !aborted) {
     const double snap = theta;
+    if constexpr (CHAIN) {                          // no load inside the send loop (see dense_pk_body)
+      if (!preload_ok) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          if (k < n_send) {
+            const Op& o = lop[n_recv + k];
+            if (o.pad == 0) sm[k] = ld_dual<A>(dual + o.peer_dual + (((o.info >> 5) & 1) ? Lr : 0) + g);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k) asm volatile("" :: "v"(sm[k]));
+      }
+    }
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       if (k < n_send) {
@@ -1284,6 +1314,7 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
         const int fw = o.pad;
         double cur;
         if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
+        else if constexpr (CHAIN) cur = sm[k];
         else cur = preload_ok ? sm[k] : ld_dual<A>(ms + g);
         const double delta = o.omega * snap;
         st_dual<A>(ms + g, cur + delta);
