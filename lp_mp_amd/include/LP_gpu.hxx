@@ -388,6 +388,9 @@ class LP_gpu {
   void set_flags_dirty() { dirty_ = true; }
 
   void ComputePass(const INDEX /*iteration*/) { ready_mode(); check(lpmp_compute_pass(engine_, 1)); duals_on_device_ = true; }
+  // n consecutive passes in one call (no reference counterpart: a caller that needs nothing between passes lets the
+  // engine join them — one persistent launch in Infinity-Cache order on HBM-sized models); same results
+  void ComputePasses(const INDEX n) { if (n == 0) return; ready_mode(); check(lpmp_compute_pass(engine_, (int)n)); duals_on_device_ = true; }
   void ComputeForwardPass() { ready_mode(); check(lpmp_compute_forward_pass(engine_)); duals_on_device_ = true; }
   void ComputeBackwardPass() { ready_mode(); check(lpmp_compute_backward_pass(engine_)); duals_on_device_ = true; }
 

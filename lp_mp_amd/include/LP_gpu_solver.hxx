@@ -6,6 +6,8 @@
 // this file is not needed.
 #pragma once
 
+#include <typeinfo>
+
 #include "LP_gpu.hxx"
 
 namespace LP_MP_gpu {
@@ -58,6 +60,21 @@ class StandardVisitor {
     if (curIter_ % lowerBoundComputationInterval_ == 0) ret.computeLowerBound = true;
     return ret;
   }
+  // How many iterations from now on (this one included) ask for neither a lower bound nor a primal and keep the weight
+  // mode of `c`: the solver may run them as ONE device call and replay the visits afterwards (same visits, same
+  // arguments, same returned controls).  1 whenever anything could intervene (a timeout is checked per visit).
+  INDEX quiet_iterations(const LpControl c) const {
+    if (c.end || c.error || c.computeLowerBound || c.computePrimal || timeout_ != std::numeric_limits<INDEX>::max()) return 1;
+    INDEX n = 1;
+    for (INDEX j = 1; j + 1 < remainingIter_; ++j) {            // the control visit j returns (see visit())
+      const INDEX it = curIter_ + j;
+      if (remainingIter_ - j <= 1) break;
+      if (it >= primalComputationStart_ && (it - primalComputationStart_) % primalComputationInterval_ == 0) break;
+      if (it % lowerBoundComputationInterval_ == 0) break;
+      ++n;
+    }
+    return n;
+  }
   void end(const REAL lower_bound, const REAL upper_bound) {
     if (verbosity_ >= 1) std::cout << "final lower bound = " << lower_bound << ", upper bound = " << upper_bound << "\n";
   }
@@ -98,6 +115,14 @@ class Solver {
     LpControl c = visitor_.begin(lp_);
     while (!c.end && !c.error) {
       PreIterate(c);
+      // iterations in which the visitor asks for nothing run as one device call (the engine joins consecutive passes,
+      // DESIGN.md 4); the visits are replayed afterwards with what the reference would have passed them
+      const INDEX quiet = plain_iterate() ? quiet_iterations(visitor_, c, 0) : 1;
+      if (quiet > 1) {
+        lp_.ComputePasses(quiet);
+        for (INDEX j = 0; j < quiet && !c.end && !c.error; ++j) { c = visitor_.visit(c, lowerBound_, bestPrimalCost_); ++iter; }
+        continue;
+      }
       Iterate(c);
       PostIterate(c);
       c = visitor_.visit(c, lowerBound_, bestPrimalCost_);
@@ -120,6 +145,11 @@ class Solver {
   // the reference registers a primal after End() in every solver (solver.hxx:247); without rounding passes every
   // primal_ is unset and the cost +inf, so the base class skips the evaluation
   virtual bool rounds() const { return false; }
+  // true when Iterate is known to be nothing but ComputePass in a quiet iteration: this class and MpRoundingSolver
+  // themselves; a class derived further (it may override Iterate) is never batched unless it says so
+  virtual bool plain_iterate() const { return typeid(*this) == typeid(Solver); }
+  template <class V> static auto quiet_iterations(const V& v, const LpControl c, int) -> decltype(v.quiet_iterations(c)) { return v.quiet_iterations(c); }
+  template <class V> static INDEX quiet_iterations(const V&, const LpControl, long) { return 1; }   // a visitor that does not say: never batched
   LP_TYPE lp_;
   VISITOR visitor_;
   REAL lowerBound_ = -std::numeric_limits<REAL>::infinity();
@@ -144,6 +174,7 @@ class MpRoundingSolver : public SOLVER {
   }
  protected:
   bool rounds() const override { return true; }
+  bool plain_iterate() const override { return typeid(*this) == typeid(MpRoundingSolver); }
 };
 
 }  // namespace LP_MP_gpu

@@ -352,6 +352,8 @@ class offloaded : public LP_BASE {
   lpmp_engine* engine() { sync_to_device(); return engine_; }
 
   void ComputePass(const std::size_t /*iteration*/) { ready_mode(); check(lpmp_compute_pass(engine_, 1)); device_ahead_ = true; }
+  // n consecutive passes in one call (the engine joins them); results equal n calls of ComputePass
+  void ComputePasses(const std::size_t n) { if (n == 0) return; ready_mode(); check(lpmp_compute_pass(engine_, (int)n)); device_ahead_ = true; }
   void ComputeForwardPass() { ready_mode(); check(lpmp_compute_forward_pass(engine_)); device_ahead_ = true; }
   void ComputeBackwardPass() { ready_mode(); check(lpmp_compute_backward_pass(engine_)); device_ahead_ = true; }
   void ComputeForwardPassAndPrimal(const std::size_t iteration) { ready_mode(); check(lpmp_compute_forward_pass_and_primal(engine_, iteration)); device_ahead_ = true; }

@@ -314,6 +314,11 @@ class LP:
         e.set_reparametrization(self._mode())
         e.compute_pass(1)
 
+    def ComputePasses(self, n: int):
+        """n consecutive passes in one call: same results as n x ComputePass, the engine joins them"""
+        if n > 0:
+            e = self._ready(); e.set_reparametrization(self._mode()); e.compute_pass(int(n))
+
     def ComputeForwardPass(self):
         e = self._ready(); e.set_reparametrization(self._mode()); e.forward_pass()
 
@@ -429,6 +434,23 @@ class StandardVisitor:
             ret.computeLowerBound = True
         return ret
 
+    def quiet_iterations(self, c: LpControl) -> int:
+        """how many iterations from now on (this one included) ask for neither a lower bound nor a primal: the solver
+        may run them as ONE device call and replay the visits afterwards (LP_gpu_solver.hxx has the same rule)"""
+        if c.end or c.error or c.computeLowerBound or c.computePrimal or self.timeout is not None:
+            return 1
+        n = 1
+        for j in range(1, max(1, self.remainingIter - 1)):
+            it = self.curIter + j
+            if self.remainingIter - j <= 1:
+                break
+            if it >= self.primalComputationStart and (it - self.primalComputationStart) % self.primalComputationInterval == 0:
+                break
+            if it % self.lowerBoundComputationInterval == 0:
+                break
+            n += 1
+        return n
+
     def end(self, lower_bound: float, upper_bound: float):
         if self.verbosity >= 1:
             print(f"final lower bound = {lower_bound}, upper bound = {upper_bound}")
@@ -472,6 +494,19 @@ class Solver:
         c = self.visitor_.begin(self.lp_)
         while not c.end and not c.error:
             self.PreIterate(c)
+            # iterations in which the visitor asks for nothing run as one device call (the engine joins consecutive
+            # passes); only for this class and MpRoundingSolver themselves — a subclass may override Iterate
+            quiet = 1
+            if type(self) in (Solver, MpRoundingSolver) and hasattr(self.visitor_, "quiet_iterations"):
+                quiet = self.visitor_.quiet_iterations(c)
+            if quiet > 1:
+                self.lp_.ComputePasses(quiet)
+                for _ in range(quiet):
+                    if c.end or c.error:
+                        break
+                    c = self.visitor_.visit(c, self.lowerBound_, self.bestPrimalCost_)
+                    self.iter += 1
+                continue
             self.Iterate(c)
             self.PostIterate(c)
             c = self.visitor_.visit(c, self.lowerBound_, self.bestPrimalCost_)

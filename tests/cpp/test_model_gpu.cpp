@@ -188,6 +188,50 @@ int main(int argc, char** argv) {
       test(c->GetFactor()->LowerBound() == 1.5);
     }
   }
+  {   // ---- quiet iterations: what the solver may run as one device call is exactly what the visits would return ----
+    const char* combos[][6] = {{"--maxIter", "40", "--lowerBoundComputationInterval", "7", "--primalComputationInterval", "11"},
+                               {"--maxIter", "25", "--lowerBoundComputationInterval", "1", "--primalComputationInterval", "5"},
+                               {"--maxIter", "33", "--lowerBoundComputationInterval", "100", "--primalComputationInterval", "3"},
+                               {"--maxIter", "3", "--lowerBoundComputationInterval", "2", "--primalComputationInterval", "50"}};
+    for (auto& o : combos) {
+      StandardVisitor v(std::vector<std::string>(o, o + 6));
+      int dummy = 0;
+      LpControl c = v.begin(dummy);
+      int visits = 0, batched = 0;
+      while (!c.end) {
+        const INDEX q = v.quiet_iterations(c);
+        test(q >= 1);
+        const LpControl first = c;
+        for (INDEX j = 0; j < q; ++j) {
+          // every iteration of the run sees a control that asks for nothing (unless the run is the single iteration)
+          if (q > 1) { test(!c.computeLowerBound && !c.computePrimal && !c.end && c.repam == first.repam); ++batched; }
+          c = v.visit(c, 0.0, std::numeric_limits<REAL>::infinity());
+          ++visits;
+        }
+        // and the run is maximal: what follows is not another quiet iteration of the same kind
+        if (q > 1) test(c.end || c.computeLowerBound || c.computePrimal);
+      }
+      test(visits == std::atoi(o[1]));
+      if (std::atoi(o[3]) == 7) test(batched > 20);
+    }
+  }
+  for (int interval : {1, 6}) {   // ---- a solve with batched quiet iterations ends where the unbatched one does ----
+    static REAL lb_ref = 0.0; static std::size_t hist_ref = 0;
+    Solver<LP<FMC_SRMP>, StandardVisitor> s(std::vector<std::string>{"--maxIter", "31", "--standardReparametrization", "anisotropic",
+                                                                      "--lowerBoundComputationInterval", std::to_string(interval)});
+    auto& lp = s.GetLP();
+    std::vector<typename FMC_SRMP::UnaryFactor*> u;
+    for (int i = 0; i < 6; ++i) u.push_back(lp.template add_factor<typename FMC_SRMP::UnaryFactor>(std::vector<REAL>{0.1 * i, 0.3 - 0.05 * i}));
+    const double c1[2][2] = {{0.7, 0.1}, {0.2, 0.9}}, c2[2][2] = {{0.0, 0.6}, {0.8, 0.3}};
+    for (int i = 0; i + 1 < 6; ++i) add_pairwise(lp, u[i], u[i + 1], i % 2 ? c1 : c2);
+    add_pairwise(lp, u[0], u[5], c1);
+    if (!host_only) {
+      s.Solve();
+      test(s.iter == 31);
+      if (interval == 1) { lb_ref = s.lower_bound(); hist_ref = s.GetVisitor().lower_bound_history().size(); }
+      else { test(s.lower_bound() == lb_ref); test(s.GetVisitor().lower_bound_history().size() == hist_ref); }
+    }
+  }
   {   // ---- MpRoundingSolver (reference solver.hxx:380-400) on a chain with a unique optimum ----
     using FMC = FMC_SRMP_ROUNDING;
     MpRoundingSolver<Solver<LP<FMC>, StandardVisitor>> s(std::vector<std::string>{

@@ -113,6 +113,62 @@ def test_solver_on_grid_matches_oracle_with_mode_switches():
     assert set(om) == {"forward", "backward", "receive_mask_forward", "receive_mask_backward"}
 
 
+def test_quiet_iterations_are_what_the_visits_would_return():
+    """StandardVisitor.quiet_iterations: the run it announces consists of iterations whose control asks for nothing,
+    and it is maximal — the rule that lets Solver run them as one device call"""
+    for kw in (dict(maxIter=40, lowerBoundComputationInterval=7, primalComputationInterval=11),
+               dict(maxIter=25), dict(maxIter=33, lowerBoundComputationInterval=100, primalComputationInterval=3),
+               dict(maxIter=3, lowerBoundComputationInterval=2, primalComputationInterval=50),
+               dict(maxIter=30, lowerBoundComputationInterval=5, timeout=1000)):
+        v = LPM.StandardVisitor(**kw)
+        c = v.begin(None)
+        visits = batched = 0
+        while not c.end:
+            q = v.quiet_iterations(c)
+            assert q >= 1 and (q == 1 or "timeout" not in kw)
+            first = c
+            for _ in range(q):
+                if q > 1:
+                    assert not c.computeLowerBound and not c.computePrimal and not c.end and c.repam == first.repam
+                    batched += 1
+                c = v.visit(c, 0.0, np.inf)
+                visits += 1
+            if q > 1:
+                assert c.end or c.computeLowerBound or c.computePrimal
+        assert visits == kw["maxIter"]
+        if kw.get("lowerBoundComputationInterval") == 7:
+            assert batched > 20
+
+
+@pytest.mark.gpu
+def test_solver_batches_quiet_iterations_without_changing_the_result():
+    """--lowerBoundComputationInterval 4: three of four iterations run as one joined device call; duals, bound
+    history length and iteration count equal the oracle driven pass by pass with the same visitor"""
+    from oracle.binding import Oracle
+    lp, ref = _grid_through_lp(6, 7, 4, 5)
+    kw = dict(maxIter=23, lowerBoundComputationInterval=4, primalComputationInterval=9)
+    vis = LPM.StandardVisitor(**kw)
+    s = LPM.Solver(lp, vis)
+    calls = []
+    orig = lp.ComputePasses
+    lp.ComputePasses = lambda n: (calls.append(n), orig(n))[1]
+    s.Solve()
+    assert calls and max(calls) == 3 and s.iter == 23
+    o = Oracle(lp.flat_model())
+    v2 = LPM.StandardVisitor(**kw)
+    c = v2.begin(None)
+    lb = -np.inf
+    while not c.end:
+        o.set_reparametrization(c.repam)
+        o.ComputePass(1)
+        if c.computeLowerBound:
+            lb = o.LowerBound()
+        c = v2.visit(c, lb, np.inf)
+    assert np.array_equal(lp.duals(), o.duals())
+    assert len(vis.lowerBound_) == len(v2.lowerBound_) == 23
+    assert np.allclose(vis.lowerBound_, v2.lowerBound_, rtol=1e-9)
+
+
 @pytest.mark.gpu
 def test_multicut_style_labeling_model_through_lp():
     from oracle.binding import Oracle
