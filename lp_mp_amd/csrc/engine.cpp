@@ -81,6 +81,7 @@ struct DevSchedule {
   // chain executor (deep schedules): device copies of the ChainPlans, one per kernel class; the other launches stay plain
   struct DevChain {
     int32_t kclass = 0, tickets = 0, epoch = 0;
+    bool banded = false;                     // Infinity-Cache ticket order: plain table loads, not the streaming policy
     ChainLaunchDev* launches = nullptr; int32_t *tk_launch = nullptr, *tk_block = nullptr, *dep_off = nullptr, *dep = nullptr, *done = nullptr, *next = nullptr;
   };
   std::vector<DevChain> chains;
@@ -551,7 +552,7 @@ void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream, bool
       HIP_CHECK(hipMalloc((void**)&dc.done, std::max<size_t>(1, (size_t)dc.tickets) * sizeof(int32_t)));
       HIP_CHECK(hipMalloc((void**)&dc.next, sizeof(int32_t)));
       HIP_CHECK(hipMemsetAsync(dc.done, 0, std::max<size_t>(1, (size_t)dc.tickets) * sizeof(int32_t), stream));
-      dc.kclass = c.kclass;
+      dc.kclass = c.kclass; dc.banded = c.banded;
       d.chains.push_back(dc);
     }
     for (int32_t li : s.plain_launches) d.plain.push_back(s.launches[li]);
@@ -683,7 +684,7 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
       HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
       ChainTrace tr;
       const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream)};
-      if (!launch_chain(c.kclass, rule | e->nt_flag, &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream))
+      if (!launch_chain(c.kclass, rule | (c.banded ? 0 : e->nt_flag), &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream))
         throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
       tr.end(c, e->stream);
     }

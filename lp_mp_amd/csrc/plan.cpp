@@ -703,9 +703,17 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   static const int64_t chain_min = [] { const char* v = std::getenv("LPMP_CHAIN_MIN"); return v ? (int64_t)std::atoll(v) : CHAIN_MIN_LAUNCHES; }();
   static const int bands = [] { const char* v = std::getenv("LPMP_CHAIN_BANDS"); return v ? std::atoi(v) : 0; }();
   static const int lag = [] { const char* v = std::getenv("LPMP_CHAIN_LAG"); return v ? std::atoi(v) : 2; }();
+  const bool no_auto_bands = std::getenv("LPMP_NO_BLOCKED_PASSES") != nullptr;
+  // (LPMP_BAND_MIN_BYTES, LPMP_BAND_BYTES: tests force the banded order on small models)
+  const char* bmin_env = std::getenv("LPMP_BAND_MIN_BYTES");
+  const int64_t band_min_bytes = bmin_env ? std::atoll(bmin_env) : ((int64_t)64 << 20);
+  const char* bb_env = std::getenv("LPMP_BAND_BYTES");
+  const int64_t band_bytes = bb_env ? std::max<int64_t>(1, std::atoll(bb_env)) : ((int64_t)16 << 20);
   const char* chain_all_env = std::getenv("LPMP_CHAIN_ALL");
   const bool chain_all = chain_all_env && std::atoi(chain_all_env) != 0;
-  if ((int64_t)out.launches.size() >= chain_min && !out.launches.empty()) {
+  bool any_big = false;
+  for (const auto& lr : out.launches) any_big = any_big || (kc_is_dense(lr.kclass) && lr.bytes >= band_min_bytes);
+  if (((int64_t)out.launches.size() >= chain_min || (any_big && out.launches.size() >= 2 && !no_auto_bands)) && !out.launches.empty()) {
     std::vector<int64_t> n_launches_of(KC_COUNT, 0);
     bool ok = true;
     for (const auto& lr : out.launches) {
@@ -761,13 +769,51 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       }
       for (int c = 0; c < KC_COUNT && ok; ++c) {
         if (n_launches_of[c] == 0) continue;
-        if (n_launches_of[c] < chain_min) {               // few launches: plain
+        // A few HBM-sized launches of a dense class (the colour steps of a big grid: forward or backward sweep alone,
+        // a fused pass in a weight mode that does not rotate, the per-pass schedule of a multi-GPU part) are worth a
+        // chain as well: not for the launch gaps but for the ORDER — consecutive steps read the same pairwise tables,
+        // and band j of step l issued at time j + lag * l finds them in the 256 MiB Infinity Cache.
+        int64_t max_bytes = 0;
+        for (const auto& lr : out.launches) if (lr.kclass == c) max_bytes = std::max(max_bytes, lr.bytes);
+        const bool dense_cls = kc_is_dense(c);
+        const bool big_steps = dense_cls && max_bytes >= band_min_bytes && n_launches_of[c] >= 2 && n_launches_of[c] <= 8 && !no_auto_bands;
+        if (n_launches_of[c] < chain_min && !big_steps && !(bands > 1)) {               // few launches: plain
           for (size_t li = 0; li < out.launches.size(); ++li) if (out.launches[li].kclass == c) out.plain_launches.push_back((int32_t)li);
           continue;
         }
         ChainPlan& cp = cps[c];
         auto& ed = edges[c];
         const int64_t n_tickets = (int64_t)cp.tk_launch.size();
+        if (big_steps && !(bands > 1) && n_tickets > 0) {
+          // about 16 MiB of algorithmic bytes per band; the smallest lag from 3 on that keeps every dependency backwards
+          const int nbands = (int)std::max<int64_t>(2, max_bytes / band_bytes);
+          const int64_t nl = (int64_t)cp.launches.size();
+          const int gpb = kc_block_records(c);
+          std::vector<int32_t> order((size_t)n_tickets), new_of((size_t)n_tickets);
+          std::vector<int64_t> key((size_t)n_tickets);
+          for (int lg = 3; lg <= 16 && !cp.banded; ++lg) {
+            for (int64_t t = 0; t < n_tickets; ++t) {
+              const int64_t l = cp.tk_launch[t];
+              const int64_t nb = (cp.launches[l].count + gpb - 1) / gpb;
+              key[t] = ((int64_t)cp.tk_block[t] * nbands / nb + (int64_t)lg * l) * (nl + 1) + l;
+            }
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+            for (int64_t i = 0; i < n_tickets; ++i) new_of[order[i]] = (int32_t)i;
+            bool fine = true;
+            for (const auto& e : ed) if (new_of[e.second] >= new_of[e.first]) { fine = false; break; }
+            if (!fine) continue;
+            for (auto& e : ed) { e.first = new_of[e.first]; e.second = new_of[e.second]; }
+            std::vector<int32_t> tl((size_t)n_tickets), tb((size_t)n_tickets);
+            for (int64_t i = 0; i < n_tickets; ++i) { tl[i] = cp.tk_launch[order[i]]; tb[i] = cp.tk_block[order[i]]; }
+            cp.tk_launch.swap(tl); cp.tk_block.swap(tb);
+            cp.banded = true;
+          }
+          if (!cp.banded && n_launches_of[c] < chain_min) {   // no valid order and nothing else to gain: plain launches
+            for (size_t li = 0; li < out.launches.size(); ++li) if (out.launches[li].kclass == c) out.plain_launches.push_back((int32_t)li);
+            continue;
+          }
+        }
         // Temporal blocking (LPMP_CHAIN_BANDS=NB, experiments): tickets are not taken level by level but in a skewed
         // order — band j of the l-th launch at time j + LAG * l — so that what a level reads (pairwise tables) is read
         // again by the next level while it is still in the Infinity Cache.  Only an order: the dependency flags keep
@@ -790,6 +836,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
           std::vector<int32_t> tl((size_t)n_tickets), tb((size_t)n_tickets);
           for (int64_t i = 0; i < n_tickets; ++i) { tl[i] = cp.tk_launch[order[i]]; tb[i] = cp.tk_block[order[i]]; }
           cp.tk_launch.swap(tl); cp.tk_block.swap(tb);
+          cp.banded = true;
         }
         std::sort(ed.begin(), ed.end());
         ed.erase(std::unique(ed.begin(), ed.end()), ed.end());

@@ -85,6 +85,7 @@ constexpr int kc_width(int kclass) {
   if (kclass >= KC_PW_4 && kclass <= KC_PW_32) return 4 << (kclass - KC_PW_4);
   return (kclass == KC_GENERIC || kclass >= KC_DENSE_BIG) ? 0 : 4 << ((kclass - 1) % 4);
 }
+constexpr bool kc_is_dense(int kclass) { return (kclass >= KC_DENSE_4 && kclass <= KC_DENSE_32) || (kclass >= KC_DENSE_V4 && kclass <= KC_DENSE_V32); }
 constexpr bool kc_is_var(int kclass) { return kclass >= KC_DENSE_V4 && kclass <= KC_POTTS_V32; }
 
 struct LevelRange {            // one kernel launch: a range of UpdRec indices of one level and class
@@ -126,6 +127,7 @@ struct ChainPlan {
   std::vector<int32_t> tk_launch;           // [n_tickets]
   std::vector<int32_t> tk_block;            // [n_tickets]: block of records inside that launch
   std::vector<int32_t> dep_off, dep;        // CSR over tickets
+  bool banded = false;                      // tickets in Infinity-Cache order: the tables are read with plain loads
 };
 // records one workgroup of the packed kernels takes (256 threads / lanes per record)
 constexpr int GENERIC_BLOCK_RECORDS = 4, SMALL_BLOCK_RECORDS = 64;   // sweep_generic_kernel<64> / <1> (kernels.hip asserts them)

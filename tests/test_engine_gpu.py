@@ -449,6 +449,46 @@ def test_chain_executor_deep_schedules(pairwise, L, H, W, monkeypatch):
             e.close()
 
 
+@pytest.mark.parametrize("pairwise,L,H,W,band_bytes", [("dense", 8, 24, 30, 6000), ("dense", 32, 10, 12, 40000), ("dense", 5, 20, 16, 3000),
+                                                        ("dense", 16, 16, 16, 100000), ("dense", 21, 9, 14, 20000)])
+def test_few_big_launches_run_as_a_banded_chain(pairwise, L, H, W, band_bytes, monkeypatch):
+    """the colour steps of an HBM-sized dense grid — a directional sweep, a fused pass in a mode that does not rotate, a
+    fused custom schedule like the per-pass schedule of a multi-GPU part — run as one chain launch in Infinity-Cache
+    order (plan.cpp make_schedule).  Forced onto small models here (LPMP_BAND_MIN_BYTES / LPMP_BAND_BYTES); bit for bit
+    against the oracle"""
+    from lp_mp_amd.multi_gpu import _cat_rows
+    monkeypatch.setenv("LPMP_BAND_MIN_BYTES", "1000"); monkeypatch.setenv("LPMP_BAND_BYTES", str(band_bytes))
+    m = S.grid_model(H, W, L, pairwise=pairwise, order="colour_major", seed=L + W)
+    o = Oracle(m)
+    e = E.Engine(0); e.upload(m)
+    try:
+        banded = 0
+        for mode in MODES:
+            o.set_reparametrization(mode); e.set_reparametrization(mode)
+            banded += e.plan.chain_info(M.FORWARD, mode)["n_chains"] + e.plan.chain_info(-1, mode)["n_chains"]
+            for step in range(2):
+                e.forward_pass(); o.ComputeForwardPass()
+                assert np.array_equal(e.download_duals(), o.duals()), (mode, "forward")
+                e.backward_pass(); o.ComputeBackwardPass()
+                assert np.array_equal(e.download_duals(), o.duals()), (mode, "backward")
+                e.compute_pass(1); o.ComputePass(1)
+                assert np.array_equal(e.download_duals(), o.duals()), (mode, "pass")
+                assert abs(e.lower_bound() - o.LowerBound()) <= LB_RTOL * max(1.0, abs(o.LowerBound()))
+            rows = []
+            for d in (M.FORWARD, M.BACKWARD, M.FORWARD):
+                oo, om = o.omega(d, mode); mo, mk = o.mask(d, mode)
+                rows.append((o.update_order(d), oo, om, mo, mk))
+            cat = _cat_rows(*rows)
+            sid = e.schedule_create(*cat, fuse=True)
+            for _ in range(2):
+                e.schedule_run(sid); o.compute_pass_custom(*cat)
+                assert np.array_equal(e.download_duals(), o.duals()), (mode, "custom")
+            e.schedule_destroy(sid)
+        assert banded >= 4
+    finally:
+        e.close()
+
+
 def test_chain_executor_lane_per_factor_class_is_opt_in(monkeypatch):
     """the chain kernels of the lane-per-factor and generic classes are not the default (slower than graph replay:
     plan.cpp make_schedule) but stay a supported path: LPMP_CHAIN_ALL=1, against the oracle bit for bit"""
