@@ -786,9 +786,11 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         const int64_t n_tickets = (int64_t)cp.tk_launch.size();
         if (big_steps && !(bands > 1) && n_tickets > 0) {
           // about 16 MiB of algorithmic bytes per band; the smallest lag from 3 on that keeps every dependency backwards
-          const int nbands = (int)std::max<int64_t>(2, max_bytes / band_bytes);
           const int64_t nl = (int64_t)cp.launches.size();
           const int gpb = kc_block_records(c);
+          int64_t max_nb = 1;                               // (a band narrower than a few blocks cannot keep the dependencies)
+          for (const auto& l : cp.launches) max_nb = std::max<int64_t>(max_nb, (l.count + gpb - 1) / gpb);
+          const int nbands = (int)std::max<int64_t>(2, std::min<int64_t>(max_bytes / band_bytes, max_nb / 4));
           std::vector<int32_t> order((size_t)n_tickets), new_of((size_t)n_tickets);
           std::vector<int64_t> key((size_t)n_tickets);
           for (int lg = 3; lg <= 16 && !cp.banded; ++lg) {

@@ -449,7 +449,7 @@ def test_chain_executor_deep_schedules(pairwise, L, H, W, monkeypatch):
             e.close()
 
 
-@pytest.mark.parametrize("pairwise,L,H,W,band_bytes", [("dense", 8, 24, 30, 6000), ("dense", 32, 10, 12, 40000), ("dense", 5, 20, 16, 3000),
+@pytest.mark.parametrize("pairwise,L,H,W,band_bytes", [("dense", 8, 40, 50, 6000), ("dense", 32, 10, 12, 40000), ("dense", 5, 40, 36, 3000),
                                                         ("dense", 16, 16, 16, 100000), ("dense", 21, 9, 14, 20000)])
 def test_few_big_launches_run_as_a_banded_chain(pairwise, L, H, W, band_bytes, monkeypatch):
     """the colour steps of an HBM-sized dense grid — a directional sweep, a fused pass in a mode that does not rotate, a
