@@ -23,7 +23,7 @@ void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, c
 bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, const Op* ops, int stride, double* dual, const double* cdata,
                          double* lb, int32_t* primal, int64_t count, int flags, hipStream_t s);
 bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, double* dual, const double* cdata,
-                  const int32_t* tabs, double* lb, hipStream_t s);
+                  const int32_t* tabs, double* lb, int32_t* primal, hipStream_t s);
 void launch_primal_init(const PrimalInit* list, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_propagate(const PrimalLink* links, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_check(const PrimalLink* links, int64_t n, const int32_t* primal, int* bad, hipStream_t s);
@@ -670,9 +670,17 @@ struct ChainTrace {
 void run_schedule(lpmp_engine* e, DevSchedule& s) {
   if (s.launches.empty()) return;
   if (e->timing) { issue_launches(e, s, true, e->stream); if (e->pending.size() > 4096) e->drain_timing(); return; }
-  if (s.chain && e->use_chain && !e->primal_pass) {
+  // (a primal pass rounds inside the packed kernels' chain form too; the generic chain kernels carry no labels, and
+  // pairwise factors that round themselves need the generic kernels: those passes stay launch by launch)
+  bool chain_ok = s.chain && e->use_chain;
+  if (chain_ok && e->primal_pass) {
+    if (e->d_pw_unary) chain_ok = false;
+    for (const auto& c : s.chains) if (kc_width(c.kclass) == 0) chain_ok = false;
+  }
+  if (chain_ok) {
     if (!e->d_chain_abort) { HIP_CHECK(hipMalloc((void**)&e->d_chain_abort, sizeof(int32_t))); HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, sizeof(int32_t), e->stream)); }
-    const int rule = e->rtype == LPMP_RTYPE_RESIDUAL ? SWEEP_RESIDUAL : 0;
+    // UpdateFactorPrimal always sends 'shared' (issue_launches)
+    const int rule = e->primal_pass ? SWEEP_PRIMAL : e->rtype == LPMP_RTYPE_RESIDUAL ? SWEEP_RESIDUAL : 0;
     // classes are independent of each other (plan.cpp): the plain launches first, then one persistent launch per class
     if (!s.plain.empty()) {
       DevSchedule tmp;                       // a view: issue_launches only reads recs / ops / packets / launches
@@ -684,7 +692,7 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
       HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
       ChainTrace tr;
       const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream)};
-      if (!launch_chain(c.kclass, rule | (c.banded ? 0 : e->nt_flag), &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream))
+      if (!launch_chain(c.kclass, rule | (c.banded ? 0 : e->nt_flag), &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->d_primal, e->stream))
         throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
       tr.end(c, e->stream);
     }
@@ -837,7 +845,7 @@ bool run_rotation_chain(lpmp_engine* e, int mode, int n) {
   hipEvent_t a = nullptr, b = nullptr;
   if (e->timing) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, e->stream)); }
   // (plain table loads, not the streaming policy: the second reader of a table is meant to find it in the Infinity Cache)
-  if (!launch_chain(c.kclass, 0, &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream)) throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
+  if (!launch_chain(c.kclass, 0, &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, nullptr, e->stream)) throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
   tr.end(c, e->stream);
   if (e->timing) {
     HIP_CHECK(hipEventRecord(b, e->stream));

@@ -1052,9 +1052,9 @@ __device__ __forceinline__ void chain_loop(const ChainArgs& ca, const ChainLaunc
 template <int L, int KMAX, bool VAR, bool NT>
 __global__ void __launch_bounds__(256)
 chain_dense_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, double* __restrict__ dual,
-                      const double* __restrict__ cdata, double* __restrict__ lb, int flags) {
+                      const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal, int flags) {
   chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
-    dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, nullptr, ln.count, ln.stride, flags, block, &ca, ticket);
+    dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket);
   });
 }
 
@@ -1356,9 +1356,9 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
 template <int L, bool VAR>
 __global__ void __launch_bounds__(256)
 chain_potts_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, double* __restrict__ dual,
-                      const double* __restrict__ cdata, double* __restrict__ lb, int flags) {
+                      const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal, int flags) {
   chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
-    potts_pk_body<L, VAR, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, nullptr, ln.count, ln.stride, flags, block, &ca, ticket);
+    potts_pk_body<L, VAR, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket);
   });
 }
 
@@ -1939,12 +1939,12 @@ static unsigned chain_grid(K kernel, int n_tickets, int threads = 256) {
   return (unsigned)(n_tickets < cap ? n_tickets : cap);
 }
 bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, double* dual, const double* cdata,
-                  const int32_t* tabs, double* lb, hipStream_t s) {
+                  const int32_t* tabs, double* lb, int32_t* primal, hipStream_t s) {
   const ChainArgs ca = *static_cast<const ChainArgs*>(chain_args);
   const ChainLaunch* ln = static_cast<const ChainLaunch*>(launches);
   const bool nt = (flags & SWEEP_NT) != 0;
 #define CHAIN_LAUNCH1(LL, KK, VV, NTT) do { auto k = chain_dense_pk_kernel<LL, KK, VV, NTT>; \
-    hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, dual, cdata, lb, flags); } while (0)
+    hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, dual, cdata, lb, primal, flags); } while (0)
 #define CHAIN_LAUNCH(LL, KK) do { if (nt) CHAIN_LAUNCH1(LL, KK, false, true); else CHAIN_LAUNCH1(LL, KK, false, false); } while (0)
   switch (kclass) {
     case KC_GENERIC: { auto k = chain_generic_kernel<64>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<64>::THREADS)), dim3(GenCtx<64>::THREADS), 0, s, ca, ln, dual, cdata, tabs, lb, flags); return true; }
@@ -1958,7 +1958,7 @@ bool launch_chain(int kclass, int flags, const void* chain_args, const void* lau
     case KC_DENSE_V8: CHAIN_LAUNCH1(8, 4, true, false); return true;
     case KC_DENSE_V4: CHAIN_LAUNCH1(4, 4, true, false); return true;
 #define CHAIN_POTTS(LL, VV) do { auto k = chain_potts_pk_kernel<LL, VV>; \
-    hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, dual, cdata, lb, flags); } while (0)
+    hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, dual, cdata, lb, primal, flags); } while (0)
     case KC_POTTS_32: CHAIN_POTTS(32, false); return true;
     case KC_POTTS_16: CHAIN_POTTS(16, false); return true;
     case KC_POTTS_8: CHAIN_POTTS(8, false); return true;

@@ -56,6 +56,23 @@ def test_grids_every_kernel_class(eng, L, pairwise, order):
         _run(eng, m, mode)
 
 
+@pytest.mark.parametrize("L,pairwise", [(8, "dense"), (32, "dense"), (5, "dense"), (16, "potts")])
+def test_rounding_passes_in_the_chain_executor(L, pairwise, monkeypatch):
+    """rounding passes run the chain form of the packed kernels too: deep (row-major) sweeps as one persistent launch,
+    big colour steps as a banded chain (forced here on a small grid), labels and duals against the oracle"""
+    monkeypatch.setenv("LPMP_BAND_MIN_BYTES", "1000"); monkeypatch.setenv("LPMP_BAND_BYTES", "20000")
+    e = E.Engine(0)
+    try:
+        for order, H, W in (("row_major", 14, 17), ("colour_major", 24, 26)):
+            m = S.grid_model(H, W, L, pairwise=pairwise, order=order, seed=L + H, compute_primal=True)
+            for mode in (M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM):
+                _run(e, m, mode, iterations=2)
+                if pairwise == "dense":
+                    assert e.plan.chain_info(M.FORWARD, mode)["n_chains"] == 1
+    finally:
+        e.close()
+
+
 def test_ties_take_the_first_minimum(eng):
     H, W, L = 8, 8, 8
     un = np.round(S.u01(H * W * L, 3) * 2.0) / 2.0            # costs in {0, 0.5, 1}: ties everywhere
