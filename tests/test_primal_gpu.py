@@ -67,7 +67,8 @@ def test_rounding_passes_in_the_chain_executor(L, pairwise, monkeypatch):
             m = S.grid_model(H, W, L, pairwise=pairwise, order=order, seed=L + H, compute_primal=True)
             for mode in (M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM):
                 _run(e, m, mode, iterations=2)
-                if pairwise == "dense":
+                # (an anisotropic directional sweep of a 2-colour grid has one table-reading step: not banded)
+                if pairwise == "dense" and (order == "row_major" or mode == M.REPAM_DAMPED_UNIFORM):
                     assert e.plan.chain_info(M.FORWARD, mode)["n_chains"] == 1
     finally:
         e.close()
