@@ -24,6 +24,8 @@ bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, cons
                          double* lb, int32_t* primal, int64_t count, int flags, hipStream_t s);
 bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, double* dual, const double* cdata,
                   const int32_t* tabs, double* lb, int32_t* primal, hipStream_t s);
+bool launch_level_loop(int kclass, int flags, const void* launches, int n_launches, double* dual, const double* cdata,
+                       const int32_t* tabs, double* lb, hipStream_t s);
 void launch_primal_init(const PrimalInit* list, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_propagate(const PrimalLink* links, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_check(const PrimalLink* links, int64_t n, const int32_t* primal, int* bad, hipStream_t s);
@@ -82,6 +84,7 @@ struct DevSchedule {
   struct DevChain {
     int32_t kclass = 0, tickets = 0, epoch = 0;
     bool banded = false;                     // Infinity-Cache ticket order: plain table loads, not the streaming policy
+    bool level_loop = false; int32_t n_launches = 0;   // one workgroup walks the launches (tiny levels of a generic class)
     ChainLaunchDev* launches = nullptr; int32_t *tk_launch = nullptr, *tk_block = nullptr, *dep_off = nullptr, *dep = nullptr, *done = nullptr, *next = nullptr;
   };
   std::vector<DevChain> chains;
@@ -552,7 +555,7 @@ void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream, bool
       HIP_CHECK(hipMalloc((void**)&dc.done, std::max<size_t>(1, (size_t)dc.tickets) * sizeof(int32_t)));
       HIP_CHECK(hipMalloc((void**)&dc.next, sizeof(int32_t)));
       HIP_CHECK(hipMemsetAsync(dc.done, 0, std::max<size_t>(1, (size_t)dc.tickets) * sizeof(int32_t), stream));
-      dc.kclass = c.kclass; dc.banded = c.banded;
+      dc.kclass = c.kclass; dc.banded = c.banded; dc.level_loop = c.level_loop; dc.n_launches = (int32_t)c.launches.size();
       d.chains.push_back(dc);
     }
     for (int32_t li : s.plain_launches) d.plain.push_back(s.launches[li]);
@@ -689,6 +692,11 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
       tmp.recs = nullptr; tmp.ops = nullptr; tmp.packets = nullptr;
     }
     for (auto& c : s.chains) {
+      if (c.level_loop) {
+        if (!launch_level_loop(c.kclass, rule, c.launches, c.n_launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream))
+          throw DeviceError("level loop: no kernel for class " + std::to_string(c.kclass));
+        continue;
+      }
       HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
       ChainTrace tr;
       const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream)};

@@ -1070,6 +1070,29 @@ chain_generic_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, dou
   });
 }
 
+// Level loop: a deep schedule of TINY levels of a generic class as one launch of ONE workgroup that walks the launches in
+// order with a workgroup barrier in between (plan.cpp decides; C5 with local triples).  What a level hands to the next
+// travels through this compute unit's caches: a workgroup barrier orders plain loads and stores of one workgroup, so the
+// body is the plain one.  The next level's record is touched ahead so that its (cold, read-once) line is on its way.
+template <int G>
+__global__ void __launch_bounds__(GenCtx<G>::THREADS)
+level_loop_kernel(const ChainLaunch* __restrict__ launches, int n_launches, double* __restrict__ dual, const double* __restrict__ cdata,
+                  const int32_t* __restrict__ tabs, double* __restrict__ lb, int flags) {
+  using C = GenCtx<G>;
+  for (int l = 0; l < n_launches; ++l) {
+    const ChainLaunch ln = launches[l];
+    if (l + 1 < n_launches) {                      // prefetch: first record of the next level (result unused)
+      const ChainLaunch nx = launches[l + 1];
+      const int64_t i = G == 64 ? (int64_t)(threadIdx.x >> 6) : (int64_t)threadIdx.x;
+      if (i < nx.count) asm volatile("" :: "v"(__builtin_nontemporal_load(&nx.recs[i].op_begin)));
+    }
+    const int64_t nblk = (ln.count + C::FPB - 1) / C::FPB;
+    for (int64_t b = 0; b < nblk; ++b)
+      [&] { generic_body<G, ACC_PLAIN>(ln.recs, ln.ops, dual, cdata, tabs, lb, nullptr, nullptr, 0, ln.count, flags, b); }();
+    __syncthreads();
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // Potts fast path: L lanes per unary factor; peers are pairwise_potts_factor(L, diff).
 // min_b (diff*[a!=b] + m_o[b]) = min(m_o[a], diff + min_{b != a} m_o[b]), with min_{b != a} from the two
@@ -1937,6 +1960,14 @@ static unsigned chain_grid(K kernel, int n_tickets, int threads = 256) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
   const long cap = (long)n_cu * per_cu;
   return (unsigned)(n_tickets < cap ? n_tickets : cap);
+}
+bool launch_level_loop(int kclass, int flags, const void* launches, int n_launches, double* dual, const double* cdata,
+                       const int32_t* tabs, double* lb, hipStream_t s) {
+  const ChainLaunch* ln = static_cast<const ChainLaunch*>(launches);
+  if (kclass == KC_SMALL) hipLaunchKernelGGL(level_loop_kernel<1>, dim3(1), dim3(GenCtx<1>::THREADS), 0, s, ln, n_launches, dual, cdata, tabs, lb, flags);
+  else if (kclass == KC_GENERIC) hipLaunchKernelGGL(level_loop_kernel<64>, dim3(1), dim3(GenCtx<64>::THREADS), 0, s, ln, n_launches, dual, cdata, tabs, lb, flags);
+  else return false;
+  return true;
 }
 bool launch_chain(int kclass, int flags, const void* chain_args, const void* launches, double* dual, const double* cdata,
                   const int32_t* tabs, double* lb, int32_t* primal, hipStream_t s) {

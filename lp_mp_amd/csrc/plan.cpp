@@ -703,6 +703,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   static const int64_t chain_min = [] { const char* v = std::getenv("LPMP_CHAIN_MIN"); return v ? (int64_t)std::atoll(v) : CHAIN_MIN_LAUNCHES; }();
   static const int bands = [] { const char* v = std::getenv("LPMP_CHAIN_BANDS"); return v ? std::atoi(v) : 0; }();
   static const int lag = [] { const char* v = std::getenv("LPMP_CHAIN_LAG"); return v ? std::atoi(v) : 2; }();
+  const bool no_level_loop = std::getenv("LPMP_NO_LEVEL_LOOP") != nullptr;
   const bool no_auto_bands = std::getenv("LPMP_NO_BLOCKED_PASSES") != nullptr;
   // (LPMP_BAND_MIN_BYTES, LPMP_BAND_BYTES: tests force the banded order on small models)
   const char* bmin_env = std::getenv("LPMP_BAND_MIN_BYTES");
@@ -722,7 +723,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       // lane-per-factor and generic records: every dual access of a chain kernel is a device-scope access that goes past
       // the L2, and these bodies issue them one dependent access at a time — measured slower than replaying a hipGraph
       // of plain launches (C5: 202 ms against 188 ms per pass).  The kernels stay available: LPMP_CHAIN_ALL=1
-      ok = ok && (kc_width(lr.kclass) != 0 || chain_all);
+      // Those classes get the level loop instead when their levels are tiny (below).
     }
     if (ok) {
       // tickets per class
@@ -773,6 +774,22 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         // a fused pass in a weight mode that does not rotate, the per-pass schedule of a multi-GPU part) are worth a
         // chain as well: not for the launch gaps but for the ORDER — consecutive steps read the same pairwise tables,
         // and band j of step l issued at time j + lag * l finds them in the 256 MiB Infinity Cache.
+        if (kc_width(c) == 0 && !chain_all) {
+          // Many TINY levels of the lane-per-factor / generic class (C5 with local triples: 11 887 levels of a dozen
+          // one-lane updates): one workgroup walks the levels with a workgroup barrier in between — no launch per level,
+          // no flags through memory, and the duals it hands from level to level stay in its L2.  Wide levels stay plain.
+          int64_t recs_c = 0;
+          for (const auto& lr : out.launches) if (lr.kclass == c) recs_c += lr.end - lr.begin;
+          if (n_launches_of[c] >= chain_min && recs_c <= (int64_t)kc_block_records(c) * n_launches_of[c] && !no_level_loop) {
+            ChainPlan& lp = cps[c];
+            lp.level_loop = true; lp.valid = true;
+            lp.tk_launch.clear(); lp.tk_block.clear(); lp.dep_off.assign(1, 0); lp.dep.clear();
+            out.chains.push_back(std::move(lp));
+          } else {
+            for (size_t li = 0; li < out.launches.size(); ++li) if (out.launches[li].kclass == c) out.plain_launches.push_back((int32_t)li);
+          }
+          continue;
+        }
         // (only receives read tables: a directional sweep of a 2-colour grid has ONE such step and gains nothing)
         int64_t max_bytes = 0; int n_table_steps = 0;
         for (const auto& lr : out.launches) if (lr.kclass == c) { max_bytes = std::max(max_bytes, lr.bytes); if (lr.n_recv > 0 && lr.bytes >= band_min_bytes) ++n_table_steps; }

@@ -128,6 +128,7 @@ struct ChainPlan {
   std::vector<int32_t> tk_block;            // [n_tickets]: block of records inside that launch
   std::vector<int32_t> dep_off, dep;        // CSR over tickets
   bool banded = false;                      // tickets in Infinity-Cache order: the tables are read with plain loads
+  bool level_loop = false;                  // many tiny levels of a generic class: ONE workgroup walks the launches (kernels.hip)
 };
 // records one workgroup of the packed kernels takes (256 threads / lanes per record)
 constexpr int GENERIC_BLOCK_RECORDS = 4, SMALL_BLOCK_RECORDS = 64;   // sweep_generic_kernel<64> / <1> (kernels.hip asserts them)

@@ -489,28 +489,39 @@ def test_few_big_launches_run_as_a_banded_chain(pairwise, L, H, W, band_bytes, m
         e.close()
 
 
-def test_chain_executor_lane_per_factor_class_is_opt_in(monkeypatch):
-    """the chain kernels of the lane-per-factor and generic classes are not the default (slower than graph replay:
-    plan.cpp make_schedule) but stay a supported path: LPMP_CHAIN_ALL=1, against the oracle bit for bit"""
-    m = S.c5_model(24, 24, 8, 400, 300, 100, seed=5, window=16)      # backward sweep: 178 levels of labeling-list factors
+def test_tiny_levels_of_the_lane_per_factor_class_three_ways(monkeypatch):
+    """178 levels of labeling-list factors (C5 with local triples, in miniature): by default ONE workgroup walks the
+    levels (level_loop_kernel); LPMP_NO_LEVEL_LOOP=1 replays a hipGraph of launches; LPMP_CHAIN_ALL=1 runs the ticket
+    form of the generic chain kernel.  All three against the oracle bit for bit, residual sends included"""
+    m = S.c5_model(24, 24, 8, 400, 300, 100, seed=5, window=16)
     o = Oracle(m)
-    e0 = E.Engine(0); e0.upload(m)
-    assert e0.plan.chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)["n_chains"] == 0
-    monkeypatch.setenv("LPMP_CHAIN_ALL", "1")
-    e1 = E.Engine(0); e1.upload(m)
+    engines = []
+    e = E.Engine(0); e.upload(m); engines.append(e)
+    ci = e.plan.chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)
+    assert ci["n_chains"] == 1 and ci["n_tickets"] == 0
+    monkeypatch.setenv("LPMP_NO_LEVEL_LOOP", "1")
+    e = E.Engine(0); e.upload(m); engines.append(e)
+    assert e.plan.chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)["n_chains"] == 0
+    monkeypatch.delenv("LPMP_NO_LEVEL_LOOP"); monkeypatch.setenv("LPMP_CHAIN_ALL", "1")
+    e = E.Engine(0); e.upload(m); engines.append(e)
+    assert e.plan.chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)["n_tickets"] > 0
     try:
-        assert e1.plan.chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)["n_chains"] == 1
-        for mode in (M.REPAM_ANISOTROPIC, M.REPAM_UNIFORM):
-            o.set_reparametrization(mode)
-            for e in (e0, e1):
-                e.set_reparametrization(mode)
-            o.ComputePass(2)
-            for e in (e0, e1):
-                e.compute_pass(2)
-                assert np.array_equal(e.download_duals(), o.duals()), mode
-                assert abs(e.lower_bound() - o.LowerBound()) <= LB_RTOL * max(1.0, abs(o.LowerBound()))
+        for rtype in (0, 1):
+            o.set_reparametrization_type(rtype)
+            for e in engines:
+                e.set_reparametrization_type(rtype)
+            for mode in (M.REPAM_ANISOTROPIC, M.REPAM_UNIFORM):
+                o.set_reparametrization(mode)
+                for e in engines:
+                    e.set_reparametrization(mode)
+                o.ComputePass(2); o.ComputeBackwardPass()
+                for e in engines:
+                    e.compute_pass(2); e.backward_pass()
+                    assert np.array_equal(e.download_duals(), o.duals()), (rtype, mode)
+                    assert abs(e.lower_bound() - o.LowerBound()) <= LB_RTOL * max(1.0, abs(o.LowerBound()))
     finally:
-        e0.close(); e1.close()
+        for e in engines:
+            e.close()
 
 
 def test_chain_executor_repeated_runs_are_deterministic():

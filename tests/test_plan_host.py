@@ -315,14 +315,19 @@ def test_baseline_configs_run_on_the_fast_kernel_classes():
 
 
 def test_chain_plans_default_to_the_packed_classes(monkeypatch):
-    """deep schedules of the packed dense / Potts classes become chain launches; the lane-per-factor class only on
+    """deep schedules of the packed dense / Potts classes become chain launches (tickets + flags); many tiny levels of the
+    lane-per-factor class become the level loop (one workgroup, no tickets); the ticket form of that class only on
     request (LPMP_CHAIN_ALL=1: measured slower than graph replay, plan.cpp make_schedule)"""
     assert E.Plan(S.grid_model(40, 30, 8, order="row_major")).chain_info(M.FORWARD, M.REPAM_ANISOTROPIC)["n_chains"] == 1
     m = S.c5_model(24, 24, 8, 400, 300, 100, seed=5, window=16)
+    ci = E.Plan(m).chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)
+    assert ci["n_chains"] == 1 and ci["n_tickets"] == 0 and ci["n_plain_launches"] == 2          # level loop + the two Potts steps
+    monkeypatch.setenv("LPMP_NO_LEVEL_LOOP", "1")
     assert E.Plan(m).chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)["n_chains"] == 0
+    monkeypatch.delenv("LPMP_NO_LEVEL_LOOP")
     monkeypatch.setenv("LPMP_CHAIN_ALL", "1")
     ci = E.Plan(m).chain_info(M.BACKWARD, M.REPAM_ANISOTROPIC)
-    assert ci["n_chains"] == 1 and ci["n_plain_launches"] == 2 and ci["n_dependencies"] >= ci["n_tickets"] - 1
+    assert ci["n_chains"] == 1 and ci["n_plain_launches"] == 2 and ci["n_dependencies"] >= ci["n_tickets"] - 1 > 0
 
 
 def test_pass_rotation_is_decided_op_by_op():
