@@ -683,7 +683,7 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
   if (chain_ok) {
     if (!e->d_chain_abort) { HIP_CHECK(hipMalloc((void**)&e->d_chain_abort, sizeof(int32_t))); HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, sizeof(int32_t), e->stream)); }
     // UpdateFactorPrimal always sends 'shared' (issue_launches)
-    const int rule = e->primal_pass ? SWEEP_PRIMAL : e->rtype == LPMP_RTYPE_RESIDUAL ? SWEEP_RESIDUAL : 0;
+    const int rule = e->primal_pass ? SWEEP_PRIMAL : e->rtype == LPMP_RTYPE_RESIDUAL ? SWEEP_RESIDUAL : e->rtype == LPMP_RTYPE_ADAPTIVE ? SWEEP_ADAPTIVE : 0;
     // classes are independent of each other (plan.cpp): the plain launches first, then one persistent launch per class
     if (!s.plain.empty()) {
       DevSchedule tmp;                       // a view: issue_launches only reads recs / ops / packets / launches

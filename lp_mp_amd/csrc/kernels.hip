@@ -52,9 +52,11 @@ template <bool NT, class T> __device__ __forceinline__ void st_stream(T* p, T v)
 // (global_load / global_store ... sc1: write-through stores, loads that do not hit a stale line of this CU's L1; the
 // XCDs' L2s are not coherent with each other, MI355X_MICROARCH.md "inter-workgroup visibility").  The pairwise tables
 // are constants and keep the streaming policy in every mode.
-enum Access : int { ACC_PLAIN = 0, ACC_NT = 1, ACC_COH = 2 };
+// ACC_WG: the level loop below — one WAVE hands values from level to level: loads that do not stop at this CU's L1 (sc0).
+enum Access : int { ACC_PLAIN = 0, ACC_NT = 1, ACC_COH = 2, ACC_WG = 3 };
 template <int A> __device__ __forceinline__ double ld_dual(const double* p) {
   if constexpr (A == ACC_COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if constexpr (A == ACC_WG) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else if constexpr (A == ACC_NT) return __builtin_nontemporal_load(p);
   else return *p;
 }
@@ -1071,25 +1073,62 @@ chain_generic_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, dou
 }
 
 // Level loop: a deep schedule of TINY levels of a generic class as one launch of ONE workgroup that walks the launches in
-// order with a workgroup barrier in between (plan.cpp decides; C5 with local triples).  What a level hands to the next
-// travels through this compute unit's caches: a workgroup barrier orders plain loads and stores of one workgroup, so the
-// body is the plain one.  The next level's record is touched ahead so that its (cold, read-once) line is on its way.
+// order (plan.cpp decides; C5 with local triples: 11 887 levels of a dozen one-lane updates).  No launch per level, no
+// flags through memory; what a level hands to the next stays in this compute unit's L2.
+//   G = 64 (wave per factor): the plain body, a workgroup barrier between levels.
+//   G = 1 (lane per factor): ONE wave computes — in-order issue, stores drained between levels, dual loads that bypass
+//   the L1 (ACC_WG) — and a second wave runs a few levels AHEAD touching every line the computing wave will need
+//   (records, op lists, match tables, own and peer duals): a level is a chain of ~6 dependent loads, cold ones cost
+//   1-2 us each, touched ones a fraction.
+constexpr int LEVEL_LOOP_AHEAD = 8;
 template <int G>
-__global__ void __launch_bounds__(GenCtx<G>::THREADS)
+__global__ void __launch_bounds__(GenCtx<G>::THREADS + (G == 1 ? 64 : 0))
 level_loop_kernel(const ChainLaunch* __restrict__ launches, int n_launches, double* __restrict__ dual, const double* __restrict__ cdata,
                   const int32_t* __restrict__ tabs, double* __restrict__ lb, int flags) {
   using C = GenCtx<G>;
-  for (int l = 0; l < n_launches; ++l) {
-    const ChainLaunch ln = launches[l];
-    if (l + 1 < n_launches) {                      // prefetch: first record of the next level (result unused)
-      const ChainLaunch nx = launches[l + 1];
-      const int64_t i = G == 64 ? (int64_t)(threadIdx.x >> 6) : (int64_t)threadIdx.x;
-      if (i < nx.count) asm volatile("" :: "v"(__builtin_nontemporal_load(&nx.recs[i].op_begin)));
-    }
-    const int64_t nblk = (ln.count + C::FPB - 1) / C::FPB;
-    for (int64_t b = 0; b < nblk; ++b)
-      [&] { generic_body<G, ACC_PLAIN>(ln.recs, ln.ops, dual, cdata, tabs, lb, nullptr, nullptr, 0, ln.count, flags, b); }();
+  if constexpr (G == 1) {
+    __shared__ int s_level;
+    if (threadIdx.x == 0) s_level = 0;
     __syncthreads();
+    volatile int* level = &s_level;
+    if (threadIdx.x >= C::THREADS) {               // the wave that runs ahead
+      const int lane = threadIdx.x & 63;
+      for (int l = 0; l < n_launches; ++l) {
+        while (l - *level > LEVEL_LOOP_AHEAD) __builtin_amdgcn_s_sleep(4);
+        const ChainLaunch ln = launches[l];
+        for (int64_t i = lane; i < ln.count; i += 64) {
+          const UpdRec r = ln.recs[i];
+          const double* own = dual + r.dual_off;
+          double acc = __hip_atomic_load(own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const int n_ops = r.n_recv + r.n_send;
+          for (int k = 0; k < n_ops; ++k) {
+            const Op o = ln.ops[r.op_begin + k];
+            const double* pd = dual + o.peer_dual;
+            acc += __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            acc += __hip_atomic_load(pd + max(o.pd0 + o.pd1 - 1, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a peer of this class spans at most two lines
+            if ((o.info & 15) == OP_LABELING) acc += (double)tabs[o.peer_const];
+          }
+          asm volatile("" :: "v"(acc));
+        }
+      }
+      return;
+    }
+    for (int l = 0; l < n_launches; ++l) {
+      const ChainLaunch ln = launches[l];
+      const int64_t nblk = (ln.count + C::FPB - 1) / C::FPB;
+      for (int64_t b = 0; b < nblk; ++b)
+        [&] { generic_body<1, ACC_WG>(ln.recs, ln.ops, dual, cdata, tabs, lb, nullptr, nullptr, 0, ln.count, flags, b); }();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this level's stores are in the L2 before the next level loads
+      if (threadIdx.x == 0) *level = l + 1;
+    }
+  } else {
+    for (int l = 0; l < n_launches; ++l) {
+      const ChainLaunch ln = launches[l];
+      const int64_t nblk = (ln.count + C::FPB - 1) / C::FPB;
+      for (int64_t b = 0; b < nblk; ++b)
+        [&] { generic_body<G, ACC_PLAIN>(ln.recs, ln.ops, dual, cdata, tabs, lb, nullptr, nullptr, 0, ln.count, flags, b); }();
+      __syncthreads();
+    }
   }
 }
 
@@ -1964,7 +2003,7 @@ static unsigned chain_grid(K kernel, int n_tickets, int threads = 256) {
 bool launch_level_loop(int kclass, int flags, const void* launches, int n_launches, double* dual, const double* cdata,
                        const int32_t* tabs, double* lb, hipStream_t s) {
   const ChainLaunch* ln = static_cast<const ChainLaunch*>(launches);
-  if (kclass == KC_SMALL) hipLaunchKernelGGL(level_loop_kernel<1>, dim3(1), dim3(GenCtx<1>::THREADS), 0, s, ln, n_launches, dual, cdata, tabs, lb, flags);
+  if (kclass == KC_SMALL) hipLaunchKernelGGL(level_loop_kernel<1>, dim3(1), dim3(GenCtx<1>::THREADS + 64), 0, s, ln, n_launches, dual, cdata, tabs, lb, flags);
   else if (kclass == KC_GENERIC) hipLaunchKernelGGL(level_loop_kernel<64>, dim3(1), dim3(GenCtx<64>::THREADS), 0, s, ln, n_launches, dual, cdata, tabs, lb, flags);
   else return false;
   return true;
