@@ -490,6 +490,12 @@ class PartitionedSweep:
             mk_off, mk = plan.mask(d, mode)
             keep = ~ghost[upd]
             rows = _select_rows(upd, om_off, om, mk_off, mk, keep)
+            scale = getattr(part, "main_send_scale", None)      # experiments (tools/gap_probe.py): weight kept back for the cut messages
+            if scale is None and d == M.BACKWARD:
+                scale = getattr(part, "main_send_scale_backward", None)
+            if scale is not None:
+                lens = rows[1][1:] - rows[1][:-1]
+                rows = (rows[0], rows[1], rows[2] * np.repeat(scale[rows[0]], lens), rows[3], rows[4])
             self.main_rows.append(rows)
             self.main.append(engine.schedule_create(*rows))
         # forward then backward main sweep as one (fused) sequence, and its steady-state variants: the first level
