@@ -436,6 +436,11 @@ class LocalComm:
 
 
 BOUNDARY_SHARE = 0.375
+# Part of its send weight a variable with k cut messages and d local ones keeps back in the main sweeps (GraphSweep):
+# every send row is scaled by 1 - BOUNDARY_RESERVE * k / (d + k), so that what the boundary step then shares out is not
+# only what it just pulled in.  G(20 000, 100 000), 16 labels, 8 passes, gap to the unpartitioned bound without -> with
+# 0.75: 2 parts (31 % cut) 1.10 -> 1.06 %, 4 parts (49 %) 2.20 -> 1.69 %, 8 parts (61 %) 3.37 -> 2.33 % (tools/gap_probe.py)
+BOUNDARY_RESERVE = 0.75
 
 
 # ---- the sweep ---------------------------------------------------------------------------------------
@@ -445,7 +450,7 @@ class PartitionedSweep:
     buffer, so the boundary arithmetic is done in place with torch ops on the engine's stream."""
 
     def __init__(self, torch, part: LocalPart, engine, dual_tensor, mode: int = M.REPAM_ANISOTROPIC,
-                 omega_b: Optional[float] = None, boundary_every: str = "sweep"):
+                 omega_b: Optional[float] = None, boundary_every: str = "sweep", reserve: float = 0.0):
         """boundary_every: "sweep" — one boundary step after each directional main sweep (tighter bound per pass:
         on a random graph with 69 % cut edges the gap to the unpartitioned sweep after 8 passes is 3.6 % against
         18 % for "pass"; on 4 strips of 32 rows 0.07 % against 0.31 %); "pass" — one after the forward+backward
@@ -490,9 +495,16 @@ class PartitionedSweep:
             mk_off, mk = plan.mask(d, mode)
             keep = ~ghost[upd]
             rows = _select_rows(upd, om_off, om, mk_off, mk, keep)
-            scale = getattr(part, "main_send_scale", None)      # experiments (tools/gap_probe.py): weight kept back for the cut messages
+            scale = getattr(part, "main_send_scale", None)      # (tools/gap_probe.py sets it for experiments)
             if scale is None and d == M.BACKWARD:
                 scale = getattr(part, "main_send_scale_backward", None)
+            if scale is None and reserve > 0.0 and part.in_unary.size:
+                nf = part.model.n_factors
+                deg = np.bincount(part.model.m_left, minlength=nf).astype(np.float64)
+                kc = np.bincount(part.in_unary, minlength=nf).astype(np.float64)
+                scale = np.ones(nf)
+                has = kc > 0
+                scale[has] = 1.0 - reserve * kc[has] / (deg[has] + kc[has])
             if scale is not None:
                 lens = rows[1][1:] - rows[1][:-1]
                 rows = (rows[0], rows[1], rows[2] * np.repeat(scale[rows[0]], lens), rows[3], rows[4])
@@ -808,7 +820,7 @@ class GraphSweep:
             boundary_every = "sweep" if self.cut_fraction > 0.10 else "pass"
         self.boundary_every = boundary_every
         self.engine.set_reparametrization(mode)
-        self.sweep = PartitionedSweep(torch, part, self.engine, self.dualt, mode, omega_b, boundary_every)
+        self.sweep = PartitionedSweep(torch, part, self.engine, self.dualt, mode, omega_b, boundary_every, BOUNDARY_RESERVE)
         vals = [self.sweep.updates_per_pass(), self.sweep.bytes_per_pass(), part.out_ghost.shape[0], m]
         if self.comm:
             t = torch.tensor(vals[:3], dtype=torch.float64, device="cpu" if self.comm.stage_cpu else dev)

@@ -1,6 +1,7 @@
 """Dual-bound gap of the partitioned sweep against the unpartitioned one, on the CPU (oracle-backed engines, lock-stepped
 parts): the experiment behind BOUNDARY_SHARE and the boundary schedule.
-    python tools/gap_probe.py [n] [m] [L] [world] [passes] [share,share,...] [every]"""
+    python tools/gap_probe.py [n] [m] [L] [world] [passes] [share,share,...] [every]
+GAP_RESERVE=x overrides multi_gpu.BOUNDARY_RESERVE (0: the main sweeps keep nothing back); GAP_VARIANT: experiments."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -88,7 +89,7 @@ for share in shares:
             sc = np.ones(nf); has = k > 0
             sc[has] = 1.0 - alpha * k[has] / (deg[has] + k[has])
             p.main_send_scale_backward = sc
-        sweeps.append(cls(torch, p, eng, torch.from_numpy(dual), M.REPAM_ANISOTROPIC, None, every))
+        sweeps.append(cls(torch, p, eng, torch.from_numpy(dual), M.REPAM_ANISOTROPIC, None, every, float(os.environ.get("GAP_RESERVE", MG.BOUNDARY_RESERVE))))
     MG.run_lockstep(sweeps, passes)
     lb = sum(s.local_lower_bound() for s in sweeps)
     print(f"  share {share:.3f} every {every}: LB {lb:.3f}  gap {100 * (lb_ref - lb) / abs(lb_ref):.3f} %  ({time.time() - t0:.0f} s)", flush=True)
