@@ -439,7 +439,8 @@ BOUNDARY_SHARE = 0.375
 # Part of its send weight a variable with k cut messages and d local ones keeps back in the main sweeps (GraphSweep):
 # every send row is scaled by 1 - BOUNDARY_RESERVE * k / (d + k), so that what the boundary step then shares out is not
 # only what it just pulled in.  G(20 000, 100 000), 16 labels, 8 passes, gap to the unpartitioned bound without -> with
-# 0.75: 2 parts (31 % cut) 1.10 -> 1.06 %, 4 parts (49 %) 2.20 -> 1.69 %, 8 parts (61 %) 3.37 -> 2.33 % (tools/gap_probe.py)
+# 0.75 (boundary step after each sweep): 2 parts (31 % cut) 1.10 -> 1.06 %, 4 parts (49 %) 2.20 -> 1.69 %, 8 parts (61 %) 3.37 -> 2.33 %;
+# with the boundary step BEFORE each sweep (what program() does): 0.97 / 1.54 / 2.15 % (tools/gap_probe.py)
 BOUNDARY_RESERVE = 0.75
 
 
@@ -594,7 +595,9 @@ class PartitionedSweep:
     # -- the steps of n passes: ("run", key of self.rows / self.sched) and ("boundary",) ------------------------
     def program(self, n: int):
         if self.boundary_every == "sweep":
-            return [step for _ in range(n) for step in (("run", "F"), ("boundary",), ("run", "B"), ("boundary",))]
+            # the boundary step BEFORE each directional sweep: what it pulls in is sent on by the sweep that follows
+            # (after the sweeps instead: gap 1.06 % instead of 0.97 % on the C4-shaped graph in 2 parts)
+            return [step for _ in range(n) for step in (("boundary",), ("run", "F"), ("boundary",), ("run", "B"))]
         if n >= 2 and "mid" in self.sched:
             keys = ["first"] + ["mid"] * (n - 2) + ["last"]
         else:

@@ -80,6 +80,18 @@ for share in shares:
         dual = p.model.dual_data.copy()
         eng = OracleEngine(p.model, dual)
         cls = MG.PartitionedSweep
+        if variant.startswith("double"):              # two boundary steps after each directional sweep
+            class cls(MG.PartitionedSweep):
+                def program(self, n):
+                    return [step for _ in range(n) for step in (("run", "F"), ("boundary",), ("boundary",), ("run", "B"), ("boundary",), ("boundary",))]
+        if variant.startswith("before"):              # the boundary step BEFORE each directional sweep (same number of exchanges)
+            class cls(MG.PartitionedSweep):
+                def program(self, n):
+                    return [step for _ in range(n) for step in (("boundary",), ("run", "F"), ("boundary",), ("run", "B"))]
+        if variant.startswith("pre"):                 # a boundary step before AND after each directional sweep
+            class cls(MG.PartitionedSweep):
+                def program(self, n):
+                    return [("boundary",)] + [step for _ in range(n) for step in (("run", "F"), ("boundary",), ("run", "B"), ("boundary",))]
         if variant.startswith("dir"):                 # direction-aware boundary: pull after the forward sweep, push after the backward one
             cls = DirectionalSweep
             nf = p.model.n_factors
