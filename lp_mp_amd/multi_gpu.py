@@ -440,7 +440,7 @@ BOUNDARY_SHARE = 0.375
 # every send row is scaled by 1 - BOUNDARY_RESERVE * k / (d + k), so that what the boundary step then shares out is not
 # only what it just pulled in.  G(20 000, 100 000), 16 labels, 8 passes, gap to the unpartitioned bound without -> with
 # 0.75 (boundary step after each sweep): 2 parts (31 % cut) 1.10 -> 1.06 %, 4 parts (49 %) 2.20 -> 1.69 %, 8 parts (61 %) 3.37 -> 2.33 %;
-# with the boundary step BEFORE each sweep (what program() does): 0.97 / 1.54 / 2.15 % (tools/gap_probe.py)
+# with the boundary step BEFORE each sweep (what program() does): 0.97 / 1.54 / 2.15 % (tests/gap_probe.py)
 BOUNDARY_RESERVE = 0.75
 
 
@@ -496,7 +496,7 @@ class PartitionedSweep:
             mk_off, mk = plan.mask(d, mode)
             keep = ~ghost[upd]
             rows = _select_rows(upd, om_off, om, mk_off, mk, keep)
-            scale = getattr(part, "main_send_scale", None)      # (tools/gap_probe.py sets it for experiments)
+            scale = getattr(part, "main_send_scale", None)      # (tests/gap_probe.py sets it for experiments)
             if scale is None and d == M.BACKWARD:
                 scale = getattr(part, "main_send_scale_backward", None)
             if scale is None and reserve > 0.0 and part.in_unary.size:

@@ -1,10 +1,10 @@
 """Dual-bound gap of the partitioned sweep against the unpartitioned one, on the CPU (oracle-backed engines, lock-stepped
 parts): the experiment behind BOUNDARY_SHARE and the boundary schedule.
-    python tools/gap_probe.py [n] [m] [L] [world] [passes] [share,share,...] [every]
+    python tests/gap_probe.py [n] [m] [L] [world] [passes] [share,share,...] [every]
 GAP_RESERVE=x overrides multi_gpu.BOUNDARY_RESERVE (0: the main sweeps keep nothing back); GAP_VARIANT: experiments."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # lives in tests/: it runs the oracle (test infrastructure)
 import numpy as np
 import torch
 from lp_mp_amd import model as M, multi_gpu as MG, synthetic as S
