@@ -789,13 +789,31 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
   double sm[KS];                                 // target vectors of the first KS sends
 #pragma unroll
   for (int k = 0; k < KS; ++k) sm[k] = 0.0;
+  // chain executor: the fields of the first KS send ops, read from the LDS packet ONCE, before the receives write to
+  // LDS — otherwise every field is re-read after those writes, one dependent LDS round trip each on the critical path
+  // of a dependent level (0.64 us for two sends, tools/chain_trace.py)
+  [[maybe_unused]] double* s_ms[KS]; [[maybe_unused]] double s_om[KS]; [[maybe_unused]] int s_fw[KS], s_peer[KS];
+  if constexpr (CHAIN) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      s_ms[k] = dual; s_om[k] = 0.0; s_fw[k] = 0; s_peer[k] = 0;
+      if (k < n_send) {
+        const Op& o = lop[n_recv + k];
+        s_ms[k] = dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0);
+        s_om[k] = o.omega; s_fw[k] = uni<G>(o.pad); s_peer[k] = uni<G>(o.peer);
+      }
+    }
+  }
   auto load_own_and_targets = [&]() {
     theta = vl ? ld_dual<A>(own_g + g) : 0.0;
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       if (preload_ok && k < n_send && g < Lr) {
-        const Op& o = lop[n_recv + k];
-        sm[k] = ld_dual<A>(dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0) + g);
+        if constexpr (CHAIN) sm[k] = ld_dual<A>(s_ms[k] + g);
+        else {
+          const Op& o = lop[n_recv + k];
+          sm[k] = ld_dual<A>(dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0) + g);
+        }
       }
     }
   };
@@ -970,32 +988,40 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
       // write-through stores of the receives on EVERY path (measured: 1 us per record, tools/chain_trace.py)
       if (!preload_ok) {
 #pragma unroll
-        for (int k = 0; k < KS; ++k) {
-          if (k < n_send) {
-            const Op& o = lop[n_recv + k];
-            if (uni<G>(o.pad) == 0) sm[k] = ld_dual<A>(dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0) + g);
-          }
-        }
+        for (int k = 0; k < KS; ++k) if (k < n_send && s_fw[k] == 0) sm[k] = ld_dual<A>(s_ms[k] + g);
 #pragma unroll
         for (int k = 0; k < KS; ++k) asm volatile("" :: "v"(sm[k]));
       }
-    }
 #pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      if (k < n_send) {
-        const Op& o = lop[n_recv + k];
-        double* ms = dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0);
-        const int fw = uni<G>(o.pad);
-        double cur;
-        if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
-        else if constexpr (CHAIN) cur = sm[k];
-        else cur = preload_ok ? sm[k] : ld_dual<A>(ms + g);
-        const double delta = o.omega * snap;
-        st_dual<A>(ms + g, cur + delta);
-        theta -= delta;
+      for (int k = 0; k < KS; ++k) {
+        if (k < n_send) {
+          const int fw = s_fw[k];
+          const double cur = fw > 0 ? (fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3]) : sm[k];
+          const double delta = s_om[k] * snap;
+          st_dual<A>(s_ms[k] + g, cur + delta);
+          theta -= delta;
 #ifndef LPMP_ABLATE_LB_TRACK
-        if (g == 0) st_lb<A>(lb + uni<G>(o.peer), LPMP_NAN);
+          if (g == 0) st_lb<A>(lb + s_peer[k], LPMP_NAN);
 #endif
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        if (k < n_send) {
+          const Op& o = lop[n_recv + k];
+          double* ms = dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0);
+          const int fw = uni<G>(o.pad);
+          double cur;
+          if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
+          else cur = preload_ok ? sm[k] : ld_dual<A>(ms + g);
+          const double delta = o.omega * snap;
+          st_dual<A>(ms + g, cur + delta);
+          theta -= delta;
+#ifndef LPMP_ABLATE_LB_TRACK
+          if (g == 0) st_lb<A>(lb + uni<G>(o.peer), LPMP_NAN);
+#endif
+        }
       }
     }
     for (int k = KS; k < n_send; ++k) {
