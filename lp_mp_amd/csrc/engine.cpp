@@ -314,6 +314,7 @@ struct lpmp_engine {
   bool have_primal = false;
   bool primal_pass = false;       // the launches being issued belong to an ...AndPrimal pass
   int nt_flag = 0;                // SWEEP_NT when tables + duals are far larger than L2 + Infinity Cache
+  bool model_big = false;         // tables + duals > 1 GiB: only then is an Infinity-Cache ticket order worth a chain launch
   struct LbRun { int cls; int64_t first, count; };
   std::vector<LbRun> lb_runs;
   DevSchedule sched[2][LPMP_REPAM_COUNT];
@@ -762,7 +763,9 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
   const int64_t N = base[n_steps];
   if (N > (int64_t)48 << 20) return nullptr;                   // too many tickets for one launch: the caller splits the passes
   // a model whose tables fit the caches gains nothing from the order and is launch-bound: one launch per step then
-  if (e->rot_bands <= 0 && ri.t[1].bytes < ((int64_t)64 << 20)) return nullptr;
+  // (nor does one that fits the Infinity Cache as a whole: plain launches already re-read it on-die, and the chain's
+  // agent-scope accesses only cost — C2, 512 x 512 8-label Potts: 0.065 ms per pass as launches, 0.10 as a chain)
+  if (e->rot_bands <= 0 && (ri.t[1].bytes < ((int64_t)64 << 20) || !e->model_big)) return nullptr;
   // bands: about 16 MiB of algorithmic bytes per band of a step.  What a group keeps alive between two reads of a table is
   // lag * depth bands (3 * 4 * 16 MiB = 192 MiB of the 256 MiB Infinity Cache); measured on C3: windows of 200-230 MB are
   // the fastest whatever the split (1024:3:4 5.09, 2048:4:6 5.03, 1536:3:6 5.09 ms per pass), 290 MB and more lose the
@@ -1137,6 +1140,7 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
       const char* env = getenv("LPMP_NT");
       const bool big = (n_const + n_dual) * (int64_t)sizeof(double) > (int64_t)1 << 30;
       e->nt_flag = (env ? atoi(env) != 0 : big) ? SWEEP_NT : 0;
+      e->model_big = big;
     }
     if (const_mem == LPMP_MEM_DEVICE) {
       e->d_const = const_cast<double*>(m->const_data);

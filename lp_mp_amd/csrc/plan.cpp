@@ -708,12 +708,14 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   // (LPMP_BAND_MIN_BYTES, LPMP_BAND_BYTES: tests force the banded order on small models)
   const char* bmin_env = std::getenv("LPMP_BAND_MIN_BYTES");
   const int64_t band_min_bytes = bmin_env ? std::atoll(bmin_env) : ((int64_t)64 << 20);
+  // a model that fits the 256 MiB Infinity Cache as a whole is re-read on-die by plain launches already
+  const bool model_big = bmin_env != nullptr || (f_coff[nf] + f_doff[nf]) * (int64_t)sizeof(double) > ((int64_t)1 << 30);
   const char* bb_env = std::getenv("LPMP_BAND_BYTES");
   const int64_t band_bytes = bb_env ? std::max<int64_t>(1, std::atoll(bb_env)) : ((int64_t)16 << 20);
   const char* chain_all_env = std::getenv("LPMP_CHAIN_ALL");
   const bool chain_all = chain_all_env && std::atoi(chain_all_env) != 0;
   bool any_big = false;
-  for (const auto& lr : out.launches) any_big = any_big || (kc_is_dense(lr.kclass) && lr.n_recv > 0 && lr.bytes >= band_min_bytes);
+  for (const auto& lr : out.launches) any_big = any_big || (model_big && kc_is_dense(lr.kclass) && lr.n_recv > 0 && lr.bytes >= band_min_bytes);
   if (((int64_t)out.launches.size() >= chain_min || (any_big && out.launches.size() >= 2 && !no_auto_bands)) && !out.launches.empty()) {
     std::vector<int64_t> n_launches_of(KC_COUNT, 0);
     bool ok = true;
@@ -794,7 +796,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         int64_t max_bytes = 0; int n_table_steps = 0;
         for (const auto& lr : out.launches) if (lr.kclass == c) { max_bytes = std::max(max_bytes, lr.bytes); if (lr.n_recv > 0 && lr.bytes >= band_min_bytes) ++n_table_steps; }
         const bool dense_cls = kc_is_dense(c);
-        const bool big_steps = dense_cls && n_table_steps >= 2 && n_launches_of[c] <= 8 && !no_auto_bands;
+        const bool big_steps = model_big && dense_cls && n_table_steps >= 2 && n_launches_of[c] <= 8 && !no_auto_bands;
         if (n_launches_of[c] < chain_min && !big_steps && !(bands > 1)) {               // few launches: plain
           for (size_t li = 0; li < out.launches.size(); ++li) if (out.launches[li].kclass == c) out.plain_launches.push_back((int32_t)li);
           continue;
