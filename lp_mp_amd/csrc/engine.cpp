@@ -251,6 +251,7 @@ static void plan_rotation_chain(lpmp_plan* pl, int mode) {
   if (!only_launch(fb, 1, h) || !only_launch(fb, 2, w) || !only_launch(fb, 3, t) || !only_launch(bf, 2, k)) return;
   const int kc = w.kclass;
   if (h.kclass != kc || k.kclass != kc || t.kclass != kc || !kc_chain_capable(kc) || kc_width(kc) == 0) return;
+
   if (h.stride == 0 || w.stride == 0 || k.stride == 0 || t.stride == 0) return;
   ri.kclass = kc; ri.gpb = kc_block_records(kc);
   const LevelRange* lrs[4] = {&h, &w, &k, &t};
@@ -766,6 +767,9 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
   // (nor does one that fits the Infinity Cache as a whole: plain launches already re-read it on-die, and the chain's
   // agent-scope accesses only cost — C2, 512 x 512 8-label Potts: 0.065 ms per pass as launches, 0.10 as a chain)
   if (e->rot_bands <= 0 && (ri.t[1].bytes < ((int64_t)64 << 20) || !e->model_big)) return nullptr;
+  // (the run-time-dims classes read their tables with 8-byte loads of rows that are not line-aligned: as a chain in
+  // Infinity-Cache order 1024 x 1024 x 21 labels takes 5.48 ms per pass against 4.38 launch by launch)
+  if (e->rot_bands <= 0 && kc_is_var(ri.kclass)) return nullptr;
   // bands: about 16 MiB of algorithmic bytes per band of a step.  What a group keeps alive between two reads of a table is
   // lag * depth bands (3 * 4 * 16 MiB = 192 MiB of the 256 MiB Infinity Cache); measured on C3: windows of 200-230 MB are
   // the fastest whatever the split (1024:3:4 5.09, 2048:4:6 5.03, 1536:3:6 5.09 ms per pass), 290 MB and more lose the

@@ -715,7 +715,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   const char* chain_all_env = std::getenv("LPMP_CHAIN_ALL");
   const bool chain_all = chain_all_env && std::atoi(chain_all_env) != 0;
   bool any_big = false;
-  for (const auto& lr : out.launches) any_big = any_big || (model_big && kc_is_dense(lr.kclass) && lr.n_recv > 0 && lr.bytes >= band_min_bytes);
+  for (const auto& lr : out.launches) any_big = any_big || (model_big && kc_is_dense(lr.kclass) && !kc_is_var(lr.kclass) && lr.n_recv > 0 && lr.bytes >= band_min_bytes);
   if (((int64_t)out.launches.size() >= chain_min || (any_big && out.launches.size() >= 2 && !no_auto_bands)) && !out.launches.empty()) {
     std::vector<int64_t> n_launches_of(KC_COUNT, 0);
     bool ok = true;
@@ -795,7 +795,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         // (only receives read tables: a directional sweep of a 2-colour grid has ONE such step and gains nothing)
         int64_t max_bytes = 0; int n_table_steps = 0;
         for (const auto& lr : out.launches) if (lr.kclass == c) { max_bytes = std::max(max_bytes, lr.bytes); if (lr.n_recv > 0 && lr.bytes >= band_min_bytes) ++n_table_steps; }
-        const bool dense_cls = kc_is_dense(c);
+        const bool dense_cls = kc_is_dense(c) && !kc_is_var(c);   // (run-time-dims classes: slower as a banded chain, engine.cpp plan_rotation_chain)
         const bool big_steps = model_big && dense_cls && n_table_steps >= 2 && n_launches_of[c] <= 8 && !no_auto_bands;
         if (n_launches_of[c] < chain_min && !big_steps && !(bands > 1)) {               // few launches: plain
           for (size_t li = 0; li < out.launches.size(); ++li) if (out.launches[li].kclass == c) out.plain_launches.push_back((int32_t)li);

@@ -484,7 +484,8 @@ def test_few_big_launches_run_as_a_banded_chain(pairwise, L, H, W, band_bytes, m
                 e.schedule_run(sid); o.compute_pass_custom(*cat)
                 assert np.array_equal(e.download_duals(), o.duals()), (mode, "custom")
             e.schedule_destroy(sid)
-        assert banded >= 4
+        # (the run-time-dims classes are not banded: slower that way, engine.cpp plan_rotation_chain)
+        assert banded >= 4 if L in (4, 8, 16, 32) else banded == 0
     finally:
         e.close()
 
