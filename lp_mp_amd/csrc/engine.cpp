@@ -752,7 +752,9 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
   if (it != e->rot_chain[mode].end()) return it->second.n_steps > 0 ? &it->second : nullptr;
   lpmp_engine::RotChain& rc = e->rot_chain[mode][n];           // n_steps == 0: tried, not possible
   const RotationInfo& ri = e->plan->rot[mode];
-  if (!ri.valid) return nullptr;
+  const bool verbose = std::getenv("LPMP_ROT_VERBOSE") != nullptr;
+  auto no = [&](const char* why) -> lpmp_engine::RotChain* { if (verbose) std::fprintf(stderr, "lpmp: %d passes stay one launch per step: %s\n", n, why); return nullptr; };
+  if (!ri.valid) return no("the pass does not have the H, W, K, T shape of one packed class");
   const int n_steps = 2 * n + 1;
   std::vector<int> tmpl(n_steps), kind(n_steps, -1);
   tmpl[0] = 0;
@@ -762,14 +764,14 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
   std::vector<int64_t> base(n_steps + 1, 0);
   for (int s = 0; s < n_steps; ++s) base[s + 1] = base[s] + ri.t[tmpl[s]].nb;
   const int64_t N = base[n_steps];
-  if (N > (int64_t)48 << 20) return nullptr;                   // too many tickets for one launch: the caller splits the passes
+  if (N > (int64_t)48 << 20) return no("too many tickets");                   // too many tickets for one launch: the caller splits the passes
   // a model whose tables fit the caches gains nothing from the order and is launch-bound: one launch per step then
   // (nor does one that fits the Infinity Cache as a whole: plain launches already re-read it on-die, and the chain's
   // agent-scope accesses only cost — C2, 512 x 512 8-label Potts: 0.065 ms per pass as launches, 0.10 as a chain)
-  if (e->rot_bands <= 0 && (ri.t[1].bytes < ((int64_t)64 << 20) || !e->model_big)) return nullptr;
+  if (e->rot_bands <= 0 && (ri.t[1].bytes < ((int64_t)64 << 20) || !e->model_big)) return no("the model fits the caches");
   // (the run-time-dims classes read their tables with 8-byte loads of rows that are not line-aligned: as a chain in
   // Infinity-Cache order 1024 x 1024 x 21 labels takes 5.48 ms per pass against 4.38 launch by launch)
-  if (e->rot_bands <= 0 && kc_is_var(ri.kclass)) return nullptr;
+  if (e->rot_bands <= 0 && kc_is_var(ri.kclass)) return no("run-time-dims class");
   // bands: about 16 MiB of algorithmic bytes per band of a step.  What a group keeps alive between two reads of a table is
   // lag * depth bands (3 * 4 * 16 MiB = 192 MiB of the 256 MiB Infinity Cache); measured on C3: windows of 200-230 MB are
   // the fastest whatever the split (1024:3:4 5.09, 2048:4:6 5.03, 1536:3:6 5.09 ms per pass), 290 MB and more lose the
@@ -845,7 +847,7 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
       std::fprintf(stderr, "lpmp: %d passes as one launch: %lld tickets, %d bands, lag %d, depth %d\n", n, (long long)N, bands, lag, depth);
     return &rc;
   }
-  return nullptr;
+  return no("no band order keeps the dependencies backwards");
 }
 
 bool run_rotation_chain(lpmp_engine* e, int mode, int n) {
