@@ -804,7 +804,11 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
       const auto& off = ri.off[kd];
       for (int64_t j = 0; j < ri.t[tmpl[s]].nb && ok; ++j)
         for (int64_t q = off[j]; q < off[j + 1]; ++q)
-          if (new_of[base[s - ri.delta[kd][q]] + ri.block[kd][q]] >= new_of[base[s] + j]) { ok = false; break; }
+          if (new_of[base[s - ri.delta[kd][q]] + ri.block[kd][q]] >= new_of[base[s] + j]) {
+            if (verbose) std::fprintf(stderr, "lpmp:   lag %d: step %d (kind %d) block %lld of %lld needs block %d of step %d (%lld blocks), %d bands\n", lag, s, kd,
+                                      (long long)j, (long long)ri.t[tmpl[s]].nb, ri.block[kd][q], s - ri.delta[kd][q], (long long)ri.t[tmpl[s - ri.delta[kd][q]]].nb, bands);
+            ok = false; break;
+          }
     }
     if (!ok) continue;
     // dependencies in ticket order

@@ -603,13 +603,19 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   }
   out.ops = std::move(ops);
   // inside a launch the order of the records is free (they are independent): sub-wave kernels run several
-  // factors per wavefront, so neighbours in the list should have similar amounts of work
+  // factors per wavefront, so neighbours in the list should have similar amounts of work.  Sorted inside windows of
+  // 1024 records only: the order of the sequence carries the model's locality (rows of a grid), and the Infinity-Cache
+  // ticket orders (make_schedule below, engine.cpp rotation_chain) need blocks that are near in the list to be near in
+  // the model — sorted globally, the border rows of a grid ended up in the last blocks and no band order was valid
+  constexpr int64_t SORT_WINDOW = 1024;
   for (const auto& lr : out.launches)
     if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32 && lr.kclass != KC_DENSE_V32 && lr.kclass != KC_DENSE_BIG && lr.kclass != KC_PW_32) {   // incl. KC_SMALL
       std::vector<int64_t> perm(lr.end - lr.begin);
       std::iota(perm.begin(), perm.end(), lr.begin);
       std::stable_sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) {
         const UpdRec& a = out.recs[x]; const UpdRec& b = out.recs[y];
+        const int64_t wx = (x - lr.begin) / SORT_WINDOW, wy = (y - lr.begin) / SORT_WINDOW;
+        if (wx != wy) return wx < wy;
         return a.n_recv != b.n_recv ? a.n_recv > b.n_recv : a.n_send > b.n_send;
       });
       std::vector<UpdRec> tr(perm.size()); std::vector<int32_t> tu(perm.size());

@@ -15,4 +15,4 @@ for cfg in cfgs:
         if not line:
             print(cfg, "FAILED", r.stderr[-300:]); continue
         d = json.loads(line[-1])
-        print(f"{cfg:45s} {'launch per step' if off else 'default        '} {d['ms_per_step']:.4f} ms  {d['roofline']['kernel'][:44]}  {notes[-1:] if notes else ''}", flush=True)
+        print(f"{cfg:45s} {'launch per step' if off else 'default        '} {d['ms_per_step']:.4f} ms  {d['roofline']['kernel'][:44]}  {notes[-3:] if notes else ''}", flush=True)
