@@ -772,6 +772,9 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
   // (the run-time-dims classes read their tables with 8-byte loads of rows that are not line-aligned: as a chain in
   // Infinity-Cache order 1024 x 1024 x 21 labels takes 5.48 ms per pass against 4.38 launch by launch)
   if (e->rot_bands <= 0 && kc_is_var(ri.kclass)) return no("run-time-dims class");
+  // (Potts steps stream message vectors only, at 7.6 TB/s with the non-temporal policy; as a chain their agent-scope
+  // vector loads make 2048 x 2048 x 32 labels 6.4 ms per pass against 3.2)
+  if (e->rot_bands <= 0 && !kc_is_dense(ri.kclass)) return no("no pairwise tables to re-read (Potts)");
   // bands: about 16 MiB of algorithmic bytes per band of a step.  What a group keeps alive between two reads of a table is
   // lag * depth bands (3 * 4 * 16 MiB = 192 MiB of the 256 MiB Infinity Cache); measured on C3: windows of 200-230 MB are
   // the fastest whatever the split (1024:3:4 5.09, 2048:4:6 5.03, 1536:3:6 5.09 ms per pass), 290 MB and more lose the

@@ -612,9 +612,17 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     if (lr.kclass != KC_GENERIC && lr.kclass != KC_DENSE_32 && lr.kclass != KC_DENSE_V32 && lr.kclass != KC_DENSE_BIG && lr.kclass != KC_PW_32) {   // incl. KC_SMALL
       std::vector<int64_t> perm(lr.end - lr.begin);
       std::iota(perm.begin(), perm.end(), lr.begin);
+      // (a launch with many different amounts of work per record — a random graph, degrees 2 ... 25 — has no locality
+      // worth keeping and balances better sorted as a whole: C4 12.1 against 13.6 ms per pass)
+      std::vector<int32_t> shapes;
+      for (int64_t i = lr.begin; i < lr.end && shapes.size() <= 6; ++i) {
+        const int32_t sh = out.recs[i].n_recv * 65536 + out.recs[i].n_send;
+        if (std::find(shapes.begin(), shapes.end(), sh) == shapes.end()) shapes.push_back(sh);
+      }
+      const int64_t window = shapes.size() <= 6 ? SORT_WINDOW : std::numeric_limits<int64_t>::max();
       std::stable_sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) {
         const UpdRec& a = out.recs[x]; const UpdRec& b = out.recs[y];
-        const int64_t wx = (x - lr.begin) / SORT_WINDOW, wy = (y - lr.begin) / SORT_WINDOW;
+        const int64_t wx = (x - lr.begin) / window, wy = (y - lr.begin) / window;
         if (wx != wy) return wx < wy;
         return a.n_recv != b.n_recv ? a.n_recv > b.n_recv : a.n_send > b.n_send;
       });
