@@ -1,6 +1,7 @@
 """Latency budget of the chain executor from its per-ticket time stamps (engine.cpp, LPMP_CHAIN_TRACE).
 
     python tools/chain_trace.py run [grid] [labels] [order]   on the GPU box: one traced pass of a grid, then the analysis
+                                                               (order c5: C5 with local triples instead of a grid)
     python tools/chain_trace.py show FILE                      analysis of a dump
 
 Per ticket: t0 ticket in hand, t1 predecessors seen (wait over), t2 body done (stores issued), t3 published.
@@ -103,7 +104,18 @@ e.set_reparametrization(M.REPAM_ANISOTROPIC)
 e.compute_pass(1); e.compute_pass(1); e.forward_pass()
 e.synchronize()
 """
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LPMP_CHAIN_TRACE=path), capture_output=True, text=True)
+        env = dict(os.environ, LPMP_CHAIN_TRACE=path)
+        if order == "c5":      # C5 with local triples: the ticket form of the generic chain kernel (LPMP_CHAIN_ALL=1), backward sweep
+            env["LPMP_CHAIN_ALL"] = "1"
+            code = f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+from lp_mp_amd import engine as E, model as M, synthetic as S
+m = S.c5_model(512, 512, 8, 150000, 70000, 30000, seed=4, window=64)
+e = E.Engine(0); e.upload(m); e.set_reparametrization(0)
+e.compute_pass(1); e.backward_pass(); e.synchronize()
+"""
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         if r.returncode != 0:
             print(r.stderr[-2000:]); sys.exit(1)
         show(path)
