@@ -333,67 +333,6 @@ __device__ __forceinline__ void generic_body(const UpdRec* __restrict__ recs, co
   C::sync();
 
   const int n_ops = rec.n_recv + rec.n_send;
-  if constexpr (G == 1) {
-    // Labeling-list records in chunks (plan.cpp, UPD_LABEL_PK: every op a labeling message with this factor on the left,
-    // all peers distinct — multicut edge variables): the op records of a chunk of 4, then the match tables and the
-    // costs of all 4 peers are requested together, the ops are worked off in order from registers, the peers stored at
-    // the end of the chunk.  Op by op (below) an update is a chain of 2 memory round trips per op — 16 us for a dozen
-    // edge variables of C5 (tools/chain_trace.py ... c5); same arithmetic, same order.
-    if ((rec.kind_flags & UPD_LABEL_PK) && !(flags & (SWEEP_RESIDUAL | SWEEP_ADAPTIVE | SWEEP_PRIMAL))) {
-      constexpr int CH = 4;
-      bool snapped = false;
-      for (int c0 = 0; c0 < n_ops; c0 += CH) {
-        Op o[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) if (c0 + j < n_ops) o[j] = ops[rec.op_begin + c0 + j]; else { o[j].pd0 = 0; o[j].pd1 = 0; o[j].len = 0; o[j].peer_dual = 0; o[j].peer_const = 0; o[j].info = 0; o[j].omega = 0.0; o[j].peer = 0; }
-        double R[CH][SMALL_MAXD]; int tv[CH][SMALL_MAXD];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          const double* peer = dual + o[j].peer_dual;
-          const int32_t* tab = tabs + o[j].peer_const;
-#pragma unroll
-          for (int r = 0; r < SMALL_MAXD; ++r) { const bool in = r < o[j].pd0; tv[j][r] = in ? tab[r] : o[j].pd1; R[j][r] = in ? ld_dual<A>(peer + r) : LPMP_INF; }
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          if (c0 + j < n_ops) {
-            const bool recv = c0 + j < rec.n_recv;
-            if (!recv && !snapped) { for (int i = 0; i < on; ++i) c.snap(i) = c.own(i); snapped = true; }
-            const int nl = o[j].pd1, len = o[j].len;
-            st_lb<A>(lb + o[j].peer, LPMP_NAN);
-            if (recv) {
-              double nt = ((o[j].info >> 6) & 1) ? 0.0 : LPMP_INF;
-#pragma unroll
-              for (int r = 0; r < SMALL_MAXD; ++r) if (tv[j][r] >= nl) nt = fmin(nt, R[j][r]);
-              for (int l = 0; l < nl; ++l) {
-                double v = LPMP_INF;
-#pragma unroll
-                for (int r = 0; r < SMALL_MAXD; ++r) if (tv[j][r] == l) v = fmin(v, R[j][r]);
-                c.dl(l) = o[j].omega * (v - nt);
-              }
-              for (int i = 0; i < len; ++i) c.own(i) += +1.0 * c.dl(i);
-#pragma unroll
-              for (int r = 0; r < SMALL_MAXD; ++r) if (tv[j][r] < nl) R[j][r] = R[j][r] + -1.0 * c.dl(tv[j][r]);
-            } else {
-              for (int i = 0; i < len; ++i) c.dl(i) = o[j].omega * c.snap(i);
-              for (int i = 0; i < len; ++i) c.own(i) += -1.0 * c.dl(i);
-#pragma unroll
-              for (int r = 0; r < SMALL_MAXD; ++r) if (tv[j][r] < nl) R[j][r] = R[j][r] + +1.0 * c.dl(tv[j][r]);
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          double* peer = dual + o[j].peer_dual;
-#pragma unroll
-          for (int r = 0; r < SMALL_MAXD; ++r) if (r < o[j].pd0 && tv[j][r] < o[j].pd1) st_dual<A>(peer + r, R[j][r]);
-        }
-      }
-      st_lb<A>(lb + rec.factor, LPMP_NAN);
-      for (int i = 0; i < on; ++i) st_dual<A>(own_g + i, c.own(i));
-      return;
-    }
-  }
   // delta of one message into c.dl: computed from the peer (receive) or from the snapshot / live own state (send)
   auto compute_delta = [&](const Op& op, const bool recv, const bool live_src, const double omega) {
     const int code = op.info & 15, role = (op.info >> 4) & 1, side = (op.info >> 5) & 1, imp = (op.info >> 6) & 1;

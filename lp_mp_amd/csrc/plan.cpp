@@ -648,23 +648,6 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       }
       continue;
     }
-    if (lr.kclass == KC_SMALL) {
-      // records whose ops are all labeling messages with the updated (vector) factor on the left and pairwise distinct
-      // peers (multicut edge variables under anisotropic weights): the kernel may request all peers of a chunk of ops at
-      // once instead of going op by op (kernels.hip, generic_body<1>)
-      for (int64_t i = lr.begin; i < lr.end; ++i) {
-        UpdRec& r = out.recs[i];
-        const Op* o = out.ops.data() + r.op_begin;
-        const int n = r.n_recv + r.n_send;
-        bool ok = n > 0 && (r.kind_flags & 15) == LPMP_F_VECTOR;
-        for (int a = 0; a < n && ok; ++a) {
-          if ((o[a].info & 15) != OP_LABELING || ((o[a].info >> 4) & 1) != 0 || o[a].pd0 > SMALL_MAXD || o[a].len > SMALL_MAXD) ok = false;
-          for (int b = a + 1; b < n && ok; ++b) if (o[a].peer_dual == o[b].peer_dual) ok = false;
-        }
-        if (ok) r.kind_flags |= UPD_LABEL_PK;
-      }
-      continue;
-    }
     if (lr.kclass == KC_GENERIC || lr.kclass >= KC_DENSE_BIG) continue;   // packed dense and Potts classes
     auto same_vec = [](const Op* o, int a, int b) { return o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1); };
     if (kc_is_var(lr.kclass)) {

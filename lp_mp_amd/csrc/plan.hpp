@@ -104,7 +104,6 @@ constexpr int PK_MAX_OPS = 8;                 // packets hold at most this many 
 constexpr int pk_indirect_cap(int labels) { return labels >= 16 ? 32 : labels >= 8 ? 16 : 8; }
 constexpr int32_t UPD_PRELOAD_OK = 1 << 16;   // UpdRec::kind_flags: no send targets a vector a receive writes
 constexpr int32_t UPD_PRIMAL = 1 << 17;       // UpdRec::kind_flags: the factor type has COMPUTE_PRIMAL_SOLUTION
-constexpr int32_t UPD_LABEL_PK = 1 << 18;     // lane-per-factor class: every op a labeling message with the factor on the left, all peers distinct
 
 // kernel flags of the sweep kernels
 constexpr int SWEEP_RESIDUAL = 1;   // --reparametrizationType residual
