@@ -162,6 +162,17 @@ int main(int argc, char** argv) {
       test(om.forward.size() == u.size());
     }
   }
+  {   // ---- test/factor_message_containers.cpp:8-88: message counts of the unaries of a 5-variable MRF ----
+    LP<FMC_SRMP> lp;
+    std::vector<typename FMC_SRMP::UnaryFactor*> u;
+    for (int i = 0; i < 5; ++i) u.push_back(lp.template add_factor<typename FMC_SRMP::UnaryFactor>(std::vector<REAL>(2, 0.0)));
+    const double zero[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    const int edges[8][2] = {{0, 1}, {1, 2}, {2, 3}, {0, 3}, {0, 4}, {1, 4}, {2, 4}, {3, 4}};
+    for (auto& e : edges) add_pairwise(lp, u[e[0]], u[e[1]], zero);
+    test(u[0]->no_messages() == 3 && u[0]->no_send_messages() == 3);      // (GetNoMessages / no_send_messages there)
+    test(u[4]->no_messages() == 4 && u[4]->no_send_messages() == 4);
+    test(lp.GetNumberOfFactors() == 13 && lp.GetNumberOfMessages() == 16);
+  }
   {   // ---- ConstantFactor: an offset that takes part in the bound and is never touched by the sweep ----
     using FMC = FMC_SRMP_CONST;
     ConstantFactor cf(2.5);

@@ -115,6 +115,31 @@ static double u01(uint64_t& st) { st = st * 6364136223846793005ULL + 14426950408
 int main(int argc, char** argv) {
   const bool host_only = argc > 1 && !std::strcmp(argv[1], "--host-only");
   LP_MP::mock_cmd_line cmd;
+  {   // reference test/serialization.cpp:16-124 against the offload's archives (allocate / save / load, in doubles): the
+      // same member kinds, the same sizes (a 5 x 3 matrix is 15 entries: padding stripped), the same round trips
+    using user::REAL; using user::INDEX;
+    struct bin { REAL* pointer; INDEX no_elements; };             // serialization.hxx binary_data<T>
+    REAL i_r = 10; std::array<REAL, 2> a_r{20, 30}; std::vector<REAL> v_r{30, 40, 50}; REAL p_r[4] = {60, 70, 80, 90};
+    user::my_vector r_r{1.5, 2.5, 3.5};
+    user::my_matrix m_r(5, 3);
+    for (INDEX a = 0; a < 5; ++a) { m_r(a, 0) = 1.0 + a; m_r(a, 1) = 11.0 + a; m_r(a, 2) = 111.0 + a; }
+    auto size_of = [](auto&& e) { lpmp_offload::dual_counter c; c(e); return c.count; };
+    test(size_of(i_r) == 1 && size_of(a_r) == 2 && size_of(v_r) == 3 && size_of(bin{p_r, 4}) == 4 && size_of(r_r) == 3 && size_of(m_r) == 15, "archive sizes");
+    lpmp_offload::dual_counter all; all(i_r, a_r, v_r, bin{p_r, 4}, r_r, m_r);
+    test(all.count == 28, "collective size");
+    for (int collective = 0; collective < 2; ++collective) {
+      std::vector<double> ar(all.count, -1.0);
+      lpmp_offload::dual_saver sv(ar.data());
+      if (collective) sv(i_r, a_r, v_r, bin{p_r, 4}, r_r, m_r);
+      else { sv(i_r); sv(a_r); sv(v_r); sv(bin{p_r, 4}); sv(r_r); sv(m_r); }
+      test(sv.out == ar.data() + ar.size() && ar[0] == 10 && ar[3] == 30 && ar[6] == 60 && ar[13] == 1.0 && ar[14] == 11.0 && ar[15] == 111.0 && ar[27] == 115.0, "saved layout");
+      REAL i_t = 0; std::array<REAL, 2> a_t{0, 0}; std::vector<REAL> v_t(3); REAL p_t[4] = {0, 0, 0, 0}; user::my_vector r_t(3); user::my_matrix m_t(5, 3);
+      lpmp_offload::dual_loader ld(ar.data());
+      if (collective) ld(i_t, a_t, v_t, bin{p_t, 4}, r_t, m_t);
+      else { ld(i_t); ld(a_t); ld(v_t); ld(bin{p_t, 4}); ld(r_t); ld(m_t); }
+      test(i_t == i_r && a_t == a_r && v_t == v_r && p_t[0] == 60 && p_t[3] == 90 && r_t == r_r && m_t.v_ == m_r.v_, "round trip");
+    }
+  }
   {   // reference test/test_model.cpp:18-48 on the offloaded LP
     using LP_device = lpmp_offload::offloaded<LP_MP::LP<test_FMC>>;
     LP_device lp(cmd);
