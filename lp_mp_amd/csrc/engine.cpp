@@ -337,7 +337,8 @@ struct lpmp_engine {
   bool use_chain = true;          // deep single-class schedules as one persistent launch (LPMP_NO_CHAIN=1: graph replay)
   int32_t* d_chain_abort = nullptr; bool chain_ran = false;
   // joined passes as one persistent launch: expansions of RotationInfo, by mode and pass count
-  struct RotChain { DevSchedule::DevChain dc; int n_steps = 0; int64_t factors = 0, recv = 0, bytes = 0; };
+  struct RotChain { DevSchedule::DevChain dc; int n_steps = 0; int64_t factors = 0, recv = 0, bytes = 0; uint64_t last_use = 0; };
+  uint64_t rot_clock = 0;             // the ticket lists of a pass count are device memory (C3, 32 passes: ~350 MB): at most 4 per mode stay
   std::map<int, RotChain> rot_chain[LPMP_REPAM_COUNT];
   bool use_blocked_passes = true;     // LPMP_NO_BLOCKED_PASSES=1: the joined passes as one launch per step
   int rot_bands = 0, rot_lag = 3, rot_depth = 4;   // skewed ticket order (0 bands: from the table bytes per step); DESIGN.md 6 has the sweep
@@ -749,8 +750,22 @@ void check_rows(int64_t n, const int64_t* om_off, const double* om, const int64_
 // does not qualify (then the steps run as one launch each).
 lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
   auto it = e->rot_chain[mode].find(n);
-  if (it != e->rot_chain[mode].end()) return it->second.n_steps > 0 ? &it->second : nullptr;
+  if (it != e->rot_chain[mode].end()) { it->second.last_use = ++e->rot_clock; return it->second.n_steps > 0 ? &it->second : nullptr; }
+  {   // bound the cache: drop the least recently used built chain of this mode (the stream is drained first)
+    auto& m = e->rot_chain[mode];
+    size_t built = 0;
+    for (const auto& kv : m) if (kv.second.n_steps > 0) ++built;
+    if (built >= 4) {
+      auto victim = m.end();
+      for (auto i2 = m.begin(); i2 != m.end(); ++i2) if (i2->second.n_steps > 0 && (victim == m.end() || i2->second.last_use < victim->second.last_use)) victim = i2;
+      HIP_CHECK(hipStreamSynchronize(e->stream));
+      auto& c = victim->second.dc;
+      for (void* p : {(void*)c.launches, (void*)c.tk_launch, (void*)c.tk_block, (void*)c.dep_off, (void*)c.dep, (void*)c.done, (void*)c.next}) if (p) (void)hipFree(p);
+      m.erase(victim);
+    }
+  }
   lpmp_engine::RotChain& rc = e->rot_chain[mode][n];           // n_steps == 0: tried, not possible
+  rc.last_use = ++e->rot_clock;
   const RotationInfo& ri = e->plan->rot[mode];
   const bool verbose = std::getenv("LPMP_ROT_VERBOSE") != nullptr;
   auto no = [&](const char* why) -> lpmp_engine::RotChain* { if (verbose) std::fprintf(stderr, "lpmp: %d passes stay one launch per step: %s\n", n, why); return nullptr; };
