@@ -26,6 +26,7 @@ bool launch_chain(int kclass, int flags, const void* chain_args, const void* lau
                   const int32_t* tabs, double* lb, int32_t* primal, hipStream_t s);
 bool launch_level_loop(int kclass, int flags, const void* launches, int n_launches, double* dual, const double* cdata,
                        const int32_t* tabs, double* lb, hipStream_t s);
+void debug_set_level_trace(long long* p);
 void launch_primal_init(const PrimalInit* list, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_propagate(const PrimalLink* links, int64_t n, int32_t* primal, hipStream_t s);
 void launch_primal_check(const PrimalLink* links, int64_t n, const int32_t* primal, int* bad, hipStream_t s);
@@ -696,8 +697,20 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
     }
     for (auto& c : s.chains) {
       if (c.level_loop) {
+        // LPMP_LEVEL_TRACE=<file> (debugging): time stamps of the first 4000 levels, written after a synchronisation
+        static const char* lt_path = std::getenv("LPMP_LEVEL_TRACE");
+        long long* d_lt = nullptr;
+        const size_t lt_n = 8 + 8 * 4000;
+        if (lt_path) { HIP_CHECK(hipMalloc((void**)&d_lt, lt_n * sizeof(long long))); HIP_CHECK(hipMemset(d_lt, 0, lt_n * sizeof(long long))); debug_set_level_trace(d_lt); }
         if (!launch_level_loop(c.kclass, rule, c.launches, c.n_launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->stream))
           throw DeviceError("level loop: no kernel for class " + std::to_string(c.kclass));
+        if (lt_path) {
+          HIP_CHECK(hipStreamSynchronize(e->stream));
+          std::vector<long long> h(lt_n);
+          HIP_CHECK(hipMemcpy(h.data(), d_lt, lt_n * sizeof(long long), hipMemcpyDeviceToHost));
+          debug_set_level_trace(nullptr); (void)hipFree(d_lt);
+          if (FILE* f = std::fopen(lt_path, "wb")) { std::fwrite(h.data(), sizeof(long long), h.size(), f); std::fclose(f); }
+        }
         continue;
       }
       HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));

@@ -93,6 +93,13 @@ struct ChainArgs {
   int32_t epoch;
   long long* trace;          // debugging (LPMP_CHAIN_TRACE): 8 slots of time stamps per ticket, 100 MHz; nullptr otherwise
 };
+// debugging (LPMP_LEVEL_TRACE, engine.cpp): time stamps of the first levels of a level-loop launch, 8 slots per level
+__device__ long long* g_level_trace = nullptr;
+constexpr int LEVEL_TRACE_MAX = 4000;
+__device__ __forceinline__ void level_stamp(int slot) {
+  long long* p = g_level_trace;
+  if (p && threadIdx.x == 0) { const long long l = p[0]; if (l < LEVEL_TRACE_MAX) p[8 + 8 * l + slot] = (long long)__builtin_amdgcn_s_memrealtime(); }
+}
 __device__ __forceinline__ void chain_stamp(const ChainArgs& ca, int ticket, int k) {
   if (ca.trace && threadIdx.x == 0) ca.trace[8 * (int64_t)ticket + k] = (long long)__builtin_amdgcn_s_memrealtime();
 }
@@ -331,6 +338,7 @@ __device__ __forceinline__ void generic_body(const UpdRec* __restrict__ recs, co
   double* own_g = dual + rec.dual_off;
   for (int i = c.first(); i < on; i += C::STRIDE) c.own(i) = ld_dual<A>(own_g + i);
   C::sync();
+  if constexpr (G == 1 && A == ACC_WG) { asm volatile("" :: "v"(c.own(0))); level_stamp(1); }
 
   const int n_ops = rec.n_recv + rec.n_send;
   // delta of one message into c.dl: computed from the peer (receive) or from the snapshot / live own state (send)
@@ -519,6 +527,7 @@ __device__ __forceinline__ void generic_body(const UpdRec* __restrict__ recs, co
   if (n_ops > 0) nxt = ops[rec.op_begin];
   for (int k = 0; k < n_ops; ++k) {
     if (k == rec.n_recv) {   // state after the receives: what every shared send is computed from
+      if constexpr (G == 1 && A == ACC_WG) level_stamp(2);
       round_label();
       for (int i = c.first(); i < on; i += C::STRIDE) c.snap(i) = c.own(i);
       C::sync();
@@ -559,6 +568,7 @@ __device__ __forceinline__ void generic_body(const UpdRec* __restrict__ recs, co
       run_op(op, false, true, residual);
     }
   }
+  if constexpr (G == 1 && A == ACC_WG) level_stamp(3);
   if (c.leader()) st_lb<A>(lb + rec.factor, LPMP_NAN);
   for (int i = c.first(); i < on; i += C::STRIDE) st_dual<A>(own_g + i, c.own(i));
 }
@@ -1140,11 +1150,15 @@ level_loop_kernel(const ChainLaunch* __restrict__ launches, int n_launches, doub
       return;
     }
     for (int l = 0; l < n_launches; ++l) {
+      if (g_level_trace && threadIdx.x == 0) g_level_trace[0] = l;
+      level_stamp(0);
       const ChainLaunch ln = launches[l];
       const int64_t nblk = (ln.count + C::FPB - 1) / C::FPB;
       for (int64_t b = 0; b < nblk; ++b)
         [&] { generic_body<1, ACC_WG>(ln.recs, ln.ops, dual, cdata, tabs, lb, nullptr, nullptr, 0, ln.count, flags, b); }();
+      level_stamp(4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this level's stores are in the L2 before the next level loads
+      level_stamp(5);
       if (threadIdx.x == 0) *level = l + 1;
     }
   } else {
@@ -2026,6 +2040,7 @@ static unsigned chain_grid(K kernel, int n_tickets, int threads = 256) {
   const long cap = (long)n_cu * per_cu;
   return (unsigned)(n_tickets < cap ? n_tickets : cap);
 }
+void debug_set_level_trace(long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_level_trace), &p, sizeof(p)); }
 bool launch_level_loop(int kclass, int flags, const void* launches, int n_launches, double* dual, const double* cdata,
                        const int32_t* tabs, double* lb, hipStream_t s) {
   const ChainLaunch* ln = static_cast<const ChainLaunch*>(launches);
