@@ -553,7 +553,7 @@ void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream, bool
     for (const ChainPlan& c : s.chains) {
       DevSchedule::DevChain dc;
       std::vector<ChainLaunchDev> lds;
-      for (const auto& l : c.launches) lds.push_back({l.stride > 0 ? d.packets + l.pk_begin : nullptr, d.recs + l.rec_begin, d.ops, l.count, l.stride, 0});
+      for (const auto& l : c.launches) lds.push_back({l.stride > 0 ? d.packets + l.pk_begin : nullptr, d.recs + l.rec_begin, d.ops, l.count, l.stride, l.flags});
       up(dc.launches, lds); up(dc.tk_launch, c.tk_launch); up(dc.tk_block, c.tk_block); up(dc.dep_off, c.dep_off); up(dc.dep, c.dep);
       dc.tickets = (int32_t)c.tk_launch.size();
       HIP_CHECK(hipMalloc((void**)&dc.done, std::max<size_t>(1, (size_t)dc.tickets) * sizeof(int32_t)));

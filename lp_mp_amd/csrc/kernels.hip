@@ -1109,57 +1109,118 @@ chain_generic_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, dou
 }
 
 // Level loop: a deep schedule of TINY levels of a generic class as one launch of ONE workgroup that walks the launches in
-// order (plan.cpp decides; C5 with local triples: 11 887 levels of a dozen one-lane updates).  No launch per level, no
-// flags through memory; what a level hands to the next stays in this compute unit's L2.
-//   G = 64 (wave per factor): the plain body, a workgroup barrier between levels.
-//   G = 1 (lane per factor): ONE wave computes — in-order issue, stores drained between levels, dual loads that bypass
-//   the L1 (ACC_WG) — and a second wave runs a few levels AHEAD touching every line the computing wave will need
-//   (records, op lists, match tables, own and peer duals): a level is a chain of ~6 dependent loads, cold ones cost
-//   1-2 us each, touched ones a fraction.
+// order with a workgroup barrier in between (plan.cpp decides; C5 with local triples: 11 887 levels of a dozen one-lane
+// updates).  No launch per level, no flags through memory; what a level hands to the next stays in this compute unit's L2
+// (stores drained before the barrier, dual loads that bypass the L1: ACC_WG).
+//   G = 64 (wave per factor): the plain body.
+//   G = 1 (lane per factor): LL_WAVES computing waves + one wave that touches, LEVEL_LOOP_AHEAD levels ahead, every
+//   line the computing waves will need (records, op lists, match tables, own and peer duals).  Launches of
+//   labeling-list records run with one lane per op (label_ops_body), the others on the generic body (one wave).
 constexpr int LEVEL_LOOP_AHEAD = 8;
+constexpr int LL_WAVES = 2;                        // computing waves of level_loop_kernel<1> (+ one that runs ahead)
+constexpr int CHAIN_LAUNCH_LABEL_OPS_DEV = 1;      // ChainLaunch::pad (plan.hpp CHAIN_LAUNCH_LABEL_OPS)
+
+// Labeling-list records with one LANE PER OP (plan.cpp marks the launches: vector factors whose ops are all labeling
+// messages with the factor on the left, pairwise distinct peers, at most 8 ops, message length = the factor's size).
+// One record per lane runs as many op rounds as its longest receive and send lists (generic_body<1>; measured
+// 9.8 + 4.3 us per level on C5 with local triples); but the receives of one record do not depend on each other —
+// each delta comes from its peer alone — and neither do its sends, which all start from the snapshot.  So 8 lanes
+// take one record: lane j computes op j, the deltas meet in LDS and are added to the factor's vector in op order
+// (same additions, same order as the sequential form: bit-identical), two rounds instead of n_recv + n_send.
+template <int A>
+__device__ __forceinline__ void label_ops_body(const ChainLaunch& ln, int64_t first, double* __restrict__ dual, const int32_t* __restrict__ tabs,
+                                               double* __restrict__ lb, double (*D)[8][8], double (*S)[8]) {
+  const int lane = threadIdx.x & 63, q = lane >> 3, j = lane & 7;
+  const int64_t idx = first + q;
+  const bool live = idx < ln.count;
+  UpdRec rec;
+  if (live) rec = ln.recs[idx]; else { rec.n_recv = 0; rec.n_send = 0; rec.d0 = 0; rec.dual_off = 0; rec.op_begin = 0; rec.factor = 0; }
+  const int n_recv = rec.n_recv, n_ops = rec.n_recv + rec.n_send, on = rec.d0;
+  const bool has_op = live && j < n_ops, recv = has_op && j < n_recv;
+  Op o;
+  if (has_op) o = ln.ops[rec.op_begin + j]; else { o.peer_dual = 0; o.peer_const = 0; o.omega = 0.0; o.info = 0; o.pd0 = 0; o.pd1 = 0; o.peer = 0; o.len = 0; }
+  double* own_g = dual + rec.dual_off;
+  double theta = (live && j < on) ? ld_dual<A>(own_g + j) : 0.0;      // lane j of the group holds element j
+  double* peer = dual + o.peer_dual;
+  const int32_t* tab = tabs + o.peer_const;
+  const int nr = o.pd0, nl = o.pd1, len = o.len;
+  int tv[SMALL_MAXD]; double R[SMALL_MAXD];
+#pragma unroll
+  for (int r = 0; r < SMALL_MAXD; ++r) { const bool in = has_op && r < nr; tv[r] = in ? tab[r] : nl; R[r] = in ? ld_dual<A>(peer + r) : LPMP_INF; }
+  if (has_op) st_lb<A>(lb + o.peer, LPMP_NAN);
+  if (recv) {
+    double nt = ((o.info >> 6) & 1) ? 0.0 : LPMP_INF;
+#pragma unroll
+    for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] >= nl) nt = fmin(nt, R[r]);
+    for (int l = 0; l < nl; ++l) {
+      double v = LPMP_INF;
+#pragma unroll
+      for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] == l) v = fmin(v, R[r]);
+      D[q][j][l] = o.omega * (v - nt);
+    }
+#pragma unroll
+    for (int r = 0; r < SMALL_MAXD; ++r) if (r < nr && tv[r] < nl) st_dual<A>(peer + r, R[r] + -1.0 * D[q][j][tv[r]]);
+  }
+  wave_sync();
+  for (int k = 0; k < n_recv; ++k) if (j < on) theta += +1.0 * D[q][k][j];   // own(i) += +1.0 * dl(i), receive by receive
+  if (live && j < on) S[q][j] = theta;                                        // the state every send starts from
+  wave_sync();
+  if (has_op && !recv) {
+    for (int l = 0; l < len; ++l) D[q][j][l] = o.omega * S[q][l];
+#pragma unroll
+    for (int r = 0; r < SMALL_MAXD; ++r) if (r < nr && tv[r] < nl) st_dual<A>(peer + r, R[r] + +1.0 * D[q][j][tv[r]]);
+  }
+  wave_sync();
+  for (int k = n_recv; k < n_ops; ++k) if (j < on) theta += -1.0 * D[q][k][j];  // own(i) += -1.0 * dl(i), send by send
+  if (live && j == 0) st_lb<A>(lb + rec.factor, LPMP_NAN);
+  if (live && j < on) st_dual<A>(own_g + j, theta);
+}
+
 template <int G>
-__global__ void __launch_bounds__(GenCtx<G>::THREADS + (G == 1 ? 64 : 0))
+__global__ void __launch_bounds__(G == 1 ? 64 * (LL_WAVES + 1) : GenCtx<G>::THREADS)
 level_loop_kernel(const ChainLaunch* __restrict__ launches, int n_launches, double* __restrict__ dual, const double* __restrict__ cdata,
                   const int32_t* __restrict__ tabs, double* __restrict__ lb, int flags) {
   using C = GenCtx<G>;
   if constexpr (G == 1) {
-    __shared__ int s_level;
-    if (threadIdx.x == 0) s_level = 0;
-    __syncthreads();
-    volatile int* level = &s_level;
-    if (threadIdx.x >= C::THREADS) {               // the wave that runs ahead
-      const int lane = threadIdx.x & 63;
-      for (int l = 0; l < n_launches; ++l) {
-        while (l - *level > LEVEL_LOOP_AHEAD) __builtin_amdgcn_s_sleep(4);
-        const ChainLaunch ln = launches[l];
-        for (int64_t i = lane; i < ln.count; i += 64) {
-          const UpdRec r = ln.recs[i];
-          const double* own = dual + r.dual_off;
-          double acc = __hip_atomic_load(own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const int n_ops = r.n_recv + r.n_send;
-          for (int k = 0; k < n_ops; ++k) {
-            const Op o = ln.ops[r.op_begin + k];
-            const double* pd = dual + o.peer_dual;
-            acc += __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            acc += __hip_atomic_load(pd + max(o.pd0 + o.pd1 - 1, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a peer of this class spans at most two lines
-            if ((o.info & 15) == OP_LABELING) acc += (double)tabs[o.peer_const];
-          }
-          asm volatile("" :: "v"(acc));
-        }
-      }
-      return;
-    }
+    __shared__ double D[LL_WAVES][8][8][8];
+    __shared__ double S[LL_WAVES][8][8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool plain_rule = !(flags & (SWEEP_RESIDUAL | SWEEP_ADAPTIVE | SWEEP_PRIMAL));
     for (int l = 0; l < n_launches; ++l) {
       if (g_level_trace && threadIdx.x == 0) g_level_trace[0] = l;
       level_stamp(0);
-      const ChainLaunch ln = launches[l];
-      const int64_t nblk = (ln.count + C::FPB - 1) / C::FPB;
-      for (int64_t b = 0; b < nblk; ++b)
-        [&] { generic_body<1, ACC_WG>(ln.recs, ln.ops, dual, cdata, tabs, lb, nullptr, nullptr, 0, ln.count, flags, b); }();
+      if (wave == LL_WAVES) {                        // the wave that runs ahead: level l + AHEAD, between the same barriers
+        const int la = l + LEVEL_LOOP_AHEAD;
+        if (la < n_launches) {
+          const ChainLaunch ln = launches[la];
+          for (int64_t i = lane; i < ln.count; i += 64) {
+            const UpdRec r = ln.recs[i];
+            double acc = __hip_atomic_load(dual + r.dual_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int n_ops = r.n_recv + r.n_send;
+            for (int k = 0; k < n_ops; ++k) {
+              const Op o = ln.ops[r.op_begin + k];
+              const double* pd = dual + o.peer_dual;
+              acc += __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              acc += __hip_atomic_load(pd + max(o.pd0 + o.pd1 - 1, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a peer of this class spans at most two lines
+              if ((o.info & 15) == OP_LABELING) acc += (double)tabs[o.peer_const];
+            }
+            asm volatile("" :: "v"(acc));
+          }
+        }
+      } else {
+        const ChainLaunch ln = launches[l];
+        if ((ln.pad & CHAIN_LAUNCH_LABEL_OPS_DEV) && plain_rule) {
+          for (int64_t first = 8 * wave; first < ln.count; first += 8 * LL_WAVES) label_ops_body<ACC_WG>(ln, first, dual, tabs, lb, D[wave], S[wave]);
+        } else if (wave == 0) {
+          const int64_t nblk = (ln.count + C::FPB - 1) / C::FPB;
+          for (int64_t b = 0; b < nblk; ++b)
+            [&] { generic_body<1, ACC_WG>(ln.recs, ln.ops, dual, cdata, tabs, lb, nullptr, nullptr, 0, ln.count, flags, b); }();
+        }
+      }
       level_stamp(4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this level's stores are in the L2 before the next level loads
+      __syncthreads();
       level_stamp(5);
-      if (threadIdx.x == 0) *level = l + 1;
     }
   } else {
     for (int l = 0; l < n_launches; ++l) {
@@ -2044,7 +2105,7 @@ void debug_set_level_trace(long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 bool launch_level_loop(int kclass, int flags, const void* launches, int n_launches, double* dual, const double* cdata,
                        const int32_t* tabs, double* lb, hipStream_t s) {
   const ChainLaunch* ln = static_cast<const ChainLaunch*>(launches);
-  if (kclass == KC_SMALL) hipLaunchKernelGGL(level_loop_kernel<1>, dim3(1), dim3(GenCtx<1>::THREADS + 64), 0, s, ln, n_launches, dual, cdata, tabs, lb, flags);
+  if (kclass == KC_SMALL) hipLaunchKernelGGL(level_loop_kernel<1>, dim3(1), dim3(64 * (LL_WAVES + 1)), 0, s, ln, n_launches, dual, cdata, tabs, lb, flags);
   else if (kclass == KC_GENERIC) hipLaunchKernelGGL(level_loop_kernel<64>, dim3(1), dim3(GenCtx<64>::THREADS), 0, s, ln, n_launches, dual, cdata, tabs, lb, flags);
   else return false;
   return true;

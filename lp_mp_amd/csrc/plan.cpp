@@ -799,6 +799,21 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
           if (n_launches_of[c] >= chain_min && recs_c <= (int64_t)kc_block_records(c) * n_launches_of[c] && !no_level_loop) {
             ChainPlan& lp = cps[c];
             lp.level_loop = true; lp.valid = true;
+            if (c == KC_SMALL)
+              for (auto& cl : lp.launches) {           // launches the op-parallel labeling body can run (kernels.hip, label_ops_body)
+                bool fine = true;
+                for (int64_t i = cl.rec_begin; i < cl.rec_begin + cl.count && fine; ++i) {
+                  const UpdRec& r = out.recs[i];
+                  const Op* o = out.ops.data() + r.op_begin;
+                  const int n = r.n_recv + r.n_send;
+                  fine = n <= 8 && (r.kind_flags & 15) == LPMP_F_VECTOR && r.d0 <= SMALL_MAXD;
+                  for (int a = 0; a < n && fine; ++a) {
+                    if ((o[a].info & 15) != OP_LABELING || ((o[a].info >> 4) & 1) != 0 || o[a].pd0 > SMALL_MAXD || o[a].len != r.d0 || o[a].pd1 != r.d0) fine = false;   // message length = label count of the table = the factor's size
+                    for (int b = a + 1; b < n && fine; ++b) if (o[a].peer_dual == o[b].peer_dual) fine = false;
+                  }
+                }
+                if (fine) cl.flags |= CHAIN_LAUNCH_LABEL_OPS;
+              }
             lp.tk_launch.clear(); lp.tk_block.clear(); lp.dep_off.assign(1, 0); lp.dep.clear();
             out.chains.push_back(std::move(lp));
           } else {
