@@ -1121,12 +1121,14 @@ constexpr int LL_WAVES = 2;                        // computing waves of level_l
 constexpr int CHAIN_LAUNCH_LABEL_OPS_DEV = 1;      // ChainLaunch::pad (plan.hpp CHAIN_LAUNCH_LABEL_OPS)
 
 // Labeling-list records with one LANE PER OP (plan.cpp marks the launches: vector factors whose ops are all labeling
-// messages with the factor on the left, pairwise distinct peers, at most 8 ops, message length = the factor's size).
+// messages with the factor on the left, at most 8 receives with distinct peers and 8 sends with distinct peers, message
+// length = the factor's size).
 // One record per lane runs as many op rounds as its longest receive and send lists (generic_body<1>; measured
 // 9.8 + 4.3 us per level on C5 with local triples); but the receives of one record do not depend on each other —
 // each delta comes from its peer alone — and neither do its sends, which all start from the snapshot.  So 8 lanes
 // take one record: lane j computes op j, the deltas meet in LDS and are added to the factor's vector in op order
-// (same additions, same order as the sequential form: bit-identical), two rounds instead of n_recv + n_send.
+// (same additions, same order as the sequential form: bit-identical), two rounds — the receives, then the sends —
+// instead of n_recv + n_send.
 template <int A>
 __device__ __forceinline__ void label_ops_body(const ChainLaunch& ln, int64_t first, double* __restrict__ dual, const int32_t* __restrict__ tabs,
                                                double* __restrict__ lb, double (*D)[8][8], double (*S)[8]) {
@@ -1135,43 +1137,58 @@ __device__ __forceinline__ void label_ops_body(const ChainLaunch& ln, int64_t fi
   const bool live = idx < ln.count;
   UpdRec rec;
   if (live) rec = ln.recs[idx]; else { rec.n_recv = 0; rec.n_send = 0; rec.d0 = 0; rec.dual_off = 0; rec.op_begin = 0; rec.factor = 0; }
-  const int n_recv = rec.n_recv, n_ops = rec.n_recv + rec.n_send, on = rec.d0;
-  const bool has_op = live && j < n_ops, recv = has_op && j < n_recv;
-  Op o;
-  if (has_op) o = ln.ops[rec.op_begin + j]; else { o.peer_dual = 0; o.peer_const = 0; o.omega = 0.0; o.info = 0; o.pd0 = 0; o.pd1 = 0; o.peer = 0; o.len = 0; }
+  const int n_recv = rec.n_recv, n_send = rec.n_send, on = rec.d0;
   double* own_g = dual + rec.dual_off;
   double theta = (live && j < on) ? ld_dual<A>(own_g + j) : 0.0;      // lane j of the group holds element j
-  double* peer = dual + o.peer_dual;
-  const int32_t* tab = tabs + o.peer_const;
-  const int nr = o.pd0, nl = o.pd1, len = o.len;
-  int tv[SMALL_MAXD]; double R[SMALL_MAXD];
+  // one op of this lane: its record, match table and the peer's costs; entries beyond the peer's size count as no match
+  auto load_op = [&](bool has, int k, Op& o, int (&tv)[SMALL_MAXD], double (&R)[SMALL_MAXD]) {
+    if (has) o = ln.ops[rec.op_begin + k]; else { o.peer_dual = 0; o.peer_const = 0; o.omega = 0.0; o.info = 0; o.pd0 = 0; o.pd1 = 0; o.peer = 0; o.len = 0; }
+    const double* peer = dual + o.peer_dual;
+    const int32_t* tab = tabs + o.peer_const;
 #pragma unroll
-  for (int r = 0; r < SMALL_MAXD; ++r) { const bool in = has_op && r < nr; tv[r] = in ? tab[r] : nl; R[r] = in ? ld_dual<A>(peer + r) : LPMP_INF; }
-  if (has_op) st_lb<A>(lb + o.peer, LPMP_NAN);
-  if (recv) {
-    double nt = ((o.info >> 6) & 1) ? 0.0 : LPMP_INF;
+    for (int r = 0; r < SMALL_MAXD; ++r) { const bool in = has && r < o.pd0; tv[r] = in ? tab[r] : o.pd1; R[r] = in ? ld_dual<A>(peer + r) : LPMP_INF; }
+  };
+  {   // round 1: the receives, lane j = receive j
+    const bool recv = live && j < n_recv;
+    Op o; int tv[SMALL_MAXD]; double R[SMALL_MAXD];
+    load_op(recv, j, o, tv, R);
+    if (recv) {
+      const int nl = o.pd1;
+      double* peer = dual + o.peer_dual;
+      st_lb<A>(lb + o.peer, LPMP_NAN);
+      double nt = ((o.info >> 6) & 1) ? 0.0 : LPMP_INF;
 #pragma unroll
-    for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] >= nl) nt = fmin(nt, R[r]);
-    for (int l = 0; l < nl; ++l) {
-      double v = LPMP_INF;
+      for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] >= nl) nt = fmin(nt, R[r]);
+      for (int l = 0; l < nl; ++l) {
+        double v = LPMP_INF;
 #pragma unroll
-      for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] == l) v = fmin(v, R[r]);
-      D[q][j][l] = o.omega * (v - nt);
+        for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] == l) v = fmin(v, R[r]);
+        D[q][j][l] = o.omega * (v - nt);
+      }
+#pragma unroll
+      for (int r = 0; r < SMALL_MAXD; ++r) if (r < o.pd0 && tv[r] < nl) st_dual<A>(peer + r, R[r] + -1.0 * D[q][j][tv[r]]);
     }
-#pragma unroll
-    for (int r = 0; r < SMALL_MAXD; ++r) if (r < nr && tv[r] < nl) st_dual<A>(peer + r, R[r] + -1.0 * D[q][j][tv[r]]);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a send of this record may go to the peer a receive has just rewritten
   wave_sync();
   for (int k = 0; k < n_recv; ++k) if (j < on) theta += +1.0 * D[q][k][j];   // own(i) += +1.0 * dl(i), receive by receive
   if (live && j < on) S[q][j] = theta;                                        // the state every send starts from
   wave_sync();
-  if (has_op && !recv) {
-    for (int l = 0; l < len; ++l) D[q][j][l] = o.omega * S[q][l];
+  {   // round 2: the sends, lane j = send j
+    const bool send = live && j < n_send;
+    Op o; int tv[SMALL_MAXD]; double R[SMALL_MAXD];
+    load_op(send, n_recv + j, o, tv, R);
+    if (send) {
+      const int nl = o.pd1;
+      double* peer = dual + o.peer_dual;
+      st_lb<A>(lb + o.peer, LPMP_NAN);
+      for (int l = 0; l < o.len; ++l) D[q][j][l] = o.omega * S[q][l];
 #pragma unroll
-    for (int r = 0; r < SMALL_MAXD; ++r) if (r < nr && tv[r] < nl) st_dual<A>(peer + r, R[r] + +1.0 * D[q][j][tv[r]]);
+      for (int r = 0; r < SMALL_MAXD; ++r) if (r < o.pd0 && tv[r] < nl) st_dual<A>(peer + r, R[r] + +1.0 * D[q][j][tv[r]]);
+    }
   }
   wave_sync();
-  for (int k = n_recv; k < n_ops; ++k) if (j < on) theta += -1.0 * D[q][k][j];  // own(i) += -1.0 * dl(i), send by send
+  for (int k = 0; k < n_send; ++k) if (j < on) theta += -1.0 * D[q][k][j];   // own(i) += -1.0 * dl(i), send by send
   if (live && j == 0) st_lb<A>(lb + rec.factor, LPMP_NAN);
   if (live && j < on) st_dual<A>(own_g + j, theta);
 }

@@ -3,6 +3,7 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -799,6 +800,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
           if (n_launches_of[c] >= chain_min && recs_c <= (int64_t)kc_block_records(c) * n_launches_of[c] && !no_level_loop) {
             ChainPlan& lp = cps[c];
             lp.level_loop = true; lp.valid = true;
+            int dbg_left = 5;
             if (c == KC_SMALL)
               for (auto& cl : lp.launches) {           // launches the op-parallel labeling body can run (kernels.hip, label_ops_body)
                 bool fine = true;
@@ -806,14 +808,24 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
                   const UpdRec& r = out.recs[i];
                   const Op* o = out.ops.data() + r.op_begin;
                   const int n = r.n_recv + r.n_send;
-                  fine = n <= 8 && (r.kind_flags & 15) == LPMP_F_VECTOR && r.d0 <= SMALL_MAXD;
+                  fine = r.n_recv <= 8 && r.n_send <= 8 && (r.kind_flags & 15) == LPMP_F_VECTOR && r.d0 <= SMALL_MAXD;
                   for (int a = 0; a < n && fine; ++a) {
                     if ((o[a].info & 15) != OP_LABELING || ((o[a].info >> 4) & 1) != 0 || o[a].pd0 > SMALL_MAXD || o[a].len != r.d0 || o[a].pd1 != r.d0) fine = false;   // message length = label count of the table = the factor's size
-                    for (int b = a + 1; b < n && fine; ++b) if (o[a].peer_dual == o[b].peer_dual) fine = false;
+                    // the receives run side by side, and so do the sends: no two of a kind on one peer
+                    for (int b = a + 1; b < n && fine; ++b) if (o[a].peer_dual == o[b].peer_dual && (a < r.n_recv) == (b < r.n_recv)) fine = false;
                   }
                 }
                 if (fine) cl.flags |= CHAIN_LAUNCH_LABEL_OPS;
+                else if (std::getenv("LPMP_ROT_VERBOSE") && dbg_left-- > 0) {
+                  const UpdRec& r = out.recs[cl.rec_begin]; const Op* o = out.ops.data() + r.op_begin;
+                  std::fprintf(stderr, "lpmp:   not eligible: first record kind %d d0 %d ops %d+%d; op0 code %d role %d pd0 %d pd1 %d len %d\n", r.kind_flags & 15, r.d0, r.n_recv, r.n_send,
+                               (r.n_recv + r.n_send) ? (o[0].info & 15) : -1, (r.n_recv + r.n_send) ? ((o[0].info >> 4) & 1) : -1, (r.n_recv + r.n_send) ? o[0].pd0 : -1, (r.n_recv + r.n_send) ? o[0].pd1 : -1, (r.n_recv + r.n_send) ? o[0].len : -1);
+                }
               }
+            if (std::getenv("LPMP_ROT_VERBOSE")) {
+              int64_t nf_ = 0; for (const auto& cl : lp.launches) nf_ += (cl.flags & CHAIN_LAUNCH_LABEL_OPS) != 0;
+              std::fprintf(stderr, "lpmp: level loop over %zu launches of class %d, %lld of them with one lane per op\n", lp.launches.size(), c, (long long)nf_);
+            }
             lp.tk_launch.clear(); lp.tk_block.clear(); lp.dep_off.assign(1, 0); lp.dep.clear();
             out.chains.push_back(std::move(lp));
           } else {
