@@ -1140,53 +1140,52 @@ __device__ __forceinline__ void label_ops_body(const ChainLaunch& ln, int64_t fi
   const int n_recv = rec.n_recv, n_send = rec.n_send, on = rec.d0;
   double* own_g = dual + rec.dual_off;
   double theta = (live && j < on) ? ld_dual<A>(own_g + j) : 0.0;      // lane j of the group holds element j
-  // one op of this lane: its record and match table (constants: both rounds' are requested at once), then the peer's
-  // costs; entries beyond the peer's size count as no match
-  auto load_op = [&](bool has, int k, Op& o, int (&tv)[SMALL_MAXD]) {
+  // one op of this lane: its record, match table and the peer's costs; entries beyond the peer's size count as no match
+  auto load_op = [&](bool has, int k, Op& o, int (&tv)[SMALL_MAXD], double (&R)[SMALL_MAXD]) {
     if (has) o = ln.ops[rec.op_begin + k]; else { o.peer_dual = 0; o.peer_const = 0; o.omega = 0.0; o.info = 0; o.pd0 = 0; o.pd1 = 0; o.peer = 0; o.len = 0; }
+    const double* peer = dual + o.peer_dual;
     const int32_t* tab = tabs + o.peer_const;
 #pragma unroll
-    for (int r = 0; r < SMALL_MAXD; ++r) tv[r] = (has && r < o.pd0) ? tab[r] : o.pd1;
+    for (int r = 0; r < SMALL_MAXD; ++r) { const bool in = has && r < o.pd0; tv[r] = in ? tab[r] : o.pd1; R[r] = in ? ld_dual<A>(peer + r) : LPMP_INF; }
   };
-  auto load_costs = [&](bool has, const Op& o, double (&R)[SMALL_MAXD]) {
-    const double* peer = dual + o.peer_dual;
+  {   // round 1: the receives, lane j = receive j
+    const bool recv = live && j < n_recv;
+    Op o; int tv[SMALL_MAXD]; double R[SMALL_MAXD];
+    load_op(recv, j, o, tv, R);
+    if (recv) {
+      const int nl = o.pd1;
+      double* peer = dual + o.peer_dual;
+      st_lb<A>(lb + o.peer, LPMP_NAN);
+      double nt = ((o.info >> 6) & 1) ? 0.0 : LPMP_INF;
 #pragma unroll
-    for (int r = 0; r < SMALL_MAXD; ++r) R[r] = (has && r < o.pd0) ? ld_dual<A>(peer + r) : LPMP_INF;
-  };
-  const bool recv = live && j < n_recv, send = live && j < n_send;
-  Op o1, o2; int tv1[SMALL_MAXD], tv2[SMALL_MAXD]; double R[SMALL_MAXD];
-  load_op(recv, j, o1, tv1);
-  load_op(send, n_recv + j, o2, tv2);
-  load_costs(recv, o1, R);
-  if (recv) {   // round 1: the receives, lane j = receive j
-    const int nl = o1.pd1;
-    double* peer = dual + o1.peer_dual;
-    st_lb<A>(lb + o1.peer, LPMP_NAN);
-    double nt = ((o1.info >> 6) & 1) ? 0.0 : LPMP_INF;
+      for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] >= nl) nt = fmin(nt, R[r]);
+      for (int l = 0; l < nl; ++l) {
+        double v = LPMP_INF;
 #pragma unroll
-    for (int r = 0; r < SMALL_MAXD; ++r) if (tv1[r] >= nl) nt = fmin(nt, R[r]);
-    for (int l = 0; l < nl; ++l) {
-      double v = LPMP_INF;
+        for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] == l) v = fmin(v, R[r]);
+        D[q][j][l] = o.omega * (v - nt);
+      }
 #pragma unroll
-      for (int r = 0; r < SMALL_MAXD; ++r) if (tv1[r] == l) v = fmin(v, R[r]);
-      D[q][j][l] = o1.omega * (v - nt);
+      for (int r = 0; r < SMALL_MAXD; ++r) if (r < o.pd0 && tv[r] < nl) st_dual<A>(peer + r, R[r] + -1.0 * D[q][j][tv[r]]);
     }
-#pragma unroll
-    for (int r = 0; r < SMALL_MAXD; ++r) if (r < o1.pd0 && tv1[r] < nl) st_dual<A>(peer + r, R[r] + -1.0 * D[q][j][tv1[r]]);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a send of this record may go to the peer a receive has just rewritten
   wave_sync();
-  load_costs(send, o2, R);                           // round 2: the sends, lane j = send j
   for (int k = 0; k < n_recv; ++k) if (j < on) theta += +1.0 * D[q][k][j];   // own(i) += +1.0 * dl(i), receive by receive
   if (live && j < on) S[q][j] = theta;                                        // the state every send starts from
   wave_sync();
-  if (send) {
-    const int nl = o2.pd1;
-    double* peer = dual + o2.peer_dual;
-    st_lb<A>(lb + o2.peer, LPMP_NAN);
-    for (int l = 0; l < o2.len; ++l) D[q][j][l] = o2.omega * S[q][l];
+  {   // round 2: the sends, lane j = send j
+    const bool send = live && j < n_send;
+    Op o; int tv[SMALL_MAXD]; double R[SMALL_MAXD];
+    load_op(send, n_recv + j, o, tv, R);
+    if (send) {
+      const int nl = o.pd1;
+      double* peer = dual + o.peer_dual;
+      st_lb<A>(lb + o.peer, LPMP_NAN);
+      for (int l = 0; l < o.len; ++l) D[q][j][l] = o.omega * S[q][l];
 #pragma unroll
-    for (int r = 0; r < SMALL_MAXD; ++r) if (r < o2.pd0 && tv2[r] < nl) st_dual<A>(peer + r, R[r] + +1.0 * D[q][j][tv2[r]]);
+      for (int r = 0; r < SMALL_MAXD; ++r) if (r < o.pd0 && tv[r] < nl) st_dual<A>(peer + r, R[r] + +1.0 * D[q][j][tv[r]]);
+    }
   }
   wave_sync();
   for (int k = 0; k < n_send; ++k) if (j < on) theta += -1.0 * D[q][k][j];   // own(i) += -1.0 * dl(i), send by send
