@@ -13,7 +13,7 @@ into the host heap of the test process.  This harness separates th
     python tests/fuzz_split.py FIRST COUNT [--minutes M] [--canaries N] [--families 0123]
 
 Runs the test families of tests/test_fuzz_gpu.py (other seeds; --families 0123 by default, 4 = bipartite graphs with
-joined multi-pass calls, 5 = pairwise factors that round themselves) until COUNT seeds or M minutes are over.
+joined multi-pass calls, 5 = pairwise factors that round themselves, 6 = labeling-list models in the level loop) until COUNT seeds or M minutes are over.
 LPMP_STREAM_POOL=0 in the environment makes the engine create and destroy its HIP streams per engine (the round-1
 behaviour) — the A/B switch of the hunt.  Exit code 0 = no event of any kind.
 """
@@ -189,6 +189,11 @@ class _DryRunEngine:
     def close(self): pass
 
 
+class _Env:
+    """stands in for pytest's monkeypatch in family 6 (the environment of this process is set for good)"""
+    def setenv(self, k, v): os.environ[k] = v
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
@@ -218,7 +223,8 @@ def main():
         T.E.Engine = _DryRunEngine
     fams = [T.test_random_models_all_modes_and_custom_passes, T.test_random_mrfs_fast_kernels_multi_pass_calls_and_fused_custom_schedules,
             T.test_random_mrfs_any_label_count_runtime_dims_kernels, T.test_random_mrfs_primal_rounding,
-            T.test_random_bipartite_graphs_multi_pass_calls_equal_single_passes, T.test_random_mrfs_pairwise_factors_round_themselves]
+            T.test_random_bipartite_graphs_multi_pass_calls_equal_single_passes, T.test_random_mrfs_pairwise_factors_round_themselves,
+            lambda seed: T.test_random_labeling_list_models_in_the_level_loop(seed, _Env())]
     fams = [fams[int(c)] for c in args.families]
     can = Canaries(args.canaries)
     rng = np.random.default_rng(args.first)

@@ -369,3 +369,41 @@ def test_random_bipartite_graphs_multi_pass_calls_equal_single_passes(seed):
             assert abs(eng.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_labeling_list_models_in_the_level_loop(seed, monkeypatch):
+    """multicut-style models (edge variables + triplet / quadruple labeling-list factors) of random size, density and
+    locality with the level loop forced on every deep-enough sweep (LPMP_CHAIN_MIN=2): the one-lane-per-op body
+    (kernels.hip, label_ops_body) where a launch qualifies, the generic body between the same barriers where it does not
+    (more than 8 receives or sends: uniform weights on dense instances), residual sends (always the generic body)"""
+    from lp_mp_amd import synthetic as S
+    monkeypatch.setenv("LPMP_CHAIN_MIN", "2")
+    rng = np.random.default_rng(23000 + seed)
+    if seed % 3 == 0:
+        m = S.multicut_triangle_model(int(rng.integers(6, 40)), int(rng.integers(2, 60)), seed=seed)
+    else:
+        ne = int(rng.integers(30, 500))
+        m = S.c5_model(int(rng.integers(4, 12)), int(rng.integers(4, 12)), 8, ne, int(rng.integers(ne // 4, 2 * ne)), int(rng.integers(0, ne)),
+                       seed=seed, window=int(rng.choice([6, 16, 64, 100000])), colour_edge_vars=bool(rng.integers(2)))
+    eng = E.Engine(0)
+    try:
+        for rtype in (0, 1):
+            for mode in MODES:
+                o = Oracle(m)
+                o.set_reparametrization_type(rtype); o.set_reparametrization(mode)
+                eng.upload(m)
+                eng.set_reparametrization_type(rtype); eng.set_reparametrization(mode)
+                for step in range(3):
+                    what = int(rng.integers(3))
+                    if what == 0:
+                        eng.compute_pass(2); o.ComputePass(2)
+                    elif what == 1:
+                        eng.backward_pass(); o.ComputeBackwardPass()
+                    else:
+                        eng.forward_pass(); o.ComputeForwardPass()
+                    assert np.array_equal(eng.download_duals(), o.duals()), (seed, rtype, mode, step, what)
+                    assert abs(eng.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+        eng.set_reparametrization_type(0)
+    finally:
+        eng.close()
