@@ -32,6 +32,10 @@ def test_pmc_traffic_lookup_matches_committed_profile():
     assert src is not None and os.path.exists(os.path.join(ROOT, src))
     assert 1e9 < traffic < 3e10
     assert bench.pmc_traffic("sweep_dense_pk_kernel<32, 2>", _args(grid=512)) == (None, None)
+    # the joined-pass chain launch covers all passes of a call: the summary's bytes are scaled to the call's pass count
+    t20, src20 = bench.pmc_traffic("void lpmp::chain_dense_pk_kernel<32, 2, false, false>", _args(steps=20))
+    t10, _ = bench.pmc_traffic("void lpmp::chain_dense_pk_kernel<32, 2, false, false>", _args(steps=10))
+    assert src20 is not None and "pmc_c3_dense32" in src20 and 3e10 < t20 / 20 < 4.5e10 and abs(t10 * 2 - t20) < 1e-6 * t20
 
 
 @pytest.mark.gpu
@@ -51,3 +55,14 @@ def test_bench_json_line_contract():
     assert rd["primal_cost"] >= rd["lower_bound"] and rd["ms_pass_and_primal"] > 0
     # launch per step, or the whole pass as one chain launch (engine.cpp rotation_chain): same body either way
     assert d["roofline"]["kernel"].startswith(("sweep_dense_pk_kernel<32, 2, false", "chain_dense_pk_kernel<32, 2, false"))
+
+
+@pytest.mark.gpu
+def test_bench_c4_workload_line():
+    """--workload c4 (BASELINE configs[3] in miniature on one GPU): same contract, the random-graph workload named"""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c4", "--c4-nodes", "20000", "--c4-edges", "100000",
+                                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], text=True, cwd=ROOT, timeout=600)
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "msg-updates/s" and d["value"] > 0
+    assert "random sparse graph G(20000, 100000)" in d["config"]["workload"] and d["config"]["msg_updates_per_pass"] == 400000
+    assert d["dual_bound_gap"] == 0.0 and d["lower_bound_after"] > d["lower_bound_before"]
