@@ -1118,7 +1118,7 @@ chain_generic_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, dou
 //   labeling-list records run with one lane per op (label_ops_body), the others on the generic body (one wave).
 constexpr int LEVEL_LOOP_AHEAD = 8;
 constexpr int LL_WAVES = 2;                        // computing waves of level_loop_kernel<1> (+ one that runs ahead)
-constexpr int CHAIN_LAUNCH_LABEL_OPS_DEV = 1;      // ChainLaunch::pad (plan.hpp CHAIN_LAUNCH_LABEL_OPS)
+constexpr int CHAIN_LAUNCH_LABEL_OPS_DEV = 1, CHAIN_LAUNCH_LABEL_PAIRED_DEV = 2;   // ChainLaunch::pad (plan.hpp CHAIN_LAUNCH_LABEL_*)
 
 // Labeling-list records with one LANE PER OP (plan.cpp marks the launches: vector factors whose ops are all labeling
 // messages with the factor on the left, at most 8 receives with distinct peers and 8 sends with distinct peers, message
@@ -1129,7 +1129,7 @@ constexpr int CHAIN_LAUNCH_LABEL_OPS_DEV = 1;      // ChainLaunch::pad (plan.hpp
 // take one record: lane j computes op j, the deltas meet in LDS and are added to the factor's vector in op order
 // (same additions, same order as the sequential form: bit-identical), two rounds — the receives, then the sends —
 // instead of n_recv + n_send.
-template <int A>
+template <int A, bool PAIRED>
 __device__ __forceinline__ void label_ops_body(const ChainLaunch& ln, int64_t first, double* __restrict__ dual, const int32_t* __restrict__ tabs,
                                                double* __restrict__ lb, double (*D)[8][8], double (*S)[8]) {
   const int lane = threadIdx.x & 63, q = lane >> 3, j = lane & 7;
@@ -1148,6 +1148,39 @@ __device__ __forceinline__ void label_ops_body(const ChainLaunch& ln, int64_t fi
 #pragma unroll
     for (int r = 0; r < SMALL_MAXD; ++r) { const bool in = has && r < o.pd0; tv[r] = in ? tab[r] : o.pd1; R[r] = in ? ld_dual<A>(peer + r) : LPMP_INF; }
   };
+  if constexpr (PAIRED) {
+    // every message of the record is received and then sent (send j goes where receive j came from): the peer's costs
+    // stay in this lane's registers between the two rounds — one load and one store per peer, no drain in between
+    const bool act = live && j < n_recv;
+    Op o; int tv[SMALL_MAXD]; double R[SMALL_MAXD];
+    load_op(act, j, o, tv, R);
+    const double omega_send = act ? ln.ops[rec.op_begin + n_recv + j].omega : 0.0;
+    const int nl = o.pd1;
+    if (act) {
+      st_lb<A>(lb + o.peer, LPMP_NAN);
+      double nt = ((o.info >> 6) & 1) ? 0.0 : LPMP_INF;
+#pragma unroll
+      for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] >= nl) nt = fmin(nt, R[r]);
+      for (int l = 0; l < nl; ++l) {
+        double v = LPMP_INF;
+#pragma unroll
+        for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] == l) v = fmin(v, R[r]);
+        D[q][j][l] = o.omega * (v - nt);
+      }
+#pragma unroll
+      for (int r = 0; r < SMALL_MAXD; ++r) if (r < o.pd0 && tv[r] < nl) R[r] = R[r] + -1.0 * D[q][j][tv[r]];
+    }
+    wave_sync();
+    for (int k = 0; k < n_recv; ++k) if (j < on) theta += +1.0 * D[q][k][j];
+    if (live && j < on) S[q][j] = theta;
+    wave_sync();
+    if (act) {
+      double* peer = dual + o.peer_dual;
+      for (int l = 0; l < o.len; ++l) D[q][j][l] = omega_send * S[q][l];
+#pragma unroll
+      for (int r = 0; r < SMALL_MAXD; ++r) if (r < o.pd0 && tv[r] < nl) st_dual<A>(peer + r, R[r] + +1.0 * D[q][j][tv[r]]);
+    }
+  } else {
   {   // round 1: the receives, lane j = receive j
     const bool recv = live && j < n_recv;
     Op o; int tv[SMALL_MAXD]; double R[SMALL_MAXD];
@@ -1186,6 +1219,7 @@ __device__ __forceinline__ void label_ops_body(const ChainLaunch& ln, int64_t fi
 #pragma unroll
       for (int r = 0; r < SMALL_MAXD; ++r) if (r < o.pd0 && tv[r] < nl) st_dual<A>(peer + r, R[r] + +1.0 * D[q][j][tv[r]]);
     }
+  }
   }
   wave_sync();
   for (int k = 0; k < n_send; ++k) if (j < on) theta += -1.0 * D[q][k][j];   // own(i) += -1.0 * dl(i), send by send
@@ -1227,7 +1261,8 @@ level_loop_kernel(const ChainLaunch* __restrict__ launches, int n_launches, doub
       } else {
         const ChainLaunch ln = launches[l];
         if ((ln.pad & CHAIN_LAUNCH_LABEL_OPS_DEV) && plain_rule) {
-          for (int64_t first = 8 * wave; first < ln.count; first += 8 * LL_WAVES) label_ops_body<ACC_WG>(ln, first, dual, tabs, lb, D[wave], S[wave]);
+          if (ln.pad & CHAIN_LAUNCH_LABEL_PAIRED_DEV) { for (int64_t first = 8 * wave; first < ln.count; first += 8 * LL_WAVES) label_ops_body<ACC_WG, true>(ln, first, dual, tabs, lb, D[wave], S[wave]); }
+          else { for (int64_t first = 8 * wave; first < ln.count; first += 8 * LL_WAVES) label_ops_body<ACC_WG, false>(ln, first, dual, tabs, lb, D[wave], S[wave]); }
         } else if (wave == 0) {
           const int64_t nblk = (ln.count + C::FPB - 1) / C::FPB;
           for (int64_t b = 0; b < nblk; ++b)

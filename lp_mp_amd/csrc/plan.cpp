@@ -803,7 +803,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
             int dbg_left = 5;
             if (c == KC_SMALL)
               for (auto& cl : lp.launches) {           // launches the op-parallel labeling body can run (kernels.hip, label_ops_body)
-                bool fine = true;
+                bool fine = true, paired = true;
                 for (int64_t i = cl.rec_begin; i < cl.rec_begin + cl.count && fine; ++i) {
                   const UpdRec& r = out.recs[i];
                   const Op* o = out.ops.data() + r.op_begin;
@@ -814,8 +814,11 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
                     // the receives run side by side, and so do the sends: no two of a kind on one peer
                     for (int b = a + 1; b < n && fine; ++b) if (o[a].peer_dual == o[b].peer_dual && (a < r.n_recv) == (b < r.n_recv)) fine = false;
                   }
+                  if (r.n_recv != r.n_send) paired = false;
+                  for (int a = 0; a < r.n_recv && paired && fine; ++a)
+                    if (o[a].peer_dual != o[r.n_recv + a].peer_dual || o[a].peer_const != o[r.n_recv + a].peer_const || o[a].pd0 != o[r.n_recv + a].pd0) paired = false;
                 }
-                if (fine) cl.flags |= CHAIN_LAUNCH_LABEL_OPS;
+                if (fine) cl.flags |= CHAIN_LAUNCH_LABEL_OPS | (paired ? CHAIN_LAUNCH_LABEL_PAIRED : 0);
                 else if (std::getenv("LPMP_ROT_VERBOSE") && dbg_left-- > 0) {
                   const UpdRec& r = out.recs[cl.rec_begin]; const Op* o = out.ops.data() + r.op_begin;
                   std::fprintf(stderr, "lpmp:   not eligible: first record kind %d d0 %d ops %d+%d; op0 code %d role %d pd0 %d pd1 %d len %d\n", r.kind_flags & 15, r.d0, r.n_recv, r.n_send,
@@ -823,8 +826,8 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
                 }
               }
             if (std::getenv("LPMP_ROT_VERBOSE")) {
-              int64_t nf_ = 0; for (const auto& cl : lp.launches) nf_ += (cl.flags & CHAIN_LAUNCH_LABEL_OPS) != 0;
-              std::fprintf(stderr, "lpmp: level loop over %zu launches of class %d, %lld of them with one lane per op\n", lp.launches.size(), c, (long long)nf_);
+              int64_t nf_ = 0, np_ = 0; for (const auto& cl : lp.launches) { nf_ += (cl.flags & CHAIN_LAUNCH_LABEL_OPS) != 0; np_ += (cl.flags & CHAIN_LAUNCH_LABEL_PAIRED) != 0; }
+              std::fprintf(stderr, "lpmp: level loop over %zu launches of class %d, %lld of them with one lane per op (%lld paired)\n", lp.launches.size(), c, (long long)nf_, (long long)np_);
             }
             lp.tk_launch.clear(); lp.tk_block.clear(); lp.dep_off.assign(1, 0); lp.dep.clear();
             out.chains.push_back(std::move(lp));

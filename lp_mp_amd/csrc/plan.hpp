@@ -120,6 +120,7 @@ struct PrimalInit { int32_t f, a, b, pad; };      // primal_ of factor f when un
 // block of records of one launch; dep = the tickets holding the predecessors of its records (the last earlier update
 // of every factor a record touches).  Tickets are numbered in level order, so a dependency always has a lower number.
 struct ChainLaunchHost { int64_t rec_begin, count, pk_begin; int32_t stride, ticket0; int32_t flags = 0; };   // flags: CHAIN_LAUNCH_LABEL_OPS
+constexpr int32_t CHAIN_LAUNCH_LABEL_PAIRED = 2;  // ... and in every record send j goes to the peer receive j came from (each message received, then sent)
 constexpr int32_t CHAIN_LAUNCH_LABEL_OPS = 1;   // level loop: every record a vector factor whose ops are labeling messages with it on the left, <= 8 receives and <= 8 sends, no two of a kind on one peer
 struct ChainPlan {
   bool valid = false;
