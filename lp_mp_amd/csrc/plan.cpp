@@ -715,9 +715,9 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   // other, so a schedule qualifies only if no dependency runs between records of different classes (C5: the Potts grid
   // and the labeling-list factors are separate components); classes with few launches stay plain launches.
   // (LPMP_CHAIN_MIN: experiments — the smallest number of launches that makes a class a chain)
-  static const int64_t chain_min = [] { const char* v = std::getenv("LPMP_CHAIN_MIN"); return v ? (int64_t)std::atoll(v) : CHAIN_MIN_LAUNCHES; }();
-  static const int bands = [] { const char* v = std::getenv("LPMP_CHAIN_BANDS"); return v ? std::atoi(v) : 0; }();
-  static const int lag = [] { const char* v = std::getenv("LPMP_CHAIN_LAG"); return v ? std::atoi(v) : 2; }();
+  const int64_t chain_min = [] { const char* v = std::getenv("LPMP_CHAIN_MIN"); return v ? (int64_t)std::atoll(v) : CHAIN_MIN_LAUNCHES; }();
+  const int bands = [] { const char* v = std::getenv("LPMP_CHAIN_BANDS"); return v ? std::atoi(v) : 0; }();
+  const int lag = [] { const char* v = std::getenv("LPMP_CHAIN_LAG"); return v ? std::atoi(v) : 2; }();
   const bool no_level_loop = std::getenv("LPMP_NO_LEVEL_LOOP") != nullptr;
   const bool no_auto_bands = std::getenv("LPMP_NO_BLOCKED_PASSES") != nullptr;
   // (LPMP_BAND_MIN_BYTES, LPMP_BAND_BYTES: tests force the banded order on small models)
