@@ -524,9 +524,9 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   }
   // Records with two receives, or two sends, into ONE vector (duplicate messages between the same two factors) need an
   // op-by-op kernel: the packed kernels request a record's vectors before reducing.  They get a class of their own
-  // (the streaming / generic kernels work op by op), so that one such record does not take its whole launch off the
-  // packed kernels — the C4 graph (10 M random edges) has 27 duplicate pairs, and each used to cost a launch of up to
-  // 500 000 records its packed form (13.4 against 11.9 ms per pass)
+  // (the streaming / generic / lane-per-factor kernels work op by op), so that one such record does not take its whole
+  // launch off the packed kernels.  (Two pairwise factors between the same two variables are NOT this case: their
+  // messages go to different vectors.)
   std::vector<uint8_t> dup_vec(N, 0);
   for (int64_t u = 0; u < N; ++u) {
     if (owner[u] != u) continue;
