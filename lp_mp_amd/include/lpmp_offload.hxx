@@ -55,8 +55,12 @@ namespace lpmp_offload {
 // (binary_data<T>, serialization.hxx:14-20).
 namespace detail {
 template <class T, class = void> struct is_matrix_like : std::false_type {};
+// the element access must yield an lvalue: the reference's vector<T> inherits a by-value `T operator()(i1, i2) const` and
+// dim1() / dim2() from its expression-template bases (vector.hxx:20-24, 45-47, 69-72) and is NOT a matrix — it goes the
+// range way (found by tools/check_offload_against_reference.sh against the real headers)
 template <class T> struct is_matrix_like<T, std::void_t<decltype(std::declval<const T&>().dim1()), decltype(std::declval<const T&>().dim2()),
-                                                         decltype(std::declval<const T&>()(std::size_t(0), std::size_t(0)))>> : std::true_type {};
+                                                         decltype(std::declval<T&>()(std::size_t(0), std::size_t(0)))>>
+    : std::is_lvalue_reference<decltype(std::declval<T&>()(std::size_t(0), std::size_t(0)))> {};
 template <class T, class = void> struct is_range_like : std::false_type {};
 template <class T> struct is_range_like<T, std::void_t<decltype(std::declval<T&>().begin()), decltype(std::declval<const T&>().size())>> : std::true_type {};
 template <class T, class = void> struct is_binary_data : std::false_type {};

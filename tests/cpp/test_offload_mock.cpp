@@ -23,8 +23,13 @@ static void test(const bool pred, const char* what = "") { if (!pred) throw std:
 // ---- ops as a user of the reference writes them ---------------------------------------------------------------------
 namespace user {
 using LP_MP::REAL; using LP_MP::INDEX;
-struct my_vector : std::vector<REAL> {          // like the reference's vector<REAL>: begin() + size()
+struct my_vector : std::vector<REAL> {          // like the reference's vector<REAL>: begin() + size() ...
   using std::vector<REAL>::vector;
+  // ... AND, inherited from its expression-template bases (reference vector.hxx:20-24, 45-47, 69-72), dim1() / dim2() and a
+  // BY-VALUE two-index call operator: it must still be packed as a range, not as a matrix (the real headers showed this,
+  // tools/check_offload_against_reference.sh)
+  INDEX dim1() const { return size(); } INDEX dim2() const { return 1; }
+  REAL operator()(INDEX i1, INDEX) const { return (*this)[i1]; }
 };
 struct my_matrix {                              // like the reference's matrix<REAL>: dim1() / dim2() / operator()(i, j)
   my_matrix(INDEX a, INDEX b) : d1_(a), d2_(b), v_(a * b, 0.0) {}

@@ -46,6 +46,17 @@ def test_offload_header_defines_no_reference_names():
         assert opened and set(opened) <= {"LP_MP_gpu"}, opened      # LP_MP only ever appears as an alias, guarded
 
 
+def test_offload_adapter_compiles_against_the_reference_headers(tmp_path):
+    """Build container only: offloaded<LP_MP::LP<test_FMC>> + the reference's own Solver / StandardVisitor through
+    g++ -fsyntax-only against /root/reference/include (tools/check_offload_against_reference.sh; a compile check, not an
+    oracle).  The reference tree does not exist on the GPU box: skipped there."""
+    if not os.path.isdir(os.environ.get("LPMP_REFERENCE", "/root/reference") + "/include"):
+        pytest.skip("no reference tree on this box")
+    log = str(tmp_path / "check.log")
+    rc = subprocess.call([os.path.join(ROOT, "tools", "check_offload_against_reference.sh"), log])
+    assert rc == 0, open(log).read()[-4000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", PROGRAMS)
 def test_cpp_program_full_run_on_device(tmp_path, name):

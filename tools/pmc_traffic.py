@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs with
---kernel-trace only) into per-launch HBM traffic of one kernel.
+--kernel-trace only) into per-launch traffic of one kernel as the L2 requests it from the fabric (Infinity Cache + HBM).
 
 Units and gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section) and
 cdna_hip_programming.md section 7: counters are in KiB; FETCH_SIZE reports exactly half the bytes of a
@@ -35,7 +35,8 @@ def main():
     by = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w)]
     res = {"kernel": kernel, "launches": len(by), "fetch_size_kib_avg": sum(f) / len(f), "write_size_kib_avg": sum(w) / len(w),
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
-           "hbm_bytes_per_launch_avg": sum(by) / len(by), "hbm_bytes_per_launch_min": min(by), "hbm_bytes_per_launch_max": max(by)}
+           "counts": "L2 fabric-side requests: reads served by the Infinity Cache are counted like reads served by HBM",
+           "fabric_bytes_per_launch_avg": sum(by) / len(by), "fabric_bytes_per_launch_min": min(by), "fabric_bytes_per_launch_max": max(by)}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 

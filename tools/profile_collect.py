@@ -17,6 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 kernel = sys.argv[2] if len(sys.argv) > 2 else "sweep_dense_pk_kernel<32"
 last_n, skip_tail = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (41, 8)
+# workload name inside the file names: c3 (default) / c4 ...; the PMC summary is TAG_pmc_<WL>_<class>.json
+wl = sys.argv[5] if len(sys.argv) > 5 else "c3"
+wl_class = {"c3": "c3_dense32", "c4": "c4_dense16"}.get(wl, wl)
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 
@@ -29,18 +32,18 @@ def bench_line(log, out):
     raise SystemExit(f"no bench line in {log}")
 
 
-plain = bench_line("bench_plain.log", f"{tag}_bench_c3_default.json")
-prof = bench_line("bench_stats.log", f"{tag}_bench_c3_under_rocprof.json")
+plain = bench_line("bench_plain.log", f"{tag}_bench_{wl}_default.json")
+prof = bench_line("bench_stats.log", f"{tag}_bench_{wl}_under_rocprof.json")
 db = lambda d: glob.glob(os.path.join(src, d, "*", "*.db"))[0]
 tool = os.path.join(ROOT, "tools", "rocpd_summary.py")
-subprocess.check_call([sys.executable, tool, "stats", db("stats"), os.path.join(dst, f"{tag}_bench_c3_kernel_stats.csv")])
+subprocess.check_call([sys.executable, tool, "stats", db("stats"), os.path.join(dst, f"{tag}_bench_{wl}_kernel_stats.csv")])
 for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     subprocess.check_call([sys.executable, tool, "pmc", db("pmc_" + name), counter, os.path.join(dst, f"{tag}_pmc_{name}_counter_collection.csv")])
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(dst, f"{tag}_pmc_fetch_counter_collection.csv"),
-                       os.path.join(dst, f"{tag}_pmc_write_counter_collection.csv"), kernel, os.path.join(dst, f"{tag}_pmc_c3_dense32.json"),
+                       os.path.join(dst, f"{tag}_pmc_write_counter_collection.csv"), kernel, os.path.join(dst, f"{tag}_pmc_{wl_class}.json"),
                        str(last_n), str(skip_tail)])
 # a chain launch covers as many passes as the call had: keep that with the byte count (bench.py scales by it)
-pj = os.path.join(dst, f"{tag}_pmc_c3_dense32.json")
+pj = os.path.join(dst, f"{tag}_pmc_{wl_class}.json")
 d = json.load(open(pj))
 d["passes_per_launch"] = plain["roofline"].get("passes_per_launch")
 d["note"] = ("FETCH_SIZE / WRITE_SIZE are the L2's fabric-side request counters: reads served by the 256 MiB Infinity Cache are "
