@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--c4-edges", type=int, default=10_000_000)
     ap.add_argument("--c4-labels", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-GPU code path even at WORLD_SIZE 1: init_process_group(nccl = RCCL), the partitioned "
+                         "sweep with its (empty) all_to_all_single exchanges, device all_reduce — what an N-GPU launch executes "
+                         "first, runnable on a 1-GPU box (tests/test_bench_contract.py)")
     ap.add_argument("--cpu-sample-grid", type=int, default=256)
     ap.add_argument("--also-row-major", action="store_true", help="also time the row-major ordering (extra key)")
     ap.add_argument("--prewarm-ms", type=float, default=0.0,
@@ -243,8 +247,10 @@ def main():
     from lp_mp_amd import engine as E, model as M, synthetic as S
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
         # "nccl" is RCCL on ROCm; LPMP_DIST_BACKEND=gloo only for smoke runs of this script on a 1-GPU box
         dist.init_process_group(os.environ.get("LPMP_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
@@ -264,14 +270,14 @@ def main():
     if args.workload == "c4":
         from lp_mp_amd import multi_gpu as MG
         L = args.c4_labels
-        runner = MG.GraphSweep(torch, dist if world > 1 else None, args.c4_nodes, args.c4_edges, L, mode, seed=1)
+        runner = MG.GraphSweep(torch, dist if dist_on else None, args.c4_nodes, args.c4_edges, L, mode, seed=1)
         updates_per_pass = runner.global_updates_per_pass
         bytes_per_pass = runner.global_bytes_per_pass
         levels = runner.levels
         eng = runner.engine
         parallelism = (f"{world} parts (reverse Cuthill-McKee + balanced KL refinement), {100 * runner.global_cut_fraction:.1f} % of the edges cut, "
                        f"boundary step every {runner.boundary_every}") if world > 1 else "1 GPU"
-    elif world == 1:
+    elif not dist_on:
         m, const, dual = build_device_grid(torch, H, W, L, args.pairwise, args.order, 1, E, S, stream_ptr)
         setup["model_structure_and_costs_in_hbm_s"] = time.perf_counter() - t_setup0
         t1 = time.perf_counter()
@@ -302,8 +308,8 @@ def main():
     if hasattr(runner, "prepare_passes"):            # ticket lists of the joined-pass chain launches (depends on the pass count)
         runner.prepare_passes(args.warmup); runner.prepare_passes(args.steps)
         setup["prepare_passes_s"] = time.perf_counter() - t1
-    dt = time_passes(torch, dist, runner, args.steps, args.warmup, world, args.prewarm_ms)
-    if world > 1:
+    dt = time_passes(torch, dist, runner, args.steps, args.warmup, 2 if dist_on else 1, args.prewarm_ms)
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -312,7 +318,7 @@ def main():
     # (tests/golden/make_c3_full.py, seed 1); its lower bound and the checksums of its packed duals after the same
     # number of passes are compared with the state the timed passes left in HBM
     oracle_check = None
-    if world == 1 and args.workload == "c3":
+    if not dist_on and args.workload == "c3":
         oracle_check = golden_check(torch, args, dual, lb1)
 
     # roofline leg: the same passes again with every launch bracketed by HIP events on the engine's stream
@@ -326,7 +332,7 @@ def main():
     # outside the timed region: one pass with primal rounding (what MpRoundingSolver runs every 5th iteration,
     # reference solver.hxx:387-397) and LP::EvaluatePrimal
     rounding = None
-    if world == 1 and args.workload == "c3":
+    if not dist_on and args.workload == "c3":
         eng.compute_pass_and_primal(args.steps + args.warmup)      # first call builds the label-propagation lists
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -337,7 +343,7 @@ def main():
         rounding = {"ms_pass_and_primal": (t1 - t0) * 1e3, "ms_evaluate_primal": (time.perf_counter() - t1) * 1e3,
                     "primal_cost": cost, "lower_bound": eng.lower_bound()}
 
-    gap = (dual_bound_gap_c4 if args.workload == "c4" else dual_bound_gap)(torch, dist, args, mode, world, rank) if world > 1 else \
+    gap = (dual_bound_gap_c4 if args.workload == "c4" else dual_bound_gap)(torch, dist, args, mode, world, rank) if dist_on else \
         {"dual_bound_gap": 0.0, "gap_config": "1 GPU: the unpartitioned sweep itself"}
     out = None
     if rank == 0:
@@ -348,7 +354,7 @@ def main():
             k = dom[1]
             avg_ms = k["ms"] / k["launches"]
             achieved = (k["bytes"] / k["launches"]) / (avg_ms * 1e-3) / 1e9
-            traffic, src = pmc_traffic(k["kernel"], args) if world == 1 else (None, None)
+            traffic, src = pmc_traffic(k["kernel"], args) if not dist_on else (None, None)
             hbm_min = hbm_min_bytes_per_pass(runner, args, world, bytes_per_pass, updates_per_pass, L)
             launch_s = avg_ms * 1e-3
             chain = bool(k.get("chain_launches"))
@@ -401,7 +407,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, S, M)
-    if world == 1 and args.workload == "c3" and args.also_row_major and args.order != "row_major":
+    if not dist_on and args.workload == "c3" and args.also_row_major and args.order != "row_major":
         del eng, runner
         m, const, dual = build_device_grid(torch, H, W, L, args.pairwise, "row_major", 1, E, S, stream_ptr)
         e2 = E.Engine(torch.cuda.current_device())
@@ -416,7 +422,7 @@ def main():
         e2.close()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -62,9 +62,38 @@ def build(force: bool = False) -> str:
     return SO
 
 
+# ---- host programs on the C ABI (C++): the RCCL driver of the partitioned sweep ---------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MGPU_DRIVER = os.path.join(ROOT, "build", "mgpu_rccl_driver")
+MGPU_SOURCES = [os.path.join(ROOT, "tools", "mgpu_rccl_driver.cpp"), os.path.join(ROOT, "lp_mp_amd", "include", "lpmp_multi_gpu.hxx"),
+                os.path.join(ROOT, "include", "lpmp_engine.h"), os.path.join(ROOT, "include", "lpmp_model.h")]
+
+
+def build_mgpu_driver(force: bool = False) -> str:
+    """tools/mgpu_rccl_driver.cpp -> build/mgpu_rccl_driver (links liblpmp_engine.so and RCCL; hipcc only for its include
+    and library paths — the file is plain host C++).  Stamped with a source hash like the library."""
+    build()
+    h = hashlib.sha256()
+    for f in MGPU_SOURCES:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    want, stamp = h.hexdigest(), MGPU_DRIVER + ".stamp"
+    if not force and os.path.exists(MGPU_DRIVER) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return MGPU_DRIVER
+    os.makedirs(os.path.dirname(MGPU_DRIVER), exist_ok=True)
+    tmp = MGPU_DRIVER + ".tmp%d" % os.getpid()
+    subprocess.check_call([hipcc(), "-std=c++17", "-O2", "-Wall", MGPU_SOURCES[0], "-o", tmp, "-L", CSRC, "-llpmp_engine", "-lrccl",
+                           "-Wl,-rpath," + CSRC])
+    os.replace(tmp, MGPU_DRIVER)
+    with open(stamp, "w") as fh:
+        fh.write(want)
+    return MGPU_DRIVER
+
+
 def build_on_rank0(rank: int, timeout_s: float = 900.0) -> str:
-    """multi-process launch (bench.py under torchrun): rank 0 compiles, the others wait for a matching stamp"""
-    if rank == 0:
+    """multi-process launch (bench.py under torchrun): the first rank of every NODE compiles (LOCAL_RANK 0: nodes need not
+    share a file system), the others wait for a matching stamp"""
+    if int(os.environ.get("LOCAL_RANK", rank)) == 0:
         return build()
     t0 = time.time()
     while needs_build():

@@ -822,7 +822,11 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
         if constexpr (CHAIN) sm[k] = ld_dual<A>(s_ms[k] + g);
         else {
           const Op& o = lop[n_recv + k];
+#ifdef LPMP_ABLATE_SEND_VEC
+          sm[k] = (double)o.peer_dual * 1e-300;
+#else
           sm[k] = ld_dual<A>(dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0) + g);
+#endif
         }
       }
     }
@@ -883,7 +887,11 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
         } else {
           roff[j] = side[j] == 0 ? 0 : L;
 #pragma unroll
+#ifdef LPMP_ABLATE_TABLE      // timing experiments only (tools/build_variant.sh): results are wrong
+          for (int i = 0; i < NL; ++i) t[j][i] = double2_t{(double)(uintptr_t)T * 1e-300, 0.0};
+#else
           for (int i = 0; i < NL; ++i) t[j][i] = ld_stream<NT>(reinterpret_cast<const double2_t*>(T + (int64_t)i * 2 * G + 2 * g));
+#endif
         }
       } else {
 #pragma unroll
@@ -901,8 +909,12 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
           if (g < Lr) msv[j] = ld_dual<A>(dual + pdual[j] + roff[j] + g);
           if (g < (side[j] == 0 ? dC[j] : dR[j])) mov[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? dR[j] : 0) + g);
         } else if (g < L) {
+#ifdef LPMP_ABLATE_RECV_VEC
+          msv[j] = (double)pdual[j] * 1e-300; mov[j] = 0.0;
+#else
           msv[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? 0 : L) + g);
           mov[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? L : 0) + g);
+#endif
         }
       }
     }
@@ -964,7 +976,11 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
             stored = true;
           }
         }
+#ifndef LPMP_ABLATE_RECV_VEC
         if (!stored) st_dual<A>(dual + pdual[j] + roff[j] + g, mn);
+#else
+        if (!stored && mn == 1.2345e-280) st_dual<A>(dual + pdual[j] + roff[j] + g, mn);
+#endif
       }
 #ifndef LPMP_ABLATE_LB_TRACK
       if (!(FW && defer[j])) {                    // a deferred receive is followed by a send that dirties the peer
@@ -1026,6 +1042,9 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
           if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
           else cur = preload_ok ? sm[k] : ld_dual<A>(ms + g);
           const double delta = o.omega * snap;
+#ifdef LPMP_ABLATE_SEND_VEC
+          if (cur + delta == 1.2345e-280)
+#endif
           st_dual<A>(ms + g, cur + delta);
           theta -= delta;
 #ifndef LPMP_ABLATE_LB_TRACK
@@ -1034,13 +1053,38 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
         }
       }
     }
-    for (int k = KS; k < n_send; ++k) {
-      const Op& o = lop[n_recv + k];
-      double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? (VAR ? o.pd0 : L) : 0);
-      const double delta = o.omega * snap;
-      st_dual<A>(ms + g, ld_dual<A>(ms + g) + delta);
-      theta -= delta;
-      if (g == 0) st_lb<A>(lb + o.peer, LPMP_NAN);
+    // the remaining sends four at a time: the four target vectors are requested together, then updated in message order
+    // (a record never sends twice into one vector: plan.cpp gives such records an op-by-op class).  One at a time, every
+    // send was a dependent load -> store round trip: a variable of a random graph (C4: ten neighbours on average, up to 30)
+    // spent most of its time in this loop
+    for (int k0 = KS; k0 < n_send; k0 += 4) {
+      double* msk[4]; double cur[4], om[4]; int pr[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        msk[q] = own_g; cur[q] = 0.0; om[q] = 0.0; pr[q] = 0;
+        if (k0 + q < n_send) {
+          const Op& o = lop[n_recv + k0 + q];
+          msk[q] = dual + o.peer_dual + (((o.info >> 5) & 1) ? (VAR ? o.pd0 : L) : 0);
+          om[q] = o.omega; pr[q] = o.peer;
+#ifdef LPMP_ABLATE_SEND_VEC
+          cur[q] = (double)o.peer_dual * 1e-300;
+#else
+          cur[q] = ld_dual<A>(msk[q] + g);
+#endif
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (k0 + q < n_send) {
+          const double delta = om[q] * snap;
+#ifdef LPMP_ABLATE_SEND_VEC
+          if (cur[q] + delta == 1.2345e-280)
+#endif
+          st_dual<A>(msk[q] + g, cur[q] + delta);
+          theta -= delta;
+          if (g == 0) st_lb<A>(lb + pr[q], LPMP_NAN);
+        }
+      }
     }
     if (flags & SWEEP_RESIDUAL) {
       double residual = 0.0;
@@ -1060,8 +1104,17 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
 #endif
 }
 
+// experiments (tools/build_variant.sh): receives in flight per lane group of the 16-label class, minimum waves per SIMD
+#ifndef LPMP_KMAX16
+#define LPMP_KMAX16 2
+#endif
+#ifdef LPMP_PK_WPE
+#define LPMP_PK_BOUNDS __launch_bounds__(256, LPMP_PK_WPE)
+#else
+#define LPMP_PK_BOUNDS __launch_bounds__(256)
+#endif
 template <int L, int KMAX, bool VAR, bool NT>
-__global__ void __launch_bounds__(256)
+__global__ void LPMP_PK_BOUNDS
 sweep_dense_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
                       double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
                       int32_t* __restrict__ primal, int64_t count, int stride, int flags) {
@@ -2112,7 +2165,7 @@ bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, cons
   switch (kclass) {
     // receives in flight per lane group: 2 at 16 / 32 labels (1 and 4 measured slower on C3), 4 below
     case KC_DENSE_32: PK_LAUNCH(32, 2); return true;
-    case KC_DENSE_16: PK_LAUNCH(16, 2); return true;
+    case KC_DENSE_16: PK_LAUNCH(16, LPMP_KMAX16); return true;
     case KC_DENSE_8: PK_LAUNCH(8, 4); return true;
     case KC_DENSE_4: PK_LAUNCH(4, 4); return true;
 #define PPK_LAUNCH1(LL, NTT) hipLaunchKernelGGL((sweep_potts_pk_kernel<LL, false, NTT>), blocks(256 / LL), dim3(256), 0, s, packets, recs, ops, dual, cdata, lb, primal, count, stride, flags)

@@ -554,6 +554,10 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       return KC_GENERIC;
     }
     const bool pow = d0 == 4 || d0 == 8 || d0 == 16 || d0 == 32;
+    // more ops than the LDS slab of a lane group holds (a hub of a random graph: C4 has a few 30-neighbour variables among
+    // 2 M): such a RECORD goes to the op-by-op streaming kernel — left in its class it took its whole launch off the packed
+    // kernels (21 of C4's 44 launches per pass ran on sweep_dense_kernel<16>: 5.5 of 12.6 ms, profiles/r03_c4a_*)
+    if (pow && (all_dense[u] || all_potts[u]) && n_recv_of[u] + n_send_of[u] > pk_indirect_cap(d0) && up_any[u]) return KC_DENSE_BIG;
     if (pow && all_dense[u]) return d0 == 4 ? KC_DENSE_4 : d0 == 8 ? KC_DENSE_8 : d0 == 16 ? KC_DENSE_16 : KC_DENSE_32;
     if (pow && all_potts[u]) return d0 == 4 ? KC_POTTS_4 : d0 == 8 ? KC_POTTS_8 : d0 == 16 ? KC_POTTS_16 : KC_POTTS_32;
     const int w = std::max(d0, max_dim[u]);

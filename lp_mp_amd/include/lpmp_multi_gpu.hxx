@@ -1,0 +1,358 @@
+// lpmp_multi_gpu.hxx — the partitioned (multi-GPU) sweep driven from C++ over the C ABI and RCCL.
+//
+// One process per GPU (or several parts per process: parts_per_rank), every part of the factor graph on its own
+// lpmp_engine.  A pass = the part's main sweeps (iterator-range passes of the reference, include/LP_MP.h:981-1005: the
+// part's own update lists and anisotropic rows with the ghost factors dropped) + the boundary step of DESIGN.md 7:
+//
+//     lpmp_schedule_run(ghost receive)  ->  lpmp_boundary_pack   -- ncclSend / ncclRecv, exchange #1 -->
+//     lpmp_boundary_reply               <-- ncclSend / ncclRecv, exchange #2 --
+//     lpmp_boundary_fold  ->  lpmp_schedule_run(ghost send)
+//
+// The exchange is ONE ncclGroupStart / ncclGroupEnd of point-to-point transfers per direction on the stream the engines
+// work on (an all-to-all-v: xGMI is point-to-point, every pair of parts that shares cut edges talks directly; a part
+// pair on one rank goes through ncclSend / ncclRecv to self inside the same group).  The bound of the whole model is
+// the ncclAllReduce of the parts' bounds.  This is the loop lp_mp_amd/multi_gpu.py (PartitionedSweep) runs through
+// torch.distributed; both produce the same duals bit for bit (tests/test_multi_gpu.py).
+//
+// Row strips of a grid MRF are built here in closed form (strip_part = multi_gpu.strip_local_part); any other partition
+// can be handed in as a part_model filled by the caller.
+//
+// Needs: include/lpmp_engine.h, <rccl/rccl.h>, HIP runtime; link with -llpmp_engine -lrccl -lamdhip64.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/lpmp_engine.h"
+
+namespace lpmp_mgpu {
+
+inline void hip_ok(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); }
+inline void nccl_ok(ncclResult_t r, const char* what) { if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r)); }
+inline void lpmp_ok(int rc) { if (rc != LPMP_OK) throw std::runtime_error(lpmp_last_error()); }   // the type the reference throws (LP_MP.h:458)
+
+constexpr double BOUNDARY_SHARE = 0.375;   // send weight of a boundary variable's cut messages, shared out
+
+// one part of the partitioned model: an MRF in the layout of the reference's MRF constructor (unaries, ghosts, then the
+// owned pairwise factors; per edge add_message<Left>(u_i, p), add_message<Right>(u_j, p), AddFactorRelation(u_i, p),
+// AddFactorRelation(p, u_j)) + its cut lists in EXCHANGE ORDER (by peer part, then global edge id)
+struct part_model {
+  int32_t part = 0, n_parts = 1, L = 0;
+  bool potts = false;
+  int64_t n_local = 0, n_ghost = 0, n_edges = 0;
+  std::vector<int32_t> f_type, f_dim0, f_dim1, m_type, m_left, m_right, rel;
+  std::vector<uint8_t> f_kind, f_flags;
+  lpmp_msg_type mtypes[2];
+  // costs are generated in HBM from the counter stream (lpmp_synth_fill): unaries at un_first, pairwise data at pw_first
+  uint64_t seed = 1, un_first = 0, pw_first = 0;
+  std::vector<int32_t> out_peer, out_ghost; std::vector<int64_t> out_key;   // cut messages this part owns (ghost factor ids)
+  std::vector<int32_t> in_peer, in_unary; std::vector<int64_t> in_key;     // cut messages owned elsewhere ending in a local unary
+  int64_t n_factors() const { return (int64_t)f_type.size(); }
+  int64_t const_doubles() const { return potts ? n_edges : n_edges * (int64_t)L * L; }
+  int64_t dual_doubles() const { return (n_local + n_ghost) * (int64_t)L + n_edges * 2 * (int64_t)L; }
+  lpmp_model view(const double* const_dev, const double* dual_dev) const {
+    lpmp_model m{};
+    m.n_ftypes = 2; m.ftype_computes_primal = nullptr; m.n_mtypes = 2; m.mtypes = mtypes;
+    m.n_factors = n_factors(); m.f_type = f_type.data(); m.f_kind = f_kind.data(); m.f_flags = f_flags.data();
+    m.f_dim0 = f_dim0.data(); m.f_dim1 = f_dim1.data(); m.const_data = const_dev; m.dual_data = dual_dev;
+    m.n_messages = (int64_t)m_type.size(); m.m_type = m_type.data(); m.m_left = m_left.data(); m.m_right = m_right.data();
+    m.n_rel_fwd = (int64_t)rel.size() / 2; m.rel_fwd = rel.data();
+    // AddFactorRelation(f1, f2) = forward f1 -> f2 and backward f2 -> f1 (LP_MP.h:698-702)
+    m.n_rel_bwd = (int64_t)rel_bwd.size() / 2; m.rel_bwd = rel_bwd.data();
+    return m;
+  }
+  std::vector<int32_t> rel_bwd;
+  void finish_relations() { rel_bwd.resize(rel.size()); for (size_t i = 0; i + 1 < rel.size(); i += 2) { rel_bwd[i] = rel[i + 1]; rel_bwd[i + 1] = rel[i]; } }
+};
+
+// var[r * W + c] = position of grid node (r, c) in the variable order (synthetic.grid_variable_order)
+inline std::vector<int64_t> grid_variable_order(int H, int W, bool colour_major) {
+  std::vector<int64_t> var((size_t)H * W);
+  if (!colour_major) { std::iota(var.begin(), var.end(), 0); return var; }
+  int64_t nb = 0;
+  for (int r = 0; r < H; ++r) for (int c = 0; c < W; ++c) if (((r + c) & 1) == 0) ++nb;
+  int64_t b = 0, w = nb;
+  for (int r = 0; r < H; ++r) for (int c = 0; c < W; ++c) var[(size_t)r * W + c] = ((r + c) & 1) == 0 ? b++ : w++;
+  return var;
+}
+
+// rows [part * H, (part + 1) * H) of a (n_parts * H) x W grid: multi_gpu.strip_local_part in closed form.  Edges in row-major
+// node order, right edge then down edge per node (synthetic.grid_edges), then the W cut edges to the next strip in column
+// order; a pairwise factor belongs to the strip of its earlier endpoint, the lower strip's endpoint is a ghost here.
+inline part_model strip_part(int H, int W, int L, bool potts, bool colour_major, int part, int n_parts, uint64_t seed) {
+  part_model p;
+  p.part = part; p.n_parts = n_parts; p.L = L; p.potts = potts; p.seed = seed;
+  const int64_t n_loc = (int64_t)H * W, e_int = (int64_t)H * (W - 1) + (int64_t)W * (H - 1);
+  const bool has_down = part < n_parts - 1, has_up = part > 0;
+  p.n_local = n_loc; p.n_ghost = has_down ? W : 0;
+  const std::vector<int64_t> var = grid_variable_order(H, W, colour_major);
+  std::vector<int64_t> li, lj;
+  for (int r = 0; r < H; ++r) for (int c = 0; c < W; ++c) {
+    const int64_t a = var[(size_t)r * W + c];
+    if (c < W - 1) { const int64_t b = var[(size_t)r * W + c + 1]; li.push_back(std::min(a, b)); lj.push_back(std::max(a, b)); }
+    if (r < H - 1) { const int64_t b = var[(size_t)(r + 1) * W + c]; li.push_back(std::min(a, b)); lj.push_back(std::max(a, b)); }
+  }
+  if (has_down) for (int c = 0; c < W; ++c) { li.push_back(var[(size_t)(H - 1) * W + c]); lj.push_back(n_loc + c); }
+  p.n_edges = (int64_t)li.size();
+  const int64_t n_vec = n_loc + p.n_ghost, nf = n_vec + p.n_edges;
+  p.f_type.assign((size_t)nf, 0); p.f_kind.assign((size_t)nf, LPMP_F_VECTOR); p.f_flags.assign((size_t)nf, 0);
+  p.f_dim0.assign((size_t)nf, L); p.f_dim1.assign((size_t)nf, 0);
+  for (int64_t e = 0; e < p.n_edges; ++e) {
+    const int64_t f = n_vec + e;
+    p.f_type[f] = 1; p.f_kind[f] = potts ? LPMP_F_PAIRWISE_POTTS : LPMP_F_PAIRWISE_DENSE; p.f_dim1[f] = L;
+    p.m_type.push_back(0); p.m_left.push_back((int32_t)li[e]); p.m_right.push_back((int32_t)f);
+    p.m_type.push_back(1); p.m_left.push_back((int32_t)lj[e]); p.m_right.push_back((int32_t)f);
+    p.rel.push_back((int32_t)li[e]); p.rel.push_back((int32_t)f);
+    p.rel.push_back((int32_t)f); p.rel.push_back((int32_t)lj[e]);
+  }
+  p.finish_relations();
+  // unary = left factor, schedule `left`, unary side variable count (0), pairwise side exactly 1
+  p.mtypes[0] = lpmp_msg_type{0, 1, LPMP_SCHED_LEFT, 0, 1, LPMP_M_UNARY_PAIRWISE, 0, 0};
+  p.mtypes[1] = lpmp_msg_type{0, 1, LPMP_SCHED_LEFT, 0, 1, LPMP_M_UNARY_PAIRWISE, 1, 0};
+  const int64_t n_vars = (int64_t)n_parts * n_loc, esz = potts ? 1 : (int64_t)L * L;
+  const int64_t e_first = (int64_t)part * (e_int + W);
+  p.un_first = (uint64_t)((int64_t)part * n_loc * L);
+  p.pw_first = (uint64_t)(n_vars * L + e_first * esz);
+  if (has_down) for (int c = 0; c < W; ++c) { p.out_peer.push_back(part + 1); p.out_ghost.push_back((int32_t)(n_loc + c)); p.out_key.push_back(e_first + e_int + c); }
+  if (has_up) for (int c = 0; c < W; ++c) { p.in_peer.push_back(part - 1); p.in_unary.push_back((int32_t)var[(size_t)c]); p.in_key.push_back((int64_t)(part - 1) * (e_int + W) + e_int + c); }
+  return p;
+}
+
+// the communicator: RANK / WORLD_SIZE processes, parts_per_rank parts each; part q lives on rank q / parts_per_rank
+struct rccl_world {
+  ncclComm_t comm = nullptr; int rank = 0, world = 1, parts_per_rank = 1;
+  hipStream_t stream = nullptr;
+  double* d_scalar = nullptr;
+  int rank_of(int part) const { return part / parts_per_rank; }
+  // id_file: where rank 0 leaves the ncclUniqueId for the others (a shared path, e.g. /tmp/lpmp_nccl_<MASTER_PORT>)
+  void init(int rank_, int world_, int parts_per_rank_, const std::string& id_file, hipStream_t s) {
+    rank = rank_; world = world_; parts_per_rank = parts_per_rank_; stream = s;
+    ncclUniqueId id;
+    if (rank == 0) {
+      nccl_ok(ncclGetUniqueId(&id), "ncclGetUniqueId");
+      if (world > 1) {
+        const std::string tmp = id_file + ".tmp";
+        FILE* f = std::fopen(tmp.c_str(), "wb"); if (!f) throw std::runtime_error("cannot write " + tmp);
+        std::fwrite(&id, sizeof(id), 1, f); std::fclose(f);
+        if (std::rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("cannot publish " + id_file);
+      }
+    } else {
+      FILE* f = nullptr;
+      for (int tries = 0; tries < 6000 && !f; ++tries) { f = std::fopen(id_file.c_str(), "rb"); if (!f) { struct timespec ts{0, 10000000}; nanosleep(&ts, nullptr); } }
+      if (!f || std::fread(&id, sizeof(id), 1, f) != 1) throw std::runtime_error("no ncclUniqueId in " + id_file);
+      std::fclose(f);
+    }
+    nccl_ok(ncclCommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+    hip_ok(hipMalloc((void**)&d_scalar, 2 * sizeof(double)), "hipMalloc");
+  }
+  double all_reduce_sum(double x) {
+    hip_ok(hipMemcpyAsync(d_scalar, &x, sizeof(double), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+    nccl_ok(ncclAllReduce(d_scalar, d_scalar + 1, 1, ncclDouble, ncclSum, comm, stream), "ncclAllReduce");
+    double out = 0;
+    hip_ok(hipMemcpyAsync(&out, d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+    hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    return out;
+  }
+  void destroy() {
+    if (d_scalar) { (void)hipFree(d_scalar); d_scalar = nullptr; }
+    if (comm) { (void)ncclCommDestroy(comm); comm = nullptr; }
+  }
+};
+
+// one part on its engine: schedules, boundary, exchange buffers
+class part_sweep {
+ public:
+  part_model pm;
+  lpmp_engine* e = nullptr;
+  lpmp_boundary* bd = nullptr;
+  double *d_const = nullptr, *d_dual = nullptr, *d_send = nullptr, *d_recv = nullptr, *d_reply = nullptr, *d_back = nullptr;
+  int sid_f = -1, sid_b = -1, sid_fb = -1, sid_ghost_recv = -1, sid_ghost_send = -1;
+  std::vector<int64_t> out_count, in_count;   // doubles per peer PART, exchange order
+  int64_t n_out = 0, n_in = 0;
+  int64_t updates_per_pass = 0;
+
+  part_sweep() = default;
+  part_sweep(const part_sweep&) = delete;
+  part_sweep& operator=(const part_sweep&) = delete;
+  ~part_sweep() {
+    if (bd) lpmp_boundary_destroy(bd);
+    if (e) lpmp_destroy(e);
+    for (double* p : {d_const, d_dual, d_send, d_recv, d_reply, d_back}) if (p) (void)hipFree(p);
+  }
+
+  void build(part_model&& model, int device, hipStream_t stream, int mode, bool boundary_every_pass) {
+    pm = std::move(model);
+    hip_ok(hipSetDevice(device), "hipSetDevice");
+    const int64_t nc = std::max<int64_t>(pm.const_doubles(), 2), nd = pm.dual_doubles();
+    hip_ok(hipMalloc((void**)&d_const, (size_t)nc * sizeof(double)), "hipMalloc const");
+    hip_ok(hipMalloc((void**)&d_dual, (size_t)nd * sizeof(double)), "hipMalloc dual");
+    hip_ok(hipMemsetAsync(d_dual, 0, (size_t)nd * sizeof(double), stream), "hipMemsetAsync");
+    lpmp_ok(lpmp_synth_fill(d_const, pm.const_doubles(), pm.seed, pm.pw_first, stream));
+    lpmp_ok(lpmp_synth_fill(d_dual, pm.n_local * pm.L, pm.seed, pm.un_first, stream));   // ghosts stay 0
+    hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    lpmp_ok(lpmp_create(device, &e));
+    lpmp_ok(lpmp_set_stream(e, stream));
+    const lpmp_model m = pm.view(d_const, d_dual);
+    lpmp_ok(lpmp_upload_model(e, &m, LPMP_MEM_DEVICE, LPMP_MEM_DEVICE));
+    lpmp_ok(lpmp_set_reparametrization(e, mode));
+    // 1. main sweeps: the part's own update lists and weight rows with the ghost factors dropped
+    lpmp_plan* plan = lpmp_engine_plan_mut(e);
+    const int64_t n_vec = pm.n_local + pm.n_ghost;
+    rows fwd = main_rows(plan, LPMP_FORWARD, mode, n_vec), bwd = main_rows(plan, LPMP_BACKWARD, mode, n_vec);
+    sid_f = create(fwd, false); sid_b = create(bwd, false);
+    if (boundary_every_pass) { rows fb = cat(fwd, bwd); sid_fb = create(fb, true); }
+    for (int sid : {sid_f, sid_b}) {
+      int64_t nr = 0, ns = 0;
+      lpmp_ok(lpmp_schedule_info(e, sid, nullptr, nullptr, &nr, &ns, nullptr));
+      updates_per_pass += nr + ns;
+    }
+    // 2. boundary passes on the ghosts: every ghost has exactly one message (side 1 of its cut edge)
+    rows gr, gs;
+    for (int64_t g = pm.n_local; g < n_vec; ++g) {
+      gr.f.push_back((int32_t)g); gr.om.push_back(0.0); gr.mk.push_back(1); gr.om_off.push_back((int64_t)gr.om.size()); gr.mk_off.push_back((int64_t)gr.mk.size());
+      gs.f.push_back((int32_t)g); gs.om.push_back(1.0); gs.mk.push_back(0); gs.om_off.push_back((int64_t)gs.om.size()); gs.mk_off.push_back((int64_t)gs.mk.size());
+    }
+    sid_ghost_recv = create(gr, false); sid_ghost_send = create(gs, false);
+    // 3. boundary arithmetic + exchange plan (doubles per peer part)
+    const int64_t nf = pm.n_factors();
+    std::vector<int64_t> doff((size_t)nf + 1, 0);
+    for (int64_t f = 0; f < nf; ++f) doff[f + 1] = doff[f] + lpmp_factor_dual_size(pm.f_kind[f], pm.f_dim0[f], pm.f_dim1[f]);
+    std::vector<int64_t> out_off, in_off, in_order(pm.in_unary.size());
+    std::vector<int32_t> out_len, in_len;
+    out_count.assign((size_t)pm.n_parts, 0); in_count.assign((size_t)pm.n_parts, 0);
+    for (size_t i = 0; i < pm.out_ghost.size(); ++i) { out_off.push_back(doff[pm.out_ghost[i]]); out_len.push_back(pm.f_dim0[pm.out_ghost[i]]); out_count[pm.out_peer[i]] += out_len.back(); }
+    std::vector<int64_t> k_cut((size_t)nf, 0);
+    for (int32_t u : pm.in_unary) ++k_cut[u];
+    std::vector<double> in_omega;
+    for (size_t i = 0; i < pm.in_unary.size(); ++i) {
+      in_off.push_back(doff[pm.in_unary[i]]); in_len.push_back(pm.f_dim0[pm.in_unary[i]]); in_count[pm.in_peer[i]] += in_len.back();
+      in_omega.push_back(BOUNDARY_SHARE / (double)std::max<int64_t>(k_cut[pm.in_unary[i]], 1));
+    }
+    // a variable with several cut messages receives / sends them in its message-list order: side-1 messages sit in a
+    // LIFO list (reference factors_messages.hxx:2030-2041) => descending global edge id
+    std::iota(in_order.begin(), in_order.end(), 0);
+    std::stable_sort(in_order.begin(), in_order.end(), [&](int64_t a, int64_t b) {
+      return pm.in_unary[a] != pm.in_unary[b] ? pm.in_unary[a] < pm.in_unary[b] : pm.in_key[a] > pm.in_key[b];
+    });
+    lpmp_ok(lpmp_boundary_create(e, (int64_t)out_off.size(), out_off.data(), out_len.data(), (int64_t)in_off.size(), in_off.data(), in_len.data(),
+                                 in_omega.data(), in_order.data(), &bd));
+    n_out = lpmp_boundary_out_doubles(bd); n_in = lpmp_boundary_in_doubles(bd);
+    hip_ok(hipMalloc((void**)&d_send, (size_t)std::max<int64_t>(n_out, 1) * sizeof(double)), "hipMalloc");
+    hip_ok(hipMalloc((void**)&d_back, (size_t)std::max<int64_t>(n_out, 1) * sizeof(double)), "hipMalloc");
+    hip_ok(hipMalloc((void**)&d_recv, (size_t)std::max<int64_t>(n_in, 1) * sizeof(double)), "hipMalloc");
+    hip_ok(hipMalloc((void**)&d_reply, (size_t)std::max<int64_t>(n_in, 1) * sizeof(double)), "hipMalloc");
+    updates_per_pass += 2 * (int64_t)pm.in_unary.size() * (boundary_every_pass ? 1 : 2);
+  }
+  double local_lower_bound() {
+    lpmp_ok(lpmp_invalidate_lower_bounds(e));   // the boundary kernels edit the duals
+    double lb = 0; lpmp_ok(lpmp_lower_bound(e, &lb)); return lb;
+  }
+  std::vector<double> download_duals() {
+    std::vector<double> d((size_t)lpmp_dual_size(e)); lpmp_ok(lpmp_download_duals(e, d.data())); return d;
+  }
+
+ private:
+  struct rows { std::vector<int32_t> f; std::vector<int64_t> om_off{0}, mk_off{0}; std::vector<double> om; std::vector<uint8_t> mk; };
+  rows main_rows(lpmp_plan* plan, int d, int mode, int64_t n_vec) const {
+    const int64_t nu = lpmp_plan_n_updated(plan, d);
+    std::vector<int32_t> upd((size_t)nu);
+    lpmp_ok(lpmp_plan_get_update_order(plan, d, upd.data()));
+    std::vector<int64_t> oo((size_t)nu + 1), mo((size_t)nu + 1);
+    std::vector<double> om((size_t)std::max<int64_t>(lpmp_plan_omega_nnz(plan, d), 1));
+    std::vector<uint8_t> mk((size_t)std::max<int64_t>(lpmp_plan_mask_nnz(plan, d), 1));
+    lpmp_ok(lpmp_plan_get_omega(plan, d, mode, oo.data(), om.data()));
+    lpmp_ok(lpmp_plan_get_mask(plan, d, mode, mo.data(), mk.data()));
+    rows r;
+    for (int64_t i = 0; i < nu; ++i) {
+      if (upd[i] >= pm.n_local && upd[i] < n_vec) continue;   // a ghost: not updated in the main sweeps
+      r.f.push_back(upd[i]);
+      r.om.insert(r.om.end(), om.begin() + oo[i], om.begin() + oo[i + 1]);
+      r.mk.insert(r.mk.end(), mk.begin() + mo[i], mk.begin() + mo[i + 1]);
+      r.om_off.push_back((int64_t)r.om.size()); r.mk_off.push_back((int64_t)r.mk.size());
+    }
+    return r;
+  }
+  static rows cat(const rows& a, const rows& b) {
+    rows r = a;
+    r.f.insert(r.f.end(), b.f.begin(), b.f.end());
+    for (size_t i = 1; i < b.om_off.size(); ++i) r.om_off.push_back((int64_t)a.om.size() + b.om_off[i]);
+    for (size_t i = 1; i < b.mk_off.size(); ++i) r.mk_off.push_back((int64_t)a.mk.size() + b.mk_off[i]);
+    r.om.insert(r.om.end(), b.om.begin(), b.om.end());
+    r.mk.insert(r.mk.end(), b.mk.begin(), b.mk.end());
+    return r;
+  }
+  int create(const rows& r, bool fuse) {
+    int sid = -1;
+    lpmp_ok(lpmp_schedule_create_fused(e, (int64_t)r.f.size(), r.f.data(), r.om_off.data(), r.om.data(), r.mk_off.data(), r.mk.data(), fuse ? 1 : 0, &sid));
+    return sid;
+  }
+};
+
+// One boundary step of all parts of this rank: pack, exchange #1, reply, exchange #2, fold.
+// Transfers are issued in a fixed global order — by (source part, destination part) — so that the k-th send of rank a to
+// rank b meets the k-th receive of b from a.
+inline void exchange(std::vector<part_sweep*>& parts, rccl_world& w, bool first_leg) {
+  const int n_parts = parts.empty() ? 0 : parts[0]->pm.n_parts;
+  nccl_ok(ncclGroupStart(), "ncclGroupStart");
+  for (int src = 0; src < n_parts; ++src)
+    for (int dst = 0; dst < n_parts; ++dst) {
+      const bool src_here = w.rank_of(src) == w.rank, dst_here = w.rank_of(dst) == w.rank;
+      if (!src_here && !dst_here) continue;
+      // leg 1: what src OWNS toward dst (out lists) travels src -> dst; leg 2: dst's replies travel back dst -> src
+      if (first_leg) {
+        if (src_here) { part_sweep& p = *parts[src - w.rank * w.parts_per_rank]; const int64_t c = p.out_count[dst];
+          if (c > 0) { int64_t off = 0; for (int q = 0; q < dst; ++q) off += p.out_count[q]; nccl_ok(ncclSend(p.d_send + off, (size_t)c, ncclDouble, w.rank_of(dst), w.comm, w.stream), "ncclSend"); } }
+        if (dst_here) { part_sweep& p = *parts[dst - w.rank * w.parts_per_rank]; const int64_t c = p.in_count[src];
+          if (c > 0) { int64_t off = 0; for (int q = 0; q < src; ++q) off += p.in_count[q]; nccl_ok(ncclRecv(p.d_recv + off, (size_t)c, ncclDouble, w.rank_of(src), w.comm, w.stream), "ncclRecv"); } }
+      } else {
+        if (dst_here) { part_sweep& p = *parts[dst - w.rank * w.parts_per_rank]; const int64_t c = p.in_count[src];
+          if (c > 0) { int64_t off = 0; for (int q = 0; q < src; ++q) off += p.in_count[q]; nccl_ok(ncclSend(p.d_reply + off, (size_t)c, ncclDouble, w.rank_of(src), w.comm, w.stream), "ncclSend"); } }
+        if (src_here) { part_sweep& p = *parts[src - w.rank * w.parts_per_rank]; const int64_t c = p.out_count[dst];
+          if (c > 0) { int64_t off = 0; for (int q = 0; q < dst; ++q) off += p.out_count[q]; nccl_ok(ncclRecv(p.d_back + off, (size_t)c, ncclDouble, w.rank_of(dst), w.comm, w.stream), "ncclRecv"); } }
+      }
+    }
+  nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+}
+
+inline void boundary_step(std::vector<part_sweep*>& parts, rccl_world& w) {
+  for (part_sweep* p : parts) if (p->pm.n_ghost > 0) { lpmp_ok(lpmp_schedule_run(p->e, p->sid_ghost_recv)); lpmp_ok(lpmp_boundary_pack(p->e, p->bd, p->d_send)); }
+  exchange(parts, w, true);
+  for (part_sweep* p : parts) if (!p->pm.in_unary.empty()) lpmp_ok(lpmp_boundary_reply(p->e, p->bd, p->d_recv, p->d_reply));
+  exchange(parts, w, false);
+  for (part_sweep* p : parts) if (p->pm.n_ghost > 0) { lpmp_ok(lpmp_boundary_fold(p->e, p->bd, p->d_back)); lpmp_ok(lpmp_schedule_run(p->e, p->sid_ghost_send)); }
+}
+
+// n passes.  boundary_every_pass: [forward + backward main sweeps as one fused schedule, boundary step] x n (what bench.py
+// runs on row strips); otherwise [boundary, forward, boundary, backward] x n (PartitionedSweep.program, "sweep")
+inline void compute_pass(std::vector<part_sweep*>& parts, rccl_world& w, int n, bool boundary_every_pass) {
+  for (int i = 0; i < n; ++i) {
+    if (boundary_every_pass) {
+      for (part_sweep* p : parts) lpmp_ok(lpmp_schedule_run(p->e, p->sid_fb));
+      boundary_step(parts, w);
+    } else {
+      boundary_step(parts, w);
+      for (part_sweep* p : parts) lpmp_ok(lpmp_schedule_run(p->e, p->sid_f));
+      boundary_step(parts, w);
+      for (part_sweep* p : parts) lpmp_ok(lpmp_schedule_run(p->e, p->sid_b));
+    }
+  }
+}
+
+inline double lower_bound(std::vector<part_sweep*>& parts, rccl_world& w) {
+  double lb = 0;
+  for (part_sweep* p : parts) lb += p->local_lower_bound();
+  return w.all_reduce_sum(lb);
+}
+
+}  // namespace lpmp_mgpu

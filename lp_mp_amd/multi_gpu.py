@@ -116,12 +116,26 @@ def partition_mrf(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, p
     return parts
 
 
-def graph_local_part(n: int, m: int, L: int, rank: int, world: int, seed: int = 1) -> LocalPart:
+def graph_local_part(n: int, m: int, L: int, rank: int, world: int, seed: int = 1, part: Optional[np.ndarray] = None) -> LocalPart:
     """this rank's part of the C4-style model synthetic.counter_graph_model(n, m, L, seed): structure from the counter
-    generator, partition by graph_partition (identical on every rank), costs generated in this rank's HBM"""
+    generator (every rank derives the same edge list without communication), costs generated in this rank's HBM.
+    ``part``: the variable -> rank map; a multi-process run computes it ONCE on rank 0 and broadcasts it
+    (broadcast_partition); without it every caller runs the partitioner itself (same result, deterministic)."""
     ei, ej = S.counter_graph_edges(n, m, seed)
-    part = graph_partition(n, ei, ej, world) if world > 1 else np.zeros(n, np.int64)
+    if part is None:
+        part = graph_partition(n, ei, ej, world) if world > 1 else np.zeros(n, np.int64)
     return partition_mrf(n, L, ei, ej, part, world, only=rank, stream_seed=seed)[0]
+
+
+def broadcast_partition(torch, dist, n: int, device, compute) -> np.ndarray:
+    """the partition of a multi-process run: rank 0 calls ``compute()`` (minutes of host work at 2 M variables), the others
+    receive the result — one 8 n-byte broadcast instead of N identical partitioner runs"""
+    rank = dist.get_rank()
+    t = torch.from_numpy(np.ascontiguousarray(compute(), np.int64)) if rank == 0 else torch.empty(n, dtype=torch.int64)
+    if dist.get_backend() != "gloo":
+        t = t.to(device)
+    dist.broadcast(t, 0)
+    return t.cpu().numpy()
 
 
 def partition_model(gm: M.FlatModel, part: np.ndarray, world: int) -> List[LocalPart]:
@@ -807,7 +821,10 @@ class GraphSweep:
         dev = torch.device("cuda", torch.cuda.current_device())
         if self.comm:
             self.comm._dev = dev
-        part = graph_local_part(n, m, L, rank, world, seed)
+        part_of = None
+        if self.comm and world > 1:                      # partition once, on rank 0
+            part_of = broadcast_partition(torch, dist, n, dev, lambda: graph_partition(n, *S.counter_graph_edges(n, m, seed), world))
+        part = graph_local_part(n, m, L, rank, world, seed, part_of)
         self.part = part
         mdl = part.model
         stream = torch.cuda.current_stream().cuda_stream

@@ -66,3 +66,20 @@ def test_bench_c4_workload_line():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "msg-updates/s" and d["value"] > 0
     assert "random sparse graph G(20000, 100000)" in d["config"]["workload"] and d["config"]["msg_updates_per_pass"] == 400000
     assert d["dual_bound_gap"] == 0.0 and d["lower_bound_after"] > d["lower_bound_before"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["c3", "c4"])
+def test_bench_distributed_branch_on_rccl_at_world_size_one(workload):
+    """what an N-GPU launch of bench.py executes first, on the one GPU of the test box: --force-dist takes the multi-GPU
+    branch at WORLD_SIZE 1 — init_process_group("nccl") (= RCCL), StripSweep / GraphSweep, all_to_all_single with empty
+    splits in every boundary step, device all_reduce for the bound and the timing — and must print the contract line"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
+    env.pop("LPMP_DIST_BACKEND", None)
+    extra = ["--grid", "128"] if workload == "c3" else ["--workload", "c4", "--c4-nodes", "20000", "--c4-edges", "100000"]
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1",
+                                   "--no-cpu-baseline"] + extra, text=True, cwd=ROOT, timeout=900, env=env)
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["lower_bound_after"] > d["lower_bound_before"]
+    assert abs(d["dual_bound_gap"]) <= 1e-9          # one part: the partitioned schedule IS the unpartitioned sweep
+    assert d["roofline"]["kernel"].startswith(("sweep_dense_pk_kernel", "chain_dense_pk_kernel"))

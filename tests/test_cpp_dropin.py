@@ -63,3 +63,19 @@ def test_cpp_program_full_run_on_device(tmp_path, name):
     exe = _build(tmp_path, name)
     out = subprocess.check_output([exe], text=True, timeout=600)
     assert "all tests passed" in out
+
+
+def test_rccl_driver_builds_links_rccl_and_fails_loudly_without_a_gpu():
+    """tools/mgpu_rccl_driver.cpp: the C++ host of the partitioned sweep (C ABI + <rccl/rccl.h>) compiles in build(), is
+    linked against librccl and liblpmp_engine, and — like every product path — has no CPU fallback"""
+    import torch
+    from lp_mp_amd import build as B
+    exe = B.build_mgpu_driver()
+    src = open(os.path.join(ROOT, "lp_mp_amd", "include", "lpmp_multi_gpu.hxx")).read()
+    assert "#include <rccl/rccl.h>" in src and "ncclGroupStart" in src and "ncclSend" in src and "ncclRecv" in src and "ncclAllReduce" in src
+    needed = subprocess.check_output(["ldd", exe], text=True)
+    assert "librccl" in needed and "liblpmp_engine" in needed
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the run itself is tests/test_multi_gpu.py::test_cpp_rccl_driver_equals_the_python_partitioned_sweep")
+    r = subprocess.run([exe, "--H", "4", "--W", "4", "--L", "4"], capture_output=True, text=True, env=dict(os.environ, RANK="0", WORLD_SIZE="1"))
+    assert r.returncode != 0 and r.stdout.strip() == ""

@@ -886,6 +886,17 @@ def test_c4_shape_mid_size():
         e.close()
 
 
+@pytest.mark.parametrize("pairwise", ["dense", "potts"])
+def test_hub_variable_beyond_the_packet_slab(eng, pairwise):
+    """a variable with more active messages than the packed kernels' LDS slab holds (C4 has a few among 2 M): that record
+    runs on the streaming kernel, every other record of its launch stays packed; duals bit-identical in all weight modes"""
+    from tests.test_plan_host import _hub_model
+    for n_spokes in (40, 70):
+        m = _hub_model(16, n_spokes, pairwise, seed=n_spokes)
+        for mode in MODES:
+            _check(eng, m, mode, 3)
+
+
 def test_c4_full_size_properties():
     """BASELINE.json configs[3] at FULL size on one GPU: random sparse graph, 2 M unaries / 10 M dense 16 x 16 pairwise
     factors (20.5 GB of tables generated in HBM by the per-rank generator bench.py --workload c4 uses, here with one

@@ -400,7 +400,14 @@ from lp_mp_amd import model as M, multi_gpu as MG
 from tests.mgpu_helpers import OracleEngine, materialise_fills
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-part = materialise_fills(MG.graph_local_part({n}, {m}, {L}, rank, world, seed=1))     # this rank's part only
+from lp_mp_amd import synthetic as S
+calls = []
+def partitioner():
+    calls.append(rank)
+    return MG.graph_partition({n}, *S.counter_graph_edges({n}, {m}, 1), world)
+part_of = MG.broadcast_partition(torch, dist, {n}, "cpu", partitioner)                # computed on rank 0 only, broadcast
+assert calls == ([0] if rank == 0 else [])
+part = materialise_fills(MG.graph_local_part({n}, {m}, {L}, rank, world, seed=1, part=part_of))     # this rank's part only
 d = part.model.dual_data.copy()
 sw = MG.PartitionedSweep(torch, part, OracleEngine(part.model, d), torch.from_numpy(d), M.REPAM_ANISOTROPIC, None, "sweep")
 comm = MG.DistComm(dist, torch)
@@ -520,3 +527,43 @@ def test_general_partitioner_on_randomised_models(seed):
     assert all(b >= a - 1e-9 for a, b in zip(lbs, lbs[1:])), (seed, lbs)
     o = global_replay(gm, parts, sweeps, [1, 1, 2])
     assert np.array_equal(gather_global_duals(gm, parts, duals), o.duals()), seed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pairwise,L,order,parts,every", [("dense", 16, "colour_major", 2, "pass"), ("potts", 8, "row_major", 3, "sweep"),
+                                                           ("dense", 32, "colour_major", 3, "sweep")])
+def test_cpp_rccl_driver_equals_the_python_partitioned_sweep(tmp_path, pairwise, L, order, parts, every):
+    """tools/mgpu_rccl_driver.cpp (C++ host: lpmp_multi_gpu.hxx on the C ABI, exchange = ncclSend / ncclRecv in one group,
+    bound = ncclAllReduce) at world 1 with several parts on the one GPU — their cut messages travel through RCCL to self —
+    against lp_mp_amd/multi_gpu.py's lock-stepped PartitionedSweep on the same strips: duals bit-identical part by part"""
+    from lp_mp_amd import build as B, engine as E
+    H, W, passes = 10, 12, 3
+    exe = B.build_mgpu_driver()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LPMP_NCCL_ID_FILE=str(tmp_path / "nccl_id"))
+    out = subprocess.check_output([exe, "--H", str(H), "--W", str(W), "--L", str(L), "--pairwise", pairwise, "--order", order,
+                                   "--passes", str(passes), "--parts-per-rank", str(parts), "--boundary", every,
+                                   "--out", str(tmp_path / "duals")], text=True, env=env, timeout=600)
+    import json
+    line = json.loads(out.strip().splitlines()[-1])
+    dev = torch.device("cuda:0")
+    sweeps, tensors, engines = [], [], []
+    for k in range(parts):
+        p = MG.strip_local_part(H, W, L, pairwise, order, k, parts, 1)
+        dual = torch.from_numpy(p.model.dual_data.copy()).to(dev)
+        eng = E.Engine(0)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual)
+        eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+        sweeps.append(MG.PartitionedSweep(torch, p, eng, dual, M.REPAM_ANISOTROPIC, None, every))
+        tensors.append(dual); engines.append(eng)
+    lb0 = sum(s.local_lower_bound() for s in sweeps)
+    MG.run_lockstep(sweeps, passes)
+    torch.cuda.synchronize()
+    lb1 = sum(s.local_lower_bound() for s in sweeps)
+    for k in range(parts):
+        got = np.fromfile(tmp_path / f"duals.{k}.bin", dtype=np.float64)
+        assert np.array_equal(got, tensors[k].cpu().numpy()), k
+    assert abs(line["lower_bound_before"] - lb0) <= 1e-9 * abs(lb0) and abs(line["lower_bound_after"] - lb1) <= 1e-9 * abs(lb1)
+    assert line["lower_bound_after"] > line["lower_bound_before"]
+    for e in engines:
+        e.close()

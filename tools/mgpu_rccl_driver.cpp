@@ -1,0 +1,102 @@
+// tools/mgpu_rccl_driver.cpp — the partitioned sweep of DESIGN.md 7 driven from a C++ host over the C ABI and RCCL
+// (lp_mp_amd/include/lpmp_multi_gpu.hxx): what INTEGRATION.md 2c describes, as a program.
+//
+// One process per GPU (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT from the environment, as torchrun sets them; without
+// them a single process).  Workload: row strips of a grid MRF — rank r holds parts r*P ... r*P+P-1 (P = --parts-per-rank)
+// of a (n_parts * H) x W grid, costs generated in HBM from the counter stream (the model bench.py --gpus N runs).
+//
+//   mgpu_rccl_driver [--H 64] [--W 64] [--L 8] [--pairwise dense|potts] [--order colour_major|row_major] [--passes 4]
+//                    [--parts-per-rank 1] [--boundary pass|sweep] [--mode 0] [--out PREFIX] [--time K]
+//
+// Prints one JSON line on rank 0 (lower bound before / after, msg-updates/s when --time is given); with --out every part's
+// packed duals go to PREFIX.<part>.bin (tests/test_multi_gpu.py compares them with lp_mp_amd/multi_gpu.py's run).
+// Build: hipcc -std=c++17 -O2 tools/mgpu_rccl_driver.cpp -o build/mgpu_rccl_driver -L lp_mp_amd/csrc -llpmp_engine -lrccl
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../lp_mp_amd/include/lpmp_multi_gpu.hxx"
+
+using namespace lpmp_mgpu;
+
+static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
+
+int main(int argc, char** argv) {
+  int H = 64, W = 64, L = 8, passes = 4, ppr = 1, mode = LPMP_REPAM_ANISOTROPIC, timed = 0;
+  bool potts = false, colour = true, every_pass = true;
+  std::string out;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value after %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
+    if (a == "--H") H = std::atoi(next()); else if (a == "--W") W = std::atoi(next()); else if (a == "--L") L = std::atoi(next());
+    else if (a == "--passes") passes = std::atoi(next()); else if (a == "--parts-per-rank") ppr = std::atoi(next());
+    else if (a == "--mode") mode = std::atoi(next()); else if (a == "--time") timed = std::atoi(next());
+    else if (a == "--pairwise") potts = std::string(next()) == "potts";
+    else if (a == "--order") colour = std::string(next()) == "colour_major";
+    else if (a == "--boundary") every_pass = std::string(next()) == "pass";
+    else if (a == "--out") out = next();
+    else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+  }
+  const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), local_rank = env_int("LOCAL_RANK", rank);
+  try {
+    int n_dev = 0;
+    hip_ok(hipGetDeviceCount(&n_dev), "hipGetDeviceCount");
+    if (n_dev <= 0) throw std::runtime_error("no HIP device: the engine has no CPU path");
+    const int device = local_rank % n_dev;
+    hip_ok(hipSetDevice(device), "hipSetDevice");
+    hipStream_t stream = nullptr;
+    hip_ok(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+    rccl_world w;
+    const char* idf = std::getenv("LPMP_NCCL_ID_FILE");
+    w.init(rank, world, ppr, idf ? idf : "/tmp/lpmp_nccl_id_" + std::to_string(env_int("MASTER_PORT", 29500)), stream);
+
+    const int n_parts = world * ppr;
+    std::vector<std::unique_ptr<part_sweep>> own;
+    std::vector<part_sweep*> parts;
+    for (int k = 0; k < ppr; ++k) {
+      own.emplace_back(new part_sweep());
+      own.back()->build(strip_part(H, W, L, potts, colour, rank * ppr + k, n_parts, 1), device, stream, mode, every_pass);
+      parts.push_back(own.back().get());
+    }
+    const double lb0 = lower_bound(parts, w);
+    compute_pass(parts, w, passes, every_pass);
+    const double lb1 = lower_bound(parts, w);
+    if (!out.empty())
+      for (part_sweep* p : parts) {
+        const std::vector<double> d = p->download_duals();
+        const std::string path = out + "." + std::to_string(p->pm.part) + ".bin";
+        FILE* f = std::fopen(path.c_str(), "wb");
+        if (!f || std::fwrite(d.data(), sizeof(double), d.size(), f) != d.size()) throw std::runtime_error("cannot write " + path);
+        std::fclose(f);
+      }
+    double ms_per_pass = 0, updates = 0;
+    if (timed > 0) {
+      double upd = 0;
+      for (part_sweep* p : parts) upd += (double)p->updates_per_pass;
+      updates = w.all_reduce_sum(upd);
+      (void)w.all_reduce_sum(0.0);                                     // barrier
+      const auto t0 = std::chrono::steady_clock::now();
+      compute_pass(parts, w, timed, every_pass);
+      (void)w.all_reduce_sum(0.0);                                     // every rank's stream drained + barrier
+      ms_per_pass = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
+    }
+    if (rank == 0) {
+      std::printf("{\"driver\": \"mgpu_rccl_driver (C++ host, C ABI + RCCL)\", \"world\": %d, \"parts\": %d, \"grid_per_part\": [%d, %d], \"labels\": %d, "
+                  "\"pairwise\": \"%s\", \"boundary_every\": \"%s\", \"passes\": %d, \"lower_bound_before\": %.17g, \"lower_bound_after\": %.17g",
+                  world, n_parts, H, W, L, potts ? "potts" : "dense", every_pass ? "pass" : "sweep", passes, lb0, lb1);
+      if (timed > 0) std::printf(", \"ms_per_pass\": %.6f, \"msg_updates_per_s\": %.6g", ms_per_pass, updates / (ms_per_pass * 1e-3));
+      std::printf("}\n");
+    }
+    own.clear();
+    w.destroy();
+    (void)hipStreamDestroy(stream);
+  } catch (const std::exception& ex) {
+    std::fprintf(stderr, "mgpu_rccl_driver (rank %d): %s\n", rank, ex.what());
+    return 1;
+  }
+  return 0;
+}
