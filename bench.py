@@ -420,10 +420,18 @@ def main():
         out["row_major"] = {"value": upd2 * args.steps / dt2, "ms_per_step": dt2 / args.steps * 1e3,
                             "levels_per_direction": [i["n_levels"] for i in i2], "lower_bound_after": e2.lower_bound()}
         e2.close()
-    if rank == 0:
-        print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL writes its version banner through C stdio, which a pipe buffers
+        # until exit — flush that first (seen on the GPU box: the banner landed after the line)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

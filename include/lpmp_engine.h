@@ -149,6 +149,25 @@ int lpmp_compute_pass(lpmp_engine* e, int n_passes);        /* LP::ComputePass, 
 /* optional: build ahead of time what lpmp_compute_pass(e, n_passes) needs that depends on n_passes (the ticket order of
  * n joined passes for the chain executor), e.g. outside of a timed region */
 int lpmp_prepare_passes(lpmp_engine* e, int n_passes);
+/* ---- passes that run ahead of the caller --------------------------------------------------------------------------
+ * The reference's Solver asks for ONE pass per iteration and, by default, for the bound after each (Solver::Iterate /
+ * PostIterate, include/solver.hxx:273-284, --lowerBoundComputationInterval 1), while the device is fastest when
+ * consecutive passes are one persistent launch (lpmp_compute_pass(e, n): 5.1 against 6.6 ms per pass on C3).  With
+ * max_passes_ahead >= 2, lpmp_compute_pass(e, 1) may launch up to that many passes at once (after a snapshot of the
+ * duals); the next calls of lpmp_compute_pass(e, 1) only advance a cursor, and lpmp_lower_bound returns the bound after
+ * the pass the caller is AT — the launch leaves one row of per-factor bounds per pass.  Every other call first settles:
+ * if the caller stopped inside a batch, the duals go back to the snapshot and exactly the passes asked for are run again
+ * (n joined passes equal n single ones bit for bit), so results never differ from max_passes_ahead = 0; only time does.
+ * The look-ahead adapts to the caller: it doubles while single passes keep coming and restarts at the length of the
+ * previous run (MpRoundingSolver: four plain passes between two rounding iterations).  Needs a pass whose consecutive
+ * passes join (lpmp_plan_pass_rotates) on an HBM-sized model, send rule `shared`; otherwise every call is executed as it
+ * comes.  Default 0 (off; LPMP_SPECULATION=<n> in the environment sets it for engines created afterwards); the solver
+ * adapters (lpmp_offload.hxx, LP_gpu.hxx, lp.py) switch it on.  Callers that read a BORROWED dual buffer directly
+ * (lpmp_device_duals, LPMP_MEM_DEVICE) call lpmp_synchronize first: it settles.  At most 32. */
+int lpmp_set_speculation(lpmp_engine* e, int max_passes_ahead);
+int lpmp_speculation_stats(lpmp_engine* e, int64_t* batches, int64_t* passes_launched, int64_t* passes_used, int64_t* rollbacks);
+/* device bytes held by the cached ticket lists of joined-pass launches (bounded: LPMP_CHAIN_CACHE_MB, default 2048) */
+int64_t lpmp_chain_cache_bytes(const lpmp_engine* e);
 int lpmp_compute_forward_pass(lpmp_engine* e);              /* LP::ComputeForwardPass, LP_MP.h:889-900 */
 int lpmp_compute_backward_pass(lpmp_engine* e);             /* LP::ComputeBackwardPass, LP_MP.h:902-911 */
 /* LP::ComputePass(factorIt, factorItEnd, omegaIt, receive_it), LP_MP.h:981-1005: any factor list with

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -72,20 +74,25 @@ using namespace lpmp;
 struct lpmp_boundary {
   BVec* d_out = nullptr; int64_t n_out = 0, out_doubles = 0;
   BVar* d_vars = nullptr; BMsg* d_seq = nullptr; int64_t n_vars = 0, in_doubles = 0;
+  ~lpmp_boundary() {
+    if (d_out) (void)hipFree(d_out);
+    if (d_vars) (void)hipFree(d_vars);
+    if (d_seq) (void)hipFree(d_seq);
+  }
 };
 
 extern "C" {
 void* lpmp_engine_stream(lpmp_engine* e);      // engine.cpp
 int lpmp_set_last_error(const char* msg);      // engine.cpp
+int lpmp_boundary_enter(lpmp_engine* e);       // engine.cpp: the engine's device current, speculative passes settled, no aborted chain run behind
 
 #define B_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { lpmp_set_last_error((std::string(#x) + ": " + hipGetErrorString(e_)).c_str()); return LPMP_ERR_DEVICE; } } while (0)
 
-int lpmp_boundary_create(lpmp_engine* e, int64_t n_out, const int64_t* out_dual_off, const int32_t* out_len, int64_t n_in,
-                         const int64_t* in_dual_off, const int32_t* in_len, const double* in_omega, const int64_t* in_order,
-                         lpmp_boundary** out) {
-  if (!e || !out || n_out < 0 || n_in < 0 || (n_out > 0 && (!out_dual_off || !out_len)) ||
-      (n_in > 0 && (!in_dual_off || !in_len || !in_omega || !in_order))) { lpmp_set_last_error("bad argument"); return LPMP_ERR_INVALID; }
-  auto b = new lpmp_boundary();
+// no exception crosses the C boundary (std::vector may throw), nothing leaks on an error path (the handle owns its arrays)
+static int boundary_create(lpmp_engine* e, int64_t n_out, const int64_t* out_dual_off, const int32_t* out_len, int64_t n_in,
+                           const int64_t* in_dual_off, const int32_t* in_len, const double* in_omega, const int64_t* in_order,
+                           lpmp_boundary** out) {
+  std::unique_ptr<lpmp_boundary> b(new lpmp_boundary());
   std::vector<BVec> ov((size_t)n_out);
   int64_t at = 0;
   for (int64_t i = 0; i < n_out; ++i) { ov[i] = {out_dual_off[i], at, out_len[i], 0}; at += out_len[i]; }
@@ -98,10 +105,10 @@ int lpmp_boundary_create(lpmp_engine* e, int64_t n_out, const int64_t* out_dual_
   std::vector<BVar> vars; std::vector<BMsg> seq((size_t)n_in);
   for (int64_t k = 0; k < n_in; ++k) {
     const int64_t m = in_order[k];
-    if (m < 0 || m >= n_in) { delete b; lpmp_set_last_error("boundary: in_order out of range"); return LPMP_ERR_INVALID; }
+    if (m < 0 || m >= n_in) { lpmp_set_last_error("boundary: in_order out of range"); return LPMP_ERR_INVALID; }
     seq[k] = {in_buf[m], in_omega[m]};
     if (vars.empty() || vars.back().dual_off != in_dual_off[m]) vars.push_back({in_dual_off[m], in_len[m], (int32_t)k, 0, 0});
-    if (vars.back().len != in_len[m]) { delete b; lpmp_set_last_error("boundary: messages of one variable differ in length"); return LPMP_ERR_INVALID; }
+    if (vars.back().len != in_len[m]) { lpmp_set_last_error("boundary: messages of one variable differ in length"); return LPMP_ERR_INVALID; }
     vars.back().n++;
   }
   b->n_vars = (int64_t)vars.size();
@@ -112,21 +119,26 @@ int lpmp_boundary_create(lpmp_engine* e, int64_t n_out, const int64_t* out_dual_
     B_TRY(hipMalloc((void**)&b->d_seq, seq.size() * sizeof(BMsg))); B_TRY(hipMemcpyAsync(b->d_seq, seq.data(), seq.size() * sizeof(BMsg), hipMemcpyHostToDevice, s));
   }
   B_TRY(hipStreamSynchronize(s));
-  *out = b;
+  *out = b.release();
   return LPMP_OK;
 }
-void lpmp_boundary_destroy(lpmp_boundary* b) {
-  if (!b) return;
-  if (b->d_out) (void)hipFree(b->d_out);
-  if (b->d_vars) (void)hipFree(b->d_vars);
-  if (b->d_seq) (void)hipFree(b->d_seq);
-  delete b;
+int lpmp_boundary_create(lpmp_engine* e, int64_t n_out, const int64_t* out_dual_off, const int32_t* out_len, int64_t n_in,
+                         const int64_t* in_dual_off, const int32_t* in_len, const double* in_omega, const int64_t* in_order,
+                         lpmp_boundary** out) {
+  if (!e || !out || n_out < 0 || n_in < 0 || (n_out > 0 && (!out_dual_off || !out_len)) ||
+      (n_in > 0 && (!in_dual_off || !in_len || !in_omega || !in_order))) { lpmp_set_last_error("bad argument"); return LPMP_ERR_INVALID; }
+  if (const int rc = lpmp_boundary_enter(e)) return rc;
+  try { return boundary_create(e, n_out, out_dual_off, out_len, n_in, in_dual_off, in_len, in_omega, in_order, out); }
+  catch (const std::bad_alloc&) { lpmp_set_last_error("out of host memory"); return LPMP_ERR_INVALID; }
+  catch (const std::exception& ex) { lpmp_set_last_error(ex.what()); return LPMP_ERR_INVALID; }
 }
+void lpmp_boundary_destroy(lpmp_boundary* b) { delete b; }
 int64_t lpmp_boundary_out_doubles(const lpmp_boundary* b) { return b ? b->out_doubles : 0; }
 int64_t lpmp_boundary_in_doubles(const lpmp_boundary* b) { return b ? b->in_doubles : 0; }
 
 int lpmp_boundary_pack(lpmp_engine* e, lpmp_boundary* b, double* send_dev) {
   if (!e || !b || (b->n_out > 0 && !send_dev)) { lpmp_set_last_error("bad argument"); return LPMP_ERR_INVALID; }
+  if (const int rc = lpmp_boundary_enter(e)) return rc;
   if (b->n_out > 0) hipLaunchKernelGGL(boundary_pack_kernel, dim3((unsigned)((b->n_out + 3) / 4)), dim3(256), 0, (hipStream_t)lpmp_engine_stream(e),
                                        b->d_out, b->n_out, (double*)lpmp_device_duals(e), send_dev);
   B_TRY(hipGetLastError());
@@ -134,6 +146,7 @@ int lpmp_boundary_pack(lpmp_engine* e, lpmp_boundary* b, double* send_dev) {
 }
 int lpmp_boundary_reply(lpmp_engine* e, lpmp_boundary* b, const double* recv_dev, double* reply_dev) {
   if (!e || !b || (b->n_vars > 0 && (!recv_dev || !reply_dev))) { lpmp_set_last_error("bad argument"); return LPMP_ERR_INVALID; }
+  if (const int rc = lpmp_boundary_enter(e)) return rc;
   if (b->n_vars > 0) hipLaunchKernelGGL(boundary_reply_kernel, dim3((unsigned)((b->n_vars + 3) / 4)), dim3(256), 0, (hipStream_t)lpmp_engine_stream(e),
                                         b->d_vars, b->d_seq, b->n_vars, (double*)lpmp_device_duals(e), recv_dev, reply_dev);
   B_TRY(hipGetLastError());
@@ -141,6 +154,7 @@ int lpmp_boundary_reply(lpmp_engine* e, lpmp_boundary* b, const double* recv_dev
 }
 int lpmp_boundary_fold(lpmp_engine* e, lpmp_boundary* b, const double* back_dev) {
   if (!e || !b || (b->n_out > 0 && !back_dev)) { lpmp_set_last_error("bad argument"); return LPMP_ERR_INVALID; }
+  if (const int rc = lpmp_boundary_enter(e)) return rc;
   if (b->n_out > 0) hipLaunchKernelGGL(boundary_fold_kernel, dim3((unsigned)((b->n_out + 3) / 4)), dim3(256), 0, (hipStream_t)lpmp_engine_stream(e),
                                        b->d_out, b->n_out, (double*)lpmp_device_duals(e), back_dev);
   B_TRY(hipGetLastError());

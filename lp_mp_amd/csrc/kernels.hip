@@ -92,6 +92,9 @@ struct ChainArgs {
   int32_t n_tickets;
   int32_t epoch;
   long long* trace;          // debugging (LPMP_CHAIN_TRACE): 8 slots of time stamps per ticket, 100 MHz; nullptr otherwise
+  // joined passes (engine.cpp rotation_chain) with per-pass lower bounds: row r = the tracked bounds of all factors as they
+  // are at the END OF PASS r + 1 of the call; a launch writes into the row its ChainLaunch::hist names (nullptr: no rows)
+  double* lb_hist; int64_t hist_stride;
 };
 // debugging (LPMP_LEVEL_TRACE, engine.cpp): time stamps of the first levels of a level-loop launch, 8 slots per level
 __device__ long long* g_level_trace = nullptr;
@@ -105,7 +108,15 @@ __device__ __forceinline__ void chain_stamp(const ChainArgs& ca, int ticket, int
 }
 // one launch (a level x class range of records) as the chain kernels see it: absolute device pointers, so that tickets of
 // one persistent launch may come from several schedules (the joined passes of lpmp_compute_pass(n), engine.cpp)
+// pad: flags of the level loop (CHAIN_LAUNCH_LABEL_*), or for the joined passes of the dense chain kernel HIST_* | row << 2
 struct ChainLaunch { const Op* packets; const UpdRec* recs; const Op* ops; int64_t count; int32_t stride, pad; };
+// Which tracked bounds of a launch also go to a row of ChainArgs::lb_hist.  n joined passes are H, W, (K, W)^(n-1), T
+// (DESIGN.md 4): the state "after pass i" is never in memory as a whole — K_i holds the last receives of pass i AND the
+// first sends of pass i + 1 — but every factor's bound at that moment is known to exactly one record:
+//   HIST_END  (a W step)  the updated factor's bound at the end of the record (it is not touched again in this pass)
+//   HIST_MID  (a K step)  the updated factor's bound after its receives, before its sends, and the bound of every
+//                         pairwise factor it receives from, right after that receive
+constexpr int HIST_END = 1, HIST_MID = 2;
 constexpr int CHAIN_SPIN_LIMIT = 1 << 22;   // polls of one dependency before giving up (seconds)
 
 // all threads of the workgroup; returns false when the run was aborted
@@ -130,7 +141,16 @@ __device__ __forceinline__ bool chain_wait(const ChainArgs& ca, int ticket) {
   chain_stamp(ca, ticket, 1);                      // predecessors seen
   return s_bad == 0;
 }
-// all threads: every wave drains its stores, then one lane publishes the ticket
+// all threads: every wave drains its stores, then one lane publishes the ticket.
+// MEMORY-MODEL INVARIANT (why relaxed flags suffice, and what must stay true): the hand-over is not a release / acquire
+// pair — at agent scope that would write back and invalidate the whole L2 of the XCD per ticket — but rests on three
+// properties of the accesses themselves: (1) every dual load / store and every tracked-bound store of a chain body is an
+// agent-scope atomic (sc1: stores write through to memory, loads do not hit a possibly stale L2 / L1 line) — enforced by
+// the static_asserts `!CHAIN || A == ACC_COH` in the bodies; (2) a wave's stores have left the CU when its vmcnt reaches
+// 0 (`s_waitcnt vmcnt(0)` below, then the workgroup barrier, then the flag store); (3) the waiting side reads duals only
+// after it has seen the flag (chain_wait returns, then load_own_and_targets).  Data that is NOT accessed this way must
+// not cross tickets: rounded labels (store_label) are written and read by the record of the SAME factor only, pairwise
+// tables and packets are constants.
 __device__ __forceinline__ void chain_publish(const ChainArgs& ca, int ticket) {
   chain_stamp(ca, ticket, 2);                      // body done, stores issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -773,12 +793,13 @@ template <int L, int KMAX, bool VAR, bool NT, int A, bool CHAIN>
 __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
                                               double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
                                               int32_t* __restrict__ primal, int64_t count, int stride, int flags, int64_t block,
-                                              const ChainArgs* ca, int ticket) {
+                                              const ChainArgs* ca, int ticket, double* __restrict__ lbh = nullptr, int hmode = 0) {
+  static_assert(!CHAIN || A == ACC_COH, "chain bodies hand results over through relaxed agent-scope flags: every dual access must be an agent-scope (sc1) access");
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
   constexpr int KS = 4;                          // sends whose target vectors are prefetched / forwarded
   constexpr int NFW = 4;                         // receives whose result can be forwarded in registers
-  constexpr int PIECES = 3 * (1 + pk_indirect_cap(L));   // 16-B pieces of the largest packet / op list
+  constexpr int PIECES = 3 * (1 + pk_dense_cap(L));      // 16-B pieces of the largest packet / op list
   __shared__ double2_t lds_pk[GPB][PIECES];
   __shared__ double lds_mo[GPB][L];
   __shared__ double lds_q[GPB][L];
@@ -983,9 +1004,17 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
 #endif
       }
 #ifndef LPMP_ABLATE_LB_TRACK
-      if (!(FW && defer[j])) {                    // a deferred receive is followed by a send that dirties the peer
-        pb = vec_min<G, L>(pb);
-        if (act && g == 0) st_lb<A>(lb + uni<G>(lop[c + j].peer), pb);
+      {
+        const bool track = !(FW && defer[j]);     // a deferred receive is followed by a send that dirties the peer
+        const bool hist = CHAIN && hmode == HIST_MID;   // ... but its bound at the seam between two passes is this one
+        if (track || hist) {
+          pb = vec_min<G, L>(pb);
+          if (act && g == 0) {
+            const int peer = uni<G>(lop[c + j].peer);
+            if (track) st_lb<A>(lb + peer, pb);
+            if (hist) st_lb<A>(lbh + peer, pb);
+          }
+        }
       }
 #endif
       wave_sync();
@@ -1006,6 +1035,11 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
     const int lab = group_argmin<G, L>(theta, vl, g);
     if (live && g == 0 && (uni<G>(hdr->kind_flags) & UPD_PRIMAL)) store_label(primal, uni<G>(hdr->factor), Lr, lab);
   }
+#ifndef LPMP_ABLATE_LB_TRACK
+  if constexpr (CHAIN) {
+    if (hmode == HIST_MID) { const double mb = vec_min<G, L>(vl ? theta : LPMP_INF); if (live && g == 0) st_lb<A>(lbh + uni<G>(hdr->factor), mb); }
+  }
+#endif
   if (vl && !aborted) {
     const double snap = theta;
     if constexpr (CHAIN) {
@@ -1053,14 +1087,16 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
         }
       }
     }
-    // the remaining sends four at a time: the four target vectors are requested together, then updated in message order
-    // (a record never sends twice into one vector: plan.cpp gives such records an op-by-op class).  One at a time, every
-    // send was a dependent load -> store round trip: a variable of a random graph (C4: ten neighbours on average, up to 30)
-    // spent most of its time in this loop
-    for (int k0 = KS; k0 < n_send; k0 += 4) {
-      double* msk[4]; double cur[4], om[4]; int pr[4];
+    // the remaining sends SC at a time: the target vectors are requested together, then updated in message order (a record
+    // never sends twice into one vector: plan.cpp gives such records an op-by-op class).  One at a time, every send was a
+    // dependent load -> store round trip: a variable of a random graph (C4: ten neighbours on average, up to 30) spent
+    // most of its time in this loop; the first level of C4's sweep (200 000 records that only send, nine messages each) is
+    // bound by exactly this chain (profiles/r03_c4c_launch_rates.txt)
+    constexpr int SC = 8;
+    for (int k0 = KS; k0 < n_send; k0 += SC) {
+      double* msk[SC]; double cur[SC], om[SC]; int pr[SC];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < SC; ++q) {
         msk[q] = own_g; cur[q] = 0.0; om[q] = 0.0; pr[q] = 0;
         if (k0 + q < n_send) {
           const Op& o = lop[n_recv + k0 + q];
@@ -1074,7 +1110,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
         }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < SC; ++q) {
         if (k0 + q < n_send) {
           const double delta = om[q] * snap;
 #ifdef LPMP_ABLATE_SEND_VEC
@@ -1100,7 +1136,13 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
     st_dual<A>(own_g + g, theta);
   }
 #ifndef LPMP_ABLATE_LB_TRACK
-  { const double ob = vec_min<G, L>(vl ? theta : LPMP_INF); if (live && g == 0) st_lb<A>(lb + uni<G>(hdr->factor), ob); }
+  {
+    const double ob = vec_min<G, L>(vl ? theta : LPMP_INF);
+    if (live && g == 0) {
+      st_lb<A>(lb + uni<G>(hdr->factor), ob);
+      if constexpr (CHAIN) { if (hmode == HIST_END) st_lb<A>(lbh + uni<G>(hdr->factor), ob); }
+    }
+  }
 #endif
 }
 
@@ -1145,7 +1187,9 @@ __global__ void __launch_bounds__(256)
 chain_dense_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, double* __restrict__ dual,
                       const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal, int flags) {
   chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
-    dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket);
+    const int hmode = ca.lb_hist ? (ln.pad & 3) : 0;
+    dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket,
+                                                   hmode ? ca.lb_hist + (int64_t)(ln.pad >> 2) * ca.hist_stride : nullptr, hmode);
   });
 }
 
@@ -1455,6 +1499,7 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
                                               double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
                                               int32_t* __restrict__ primal, int64_t count, int stride, int flags, int64_t block,
                                               const ChainArgs* ca, int ticket) {
+  static_assert(!CHAIN || A == ACC_COH, "chain bodies hand results over through relaxed agent-scope flags: every dual access must be an agent-scope (sc1) access");
   constexpr int GPB = 256 / L;
   constexpr int KR = 4, KS = 4;
   constexpr int PIECES = 3 * (1 + pk_indirect_cap(L));
@@ -2199,8 +2244,11 @@ bool launch_sweep_packed(int kclass, const Op* packets, const UpdRec* recs, cons
 // workgroups would only queue behind the running ones).  Returns false for a class without a chain kernel.
 template <class K>
 static unsigned chain_grid(K kernel, int n_tickets, int threads = 256) {
-  static int n_cu = 0;
-  if (n_cu == 0) { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, dev); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+  // compute units of the CURRENT device (a process may hold engines on several devices): cached per ordinal
+  static int n_cu_of[64] = {0};
+  int dev = 0; (void)hipGetDevice(&dev);
+  int& n_cu = n_cu_of[dev >= 0 && dev < 64 ? dev : 0];
+  if (n_cu == 0) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; n_cu = v; }
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
   const long cap = (long)n_cu * per_cu;

@@ -557,7 +557,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     // more ops than the LDS slab of a lane group holds (a hub of a random graph: C4 has a few 30-neighbour variables among
     // 2 M): such a RECORD goes to the op-by-op streaming kernel — left in its class it took its whole launch off the packed
     // kernels (21 of C4's 44 launches per pass ran on sweep_dense_kernel<16>: 5.5 of 12.6 ms, profiles/r03_c4a_*)
-    if (pow && (all_dense[u] || all_potts[u]) && n_recv_of[u] + n_send_of[u] > pk_indirect_cap(d0) && up_any[u]) return KC_DENSE_BIG;
+    if (pow && (all_dense[u] || all_potts[u]) && n_recv_of[u] + n_send_of[u] > (all_dense[u] ? pk_dense_cap(d0) : pk_indirect_cap(d0)) && up_any[u]) return KC_DENSE_BIG;
     if (pow && all_dense[u]) return d0 == 4 ? KC_DENSE_4 : d0 == 8 ? KC_DENSE_8 : d0 == 16 ? KC_DENSE_16 : KC_DENSE_32;
     if (pow && all_potts[u]) return d0 == 4 ? KC_POTTS_4 : d0 == 8 ? KC_POTTS_8 : d0 == 16 ? KC_POTTS_16 : KC_POTTS_32;
     const int w = std::max(d0, max_dim[u]);
@@ -680,7 +680,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       for (int64_t i = lr.begin; i < lr.end && ok; ++i) {
         const UpdRec& r = out.recs[i];
         const Op* o = out.ops.data() + r.op_begin;
-        if (r.n_recv + r.n_send > pk_indirect_cap(kc_width(lr.kclass))) ok = false;
+        if (r.n_recv + r.n_send > pk_class_cap(lr.kclass)) ok = false;
         for (int a = 0; a < r.n_recv && ok; ++a)
           for (int a2 = a + 1; a2 < r.n_recv; ++a2) if (same_vec(o, a, a2)) { ok = false; break; }
         for (int b = r.n_recv; b < r.n_recv + r.n_send && ok; ++b)
@@ -718,7 +718,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     }
     if (dup_recv) continue;                  // only the op-by-op kernels are safe for that: stride stays 0
     if (kmax > PK_MAX_OPS) {                 // too many ops for a packet: indirect mode if they fit the LDS slab
-      if (kmax <= pk_indirect_cap(kc_width(lr.kclass))) lr.stride = -1;
+      if (kmax <= pk_class_cap(lr.kclass)) lr.stride = -1;
       continue;
     }
     lr.stride = 1 + kmax;

@@ -102,6 +102,12 @@ constexpr int PK_MAX_OPS = 8;                 // packets hold at most this many 
 // same kernels in INDIRECT mode (LevelRange::stride < 0): record from recs[], then all its ops from ops[] in one
 // coalesced load — two dependent hops instead of one per op
 constexpr int pk_indirect_cap(int labels) { return labels >= 16 ? 32 : labels >= 8 ? 16 : 8; }
+// the dense classes at 16 labels hold 64 ops: 50 KB of LDS per workgroup of 16 records = three workgroups per CU, the
+// occupancy the dense kernel's registers allow anyway — so the hubs of a random graph of mean degree 10 stay on the packed
+// kernel (as launches of their own on the streaming kernel they cost C4 1.5 of 13.4 ms per pass, profiles/r03_c4b_*).
+// The Potts kernels (more waves per SIMD) keep the smaller slab.
+constexpr int pk_dense_cap(int labels) { return labels == 16 ? 64 : pk_indirect_cap(labels); }
+constexpr int pk_class_cap(int kclass) { return kc_is_dense(kclass) ? pk_dense_cap(kc_width(kclass)) : pk_indirect_cap(kc_width(kclass)); }
 constexpr int32_t UPD_PRELOAD_OK = 1 << 16;   // UpdRec::kind_flags: no send targets a vector a receive writes
 constexpr int32_t UPD_PRIMAL = 1 << 17;       // UpdRec::kind_flags: the factor type has COMPUTE_PRIMAL_SOLUTION
 

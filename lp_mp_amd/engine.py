@@ -51,6 +51,7 @@ EXPORTS = [
     "lpmp_evaluate_primal", "lpmp_download_primal", "lpmp_upload_primal", "lpmp_streaming_access",
     "lpmp_boundary_create", "lpmp_boundary_destroy", "lpmp_boundary_out_doubles", "lpmp_boundary_in_doubles", "lpmp_boundary_pack",
     "lpmp_boundary_reply", "lpmp_boundary_fold", "lpmp_engine_stream", "lpmp_synth_fill_blocks",
+    "lpmp_set_speculation", "lpmp_speculation_stats", "lpmp_chain_cache_bytes",
 ]
 
 
@@ -136,6 +137,10 @@ def lib():
         L.lpmp_reset_kernel_timing.argtypes = [C.c_void_p]
         L.lpmp_get_chain_launches.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.lpmp_prepare_passes.argtypes = [C.c_void_p, C.c_int]
+        L.lpmp_set_speculation.argtypes = [C.c_void_p, C.c_int]
+        L.lpmp_speculation_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.lpmp_chain_cache_bytes.restype = C.c_int64
+        L.lpmp_chain_cache_bytes.argtypes = [C.c_void_p]
         L.lpmp_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]
         L.lpmp_synth_fill_blocks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.lpmp_boundary_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 5
@@ -359,6 +364,18 @@ class Engine:
 
     def compute_pass(self, n: int = 1):
         _chk(self.L.lpmp_compute_pass(self.h, int(n)))
+
+    def set_speculation(self, max_passes_ahead: int):
+        """let compute_pass(1) run up to that many passes ahead of the caller (include/lpmp_engine.h); 0 = off"""
+        _chk(self.L.lpmp_set_speculation(self.h, int(max_passes_ahead)))
+
+    def speculation_stats(self) -> dict:
+        v = [C.c_int64() for _ in range(4)]
+        _chk(self.L.lpmp_speculation_stats(self.h, *[C.addressof(x) for x in v]))
+        return dict(zip(("batches", "passes_launched", "passes_used", "rollbacks"), [x.value for x in v]))
+
+    def chain_cache_bytes(self) -> int:
+        return self.L.lpmp_chain_cache_bytes(self.h)
 
     def prepare_passes(self, n: int):
         """build ahead of time what compute_pass(n) needs that depends on n (outside of a timed region)"""

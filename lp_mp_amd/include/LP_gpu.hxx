@@ -326,6 +326,8 @@ class LP_gpu {
   explicit LP_gpu(int device = 0) : device_(device) {}
   template <class CMD> explicit LP_gpu(CMD&) : device_(0) {}   // LP(TCLAP::CmdLine&) call sites (solver.hxx:57)
   ~LP_gpu() { if (engine_) lpmp_destroy(engine_); }
+  // how many passes the engine may run ahead of the Solve loop (0: every call as it comes; default 16)
+  void set_speculation(int max_passes_ahead) { speculation_ = max_passes_ahead; if (engine_) check(lpmp_set_speculation(engine_, speculation_)); }
   LP_gpu(const LP_gpu&) = delete;
   LP_gpu& operator=(const LP_gpu&) = delete;
 
@@ -533,7 +535,7 @@ class LP_gpu {
 
   void ready() {
     if (f_.size() <= 1) throw std::runtime_error("LP needs more than one factor");   // reference assert LP_MP.h:708
-    if (!engine_) check(lpmp_create(device_, &engine_));
+    if (!engine_) { check(lpmp_create(device_, &engine_)); check(lpmp_set_speculation(engine_, speculation_)); }   // passes may run ahead of the Solve loop (include/lpmp_engine.h)
     if (!dirty_) { check(lpmp_set_inner_iterations(engine_, inner_)); check(lpmp_set_reparametrization_type(engine_, rtype_)); return; }
     Flat fl;
     for (INDEX i = 0; i < f_.size(); ++i) (this->*flatteners_[i])(f_[i].get(), fl);
@@ -574,6 +576,7 @@ class LP_gpu {
   }
 
   int device_;
+  int speculation_ = 16;
   lpmp_engine* engine_ = nullptr;
   bool dirty_ = true, duals_on_device_ = false;
   int rtype_ = LPMP_RTYPE_SHARED, inner_ = 5;

@@ -353,6 +353,8 @@ class offloaded : public LP_BASE {
   offloaded& operator=(const offloaded&) = delete;
 
   void set_device(int device) { device_ = device; }
+  // how many passes the engine may run ahead of the Solve loop (0: every call as it comes; default 16)
+  void set_speculation(int max_passes_ahead) { speculation_ = max_passes_ahead; if (engine_) check(lpmp_set_speculation(engine_, speculation_)); }
   lpmp_engine* engine() { sync_to_device(); return engine_; }
 
   void ComputePass(const std::size_t /*iteration*/) { ready_mode(); check(lpmp_compute_pass(engine_, 1)); device_ahead_ = true; }
@@ -407,7 +409,12 @@ class offloaded : public LP_BASE {
   }
   void sync_to_device() {
     if (this->f_.size() <= 1) throw std::runtime_error("LP needs more than one factor");   // reference assert, LP_MP.h:708
-    if (!engine_) check(lpmp_create(device_, &engine_));
+    if (!engine_) {
+      check(lpmp_create(device_, &engine_));
+      // the reference's Solver asks for ONE pass per iteration and the bound after each (solver.hxx:273-284): let the engine
+      // run the coming passes as one launch and hand out each pass's own bound (include/lpmp_engine.h); results unchanged
+      check(lpmp_set_speculation(engine_, speculation_));
+    }
     if (uploaded_ && signature() == signature_ && this->constant_ == model_.constant) return;
     sync_to_host();                                   // duals of the factors that already existed
     flatten();
@@ -433,7 +440,7 @@ class offloaded : public LP_BASE {
     check(lpmp_set_reparametrization(engine_, mode));
   }
 
-  int device_ = 0;
+  int device_ = 0, speculation_ = 16;
   lpmp_engine* engine_ = nullptr;
   bool uploaded_ = false, device_ahead_ = false;
   std::array<std::size_t, 5> signature_{};

@@ -167,9 +167,11 @@ class LP:
 
     REPARAMETRIZATION_TYPES = {"shared": 0, "residual": 1, "partition": 2, "overlapping_partition": 3, "adaptive": 4}
 
-    def __init__(self, fmc: FMC, device: int = 0, reparametrizationType: str = "shared", innerIteration: int = 5):
+    def __init__(self, fmc: FMC, device: int = 0, reparametrizationType: str = "shared", innerIteration: int = 5, speculation: int = 16):
         """reparametrizationType / innerIteration: the reference's --reparametrizationType and --innerIteration
-        (LP_MP.h:589-593); all five types run on the device."""
+        (LP_MP.h:589-593); all five types run on the device.  speculation: how many passes the engine may run ahead of a
+        Solve loop that asks for one pass and one bound per iteration (Engine.set_speculation; results unchanged)."""
+        self._speculation = int(speculation)
         if reparametrizationType not in self.REPARAMETRIZATION_TYPES:
             raise RuntimeError("reparametrization type " + reparametrizationType + " unknown")
         self._rtype = self.REPARAMETRIZATION_TYPES[reparametrizationType]
@@ -289,6 +291,7 @@ class LP:
             raise RuntimeError("LP needs more than one factor")           # reference assert, LP_MP.h:708
         if self._engine is None:
             self._engine = Engine(self._device)
+            self._engine.set_speculation(self._speculation)
         if self._dirty:
             self._model = self.flat_model()
             self._engine.upload(self._model)

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_multi_gpu.py -x -q -m gpu -k "cpp_rccl" 2>&1 | tail -15
-for v in base notab norv nosv novec nolb nored; do
-  if [ $v = base ]; then unset LPMP_ENGINE_SO; else export LPMP_ENGINE_SO=$PWD/build/exp/liblpmp_engine_$v.so; fi
-  echo "== $v"; timeout 600 python tools/c4_probe.py 2000000 10000000 16 20 2>&1 | grep -E "ms/pass|Error|error" 
-done
+python -m pytest tests -x -q -m gpu 2>&1 | tail -8
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03a_bench_driver_command.log 2>&1
+grep -h '^{"metric"' gpurun_out/r03a_bench_driver_command.log | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(json.dumps({k:d[k] for k in ('value','ms_per_step','oracle_check','setup_s','roofline','cpu_baseline')}, indent=1))"

@@ -1,0 +1,129 @@
+// tools/offload_solver_loop.cpp — what the reference's UNMODIFIED Solve loop costs per iteration through the off-load adapter.
+//
+// A reference-shaped LP<FMC> (tests/cpp/mock_reference_lp.hxx: the reference's member names and container surface) holding a
+// grid MRF is wrapped in lpmp_offload::offloaded<> and driven exactly the way Solver::Solve drives an LP (reference
+// include/solver.hxx:238-243, :268-284): per iteration  set_reparametrization(mode); ComputePass(iter); lb = LowerBound();
+// The adapter lets the engine run passes ahead of the loop (lpmp_set_speculation); the loop is run with that on and off and
+// the two bound histories are compared (they must be identical).
+//
+//   offload_solver_loop [--grid 512] [--labels 32] [--iterations 60] [--warm 24]
+// Build: g++ -std=c++17 -O2 -I lp_mp_amd/include -I tests/cpp tools/offload_solver_loop.cpp -L lp_mp_amd/csrc -llpmp_engine -Wl,-rpath,$PWD/lp_mp_amd/csrc
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "mock_reference_lp.hxx"
+#include "lpmp_offload.hxx"
+
+namespace user {
+using LP_MP::REAL; using LP_MP::INDEX;
+struct Unary {
+  explicit Unary(const std::vector<REAL>& c_) : c(c_) {}
+  REAL LowerBound() const { return *std::min_element(c.begin(), c.end()); }
+  template <class ARCHIVE> void serialize_dual(ARCHIVE& ar) { ar(c); }
+  std::vector<REAL> c;
+};
+struct Pairwise {
+  Pairwise(INDEX a, INDEX b) : d1(a), d2(b), pw(a * b, 0.0), m1(a, 0.0), m2(b, 0.0) {}
+  REAL LowerBound() const { return 0; }
+  template <class ARCHIVE> void serialize_dual(ARCHIVE& ar) { ar(m1, m2); }
+  INDEX d1, d2; std::vector<REAL> pw, m1, m2;
+};
+template <LP_MP::Chirality C> struct UPMsg {};
+}  // namespace user
+namespace lpmp_offload {
+template <> struct device_kind<user::Unary> : vector_kind<> {};
+template <> struct device_kind<user::Pairwise> : pairwise_dense_kind<user::Pairwise> {
+  static std::size_t dim1(const user::Pairwise& f) { return f.d1; }
+  static std::size_t dim2(const user::Pairwise& f) { return f.d2; }
+  static double table(const user::Pairwise& f, std::size_t a, std::size_t b) { return f.pw[a * f.d2 + b]; }
+};
+template <LP_MP::Chirality C> struct device_message<user::UPMsg<C>> : unary_pairwise_message<C == LP_MP::Chirality::left ? 0 : 1> {};
+}  // namespace lpmp_offload
+struct FMC_MRF {
+  using U = LP_MP::FactorContainer<user::Unary, FMC_MRF, 0, true>;
+  using P = LP_MP::FactorContainer<user::Pairwise, FMC_MRF, 1>;
+  using ML = LP_MP::MessageContainer<user::UPMsg<LP_MP::Chirality::left>, 0, 1, LP_MP::message_passing_schedule::left, LP_MP::variableMessageNumber, 1, FMC_MRF, 0>;
+  using MR = LP_MP::MessageContainer<user::UPMsg<LP_MP::Chirality::right>, 0, 1, LP_MP::message_passing_schedule::left, LP_MP::variableMessageNumber, 1, FMC_MRF, 1>;
+  using FactorList = LP_MP::meta::list<U, P>;
+  using MessageList = LP_MP::meta::list<ML, MR>;
+};
+
+static double u01(uint64_t& st) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; return (double)(st >> 11) / 9007199254740992.0; }
+
+int main(int argc, char** argv) {
+  int G = 512, L = 32, iters = 60, warm = 24;
+  for (int i = 1; i + 1 < argc; i += 2) {
+    const std::string a = argv[i];
+    if (a == "--grid") G = std::atoi(argv[i + 1]); else if (a == "--labels") L = std::atoi(argv[i + 1]);
+    else if (a == "--iterations") iters = std::atoi(argv[i + 1]); else if (a == "--warm") warm = std::atoi(argv[i + 1]);
+  }
+  try {
+    using LP_device = lpmp_offload::offloaded<LP_MP::LP<FMC_MRF>>;
+    LP_MP::mock_cmd_line cmd;
+    LP_device lp(cmd);
+    // colour-major variable order (black cells first): the order whose consecutive passes join
+    std::vector<int> pos((size_t)G * G);
+    { int b = 0, w = (G * G + 1) / 2; for (int r = 0; r < G; ++r) for (int c = 0; c < G; ++c) pos[(size_t)r * G + c] = ((r + c) & 1) == 0 ? b++ : w++; }
+    std::vector<int> cell_of((size_t)G * G);
+    for (int i = 0; i < G * G; ++i) cell_of[pos[i]] = i;
+    std::vector<FMC_MRF::U*> u((size_t)G * G);
+    uint64_t st = 42;
+    std::vector<double> c((size_t)L);
+    for (int k = 0; k < G * G; ++k) { for (auto& x : c) x = u01(st); u[(size_t)cell_of[k]] = lp.add_factor<FMC_MRF::U>(c); }
+    auto edge = [&](int a, int b) {
+      if (pos[a] > pos[b]) std::swap(a, b);
+      auto* p = lp.add_factor<FMC_MRF::P>((LP_MP::INDEX)L, (LP_MP::INDEX)L);
+      for (auto& x : p->GetFactor()->pw) x = u01(st);
+      lp.add_message<FMC_MRF::ML>(u[a], p); lp.add_message<FMC_MRF::MR>(u[b], p);
+      lp.AddFactorRelation(u[a], p); lp.AddFactorRelation(p, u[b]);
+    };
+    for (int r = 0; r < G; ++r) for (int cc = 0; cc < G; ++cc) {
+      if (cc + 1 < G) edge(r * G + cc, r * G + cc + 1);
+      if (r + 1 < G) edge(r * G + cc, (r + 1) * G + cc);
+    }
+    lp.Begin();
+    auto run = [&](int n, std::vector<double>* hist) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int it = 0; it < n; ++it) {                       // Solver::Solve: PreIterate, Iterate, PostIterate (computeLowerBound)
+        lp.set_reparametrization(LP_MP::LPReparametrizationMode::Anisotropic);
+        lp.ComputePass((std::size_t)it);
+        const double lb = lp.LowerBound();
+        if (hist) hist->push_back(lb);
+      }
+      return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n;
+    };
+    // the same duals for both runs: remember the start, restore it in between
+    lp.set_reparametrization(LP_MP::LPReparametrizationMode::Anisotropic);
+    const double lb0 = lp.LowerBound();
+    lpmp_engine* e = lp.engine();
+    std::vector<double> start((size_t)lpmp_dual_size(e));
+    lpmp_offload::check(lpmp_download_duals(e, start.data()));
+    double ms[2]; std::vector<double> hist[2]; int64_t stats[2][4];
+    for (int k = 0; k < 2; ++k) {
+      lp.set_speculation(k == 0 ? 0 : 16);
+      lpmp_offload::check(lpmp_upload_duals(e, start.data()));
+      (void)lp.LowerBound();
+      run(warm, &hist[k]);                                   // builds the ticket lists of the batch sizes, warms the clocks
+      ms[k] = run(iters, &hist[k]);
+      lpmp_offload::check(lpmp_speculation_stats(e, &stats[k][0], &stats[k][1], &stats[k][2], &stats[k][3]));
+    }
+    const bool same = hist[0] == hist[1];
+    std::printf("{\"tool\": \"offload_solver_loop\", \"grid\": %d, \"labels\": %d, \"iterations\": %d, \"lower_bound_start\": %.17g, \"lower_bound_end\": %.17g, "
+                "\"ms_per_iteration_every_call_as_it_comes\": %.4f, \"ms_per_iteration_passes_running_ahead\": %.4f, "
+                "\"bound_history_identical\": %s, \"batches\": %lld, \"passes_launched\": %lld, \"passes_used\": %lld, \"rollbacks\": %lld}\n",
+                G, L, iters, lb0, hist[1].back(), ms[0], ms[1], same ? "true" : "false",
+                (long long)(stats[1][0] - stats[0][0]), (long long)(stats[1][1] - stats[0][1]), (long long)(stats[1][2] - stats[0][2]), (long long)(stats[1][3] - stats[0][3]));
+    lp.End();
+    return same ? 0 : 1;
+  } catch (const std::exception& ex) {
+    std::fprintf(stderr, "offload_solver_loop: %s\n", ex.what());
+    return 2;
+  }
+}
