@@ -103,6 +103,10 @@ __device__ __forceinline__ void level_stamp(int slot) {
   long long* p = g_level_trace;
   if (p && threadIdx.x == 0) { const long long l = p[0]; if (l < LEVEL_TRACE_MAX) p[8 + 8 * l + slot] = (long long)__builtin_amdgcn_s_memrealtime(); }
 }
+__device__ __forceinline__ void level_stamp_of(int slot, int tid) {   // the same from another thread (the wave that runs ahead: slots 6, 7)
+  long long* p = g_level_trace;
+  if (p && (int)threadIdx.x == tid) { const long long l = p[0]; if (l < LEVEL_TRACE_MAX) p[8 + 8 * l + slot] = (long long)__builtin_amdgcn_s_memrealtime(); }
+}
 __device__ __forceinline__ void chain_stamp(const ChainArgs& ca, int ticket, int k) {
   if (ca.trace && threadIdx.x == 0) ca.trace[8 * (int64_t)ticket + k] = (long long)__builtin_amdgcn_s_memrealtime();
 }
@@ -1226,24 +1230,43 @@ constexpr int CHAIN_LAUNCH_LABEL_OPS_DEV = 1, CHAIN_LAUNCH_LABEL_PAIRED_DEV = 2;
 // take one record: lane j computes op j, the deltas meet in LDS and are added to the factor's vector in op order
 // (same additions, same order as the sequential form: bit-identical), two rounds — the receives, then the sends —
 // instead of n_recv + n_send.
-template <int A, bool PAIRED>
+// A level of the level loop staged in LDS by the wave that runs ahead (level_loop_kernel<1>): the records, their ops and
+// the match tables of their labeling messages — everything CONSTANT a level needs.  Read from the L2 they are a chain of
+// three dependent round trips (launch -> record -> op -> table) in front of the one that matters (the peers' costs); of the
+// ~5 round trips a level of C5's local triples took (5.4 us, 64 ms per pass) they were more than half.
+constexpr int LL_STAGE_RECS = 16, LL_STAGE_OPS = 16, LL_RING = 4;
+struct alignas(16) StagedLevel {
+  UpdRec recs[LL_STAGE_RECS];
+  Op ops[LL_STAGE_RECS][LL_STAGE_OPS];
+  int32_t tab[LL_STAGE_RECS][LL_STAGE_OPS][SMALL_MAXD];
+  const Op* ops_base;   // the launch's op array (for the stage that copies the ops)
+  int32_t count;        // records staged, or -1: this level is read from memory (not a labeling-list launch, or too large)
+  int32_t pad[1];
+};
+template <int A, bool PAIRED, bool STAGED = false>
 __device__ __forceinline__ void label_ops_body(const ChainLaunch& ln, int64_t first, double* __restrict__ dual, const int32_t* __restrict__ tabs,
-                                               double* __restrict__ lb, double (*D)[8][8], double (*S)[8]) {
+                                               double* __restrict__ lb, double (*D)[8][8], double (*S)[8], const StagedLevel* st = nullptr) {
   const int lane = threadIdx.x & 63, q = lane >> 3, j = lane & 7;
   const int64_t idx = first + q;
   const bool live = idx < ln.count;
   UpdRec rec;
-  if (live) rec = ln.recs[idx]; else { rec.n_recv = 0; rec.n_send = 0; rec.d0 = 0; rec.dual_off = 0; rec.op_begin = 0; rec.factor = 0; }
+  if (live) { if constexpr (STAGED) rec = st->recs[idx]; else rec = ln.recs[idx]; }
+  else { rec.n_recv = 0; rec.n_send = 0; rec.d0 = 0; rec.dual_off = 0; rec.op_begin = 0; rec.factor = 0; }
   const int n_recv = rec.n_recv, n_send = rec.n_send, on = rec.d0;
   double* own_g = dual + rec.dual_off;
   double theta = (live && j < on) ? ld_dual<A>(own_g + j) : 0.0;      // lane j of the group holds element j
   // one op of this lane: its record, match table and the peer's costs; entries beyond the peer's size count as no match
   auto load_op = [&](bool has, int k, Op& o, int (&tv)[SMALL_MAXD], double (&R)[SMALL_MAXD]) {
-    if (has) o = ln.ops[rec.op_begin + k]; else { o.peer_dual = 0; o.peer_const = 0; o.omega = 0.0; o.info = 0; o.pd0 = 0; o.pd1 = 0; o.peer = 0; o.len = 0; }
+    if (has) { if constexpr (STAGED) o = st->ops[idx][k]; else o = ln.ops[rec.op_begin + k]; }
+    else { o.peer_dual = 0; o.peer_const = 0; o.omega = 0.0; o.info = 0; o.pd0 = 0; o.pd1 = 0; o.peer = 0; o.len = 0; }
     const double* peer = dual + o.peer_dual;
     const int32_t* tab = tabs + o.peer_const;
 #pragma unroll
-    for (int r = 0; r < SMALL_MAXD; ++r) { const bool in = has && r < o.pd0; tv[r] = in ? tab[r] : o.pd1; R[r] = in ? ld_dual<A>(peer + r) : LPMP_INF; }
+    for (int r = 0; r < SMALL_MAXD; ++r) {
+      const bool in = has && r < o.pd0;
+      if constexpr (STAGED) tv[r] = in ? st->tab[idx][k][r] : o.pd1; else tv[r] = in ? tab[r] : o.pd1;
+      R[r] = in ? ld_dual<A>(peer + r) : LPMP_INF;
+    }
   };
   if constexpr (PAIRED) {
     // every message of the record is received and then sent (send j goes where receive j came from): the peer's costs
@@ -1251,7 +1274,8 @@ __device__ __forceinline__ void label_ops_body(const ChainLaunch& ln, int64_t fi
     const bool act = live && j < n_recv;
     Op o; int tv[SMALL_MAXD]; double R[SMALL_MAXD];
     load_op(act, j, o, tv, R);
-    const double omega_send = act ? ln.ops[rec.op_begin + n_recv + j].omega : 0.0;
+    double omega_send = 0.0;
+    if (act) { if constexpr (STAGED) omega_send = st->ops[idx][n_recv + j].omega; else omega_send = ln.ops[rec.op_begin + n_recv + j].omega; }
     const int nl = o.pd1;
     if (act) {
       st_lb<A>(lb + o.peer, LPMP_NAN);
@@ -1278,10 +1302,17 @@ __device__ __forceinline__ void label_ops_body(const ChainLaunch& ln, int64_t fi
       for (int r = 0; r < SMALL_MAXD; ++r) if (r < o.pd0 && tv[r] < nl) st_dual<A>(peer + r, R[r] + +1.0 * D[q][j][tv[r]]);
     }
   } else {
+  // the host marks the records none of whose sends goes to a peer one of its receives rewrites (UPD_PRELOAD_OK, plan.cpp);
+  // where every record of this wave's eight is one, lane j requests the costs of ITS send's peer together with those of its receive's
+  // peer — one round trip instead of two — and the stores of the receives need not be drained before the sends
+  bool pre = false;
+  if constexpr (STAGED) pre = __all(!live || (rec.kind_flags & UPD_PRELOAD_OK) != 0) != 0;
+  Op o2; int tv2[SMALL_MAXD]; double R2[SMALL_MAXD];
   {   // round 1: the receives, lane j = receive j
     const bool recv = live && j < n_recv;
     Op o; int tv[SMALL_MAXD]; double R[SMALL_MAXD];
     load_op(recv, j, o, tv, R);
+    if (pre) load_op(live && j < n_send, n_recv + j, o2, tv2, R2);
     if (recv) {
       const int nl = o.pd1;
       double* peer = dual + o.peer_dual;
@@ -1299,24 +1330,102 @@ __device__ __forceinline__ void label_ops_body(const ChainLaunch& ln, int64_t fi
       for (int r = 0; r < SMALL_MAXD; ++r) if (r < o.pd0 && tv[r] < nl) st_dual<A>(peer + r, R[r] + -1.0 * D[q][j][tv[r]]);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a send of this record may go to the peer a receive has just rewritten
+  if constexpr (STAGED) { if (first == 0) level_stamp(pre ? 1 : 2); }      // (tools/level_trace.py: receives issued; slot 1 when the sends' peers came along)
+  if (!pre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a send of this record may go to the peer a receive has just rewritten
   wave_sync();
   for (int k = 0; k < n_recv; ++k) if (j < on) theta += +1.0 * D[q][k][j];   // own(i) += +1.0 * dl(i), receive by receive
   if (live && j < on) S[q][j] = theta;                                        // the state every send starts from
   wave_sync();
   {   // round 2: the sends, lane j = send j
     const bool send = live && j < n_send;
-    Op o; int tv[SMALL_MAXD]; double R[SMALL_MAXD];
-    load_op(send, n_recv + j, o, tv, R);
+    if (!pre) load_op(send, n_recv + j, o2, tv2, R2);
     if (send) {
-      const int nl = o.pd1;
-      double* peer = dual + o.peer_dual;
-      st_lb<A>(lb + o.peer, LPMP_NAN);
-      for (int l = 0; l < o.len; ++l) D[q][j][l] = o.omega * S[q][l];
+      const int nl = o2.pd1;
+      double* peer = dual + o2.peer_dual;
+      st_lb<A>(lb + o2.peer, LPMP_NAN);
+      for (int l = 0; l < o2.len; ++l) D[q][j][l] = o2.omega * S[q][l];
 #pragma unroll
-      for (int r = 0; r < SMALL_MAXD; ++r) if (r < o.pd0 && tv[r] < nl) st_dual<A>(peer + r, R[r] + +1.0 * D[q][j][tv[r]]);
+      for (int r = 0; r < SMALL_MAXD; ++r) if (r < o2.pd0 && tv2[r] < nl) st_dual<A>(peer + r, R2[r] + +1.0 * D[q][j][tv2[r]]);
     }
   }
+  }
+  wave_sync();
+  for (int k = 0; k < n_send; ++k) if (j < on) theta += -1.0 * D[q][k][j];   // own(i) += -1.0 * dl(i), send by send
+  if (live && j == 0) st_lb<A>(lb + rec.factor, LPMP_NAN);
+  if (live && j < on) st_dual<A>(own_g + j, theta);
+}
+
+// The staged form of the general (not PAIRED) case.  Records, ops and match tables come from LDS (StagedLevel), so the only
+// round trip in front of the arithmetic is the peers' costs — and the sends need none of their own: a send either goes to
+// a peer NO receive of the record touches (its costs are requested together with the receives': nothing in the level writes
+// them), or to the peer of one of the record's receives (the host marks the pair: Op::pad of the send = receive index + 1,
+// of the receive = 1), and then the receive's lane hands the rewritten costs over in LDS instead of storing them — the send
+// stores the final values.  One round trip per level instead of two, no drain between the rounds.  Same additions in the
+// same order as label_ops_body (bit-identical).
+template <int A>
+__device__ __forceinline__ void label_ops_body_staged(const StagedLevel& st, int64_t first, double* __restrict__ dual, double* __restrict__ lb,
+                                                      double (*D)[8][8], double (*S)[8], double (*RS)[8][8]) {
+  const int lane = threadIdx.x & 63, q = lane >> 3, j = lane & 7;
+  const int64_t idx = first + q;
+  const bool live = idx < st.count;
+  const UpdRec& rec = st.recs[live ? idx : 0];
+  const int n_recv = live ? rec.n_recv : 0, n_send = live ? rec.n_send : 0, on = live ? rec.d0 : 0;
+  double* own_g = dual + (live ? rec.dual_off : 0);
+  double theta = (live && j < on) ? ld_dual<A>(own_g + j) : 0.0;
+  const bool recv = live && j < n_recv, send = live && j < n_send;
+  Op o, o2;
+  o.peer_dual = 0; o.peer_const = 0; o.omega = 0.0; o.info = 0; o.pd0 = 0; o.pd1 = 0; o.peer = 0; o.len = 0; o.pad = 0; o2 = o;
+  if (recv) o = st.ops[idx][j];
+  if (send) o2 = st.ops[idx][n_recv + j];
+  int tv[SMALL_MAXD], tv2[SMALL_MAXD]; double R[SMALL_MAXD], R2[SMALL_MAXD];
+  const int fw = send ? o2.pad : 0;
+  double* peer = dual + o.peer_dual; double* peer2 = dual + o2.peer_dual;
+#pragma unroll
+  for (int r = 0; r < SMALL_MAXD; ++r) {
+    const bool in = recv && r < o.pd0, in2 = send && r < o2.pd0;
+    tv[r] = in ? st.tab[idx][j][r] : o.pd1;
+    tv2[r] = in2 ? st.tab[idx][n_recv + j][r] : o2.pd1;
+    R[r] = in ? ld_dual<A>(peer + r) : LPMP_INF;
+    R2[r] = (in2 && fw == 0) ? ld_dual<A>(peer2 + r) : LPMP_INF;
+  }
+  if (g_level_trace && first == 0) { asm volatile("" :: "v"(R[0]), "v"(R2[0]), "v"(theta)); level_stamp(1); }   // costs landed
+  if (recv) {
+    const int nl = o.pd1;
+    st_lb<A>(lb + o.peer, LPMP_NAN);
+    double nt = ((o.info >> 6) & 1) ? 0.0 : LPMP_INF;
+#pragma unroll
+    for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] >= nl) nt = fmin(nt, R[r]);
+    for (int l = 0; l < nl; ++l) {
+      double v = LPMP_INF;
+#pragma unroll
+      for (int r = 0; r < SMALL_MAXD; ++r) if (tv[r] == l) v = fmin(v, R[r]);
+      D[q][j][l] = o.omega * (v - nt);
+    }
+#pragma unroll
+    for (int r = 0; r < SMALL_MAXD; ++r) {
+      if (r < o.pd0) {
+        const double nv = tv[r] < nl ? R[r] + -1.0 * D[q][j][tv[r]] : R[r];
+        if (o.pad) RS[q][j][r] = nv;                       // a send of this record takes it from here
+        else if (tv[r] < nl) st_dual<A>(peer + r, nv);
+      }
+    }
+  }
+  wave_sync();
+  if (first == 0) level_stamp(2);                                             // receives done
+  for (int k = 0; k < n_recv; ++k) if (j < on) theta += +1.0 * D[q][k][j];   // own(i) += +1.0 * dl(i), receive by receive
+  if (live && j < on) S[q][j] = theta;                                        // the state every send starts from
+  wave_sync();
+  if (send) {
+    const int nl = o2.pd1;
+    st_lb<A>(lb + o2.peer, LPMP_NAN);
+    for (int l = 0; l < o2.len; ++l) D[q][j][l] = o2.omega * S[q][l];
+#pragma unroll
+    for (int r = 0; r < SMALL_MAXD; ++r) {
+      if (r < o2.pd0 && tv2[r] < nl) {
+        const double cur = fw > 0 ? RS[q][fw - 1][r] : R2[r];
+        st_dual<A>(peer2 + r, cur + +1.0 * D[q][j][tv2[r]]);
+      }
+    }
   }
   wave_sync();
   for (int k = 0; k < n_send; ++k) if (j < on) theta += -1.0 * D[q][k][j];   // own(i) += -1.0 * dl(i), send by send
@@ -1332,15 +1441,100 @@ level_loop_kernel(const ChainLaunch* __restrict__ launches, int n_launches, doub
   if constexpr (G == 1) {
     __shared__ double D[LL_WAVES][8][8][8];
     __shared__ double S[LL_WAVES][8][8];
+    __shared__ StagedLevel ring[LL_RING];
+    __shared__ double RS[LL_WAVES][8][8][8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool plain_rule = !(flags & (SWEEP_RESIDUAL | SWEEP_ADAPTIVE | SWEEP_PRIMAL));
+    // The staging pipeline of the wave that runs ahead, one stage per level and iteration (each stage's loads depend on what
+    // the previous stage left in LDS an iteration earlier, so an iteration issues all of them at once: one round trip):
+    //   iteration l:  records of level l + 3  ->  ops of level l + 2  ->  match tables of level l + 1   (slot = level % LL_RING)
+    // and the computing waves read level l from its slot.  stage(a, what) is also run for the first levels before the loop.
+    // One iteration of the pipeline for the levels (ar, ao, at) = (l + 3, l + 2, l + 1): ALL loads are issued before anything
+    // is written to LDS — three batches of independent loads, one round trip (written stage after stage, each stage's LDS
+    // stores waited for its own loads and the three round trips came back in series: no gain over reading the L2 directly).
+    // lnr: the ChainLaunch of level ar, loaded an iteration earlier; returns the one of level ar + 1.
+    auto stage = [&](int ar, int ao, int at, const ChainLaunch& lnr, bool have_lnr) -> ChainLaunch {
+      ChainLaunch next; next.packets = nullptr; next.recs = nullptr; next.ops = nullptr; next.count = 0; next.stride = 0; next.pad = 0;
+      if (ar + 1 < n_launches) next = launches[ar + 1];
+      // --- issue: records of level ar
+      const bool r_ok = have_lnr && ar < n_launches && plain_rule && (lnr.pad & CHAIN_LAUNCH_LABEL_OPS_DEV) && lnr.count <= LL_STAGE_RECS;
+      double2_t rr[3] = {double2_t{0.0, 0.0}, double2_t{0.0, 0.0}, double2_t{0.0, 0.0}};
+      if (r_ok && lane < lnr.count) { const double2_t* src = reinterpret_cast<const double2_t*>(lnr.recs + lane); rr[0] = src[0]; rr[1] = src[1]; rr[2] = src[2]; }
+      // --- issue: ops of level ao (its records are in LDS since the last iteration)
+      StagedLevel& so = ring[((ao % LL_RING) + LL_RING) % LL_RING];
+      const int no = ao < n_launches ? so.count : -1;
+      double2_t oo[4][3]; bool o_has[4];           // an Op = three 16-byte pieces (plain vector registers, constant indices)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = lane + 64 * t, r = i / LL_STAGE_OPS, k = i % LL_STAGE_OPS;
+        o_has[t] = no >= 0 && r < no && k < so.recs[r].n_recv + so.recs[r].n_send;
+        oo[t][0] = oo[t][1] = oo[t][2] = double2_t{0.0, 0.0};
+        if (o_has[t]) {
+          const double2_t* src = reinterpret_cast<const double2_t*>(so.ops_base + so.recs[r].op_begin + k);
+          oo[t][0] = src[0]; oo[t][1] = src[1]; oo[t][2] = src[2];
+        }
+      }
+      // --- issue: match tables (+ the lines of the costs) of level at (its ops are in LDS since the last iteration)
+      StagedLevel& st = ring[((at % LL_RING) + LL_RING) % LL_RING];
+      const int nt = at < n_launches ? st.count : -1;
+      int32_t tv[4][SMALL_MAXD]; bool t_has[4];
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = lane + 64 * t, r = i / LL_STAGE_OPS, k = i % LL_STAGE_OPS;
+        t_has[t] = nt >= 0 && r < nt && k < st.recs[r].n_recv + st.recs[r].n_send;
+        if (t_has[t]) {
+          const Op& o = st.ops[r][k];
+          const int32_t* tab = tabs + o.peer_const;
+#pragma unroll
+          for (int x = 0; x < SMALL_MAXD; ++x) tv[t][x] = x < o.pd0 ? tab[x] : o.pd1;
+          const double* pd = dual + o.peer_dual;
+          acc += __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          acc += __hip_atomic_load(pd + max(o.pd0 + o.pd1 - 1, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (k == 0) acc += __hip_atomic_load(dual + st.recs[r].dual_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      // --- everything has landed: into LDS
+      if (ar < n_launches) {
+        StagedLevel& sr = ring[ar % LL_RING];
+        if (lane == 0) { sr.count = r_ok ? (int32_t)lnr.count : -1; sr.pad[0] = lnr.pad; sr.ops_base = lnr.ops; }
+        if (r_ok && lane < lnr.count) { double2_t* dst = reinterpret_cast<double2_t*>(&sr.recs[lane]); dst[0] = rr[0]; dst[1] = rr[1]; dst[2] = rr[2]; }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = lane + 64 * t;
+        if (o_has[t]) { double2_t* dst = reinterpret_cast<double2_t*>(&so.ops[i / LL_STAGE_OPS][i % LL_STAGE_OPS]); dst[0] = oo[t][0]; dst[1] = oo[t][1]; dst[2] = oo[t][2]; }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = lane + 64 * t;
+        if (t_has[t]) {
+#pragma unroll
+          for (int x = 0; x < SMALL_MAXD; ++x) st.tab[i / LL_STAGE_OPS][i % LL_STAGE_OPS][x] = tv[t][x];
+        }
+      }
+      asm volatile("" :: "v"(acc));
+      return next;
+    };
+    ChainLaunch ln_ahead; ln_ahead.packets = nullptr; ln_ahead.recs = nullptr; ln_ahead.ops = nullptr; ln_ahead.count = 0; ln_ahead.stride = 0; ln_ahead.pad = 0;
+    if (threadIdx.x == 0) for (int a = 0; a < LL_RING; ++a) ring[a].count = -1;
+    __syncthreads();
+    if (wave == LL_WAVES) {                          // fill the pipeline: three iterations ahead of the loop (levels 0, 1, 2 end up staged as far as the loop expects)
+      if (n_launches > 0) ln_ahead = launches[0];
+      for (int l = -3; l < 0; ++l) { ln_ahead = stage(l + 3, l + 2, l + 1, ln_ahead, true); wave_sync(); }
+    }
+    __syncthreads();
     for (int l = 0; l < n_launches; ++l) {
       if (g_level_trace && threadIdx.x == 0) g_level_trace[0] = l;
       level_stamp(0);
-      if (wave == LL_WAVES) {                        // the wave that runs ahead: level l + AHEAD, between the same barriers
-        const int la = l + LEVEL_LOOP_AHEAD;
-        if (la < n_launches) {
-          const ChainLaunch ln = launches[la];
+      if (wave == LL_WAVES) {                        // the wave that runs ahead
+        level_stamp_of(6, 64 * LL_WAVES);
+        ln_ahead = stage(l + 3, l + 2, l + 1, ln_ahead, true);
+        level_stamp_of(7, 64 * LL_WAVES);
+        const int la = l + LEVEL_LOOP_AHEAD;         // ... and, further ahead, the touch of everything a level that will NOT be staged reads
+        ChainLaunch ln; ln.count = 0; ln.pad = 0;
+        if (la < n_launches) ln = launches[la];
+        if (la < n_launches && !(plain_rule && (ln.pad & CHAIN_LAUNCH_LABEL_OPS_DEV) && ln.count <= LL_STAGE_RECS)) {
           for (int64_t i = lane; i < ln.count; i += 64) {
             const UpdRec r = ln.recs[i];
             double acc = __hip_atomic_load(dual + r.dual_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1356,8 +1550,18 @@ level_loop_kernel(const ChainLaunch* __restrict__ launches, int n_launches, doub
           }
         }
       } else {
-        const ChainLaunch ln = launches[l];
-        if ((ln.pad & CHAIN_LAUNCH_LABEL_OPS_DEV) && plain_rule) {
+        const StagedLevel& sl = ring[l % LL_RING];
+        ChainLaunch ln;
+        if (sl.count >= 0) { ln.packets = nullptr; ln.recs = nullptr; ln.ops = nullptr; ln.count = sl.count; ln.stride = 0; ln.pad = sl.pad[0]; }
+        else ln = launches[l];
+        if (sl.count >= 0) {                         // records, ops and match tables from LDS
+          if (ln.pad & CHAIN_LAUNCH_LABEL_PAIRED_DEV) { for (int64_t first = 8 * wave; first < ln.count; first += 8 * LL_WAVES) label_ops_body<ACC_WG, true, true>(ln, first, dual, tabs, lb, D[wave], S[wave], &sl); }
+#ifdef LPMP_LL_OLD_BODY
+          else { for (int64_t first = 8 * wave; first < ln.count; first += 8 * LL_WAVES) label_ops_body<ACC_WG, false, true>(ln, first, dual, tabs, lb, D[wave], S[wave], &sl); }
+#else
+          else { for (int64_t first = 8 * wave; first < ln.count; first += 8 * LL_WAVES) label_ops_body_staged<ACC_WG>(sl, first, dual, lb, D[wave], S[wave], RS[wave]); }
+#endif
+        } else if ((ln.pad & CHAIN_LAUNCH_LABEL_OPS_DEV) && plain_rule) {
           if (ln.pad & CHAIN_LAUNCH_LABEL_PAIRED_DEV) { for (int64_t first = 8 * wave; first < ln.count; first += 8 * LL_WAVES) label_ops_body<ACC_WG, true>(ln, first, dual, tabs, lb, D[wave], S[wave]); }
           else { for (int64_t first = 8 * wave; first < ln.count; first += 8 * LL_WAVES) label_ops_body<ACC_WG, false>(ln, first, dual, tabs, lb, D[wave], S[wave]); }
         } else if (wave == 0) {

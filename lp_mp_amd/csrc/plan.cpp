@@ -672,6 +672,29 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       }
       continue;
     }
+    if (lr.kclass == KC_SMALL) {
+      // lane-per-factor records: no send goes to a peer one of the record's receives rewrites -> the level loop's staged
+      // labeling body may request the send peers' costs together with the receive peers' (kernels.hip, label_ops_body)
+      for (int64_t i = lr.begin; i < lr.end; ++i) {
+        UpdRec& r = out.recs[i];
+        const Op* o = out.ops.data() + r.op_begin;
+        bool ok = true;
+        for (int a = 0; a < r.n_recv && ok; ++a)
+          for (int b = r.n_recv; b < r.n_recv + r.n_send; ++b) if (o[a].peer_dual == o[b].peer_dual) { ok = false; break; }
+        if (ok) r.kind_flags |= UPD_PRELOAD_OK;
+        // a send into the peer ONE receive of the record has just rewritten (labeling lists: the middle variables of a
+        // triplet): the staged body hands the rewritten costs over in LDS — receive: pad = 1 (no store), send: pad = index
+        // of that receive + 1.  Only a hint: the op-by-op bodies store and reload.
+        Op* ow = out.ops.data() + r.op_begin;
+        for (int b = r.n_recv; b < r.n_recv + r.n_send; ++b) {
+          int hit = -1, n_hit = 0, n_same = 0;
+          for (int a = 0; a < r.n_recv; ++a) if (ow[a].peer_dual == ow[b].peer_dual) { hit = a; ++n_hit; }
+          for (int b2 = r.n_recv; b2 < r.n_recv + r.n_send; ++b2) if (ow[b2].peer_dual == ow[b].peer_dual) ++n_same;
+          if (n_hit == 1 && n_same == 1 && hit < 8 && ow[hit].peer_const == ow[b].peer_const && ow[hit].pd0 == ow[b].pd0 && ow[hit].pd1 == ow[b].pd1) { ow[hit].pad = 1; ow[b].pad = hit + 1; }
+        }
+      }
+      continue;
+    }
     if (lr.kclass == KC_GENERIC || lr.kclass >= KC_DENSE_BIG) continue;   // packed dense and Potts classes
     auto same_vec = [](const Op* o, int a, int b) { return o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1); };
     if (kc_is_var(lr.kclass)) {

@@ -137,10 +137,11 @@ def lib():
         L.lpmp_reset_kernel_timing.argtypes = [C.c_void_p]
         L.lpmp_get_chain_launches.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.lpmp_prepare_passes.argtypes = [C.c_void_p, C.c_int]
-        L.lpmp_set_speculation.argtypes = [C.c_void_p, C.c_int]
-        L.lpmp_speculation_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
-        L.lpmp_chain_cache_bytes.restype = C.c_int64
-        L.lpmp_chain_cache_bytes.argtypes = [C.c_void_p]
+        if hasattr(L, "lpmp_set_speculation"):       # (absent only in an older experimental build loaded through LPMP_ENGINE_SO for an A/B)
+            L.lpmp_set_speculation.argtypes = [C.c_void_p, C.c_int]
+            L.lpmp_speculation_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+            L.lpmp_chain_cache_bytes.restype = C.c_int64
+            L.lpmp_chain_cache_bytes.argtypes = [C.c_void_p]
         L.lpmp_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]
         L.lpmp_synth_fill_blocks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.lpmp_boundary_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 5

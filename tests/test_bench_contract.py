@@ -36,6 +36,11 @@ def test_pmc_traffic_lookup_matches_committed_profile():
     t20, src20 = bench.pmc_traffic("void lpmp::chain_dense_pk_kernel<32, 2, false, false>", _args(steps=20))
     t10, _ = bench.pmc_traffic("void lpmp::chain_dense_pk_kernel<32, 2, false, false>", _args(steps=10))
     assert src20 is not None and "pmc_c3_dense32" in src20 and 3e10 < t20 / 20 < 4.5e10 and abs(t10 * 2 - t20) < 1e-6 * t20
+    # C4 (round 3: the random-graph workload has counters too): bytes per launch of the 16-label packed kernel
+    c4 = _args(workload="c4", c4_nodes=2_000_000, c4_edges=10_000_000, c4_labels=16)
+    t4, src4 = bench.pmc_traffic("sweep_dense_pk_kernel<16, 2, false, true>", c4)
+    assert src4 is not None and "pmc_c4_dense16" in src4 and 5e8 < t4 < 1.5e9
+    assert bench.pmc_traffic("sweep_dense_pk_kernel<16, 2, false, true>", _args(workload="c4", c4_nodes=20000, c4_edges=100000, c4_labels=16)) == (None, None)
 
 
 @pytest.mark.gpu

@@ -678,6 +678,50 @@ def test_full_size_properties(cfg, monkeypatch):
     e2.close()
 
 
+def test_what_bench_times_against_the_oracle_at_full_size():
+    """The driver's BENCH command (--warmup 5 --steps 20) on the exact C3 inputs (seed 1): 5 passes in one call, then 20
+    passes as ONE persistent chain launch with the automatic band / lag choice of the 1024 x 1024 model — duals and bound
+    against the oracle's run on the same inputs (tests/golden/c3_full_lb.npz holds every pass count 0 ... 48) at 5 and at 25
+    passes; then four more passes the way a Solve loop asks for them (one pass + the bound per call, passes running ahead),
+    checked pass by pass."""
+    import torch
+    H = W = 1024; L = 32
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c3_full_lb.npz"))
+    assert list(g["passes_seed1"]) == list(range(49))
+    m, const, dual, n, n_e = _device_grid(torch, H, W, L, "colour_major", 1)
+    e = E.Engine(0)
+    try:
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        e.upload(m, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual))
+        e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        def check(k, lb):
+            e.synchronize()
+            assert abs(lb - g["lb_seed1"][k]) <= 1e-9 * abs(g["lb_seed1"][k]), (k, lb, g["lb_seed1"][k])
+            assert _device_dual_checksums(torch, dual) == (int(g["dual_sum_seed1"][k]), int(g["dual_wsum_seed1"][k])), ("duals differ from the oracle's after pass", k)
+        check(0, e.lower_bound())
+        e.compute_pass(5)
+        check(5, e.lower_bound())
+        e.enable_kernel_timing(True)
+        e.compute_pass(20)
+        kt = e.kernel_timing()
+        e.enable_kernel_timing(False)
+        assert [(v["kernel"], v["launches"], v["chain_launches"]) for v in kt.values()] == [("chain_dense_pk_kernel<32, 2, false, false>", 1, 1)]
+        check(25, e.lower_bound())
+        e.set_speculation(8)
+        lbs = []
+        for k in range(26, 30):
+            e.compute_pass(1)
+            lbs.append(e.lower_bound())           # the bound of pass k, while the device may already be further
+        for k, lb in zip(range(26, 30), lbs):
+            assert abs(lb - g["lb_seed1"][k]) <= 1e-9 * abs(g["lb_seed1"][k]), (k, lb)
+        st = e.speculation_stats()
+        assert st["batches"] == 2 and st["passes_used"] == 4 and st["passes_launched"] == 6, st     # batches of 2 and 4
+        check(29, lbs[-1])                         # synchronize settles: two passes of the second batch are rolled back
+        assert e.speculation_stats()["rollbacks"] == 1
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("pairwise,L", [("dense", 32), ("dense", 8), ("potts", 16)])
 @pytest.mark.parametrize("order", ["colour_major", "row_major"])
 def test_multi_pass_call_fused_and_rotated_schedules(eng, pairwise, L, order):

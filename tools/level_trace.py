@@ -28,3 +28,14 @@ print("own landed -> receives done:", q((a[:, 2] - a[:, 1])[has2]), "(%d levels 
 print("receives done -> ops done :", q((a[:, 3] - a[:, 2])[has2]))
 print("ops done -> body done     :", q(a[:, 4] - a[:, 3]))
 print("body done -> stores drained:", q(a[:, 5] - a[:, 4]))
+
+# round 3 (staged levels: kernels.hip label_ops_body_staged / level_loop_kernel<1>): slot 1 = the peers' costs of wave 0's first
+# eight records have landed, 2 = their receives are done, 4 = body done; slots 6 / 7 = the wave that runs ahead starts / ends its stage
+ok = (a[:, 1] > a[:, 0]) & (a[:, 2] > a[:, 1]) & (a[:, 4] > a[:, 2])
+print("staged levels with all stamps: %d of %d" % (ok.sum(), len(a)))
+if ok.any():
+    print("  start -> costs landed   :", q((a[:, 1] - a[:, 0])[ok]))
+    print("  costs landed -> receives:", q((a[:, 2] - a[:, 1])[ok]))
+    print("  receives -> body done   :", q((a[:, 4] - a[:, 2])[ok]))
+st = (a[:, 6] > 0) & (a[:, 7] > a[:, 6])
+if st.any(): print("run-ahead wave: start -> stage done :", q((a[:, 7] - a[:, 6])[st]))
