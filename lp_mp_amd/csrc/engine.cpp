@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -832,6 +833,8 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
   rc.last_use = ++e->rot_clock;
   const RotationInfo& ri = e->plan->rot[mode];
   const bool verbose = std::getenv("LPMP_ROT_VERBOSE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   auto no = [&](const char* why) -> lpmp_engine::RotChain* { if (verbose) std::fprintf(stderr, "lpmp: %d passes stay one launch per step: %s\n", n, why); return nullptr; };
   if (!ri.valid) return no("the pass does not have the H, W, K, T shape of one packed class");
   const int n_steps = 2 * n + 1;
@@ -879,6 +882,7 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
         }
     }
     if (at != N) throw std::runtime_error("rotation chain: ticket count");
+    if (verbose) std::fprintf(stderr, "lpmp:   %d passes, lag %d: order after %.0f ms\n", n, lag, since());
     // every predecessor must come earlier
     bool ok = true;
     for (int s = 1; s < n_steps && ok; ++s) {
@@ -892,6 +896,7 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
             ok = false; break;
           }
     }
+    if (verbose) std::fprintf(stderr, "lpmp:   checked after %.0f ms (%s)\n", since(), ok ? "valid" : "a dependency points forward");
     if (!ok) continue;
     // dependencies in ticket order
     std::vector<int32_t> dep_off((size_t)N + 1, 0);
@@ -909,6 +914,7 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
         for (int64_t q = off[j]; q < off[j + 1]; ++q) *dst++ = new_of[base[s - ri.delta[kd][q]] + ri.block[kd][q]];
       }
     }
+    if (verbose) std::fprintf(stderr, "lpmp:   dependency lists after %.0f ms (%zu)\n", since(), dep.size());
     std::vector<ChainLaunchDev> lds;
     for (int s = 0; s < n_steps; ++s) {
       const auto& t = ri.t[tmpl[s]];
@@ -937,8 +943,8 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
     HIP_CHECK(hipMemsetAsync(dc.done, 0, (size_t)N * sizeof(int32_t), e->stream));
     HIP_CHECK(hipStreamSynchronize(e->stream));
     rc.n_steps = n_steps;
-    if (std::getenv("LPMP_ROT_VERBOSE"))
-      std::fprintf(stderr, "lpmp: %d passes as one launch: %lld tickets, %d bands, lag %d, depth %d\n", n, (long long)N, bands, lag, depth);
+    if (verbose)
+      std::fprintf(stderr, "lpmp: %d passes as one launch: %lld tickets, %d bands, lag %d, depth %d; built and uploaded in %.0f ms\n", n, (long long)N, bands, lag, depth, since());
     return &rc;
   }
   return no("no band order keeps the dependencies backwards");

@@ -3,6 +3,7 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -354,6 +355,9 @@ void Plan::ensure_weights(int mode) {
 // send level of the backward sweep are the same factors).
 void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out) const {
   out = Schedule();
+  const bool timed_ = std::getenv("LPMP_PLAN_TIMES") != nullptr;
+  auto t_last_ = std::chrono::steady_clock::now();
+  auto lap_ = [&](const char* what) { if (!timed_) return; const auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "lpmp: make_schedule %-8s %.0f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last_).count()); t_last_ = now; };
   int64_t N = 0;
   for (const auto& sg : segs) N += sg.n;
   struct Upd { int32_t f; int32_t owner; int64_t om, mk; };   // om / mk: absolute pointers are per segment
@@ -388,6 +392,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       at += (size_t)ns;
     }
   }
+  lap_("rows");
   std::vector<int32_t> last_level(nf, 0), last_toucher(nf, -1), last_update_of(nf, -1);
   int32_t max_level = 0;
   std::vector<int32_t> touched;
@@ -434,6 +439,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       }
     }
   }
+  lap_("levels");
   out.n_levels = max_level;
 
   // records of the owners, ops = all receives of the members (sequence order), then all sends
@@ -522,6 +528,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     rec_bytes[o] += bytes;
     out.alg_bytes += bytes;
   }
+  lap_("ops");
   // Records with two receives, or two sends, into ONE vector (duplicate messages between the same two factors) need an
   // op-by-op kernel: the packed kernels request a record's vectors before reducing.  They get a class of their own
   // (the streaming / generic / lane-per-factor kernels work op by op), so that one such record does not take its whole
@@ -536,6 +543,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     for (int a = 0; a < nr && !dup_vec[u]; ++a) for (int b = a + 1; b < nr; ++b) if (same(a, b)) { dup_vec[u] = 1; break; }
     for (int a = nr; a < nr + ns && !dup_vec[u]; ++a) for (int b = a + 1; b < nr + ns; ++b) if (same(a, b)) { dup_vec[u] = 1; break; }
   }
+  lap_("dup");
   // bucket the owner records by (level, class); updates without any active op are dropped
   std::vector<int32_t> kclass(N, KC_GENERIC);
   auto cls_of = [&](int64_t u) -> int32_t {
@@ -625,6 +633,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     lr.n_recv = key_recv[k]; lr.n_send = key_send[k]; lr.bytes = key_bytes[k];
     out.launches.push_back(lr);
   }
+  lap_("records");
   out.ops = std::move(ops);
   // inside a launch the order of the records is free (they are independent): sub-wave kernels run several
   // factors per wavefront, so neighbours in the list should have similar amounts of work.  Sorted inside windows of
@@ -655,6 +664,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       std::copy(tr.begin(), tr.end(), out.recs.begin() + lr.begin);
       std::copy(tu.begin(), tu.end(), rec_upd.begin() + lr.begin);
     }
+  lap_("sorted");
   // flags of the fast-class records, kept in recs / ops themselves (packets are plain copies)
   static_assert(sizeof(UpdRec) == sizeof(Op), "a packet slot holds either record");
   for (auto& lr : out.launches) {
@@ -755,6 +765,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     }
   }
 
+  lap_("packets");
   // ---- chain plans: a deep schedule becomes persistent launches (kernels.hip, chain executor), one per kernel class.
   // Dependencies: update u must see the results of the last earlier update that touched u's factor or a factor u
   // touches — the same relation the levels were computed from.  Classes are separate launches and cannot wait for each

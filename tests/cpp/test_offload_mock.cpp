@@ -9,6 +9,7 @@
 //   usage: test_offload_mock [--host-only]   (host-only: construction + flattening, no device call)
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <limits>
@@ -237,6 +238,56 @@ int main(int argc, char** argv) {
       for (auto* p : ps) host_lb += p->LowerBound();
       test(std::abs(host_lb - lp.LowerBound()) <= 1e-9 * std::max(1.0, std::abs(host_lb)), "factor ops hold the device's duals after End()");
     }
+  }
+  if (!host_only) {   // the reference's Solve loop (solver.hxx:238-243, 268-284) through the adapter, with and without passes running ahead
+    // a 2-colour (checkerboard) variable order: consecutive passes join, so batches of passes run as one launch
+    // (LPMP_ROT_BANDS forces that on this small model); the bound after every iteration must be the same either way
+    setenv("LPMP_ROT_BANDS", "4", 1);
+    const int H = 18, W = 14, L = 8;
+    std::vector<double> hist[2];
+    for (int k = 0; k < 2; ++k) {
+      using LP_device = lpmp_offload::offloaded<LP_MP::LP<FMC_MRF>>;
+      LP_device lp(cmd);
+      lp.set_speculation(k == 0 ? 0 : 8);
+      std::vector<int> pos((size_t)H * W);
+      { int b = 0, w = (H * W + 1) / 2; for (int r = 0; r < H; ++r) for (int c = 0; c < W; ++c) pos[(size_t)r * W + c] = ((r + c) & 1) == 0 ? b++ : w++; }
+      std::vector<int> cell_of((size_t)H * W);
+      for (int i = 0; i < H * W; ++i) cell_of[pos[i]] = i;
+      std::vector<FMC_MRF::U*> u((size_t)H * W);
+      uint64_t st = 7;
+      for (int i = 0; i < H * W; ++i) { std::vector<double> c(L); for (auto& x : c) x = u01(st); u[(size_t)cell_of[i]] = lp.add_factor<FMC_MRF::U>(c); }
+      auto edge = [&](int a, int b) {
+        if (pos[a] > pos[b]) std::swap(a, b);
+        auto* p = lp.add_factor<FMC_MRF::P>(L, L);
+        for (int x = 0; x < L; ++x) for (int y = 0; y < L; ++y) p->GetFactor()->pw(x, y) = u01(st);
+        lp.add_message<FMC_MRF::ML>(u[a], p); lp.add_message<FMC_MRF::MR>(u[b], p);
+        lp.AddFactorRelation(u[a], p); lp.AddFactorRelation(p, u[b]);
+      };
+      for (int r = 0; r < H; ++r) for (int c = 0; c < W; ++c) { if (c + 1 < W) edge(r * W + c, r * W + c + 1); if (r + 1 < H) edge(r * W + c, (r + 1) * W + c); }
+      lp.Begin();
+      lp.set_reparametrization(LP_MP::LPReparametrizationMode::Anisotropic);
+      (void)lp.LowerBound();
+      for (int it = 0; it < 23; ++it) {
+        lp.set_reparametrization(LP_MP::LPReparametrizationMode::Anisotropic);   // Solver::PreIterate
+        lp.ComputePass(it);                                                       // Solver::Iterate
+        hist[k].push_back(lp.LowerBound());                                       // Solver::PostIterate
+        if (it % 5 == 4) {                                                        // a rounding iteration of MpRoundingSolver
+          lp.set_reparametrization(LP_MP::LPReparametrizationMode::DampedUniform);
+          lp.ComputeForwardPassAndPrimal(it); lp.ComputeBackwardPassAndPrimal(it);
+          hist[k].push_back(lp.EvaluatePrimal());
+        }
+      }
+      int64_t batches = 0, launched = 0, used = 0, rollbacks = 0;
+      lpmp_offload::check(lpmp_speculation_stats(lp.engine(), &batches, &launched, &used, &rollbacks));
+      if (k == 1) test(batches > 0 && used == 23 && launched >= used, "passes ran ahead of the loop in batches");
+      else test(batches == 0, "no batches without speculation");
+      lp.End();
+      double host_lb = 0;
+      for (auto* f : u) host_lb += f->LowerBound();
+      hist[k].push_back(host_lb);                                                 // the factor ops hold the duals the loop asked for, not more
+    }
+    test(hist[0] == hist[1], "bounds, rounded costs and final duals do not depend on passes running ahead");
+    unsetenv("LPMP_ROT_BANDS");
   }
   std::cout << "all tests passed\n";
   return 0;
