@@ -88,13 +88,14 @@ struct DevSchedule {
     bool banded = false;                     // Infinity-Cache ticket order: plain table loads, not the streaming policy
     bool level_loop = false; int32_t n_launches = 0;   // one workgroup walks the launches (tiny levels of a generic class)
     ChainLaunchDev* launches = nullptr; int32_t *tk_launch = nullptr, *tk_block = nullptr, *dep_off = nullptr, *dep = nullptr, *done = nullptr, *next = nullptr;
+    unsigned long long* mailbox = nullptr;   // tagged granules of the message vectors that travel between dependent records (plan.cpp)
   };
   std::vector<DevChain> chains;
   std::vector<LevelRange> plain;           // launches that do not belong to a chain
   bool chain = false;
   void release_chain() {
     for (auto& c : chains)
-      for (void* p : {(void*)c.launches, (void*)c.tk_launch, (void*)c.tk_block, (void*)c.dep_off, (void*)c.dep, (void*)c.done, (void*)c.next}) if (p) (void)hipFree(p);
+      for (void* p : {(void*)c.launches, (void*)c.tk_launch, (void*)c.tk_block, (void*)c.dep_off, (void*)c.dep, (void*)c.done, (void*)c.next, (void*)c.mailbox}) if (p) (void)hipFree(p);
     chains.clear(); plain.clear(); chain = false;
   }
   void release() {
@@ -114,6 +115,7 @@ struct ChainArgsHost {
   const int32_t* dep_off; const int32_t* dep; int32_t* done; int32_t* next; int32_t* abort_flag; const int32_t* tk_launch;
   const int32_t* tk_block; int32_t n_tickets; int32_t epoch; long long* trace;
   double* lb_hist; int64_t hist_stride;     // per-pass bound rows of a joined-pass launch (kernels.hip, ChainArgs)
+  unsigned long long* mailbox;              // or nullptr
 };
 constexpr int HIST_END = 1, HIST_MID = 2;   // kernels.hip
 
@@ -383,7 +385,7 @@ struct lpmp_engine {
     for (auto& m : rot_chain) {
       for (auto& kv : m) {
         auto& c = kv.second.dc;
-        for (void* p : {(void*)c.launches, (void*)c.tk_launch, (void*)c.tk_block, (void*)c.dep_off, (void*)c.dep, (void*)c.done, (void*)c.next}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)c.launches, (void*)c.tk_launch, (void*)c.tk_block, (void*)c.dep_off, (void*)c.dep, (void*)c.done, (void*)c.next, (void*)c.mailbox}) if (p) (void)hipFree(p);
       }
       m.clear();
     }
@@ -598,6 +600,12 @@ void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream, bool
       HIP_CHECK(hipMalloc((void**)&dc.next, sizeof(int32_t)));
       HIP_CHECK(hipMemsetAsync(dc.done, 0, std::max<size_t>(1, (size_t)dc.tickets) * sizeof(int32_t), stream));
       dc.kclass = c.kclass; dc.banded = c.banded; dc.level_loop = c.level_loop; dc.n_launches = (int32_t)c.launches.size();
+      if (c.mailbox_rows > 0) {
+        // a granule is valid when its tag is the epoch of the running launch: zeroed once, epochs start at 1
+        const size_t bytes = (size_t)c.mailbox_rows * c.mailbox_width * 16;
+        HIP_CHECK(hipMalloc((void**)&dc.mailbox, bytes));
+        HIP_CHECK(hipMemsetAsync(dc.mailbox, 0, bytes, stream));
+      }
       d.chains.push_back(dc);
     }
     for (int32_t li : s.plain_launches) d.plain.push_back(s.launches[li]);
@@ -763,7 +771,7 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
       }
       HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
       ChainTrace tr;
-      const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream), nullptr, 0};
+      const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream), nullptr, 0, c.mailbox};
       if (!launch_chain(c.kclass, rule | (c.banded ? 0 : e->nt_flag), &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->d_primal, e->stream))
         throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
       tr.end(c, e->stream);
@@ -824,7 +832,7 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
       if (!vm) break;
       if (!drained) { HIP_CHECK(hipStreamSynchronize(e->stream)); drained = true; }
       auto& c = victim->second.dc;
-      for (void* p : {(void*)c.launches, (void*)c.tk_launch, (void*)c.tk_block, (void*)c.dep_off, (void*)c.dep, (void*)c.done, (void*)c.next}) if (p) (void)hipFree(p);
+      for (void* p : {(void*)c.launches, (void*)c.tk_launch, (void*)c.tk_block, (void*)c.dep_off, (void*)c.dep, (void*)c.done, (void*)c.next, (void*)c.mailbox}) if (p) (void)hipFree(p);
       e->rot_cache_bytes -= std::min(e->rot_cache_bytes, victim->second.dev_bytes);
       vm->erase(victim);
     }
@@ -959,7 +967,7 @@ bool run_rotation_chain(lpmp_engine* e, int mode, int n, double* lb_hist = nullp
   HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
   ChainTrace tr;
   const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream),
-                         lb_hist, lb_hist ? e->plan->p.nf : 0};
+                         lb_hist, lb_hist ? e->plan->p.nf : 0, nullptr};
   hipEvent_t a = nullptr, b = nullptr;
   if (e->timing) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, e->stream)); }
   // (plain table loads, not the streaming policy: the second reader of a table is meant to find it in the Infinity Cache)

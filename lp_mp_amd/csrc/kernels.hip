@@ -95,6 +95,8 @@ struct ChainArgs {
   // joined passes (engine.cpp rotation_chain) with per-pass lower bounds: row r = the tracked bounds of all factors as they
   // are at the END OF PASS r + 1 of the call; a launch writes into the row its ChainLaunch::hist names (nullptr: no rows)
   double* lb_hist; int64_t hist_stride;
+  // launches with CHAIN_LAUNCH_MAILBOX (plan.cpp): rows of L granule pairs, see mailbox_put / mailbox_take
+  unsigned long long* mailbox;
 };
 // debugging (LPMP_LEVEL_TRACE, engine.cpp): time stamps of the first levels of a level-loop launch, 8 slots per level
 __device__ long long* g_level_trace = nullptr;
@@ -163,6 +165,32 @@ __device__ __forceinline__ void chain_publish(const ChainArgs& ca, int ticket) {
   chain_stamp(ca, ticket, 3);                      // published
 }
 
+
+// Mailbox of a dense chain (plan.cpp decides which vectors travel this way): the value a send has just computed, as two
+// self-validating 8-byte granules {half of the double, epoch of the running launch}.  An aligned 8-byte access is atomic,
+// so a granule whose tag is this launch's epoch IS the producer's value — no ordering with any other store is needed, and
+// the consumer has the value after ONE trip instead of two (completion flag seen, then the vector fetched).  What the
+// consumer may conclude from a granule is only this value: the producer's other stores are not yet visible, which is why
+// plan.cpp keeps a flag dependency wherever anything else of the producer is read or overwritten.
+__device__ __forceinline__ void mailbox_put(unsigned long long* q, double v, int epoch) {
+  const unsigned long long tag = (unsigned long long)(unsigned)epoch << 32;
+  __hip_atomic_store(q, tag | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, tag | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double mailbox_take(const ChainArgs& ca, const unsigned long long* q, bool& bad) {
+  const unsigned tag = (unsigned)ca.epoch;
+  for (int spins = 0;;) {
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag) return __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+    __builtin_amdgcn_s_sleep(1);
+    if (((++spins) & 1023) == 0 && (spins >= CHAIN_SPIN_LIMIT || __hip_atomic_load(ca.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      __hip_atomic_store(ca.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bad = true;
+      return 0.0;
+    }
+  }
+}
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -797,8 +825,10 @@ template <int L, int KMAX, bool VAR, bool NT, int A, bool CHAIN>
 __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
                                               double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
                                               int32_t* __restrict__ primal, int64_t count, int stride, int flags, int64_t block,
-                                              const ChainArgs* ca, int ticket, double* __restrict__ lbh = nullptr, int hmode = 0) {
+                                              const ChainArgs* ca, int ticket, double* __restrict__ lbh = nullptr, int hmode = 0,
+                                              unsigned long long* __restrict__ mbox = nullptr) {
   static_assert(!CHAIN || A == ACC_COH, "chain bodies hand results over through relaxed agent-scope flags: every dual access must be an agent-scope (sc1) access");
+  static_assert(MAILBOX_SENDS == 4, "plan.hpp: the sends whose fields are held in registers (KS)");
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
   constexpr int KS = 4;                          // sends whose target vectors are prefetched / forwarded
@@ -828,14 +858,16 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
   // LDS — otherwise every field is re-read after those writes, one dependent LDS round trip each on the critical path
   // of a dependent level (0.64 us for two sends, tools/chain_trace.py)
   [[maybe_unused]] double* s_ms[KS]; [[maybe_unused]] double s_om[KS]; [[maybe_unused]] int s_fw[KS], s_peer[KS];
+  [[maybe_unused]] unsigned long long* s_box[KS];   // mailbox row the send's vector also goes to (plan.hpp, OP_MAILBOX), or nullptr
   if constexpr (CHAIN) {
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-      s_ms[k] = dual; s_om[k] = 0.0; s_fw[k] = 0; s_peer[k] = 0;
+      s_ms[k] = dual; s_om[k] = 0.0; s_fw[k] = 0; s_peer[k] = 0; s_box[k] = nullptr;
       if (k < n_send) {
         const Op& o = lop[n_recv + k];
         s_ms[k] = dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0);
         s_om[k] = o.omega; s_fw[k] = uni<G>(o.pad); s_peer[k] = uni<G>(o.peer);
+        if constexpr (!VAR) { if (mbox && (uni<G>(o.info) & OP_MAILBOX)) s_box[k] = mbox + uni64<G>(o.peer_const) * (2 * L); }
       }
     }
   }
@@ -877,13 +909,17 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
     int64_t pdual[KMAX];
     int side[KMAX], defer[KMAX], roff[KMAX];     // roff: offset of the own-side message vector in the peer's dual
     int dR[KMAX], dC[KMAX];
+    [[maybe_unused]] const unsigned long long* box[KMAX];   // mailbox row the other side's vector is polled from, or nullptr
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {             // request everything constant first
       const bool act = c + j < n_recv;
-      pdual[j] = 0; side[j] = 0; defer[j] = 0; roff[j] = 0; msv[j] = 0.0; mov[j] = 0.0; dR[j] = L; dC[j] = L;
+      pdual[j] = 0; side[j] = 0; defer[j] = 0; roff[j] = 0; msv[j] = 0.0; mov[j] = 0.0; dR[j] = L; dC[j] = L; box[j] = nullptr;
       if (act) {
         const Op& o = lop[c + j];
         pdual[j] = uni64<G>(o.peer_dual);
+        if constexpr (CHAIN && !VAR) {
+          if (mbox && (uni<G>(o.info) & OP_MAILBOX)) { long long row; __builtin_memcpy(&row, &o.omega, 8); box[j] = mbox + uni64<G>(row) * (2 * L); }
+        }
         side[j] = (uni<G>(o.info) >> 5) & 1;
         defer[j] = FW ? uni<G>(o.pad) : 0;
         const double* T = cdata + uni64<G>(o.peer_const);
@@ -938,10 +974,15 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
           msv[j] = (double)pdual[j] * 1e-300; mov[j] = 0.0;
 #else
           msv[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? 0 : L) + g);
-          mov[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? L : 0) + g);
+          if (!(CHAIN && box[j])) mov[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? L : 0) + g);
 #endif
         }
       }
+    }
+    if constexpr (CHAIN && !VAR) {               // ... and, with everything else in flight, the vectors that come by mailbox
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j)
+        if (c + j < n_recv && box[j] && g < L) mov[j] = mailbox_take(*ca, box[j] + 2 * g, aborted);
     }
     if constexpr (CHAIN && FIRST) {
       // Loads and stores share one counter on this ISA and may complete out of order with respect to each other, so a
@@ -1062,10 +1103,14 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
           const int fw = s_fw[k];
           const double cur = fw > 0 ? (fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3]) : sm[k];
           const double delta = s_om[k] * snap;
+          // (the residual rule below adds to the vector once more: the mailbox gets the final value there)
+          if (s_box[k] && !(flags & SWEEP_RESIDUAL)) mailbox_put(s_box[k] + 2 * g, cur + delta, ca->epoch);
           st_dual<A>(s_ms[k] + g, cur + delta);
           theta -= delta;
 #ifndef LPMP_ABLATE_LB_TRACK
-          if (g == 0) st_lb<A>(lb + s_peer[k], LPMP_NAN);
+          // a vector that goes to the mailbox has a reader later in this launch, which sets the peer's tracked bound itself
+          // — and is not ordered after THIS store, so it is left out
+          if (g == 0 && !s_box[k]) st_lb<A>(lb + s_peer[k], LPMP_NAN);
 #endif
         }
       }
@@ -1133,7 +1178,9 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
         double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? (VAR ? o.pd0 : L) : 0);
         residual += o.omega;
         const double delta = residual * theta;
-        st_dual<A>(ms + g, ld_dual<A>(ms + g) + delta);
+        const double v = ld_dual<A>(ms + g) + delta;
+        if constexpr (CHAIN && !VAR) { if (k < KS && mbox && (o.info & OP_MAILBOX)) mailbox_put(mbox + o.peer_const * (2 * L) + 2 * g, v, ca->epoch); }
+        st_dual<A>(ms + g, v);
         theta -= delta;
       }
     }
@@ -1193,7 +1240,8 @@ chain_dense_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, do
   chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
     const int hmode = ca.lb_hist ? (ln.pad & 3) : 0;
     dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket,
-                                                   hmode ? ca.lb_hist + (int64_t)(ln.pad >> 2) * ca.hist_stride : nullptr, hmode);
+                                                   hmode ? ca.lb_hist + (int64_t)(ln.pad >> 2) * ca.hist_stride : nullptr, hmode,
+                                                   (ln.pad & CHAIN_LAUNCH_MAILBOX) ? ca.mailbox : nullptr);
   });
 }
 

@@ -816,6 +816,54 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         t0[lr.kclass] += nb;
         if ((int64_t)t0[lr.kclass] + nb > std::numeric_limits<int32_t>::max() / 2) ok = false;
       }
+      // ---- mailbox (kernels.hip, dense_pk_body): in a deep chain of a dense class the vector a send writes is what the
+      // neighbour's receive one level later waits for.  Through the completion flag that hand-over costs two trips (flag seen,
+      // then the vector fetched); a send therefore ALSO writes its vector as tagged granules into a mailbox row, the receive
+      // polls that row instead of the dual array, and the dependency between the two tickets needs no flag.
+      // src_rec / src_k: per receive op, the record and send index that LAST wrote the vector the receive reads (the other
+      // side of the pairwise factor) — by vector, not by factor: a record that synchronised on a granule has not seen the
+      // producer's ticket complete, so no one may read that producer's vector from the dual array on its word.
+      const bool no_mailbox = std::getenv("LPMP_NO_MAILBOX") != nullptr;
+      std::vector<char> mbox_class(KC_COUNT, 0);
+      std::vector<int32_t> src_rec, rec_of_upd, rec_launch;
+      std::vector<int8_t> src_k;
+      bool any_mbox = false;
+      if (!no_mailbox && bands <= 1 && ok) {
+        for (int c = KC_DENSE_4; c <= KC_DENSE_32; ++c) {
+          bool el = n_launches_of[c] > 8 && n_launches_of[c] >= chain_min;     // (fewer: plain launches or the banded order)
+          for (const auto& lr : out.launches) if (lr.kclass == c && lr.stride <= 0) el = false;
+          mbox_class[c] = el; any_mbox = any_mbox || el;
+        }
+      }
+      if (any_mbox) {
+        src_rec.assign(out.ops.size(), -1); src_k.assign(out.ops.size(), -1);
+        rec_of_upd.assign(N, -1); rec_launch.assign(out.recs.size(), -1);
+        std::vector<int32_t> lw_rec((size_t)2 * nf, -1);      // last writer of (factor, side): record ...
+        std::vector<int8_t> lw_k((size_t)2 * nf, -1);         // ... and its send index (-1: written by a receive)
+        for (size_t li = 0; li < out.launches.size(); ++li) {
+          const auto& lr = out.launches[li];
+          for (int64_t i = lr.begin; i < lr.end; ++i) { rec_of_upd[rec_upd[i]] = (int32_t)i; rec_launch[i] = (int32_t)li; }
+          if (!mbox_class[lr.kclass]) continue;
+          for (int64_t i = lr.begin; i < lr.end; ++i) {
+            const UpdRec& r = out.recs[i];
+            const Op* o = out.ops.data() + r.op_begin;
+            for (int j = 0; j < r.n_recv; ++j) {
+              const int64_t v = (int64_t)2 * o[j].peer + (1 - ((o[j].info >> 5) & 1));
+              const int32_t w = lw_rec[v];
+              if (w >= 0 && lw_k[v] >= 0 && lw_k[v] < MAILBOX_SENDS && out.launches[rec_launch[w]].kclass == lr.kclass) { src_rec[r.op_begin + j] = w; src_k[r.op_begin + j] = lw_k[v]; }
+            }
+            for (int j = 0; j < r.n_recv + r.n_send; ++j) {
+              const int64_t v = (int64_t)2 * o[j].peer + ((o[j].info >> 5) & 1);
+              lw_rec[v] = (int32_t)i; lw_k[v] = j < r.n_recv ? (int8_t)-1 : (int8_t)std::min(j - r.n_recv, 127);
+              // a send after a receive of the same record through the same factor whose result was NOT handed over in a
+              // register: that receive stored the factor's tracked bound, and the reader's own store of that bound is not
+              // ordered after it by a granule -> flag
+              if (j >= r.n_recv && o[j].pad == 0)
+                for (int a = 0; a < r.n_recv; ++a) if (o[a].peer == o[j].peer) lw_k[v] = -1;
+            }
+          }
+        }
+      }
       // replay the sequence: who touched each factor last
       std::vector<int32_t> toucher(nf, -1);
       std::vector<std::vector<std::pair<int32_t, int32_t>>> edges(KC_COUNT);     // per class: (ticket, predecessor ticket)
@@ -824,11 +872,21 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         const int32_t tk = ticket_of_update[o];
         if (tk < 0) continue;                             // dropped update (no active message)
         const int32_t f = uf[u];
-        auto visit = [&](int32_t g) {
+        auto visit = [&](int32_t g, bool via_message = false) {
           const int32_t w = toucher[g];
           if (w >= 0 && w != o) {
             if (class_of_update[w] != class_of_update[o]) ok = false;      // a dependency between classes
-            else if (ticket_of_update[w] != tk) edges[class_of_update[o]].emplace_back(tk, ticket_of_update[w]);
+            else if (ticket_of_update[w] != tk) {
+              // covered by the mailbox: o receives through g exactly the vector w's send wrote (and w's own reads of g
+              // precede that send in w's program order, so what o writes into g cannot overtake them)
+              bool covered = false;
+              if (via_message && mbox_class[class_of_update[o]]) {
+                const UpdRec& r = out.recs[rec_of_upd[o]];
+                for (int j = 0; j < r.n_recv; ++j)
+                  if (out.ops[r.op_begin + j].peer == g && src_rec[r.op_begin + j] == rec_of_upd[w]) covered = true;
+              }
+              if (!covered) edges[class_of_update[o]].emplace_back(tk, ticket_of_update[w]);
+            }
           }
           toucher[g] = o;
         };
@@ -839,7 +897,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
           bool active = false;
           if (e.receives && umk[u][kr++]) active = true;
           if (e.sends && uom[u][ks++] != 0.0) active = true;
-          if (active) visit(e.adjacent);
+          if (active) visit(e.adjacent, true);
         }
       }
       for (int c = 0; c < KC_COUNT && ok; ++c) {
@@ -969,6 +1027,35 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         cp.dep.resize(ed.size());
         for (size_t i = 0; i < ed.size(); ++i) cp.dep[i] = ed[i].second;   // sorted by ticket: already in CSR order
         cp.valid = true;
+        if (mbox_class[c]) {
+          if (cp.banded) fail("chain plan: mailbox in a banded order");
+          // rows for the sends some receive polls; the packet copies of both ops carry the row (plan.hpp, OP_MAILBOX)
+          std::vector<int64_t> row_of_op;                     // per op of out.ops (sends): mailbox row, assigned on first use
+          row_of_op.assign(out.ops.size(), -1);
+          auto slot_of = [&](int64_t i) { const auto& lr = out.launches[rec_launch[i]]; return out.packets.data() + lr.pk_begin + (i - lr.begin) * lr.stride; };
+          int64_t rows = 0;
+          for (const auto& cl : cp.launches)
+            for (int64_t i = cl.rec_begin; i < cl.rec_begin + cl.count; ++i) {
+              const UpdRec& r = out.recs[i];
+              for (int j = 0; j < r.n_recv; ++j) {
+                const int32_t w = src_rec[r.op_begin + j];
+                if (w < 0) continue;
+                const UpdRec& rw = out.recs[w];
+                const int64_t sop = (int64_t)rw.op_begin + rw.n_recv + src_k[r.op_begin + j];
+                if (row_of_op[sop] < 0) {
+                  row_of_op[sop] = rows++;
+                  Op& ps = slot_of(w)[1 + rw.n_recv + src_k[r.op_begin + j]];
+                  ps.peer_const = row_of_op[sop]; ps.info |= OP_MAILBOX;
+                }
+                Op& pr = slot_of(i)[1 + j];
+                std::memcpy(&pr.omega, &row_of_op[sop], sizeof(double)); pr.info |= OP_MAILBOX;
+              }
+            }
+          if (rows > 0) {
+            cp.mailbox_rows = rows; cp.mailbox_width = kc_width(c);
+            for (auto& cl : cp.launches) cl.flags |= CHAIN_LAUNCH_MAILBOX;
+          }
+        }
         out.chains.push_back(std::move(cp));
       }
       if (!ok) { out.chains.clear(); out.plain_launches.clear(); }

@@ -34,6 +34,10 @@ struct Csr {
 // Device-side records (plain structs shared with kernels.hip) -----------------------------------
 enum OpCode : int32_t { OP_UP = 0, OP_LABELING = 1, OP_MINNORM = 2 };
 constexpr int32_t OP_HAS_IMPROVEMENT = 1 << 12;   // Op::info: the message op defines send_message_to_*_improvement
+// Op::info, only in the PACKET copy of an op of a chain launch with CHAIN_LAUNCH_MAILBOX (plan.cpp, chain plans): the
+// message vector travels through the chain's mailbox.  A send: peer_const = mailbox row the new vector is also written to;
+// a receive: the bits of omega = mailbox row (int64) the OTHER side's vector is polled from instead of the dual array.
+constexpr int32_t OP_MAILBOX = 1 << 13;
 
 struct alignas(16) UpdRec {   // one updated factor
   int64_t dual_off;   // own dual start
@@ -127,6 +131,10 @@ struct PrimalInit { int32_t f, a, b, pad; };      // primal_ of factor f when un
 // of every factor a record touches).  Tickets are numbered in level order, so a dependency always has a lower number.
 struct ChainLaunchHost { int64_t rec_begin, count, pk_begin; int32_t stride, ticket0; int32_t flags = 0; };   // flags: CHAIN_LAUNCH_LABEL_OPS
 constexpr int32_t CHAIN_LAUNCH_LABEL_PAIRED = 2;  // ... and in every record send j goes to the peer receive j came from (each message received, then sent)
+// dense chain launches: message vectors between dependent records travel as tagged granules (kernels.hip, mailbox); the
+// dependencies they cover are not in dep[] any more.  Bit 30: the low bits of ChainLaunch::pad belong to the joined passes.
+constexpr int32_t CHAIN_LAUNCH_MAILBOX = 1 << 30;
+constexpr int MAILBOX_SENDS = 4;                // the sends of a record that may go to the mailbox (kernels.hip: KS)
 constexpr int32_t CHAIN_LAUNCH_LABEL_OPS = 1;   // level loop: every record a vector factor whose ops are labeling messages with it on the left, <= 8 receives and <= 8 sends, no two of a kind on one peer
 struct ChainPlan {
   bool valid = false;
@@ -137,6 +145,8 @@ struct ChainPlan {
   std::vector<int32_t> dep_off, dep;        // CSR over tickets
   bool banded = false;                      // tickets in Infinity-Cache order: the tables are read with plain loads
   bool level_loop = false;                  // many tiny levels of a generic class: ONE workgroup walks the launches (kernels.hip)
+  int64_t mailbox_rows = 0;                 // message vectors that travel through the mailbox (rows of mailbox_width granule pairs)
+  int32_t mailbox_width = 0;
 };
 // records one workgroup of the packed kernels takes (256 threads / lanes per record)
 constexpr int GENERIC_BLOCK_RECORDS = 4, SMALL_BLOCK_RECORDS = 64;   // sweep_generic_kernel<64> / <1> (kernels.hip asserts them)

@@ -14,8 +14,10 @@ torch.cuda.set_device(0)
 sp = torch.cuda.current_stream().cuda_stream
 out = {}
 duals = {}
-for name, env in (("chain", "0"), ("graph", "1")):
+for name, env, no_mb in (("chain", "0", None), ("chain_flags_only", "0", "1"), ("graph", "1", None)):
     os.environ["LPMP_NO_CHAIN"] = env
+    os.environ.pop("LPMP_NO_MAILBOX", None)
+    if no_mb: os.environ["LPMP_NO_MAILBOX"] = no_mb          # every hand-over through a completion flag (plan.cpp, mailbox)
     m, const, dual = B.build_device_grid(torch, g, g, L, pw, "row_major", 1, E, S, sp)
     e = E.Engine(0); e.set_stream(sp)
     e.upload(m, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual))
@@ -30,5 +32,5 @@ for name, env in (("chain", "0"), ("graph", "1")):
     out[name] = {"ms_per_pass": dt * 1e3, "us_per_level": dt * 1e6 / info["n_levels"], "levels": info["n_levels"], "lb": e.lower_bound()}
     duals[name] = dual.clone()
     e.close(); del e, const, dual
-out["bit_identical"] = bool(torch.equal(duals["chain"], duals["graph"]))
+out["bit_identical"] = bool(torch.equal(duals["chain"], duals["graph"])) and bool(torch.equal(duals["chain_flags_only"], duals["graph"]))
 print(json.dumps(out))
