@@ -98,6 +98,10 @@ int lpmp_plan_pass_schedule_info(lpmp_plan* p, int mode, int64_t* n_levels, int6
  * all 0 when the sweep runs as ordinary launches / graph replay */
 int lpmp_plan_chain_info(lpmp_plan* p, int direction, int mode, int64_t* n_chains, int64_t* n_tickets, int64_t* n_dependencies,
                          int64_t* n_plain_launches);
+/* ... and how many message vectors of that sweep travel between dependent records through the chain's mailbox (tagged
+ * granules polled by the receiving record instead of a completion flag followed by a fetch): rows = sends
+ * that also write a mailbox row, receives = receives that poll one.  0 / 0: every hand-over goes through flags. */
+int lpmp_plan_mailbox_info(lpmp_plan* p, int direction, int mode, int64_t* n_rows, int64_t* n_receives);
 
 /* 1 when lpmp_compute_pass(n >= 2) joins the tail of a pass with the head of the next one for this mode (2-colour
  * orders: n passes = H, W, (K, W) x (n-1), T) — decided by an op-by-op comparison of the fused

@@ -1154,6 +1154,18 @@ int lpmp_plan_chain_info(lpmp_plan* p, int d, int mode, int64_t* n_chains, int64
   });
 }
 
+int lpmp_plan_mailbox_info(lpmp_plan* p, int d, int mode, int64_t* n_rows, int64_t* n_receives) {
+  return guarded([&] {
+    if (!p || mode < 0 || mode >= LPMP_REPAM_COUNT || d < -1 || d > 1) throw std::runtime_error("bad argument");
+    const Schedule* s;
+    if (d < 0) { plan_pass_schedule(p, mode); s = &p->pass_cache[mode]; } else { plan_schedule(p, d, mode); s = &p->sched_cache[d][mode]; }
+    int64_t r = 0, v = 0;
+    for (const auto& c : s->chains) { r += c.mailbox_rows; v += c.mailbox_receives; }
+    if (n_rows) *n_rows = r;
+    if (n_receives) *n_receives = v;
+  });
+}
+
 int lpmp_plan_get_partitions(lpmp_plan* p, int64_t* n_partitions, int64_t* off, int32_t* factors) {
   return guarded([&] {
     if (!p || !n_partitions) throw std::runtime_error("bad argument");

@@ -177,13 +177,41 @@ __device__ __forceinline__ void mailbox_put(unsigned long long* q, double v, int
   __hip_atomic_store(q, tag | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(q + 1, tag | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// experiments (tools/build_variant.sh): polls of one granule pair in flight, spaced LPMP_MBOX_GAP sleeps apart
+#ifndef LPMP_MBOX_PIPE
+#define LPMP_MBOX_PIPE 1
+#endif
+#ifndef LPMP_MBOX_GAP
+#define LPMP_MBOX_GAP 5
+#endif
+#ifndef LPMP_MBOX_SLEEP
+#define LPMP_MBOX_SLEEP 1
+#endif
 __device__ __forceinline__ double mailbox_take(const ChainArgs& ca, const unsigned long long* q, bool& bad) {
   const unsigned tag = (unsigned)ca.epoch;
+#if LPMP_MBOX_PIPE > 1
+  // a poll is a round trip to the far side of the fabric; with several under way, a fraction of a trip apart, the granule is
+  // seen that much sooner after it lands (the loads of a wave return in order)
+  unsigned long long a[LPMP_MBOX_PIPE], b[LPMP_MBOX_PIPE];
+#pragma unroll
+  for (int i = 0; i < LPMP_MBOX_PIPE; ++i) {
+    a[i] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b[i] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i + 1 < LPMP_MBOX_PIPE) __builtin_amdgcn_s_sleep(LPMP_MBOX_GAP);
+  }
+  for (int spins = 0;;) {
+    if ((unsigned)(a[0] >> 32) == tag && (unsigned)(b[0] >> 32) == tag) return __hiloint2double((int)(unsigned)b[0], (int)(unsigned)a[0]);
+#pragma unroll
+    for (int i = 0; i + 1 < LPMP_MBOX_PIPE; ++i) { a[i] = a[i + 1]; b[i] = b[i + 1]; }
+    a[LPMP_MBOX_PIPE - 1] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b[LPMP_MBOX_PIPE - 1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
   for (int spins = 0;;) {
     const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag) return __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(LPMP_MBOX_SLEEP);
+#endif
     if (((++spins) & 1023) == 0 && (spins >= CHAIN_SPIN_LIMIT || __hip_atomic_load(ca.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       __hip_atomic_store(ca.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       bad = true;
@@ -821,18 +849,19 @@ __device__ __forceinline__ void load_packet(double2_t* slab, const Op* __restric
 // <= L, the own side's equal to the label count) are read at run time, lanes beyond them carry +inf / 0
 // NT: streaming policy of the table loads.  A: access policy of the duals.  CHAIN: called from the chain executor with a
 // ticket: everything constant is requested first, then the ticket's predecessors are awaited, then the duals are read.
-template <int L, int KMAX, bool VAR, bool NT, int A, bool CHAIN>
+template <int L, int KMAX, bool VAR, bool NT, int A, bool CHAIN, bool MBOX = false>
 __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
                                               double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
                                               int32_t* __restrict__ primal, int64_t count, int stride, int flags, int64_t block,
                                               const ChainArgs* ca, int ticket, double* __restrict__ lbh = nullptr, int hmode = 0,
                                               unsigned long long* __restrict__ mbox = nullptr) {
   static_assert(!CHAIN || A == ACC_COH, "chain bodies hand results over through relaxed agent-scope flags: every dual access must be an agent-scope (sc1) access");
-  static_assert(MAILBOX_SENDS == 4, "plan.hpp: the sends whose fields are held in registers (KS)");
+  static_assert(MAILBOX_SENDS >= 1 && MAILBOX_SENDS <= 4, "plan.hpp: the sends whose fields are held in registers (KS)");
+  static_assert(!MBOX || (CHAIN && !VAR), "the mailbox belongs to chains of the exact dense classes");   // (an instantiation of its own: the joined passes of the headline grid lost 8 % with the mailbox fields in their registers)
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
-  constexpr int KS = 4;                          // sends whose target vectors are prefetched / forwarded
-  constexpr int NFW = 4;                         // receives whose result can be forwarded in registers
+  constexpr int KS = MBOX ? MAILBOX_SENDS : 4;   // sends whose target vectors are prefetched / forwarded
+  constexpr int NFW = MBOX ? MAILBOX_SENDS : 4;  // receives whose result can be forwarded in registers (plan.cpp: hints of mailbox chains stay below)
   constexpr int PIECES = 3 * (1 + pk_dense_cap(L));      // 16-B pieces of the largest packet / op list
   __shared__ double2_t lds_pk[GPB][PIECES];
   __shared__ double lds_mo[GPB][L];
@@ -867,7 +896,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
         const Op& o = lop[n_recv + k];
         s_ms[k] = dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0);
         s_om[k] = o.omega; s_fw[k] = uni<G>(o.pad); s_peer[k] = uni<G>(o.peer);
-        if constexpr (!VAR) { if (mbox && (uni<G>(o.info) & OP_MAILBOX)) s_box[k] = mbox + uni64<G>(o.peer_const) * (2 * L); }
+        if constexpr (MBOX) { if (uni<G>(o.info) & OP_MAILBOX) s_box[k] = mbox + uni64<G>(o.peer_const) * (2 * L); }
       }
     }
   }
@@ -917,8 +946,8 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
       if (act) {
         const Op& o = lop[c + j];
         pdual[j] = uni64<G>(o.peer_dual);
-        if constexpr (CHAIN && !VAR) {
-          if (mbox && (uni<G>(o.info) & OP_MAILBOX)) { long long row; __builtin_memcpy(&row, &o.omega, 8); box[j] = mbox + uni64<G>(row) * (2 * L); }
+        if constexpr (MBOX) {
+          if (uni<G>(o.info) & OP_MAILBOX) { long long row; __builtin_memcpy(&row, &o.omega, 8); box[j] = mbox + uni64<G>(row) * (2 * L); }
         }
         side[j] = (uni<G>(o.info) >> 5) & 1;
         defer[j] = FW ? uni<G>(o.pad) : 0;
@@ -974,12 +1003,12 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
           msv[j] = (double)pdual[j] * 1e-300; mov[j] = 0.0;
 #else
           msv[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? 0 : L) + g);
-          if (!(CHAIN && box[j])) mov[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? L : 0) + g);
+          if (!(MBOX && box[j])) mov[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? L : 0) + g);
 #endif
         }
       }
     }
-    if constexpr (CHAIN && !VAR) {               // ... and, with everything else in flight, the vectors that come by mailbox
+    if constexpr (MBOX) {                        // ... and, with everything else in flight, the vectors that come by mailbox
 #pragma unroll
       for (int j = 0; j < KMAX; ++j)
         if (c + j < n_recv && box[j] && g < L) mov[j] = mailbox_take(*ca, box[j] + 2 * g, aborted);
@@ -1101,19 +1130,20 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
       for (int k = 0; k < KS; ++k) {
         if (k < n_send) {
           const int fw = s_fw[k];
-          const double cur = fw > 0 ? (fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3]) : sm[k];
+          const double cur = fw > 0 ? (fw == 1 ? mnew[0] : fw == 2 ? mnew[NFW > 1 ? 1 : 0] : fw == 3 ? mnew[NFW > 2 ? 2 : 0] : mnew[NFW > 3 ? 3 : 0]) : sm[k];
           const double delta = s_om[k] * snap;
           // (the residual rule below adds to the vector once more: the mailbox gets the final value there)
-          if (s_box[k] && !(flags & SWEEP_RESIDUAL)) mailbox_put(s_box[k] + 2 * g, cur + delta, ca->epoch);
+          if constexpr (MBOX) { if (s_box[k] && !(flags & SWEEP_RESIDUAL)) mailbox_put(s_box[k] + 2 * g, cur + delta, ca->epoch); }
           st_dual<A>(s_ms[k] + g, cur + delta);
           theta -= delta;
 #ifndef LPMP_ABLATE_LB_TRACK
           // a vector that goes to the mailbox has a reader later in this launch, which sets the peer's tracked bound itself
           // — and is not ordered after THIS store, so it is left out
-          if (g == 0 && !s_box[k]) st_lb<A>(lb + s_peer[k], LPMP_NAN);
+          if (g == 0 && !(MBOX && s_box[k])) st_lb<A>(lb + s_peer[k], LPMP_NAN);
 #endif
         }
       }
+      if constexpr (MBOX) chain_stamp(*ca, ticket, 6);   // first sends issued (the mailbox has them)
     } else {
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
@@ -1122,7 +1152,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
           double* ms = dual + uni64<G>(o.peer_dual) + (((uni<G>(o.info) >> 5) & 1) ? (VAR ? uni<G>(o.pd0) : L) : 0);
           const int fw = uni<G>(o.pad);
           double cur;
-          if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[1] : fw == 3 ? mnew[2] : mnew[3];
+          if (fw > 0) cur = fw == 1 ? mnew[0] : fw == 2 ? mnew[NFW > 1 ? 1 : 0] : fw == 3 ? mnew[NFW > 2 ? 2 : 0] : mnew[NFW > 3 ? 3 : 0];
           else cur = preload_ok ? sm[k] : ld_dual<A>(ms + g);
           const double delta = o.omega * snap;
 #ifdef LPMP_ABLATE_SEND_VEC
@@ -1179,7 +1209,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
         residual += o.omega;
         const double delta = residual * theta;
         const double v = ld_dual<A>(ms + g) + delta;
-        if constexpr (CHAIN && !VAR) { if (k < KS && mbox && (o.info & OP_MAILBOX)) mailbox_put(mbox + o.peer_const * (2 * L) + 2 * g, v, ca->epoch); }
+        if constexpr (MBOX) { if (k < KS && (o.info & OP_MAILBOX)) mailbox_put(mbox + o.peer_const * (2 * L) + 2 * g, v, ca->epoch); }
         st_dual<A>(ms + g, v);
         theta -= delta;
       }
@@ -1233,15 +1263,23 @@ __device__ __forceinline__ void chain_loop(const ChainArgs& ca, const ChainLaunc
     __syncthreads();                               // s_ticket[(it + 1) & 1] is written, the LDS of the body is free again
   }
 }
-template <int L, int KMAX, bool VAR, bool NT>
-__global__ void __launch_bounds__(256)
+// MBOX: a chain whose launches all carry CHAIN_LAUNCH_MAILBOX (plan.cpp marks every launch of such a chain)
+#ifndef LPMP_MBOX_WPE
+#define LPMP_MBOX_WPE 1
+#endif
+template <int L, int KMAX, bool VAR, bool NT, bool MBOX>
+__global__ void __launch_bounds__(256, MBOX ? LPMP_MBOX_WPE : 1)
 chain_dense_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, double* __restrict__ dual,
                       const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal, int flags) {
   chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
-    const int hmode = ca.lb_hist ? (ln.pad & 3) : 0;
-    dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket,
-                                                   hmode ? ca.lb_hist + (int64_t)(ln.pad >> 2) * ca.hist_stride : nullptr, hmode,
-                                                   (ln.pad & CHAIN_LAUNCH_MAILBOX) ? ca.mailbox : nullptr);
+    if constexpr (MBOX) {
+      dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket,
+                                                           nullptr, 0, ca.mailbox);
+    } else {
+      const int hmode = ca.lb_hist ? (ln.pad & 3) : 0;
+      dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket,
+                                                     hmode ? ca.lb_hist + (int64_t)(ln.pad >> 2) * ca.hist_stride : nullptr, hmode);
+    }
   });
 }
 
@@ -2520,9 +2558,11 @@ bool launch_chain(int kclass, int flags, const void* chain_args, const void* lau
   const ChainArgs ca = *static_cast<const ChainArgs*>(chain_args);
   const ChainLaunch* ln = static_cast<const ChainLaunch*>(launches);
   const bool nt = (flags & SWEEP_NT) != 0;
-#define CHAIN_LAUNCH1(LL, KK, VV, NTT) do { auto k = chain_dense_pk_kernel<LL, KK, VV, NTT>; \
+#define CHAIN_LAUNCH2(LL, KK, VV, NTT, MM) do { auto k = chain_dense_pk_kernel<LL, KK, VV, NTT, MM>; \
     hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, dual, cdata, lb, primal, flags); } while (0)
-#define CHAIN_LAUNCH(LL, KK) do { if (nt) CHAIN_LAUNCH1(LL, KK, false, true); else CHAIN_LAUNCH1(LL, KK, false, false); } while (0)
+#define CHAIN_LAUNCH1(LL, KK, VV, NTT) CHAIN_LAUNCH2(LL, KK, VV, NTT, false)
+  // (a mailbox chain is a deep schedule: latency-bound, no streaming variant)
+#define CHAIN_LAUNCH(LL, KK) do { if (ca.mailbox) CHAIN_LAUNCH2(LL, KK, false, false, true); else if (nt) CHAIN_LAUNCH1(LL, KK, false, true); else CHAIN_LAUNCH1(LL, KK, false, false); } while (0)
   switch (kclass) {
     case KC_GENERIC: { auto k = chain_generic_kernel<64>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<64>::THREADS)), dim3(GenCtx<64>::THREADS), 0, s, ca, ln, dual, cdata, tabs, lb, flags); return true; }
     case KC_SMALL: { auto k = chain_generic_kernel<1>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<1>::THREADS)), dim3(GenCtx<1>::THREADS), 0, s, ca, ln, dual, cdata, tabs, lb, flags); return true; }
@@ -2549,6 +2589,7 @@ bool launch_chain(int kclass, int flags, const void* chain_args, const void* lau
   }
 #undef CHAIN_LAUNCH
 #undef CHAIN_LAUNCH1
+#undef CHAIN_LAUNCH2
 }
 
 void launch_factor_lb(const void* recs, const double* dual, const double* cdata, double* out, int64_t count, hipStream_t s) {

@@ -844,6 +844,20 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
           const auto& lr = out.launches[li];
           for (int64_t i = lr.begin; i < lr.end; ++i) { rec_of_upd[rec_upd[i]] = (int32_t)i; rec_launch[i] = (int32_t)li; }
           if (!mbox_class[lr.kclass]) continue;
+          if (MAILBOX_SENDS < 4)                    // the mailbox body forwards fewer results in registers: take the other hints back
+            for (int64_t i = lr.begin; i < lr.end; ++i) {
+              const UpdRec& r = out.recs[i];
+              Op* o = out.ops.data() + r.op_begin;
+              Op* pk = out.packets.data() + lr.pk_begin + (i - lr.begin) * lr.stride + 1;
+              for (int b = r.n_recv; b < r.n_recv + r.n_send; ++b) {
+                const int hit = o[b].pad - 1;
+                if (hit >= 0 && (hit >= MAILBOX_SENDS || b - r.n_recv >= MAILBOX_SENDS)) {
+                  o[hit].pad = 0; o[b].pad = 0; pk[hit].pad = 0; pk[b].pad = 0;
+                  out.recs[i].kind_flags &= ~UPD_PRELOAD_OK;      // (it was clear already: the send targets what a receive writes)
+                  Op* hdr = pk - 1; UpdRec rr; std::memcpy(&rr, hdr, sizeof(rr)); rr.kind_flags &= ~UPD_PRELOAD_OK; std::memcpy(hdr, &rr, sizeof(rr));
+                }
+              }
+            }
           for (int64_t i = lr.begin; i < lr.end; ++i) {
             const UpdRec& r = out.recs[i];
             const Op* o = out.ops.data() + r.op_begin;
@@ -1049,6 +1063,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
                 }
                 Op& pr = slot_of(i)[1 + j];
                 std::memcpy(&pr.omega, &row_of_op[sop], sizeof(double)); pr.info |= OP_MAILBOX;
+                ++cp.mailbox_receives;
               }
             }
           if (rows > 0) {

@@ -134,7 +134,12 @@ constexpr int32_t CHAIN_LAUNCH_LABEL_PAIRED = 2;  // ... and in every record sen
 // dense chain launches: message vectors between dependent records travel as tagged granules (kernels.hip, mailbox); the
 // dependencies they cover are not in dep[] any more.  Bit 30: the low bits of ChainLaunch::pad belong to the joined passes.
 constexpr int32_t CHAIN_LAUNCH_MAILBOX = 1 << 30;
-constexpr int MAILBOX_SENDS = 4;                // the sends of a record that may go to the mailbox (kernels.hip: KS)
+// the sends of a record that may go to the mailbox = the sends (and forwarded receives) the mailbox form of the dense body
+// holds in registers (kernels.hip: KS, NFW)
+#ifndef LPMP_MBOX_KS
+#define LPMP_MBOX_KS 4
+#endif
+constexpr int MAILBOX_SENDS = LPMP_MBOX_KS;
 constexpr int32_t CHAIN_LAUNCH_LABEL_OPS = 1;   // level loop: every record a vector factor whose ops are labeling messages with it on the left, <= 8 receives and <= 8 sends, no two of a kind on one peer
 struct ChainPlan {
   bool valid = false;
@@ -146,6 +151,7 @@ struct ChainPlan {
   bool banded = false;                      // tickets in Infinity-Cache order: the tables are read with plain loads
   bool level_loop = false;                  // many tiny levels of a generic class: ONE workgroup walks the launches (kernels.hip)
   int64_t mailbox_rows = 0;                 // message vectors that travel through the mailbox (rows of mailbox_width granule pairs)
+  int64_t mailbox_receives = 0;             // receives that poll a row
   int32_t mailbox_width = 0;
 };
 // records one workgroup of the packed kernels takes (256 threads / lanes per record)

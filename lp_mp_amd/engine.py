@@ -40,7 +40,7 @@ EXPORTS = [
     "lpmp_last_error", "lpmp_version", "lpmp_plan_create", "lpmp_plan_destroy", "lpmp_plan_n_factors",
     "lpmp_plan_n_updated", "lpmp_plan_get_order", "lpmp_plan_get_update_order", "lpmp_plan_omega_nnz",
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
-    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_custom_schedule_info", "lpmp_plan_schedule_classes", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_plan_pass_rotates", "lpmp_plan_chain_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
+    "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_custom_schedule_info", "lpmp_plan_schedule_classes", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_plan_pass_rotates", "lpmp_plan_chain_info", "lpmp_plan_mailbox_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
     "lpmp_upload_model", "lpmp_set_reparametrization", "lpmp_set_reparametrization_type", "lpmp_set_inner_iterations", "lpmp_plan_get_partitions", "lpmp_compute_pass", "lpmp_compute_forward_pass",
     "lpmp_compute_backward_pass", "lpmp_compute_pass_custom", "lpmp_schedule_create", "lpmp_schedule_create_fused", "lpmp_schedule_run",
     "lpmp_schedule_info", "lpmp_schedule_destroy", "lpmp_lower_bound", "lpmp_factor_lower_bounds",
@@ -95,6 +95,7 @@ def lib():
         L.lpmp_plan_pass_schedule_info.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.lpmp_plan_pass_rotates.argtypes = [C.c_void_p, C.c_int]
         L.lpmp_plan_chain_info.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
+        L.lpmp_plan_mailbox_info.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 2
         L.lpmp_plan_get_update_levels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.lpmp_plan_schedule_classes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.lpmp_plan_custom_schedule_info.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 5
@@ -295,7 +296,9 @@ def _chain_info(self, d: int, mode: int) -> dict:
     dependencies, launches that stay plain (all 0: ordinary launches / graph replay)"""
     v = [C.c_int64() for _ in range(4)]
     _chk(self.L.lpmp_plan_chain_info(self.h, d, mode, *[C.addressof(x) for x in v]))
-    return dict(zip(("n_chains", "n_tickets", "n_dependencies", "n_plain_launches"), [x.value for x in v]))
+    w = [C.c_int64() for _ in range(2)]
+    _chk(self.L.lpmp_plan_mailbox_info(self.h, d, mode, *[C.addressof(x) for x in w]))
+    return dict(zip(("n_chains", "n_tickets", "n_dependencies", "n_plain_launches", "mailbox_rows", "mailbox_receives"), [x.value for x in v + w]))
 
 
 Plan.chain_info = _chain_info

@@ -1,0 +1,116 @@
+"""Mailbox of the dense chain executor (plan.cpp: which message vectors travel as tagged granules and which dependencies
+that covers; kernels.hip: mailbox_put / mailbox_take) against the oracle, bit for bit — with the mailbox, with every
+hand-over through completion flags (LPMP_NO_MAILBOX=1), and against each other."""
+import numpy as np
+import pytest
+
+from lp_mp_amd import engine as E
+from lp_mp_amd import model as M
+from lp_mp_amd import synthetic as S
+from oracle.binding import Oracle
+
+pytestmark = pytest.mark.gpu
+LB_RTOL = 1e-5
+
+
+def banded_model(n, L, offsets, seed=3, compute_primal=True):
+    """variables 0 .. n-1 in index order, an edge (i, i + o) for every offset: every sweep is n levels deep, a variable
+    receives from up to len(offsets) earlier and sends to as many later ones (several mailbox rows per record)"""
+    ei = np.concatenate([np.arange(0, n - o) for o in offsets]); ej = np.concatenate([np.arange(0, n - o) + o for o in offsets])
+    o = np.lexsort((ej, ei)); ei, ej = ei[o], ej[o]
+    return S.mrf_model(n, L, ei, ej, S.u01(n * L, seed, 0), tables=S.u01(ei.shape[0] * L * L, seed, n * L), compute_primal=compute_primal)
+
+
+MODELS = {
+    "banded 8 labels, offsets 1 5 17": lambda: banded_model(600, 8, (1, 5, 17)),
+    "banded 32 labels, offsets 1 2 3 4": lambda: banded_model(160, 32, (1, 2, 3, 4)),     # 4 + 4 messages: a full packet
+    "banded 4 labels, offset 1 (a chain)": lambda: banded_model(900, 4, (1,)),
+    "random graph, 8 labels (mailbox and flags mixed)": lambda: S.random_graph_model(3000, 3000, 8, seed=2, compute_primal=True),
+    "row-major grid, 16 labels": lambda: S.grid_model(40, 30, 16, order="row_major", seed=5, compute_primal=True),
+}
+
+
+@pytest.mark.parametrize("name", list(MODELS))
+def test_mailbox_chains_equal_the_oracle(name, monkeypatch):
+    m = MODELS[name]()
+    monkeypatch.delenv("LPMP_NO_MAILBOX", raising=False)
+    ci = E.Plan(m).chain_info(M.FORWARD, M.REPAM_ANISOTROPIC)
+    assert ci["n_chains"] == 1 and ci["mailbox_rows"] > 0 and ci["mailbox_receives"] >= ci["mailbox_rows"], ci
+    monkeypatch.setenv("LPMP_NO_MAILBOX", "1")
+    cf = E.Plan(m).chain_info(M.FORWARD, M.REPAM_ANISOTROPIC)
+    assert cf["mailbox_rows"] == 0 and cf["n_dependencies"] > ci["n_dependencies"], (ci, cf)
+    o = Oracle(m)
+    engines = []
+    for env in (None, "1"):
+        if env: monkeypatch.setenv("LPMP_NO_MAILBOX", env)
+        else: monkeypatch.delenv("LPMP_NO_MAILBOX", raising=False)
+        e = E.Engine(0); e.upload(m); engines.append(e)
+    def same(what):
+        for k, e in enumerate(engines):
+            assert np.array_equal(e.download_duals(), o.duals()), (what, k)
+            lb, lbo = e.lower_bound(), o.LowerBound()
+            assert abs(lb - lbo) <= LB_RTOL * max(1.0, abs(lbo)), (what, k)
+            # the tracked bounds (incl. the marks a mailbox send leaves to its reader) against a full recomputation
+            tracked = e.lower_bound(); e.invalidate_lower_bounds()
+            assert abs(e.lower_bound() - tracked) <= 1e-12 * max(1.0, abs(tracked)), (what, k)
+    try:
+        for mode in (M.REPAM_ANISOTROPIC, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM):
+            o.set_reparametrization(mode)
+            for e in engines: e.set_reparametrization(mode)
+            o.ComputeForwardPass(); o.ComputeBackwardPass()
+            for e in engines: e.forward_pass(); e.backward_pass()
+            same(("directional", mode))
+            for n in (1, 3):
+                o.ComputePass(n)
+                for e in engines: e.compute_pass(n)
+                same(("passes", mode, n))
+        # the residual rule adds to a sent vector once more: the mailbox carries the final value
+        o.set_reparametrization_type(1)
+        for e in engines: e.set_reparametrization_type(1)
+        o.ComputeForwardPass(); o.ComputePass(1)
+        for e in engines: e.forward_pass(); e.compute_pass(1)
+        same("residual")
+        o.set_reparametrization_type(0)
+        for e in engines: e.set_reparametrization_type(0)
+        # rounding passes run in the same chains
+        o.set_reparametrization(M.REPAM_ANISOTROPIC)
+        for e in engines: e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        for it in (1, 2):
+            o.ComputePassAndPrimal(it)
+            for k, e in enumerate(engines):
+                e.compute_pass_and_primal(it)
+                assert np.array_equal(e.download_primal(), o.primal()), (it, k)
+                c, co = e.evaluate_primal(), o.EvaluatePrimal()
+                assert abs(c - co) <= 1e-9 * max(1.0, abs(co))
+        same("after rounding")
+    finally:
+        for e in engines: e.close()
+
+
+def test_mailbox_tags_survive_many_runs_and_new_duals():
+    """a granule is valid for ONE launch (its tag is the launch's epoch): forty launches back to back on one schedule, new
+    duals uploaded in between, the fused pass and the directional sweeps interleaved — always the flags-only result"""
+    import os
+    m = banded_model(400, 16, (1, 3, 11), seed=8, compute_primal=False)
+    rng = np.random.default_rng(4)
+    res = {}
+    for env in (None, "1"):
+        if env: os.environ["LPMP_NO_MAILBOX"] = env
+        else: os.environ.pop("LPMP_NO_MAILBOX", None)
+        try:
+            e = E.Engine(0); e.upload(m); e.set_reparametrization(M.REPAM_ANISOTROPIC)
+            d0 = e.download_duals()
+            out = []
+            r = np.random.default_rng(4)
+            for k in range(40):
+                if k % 7 == 3: e.upload_duals(d0 * r.uniform(0.5, 1.5))
+                if k % 3 == 0: e.forward_pass()
+                elif k % 3 == 1: e.backward_pass()
+                else: e.compute_pass(2)
+                out.append(e.download_duals().copy())
+            res[env] = out
+            e.close()
+        finally:
+            os.environ.pop("LPMP_NO_MAILBOX", None)
+    for a, b in zip(res[None], res["1"]):
+        assert np.array_equal(a, b)

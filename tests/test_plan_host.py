@@ -367,6 +367,27 @@ def test_chain_plans_default_to_the_packed_classes(monkeypatch):
     assert ci["n_chains"] == 1 and ci["n_plain_launches"] == 2 and ci["n_dependencies"] >= ci["n_tickets"] - 1 > 0
 
 
+def test_mailbox_covers_the_hand_overs_of_a_deep_dense_chain(monkeypatch):
+    """plan.cpp: in a deep chain of an exact dense class a receive polls the mailbox row its neighbour's send writes, and the
+    dependency between the two tickets is dropped; what a granule cannot vouch for keeps its flag (the own factor's previous
+    update in the fused pass); run-time-dims and Potts classes, short schedules and LPMP_NO_MAILBOX=1 keep every flag"""
+    monkeypatch.delenv("LPMP_NO_MAILBOX", raising=False)
+    m = S.grid_model(40, 30, 8, order="row_major")
+    f = E.Plan(m).chain_info(M.FORWARD, M.REPAM_ANISOTROPIC)
+    # 40 x 30 grid: every edge is received through exactly once per sweep -> one row per edge
+    n_edges = 40 * 29 + 39 * 30
+    assert f["n_chains"] == 1 and f["mailbox_rows"] == n_edges and f["mailbox_receives"] == n_edges and f["n_dependencies"] == 0, f
+    p = E.Plan(m).chain_info(-1, M.REPAM_ANISOTROPIC)
+    assert p["mailbox_rows"] == 2 * n_edges and 0 < p["n_dependencies"] < p["n_tickets"], p      # forward record -> backward record of the same variable
+    monkeypatch.setenv("LPMP_NO_MAILBOX", "1")
+    g = E.Plan(m).chain_info(M.FORWARD, M.REPAM_ANISOTROPIC)
+    assert g["mailbox_rows"] == 0 and g["n_dependencies"] >= g["n_tickets"] - 1, g
+    monkeypatch.delenv("LPMP_NO_MAILBOX")
+    for other in (S.grid_model(40, 30, 8, order="row_major", pairwise="potts"), S.grid_model(40, 30, 7, order="row_major"),
+                  S.grid_model(40, 30, 8, order="colour_major")):
+        assert E.Plan(other).chain_info(M.FORWARD, M.REPAM_ANISOTROPIC)["mailbox_rows"] == 0
+
+
 def test_pass_rotation_is_decided_op_by_op():
     """n passes as H, W, (K, W)^(n-1), T need K = (receives of T, sends of H) and W = (receives of T', sends of H')
     record by record (engine.cpp, plan_rotation): checkerboard grids in colour-major order qualify under anisotropic

@@ -64,6 +64,34 @@ def show(path):
     np.maximum.at(last_pub, tl, t3)
     d = np.diff(last_pub)
     print("  level to level (last publish of consecutive launches):", q(d[d > 0]))
+    # mailbox chains (plan.cpp): the hand-over between levels is a granule, not a flag — per level the medians of the stamps
+    if t4.any() and n_launch > 8:
+        med = lambda a: np.array([np.median(a[tl == l]) for l in range(n_launch)])
+        m0, m1, m2, m4, m5 = med(t0), med(t1), med(t2), med(t4), med(t5)
+        inner = slice(4, n_launch - 4)
+        qq = lambda a: "median %.2f, p10 %.2f, p90 %.2f us" % tuple(us(np.percentile(a[inner], [50, 10, 90])))
+        print("  per level (medians over the level's tickets):")
+        print("    ready before the previous level's sends   t2[l-1] - t1[l] :", qq(m2[:-1] - m1[1:]))
+        print("    hand-over   t4[l] - t2[l-1]  (sends issued -> vectors in) :", qq(m4[1:] - m2[:-1]))
+        print("    receives    t5 - t4                                       :", qq(m5 - m4))
+        print("    sends       t2 - t5                                       :", qq(m2 - m5))
+        print("    level to level   t4[l] - t4[l-1]                          :", qq(np.diff(m4)))
+        t6 = st.T[6]
+        if t6.any():
+            # a row-major grid, first half of a directional sweep: record i of anti-diagonal l reads what records i - 1 and i
+            # of anti-diagonal l - 1 sent, so ticket b (4 records) waits for tickets b - 1 and b of the level before
+            first = np.zeros(n_launch + 1, np.int64); np.add.at(first, tl + 1, 1); first = np.cumsum(first)
+            hop, lead, grow = [], [], (first[1:] - first[:-1])
+            for l in range(8, min(n_launch, 1000)):
+                a0, a1, b0, b1 = first[l - 1], first[l], first[l], first[l + 1]
+                if a1 - a0 < 2 or b1 - b0 < a1 - a0: continue
+                nb = a1 - a0
+                put = np.maximum(t6[a0:a1], np.concatenate([[0], t6[a0:a1 - 1]]))
+                hop.append(t4[b0:b0 + nb] - put); lead.append(put - t1[b0:b0 + nb])
+            hop = np.concatenate(hop); lead = np.concatenate(lead)
+            print("    per ticket: sends issued (both producers) -> inputs landed   :", q(hop))
+            print("    per ticket: waiting already when the producers' sends left   :", q(lead), " (negative: not ready yet: %.1f %%)" % (100.0 * np.mean(lead < 0)))
+            print("    per ticket: landed -> own sends issued   t6 - t4              :", q(t6 - t4))
     # critical chain: follow the latest predecessor back from the last ticket
     k = int(np.argmax(t3)); hops = 0; parts = np.zeros(4)
     while True:
