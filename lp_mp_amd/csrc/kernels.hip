@@ -854,7 +854,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
                                               double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
                                               int32_t* __restrict__ primal, int64_t count, int stride, int flags, int64_t block,
                                               const ChainArgs* ca, int ticket, double* __restrict__ lbh = nullptr, int hmode = 0,
-                                              unsigned long long* __restrict__ mbox = nullptr) {
+                                              unsigned long long* __restrict__ mbox = nullptr, int n_deps = -1) {
   static_assert(!CHAIN || A == ACC_COH, "chain bodies hand results over through relaxed agent-scope flags: every dual access must be an agent-scope (sc1) access");
   static_assert(MAILBOX_SENDS >= 1 && MAILBOX_SENDS <= 4, "plan.hpp: the sends whose fields are held in registers (KS)");
   static_assert(!MBOX || (CHAIN && !VAR), "the mailbox belongs to chains of the exact dense classes");   // (an instantiation of its own: the joined passes of the headline grid lost 8 % with the mailbox fields in their registers)
@@ -989,7 +989,8 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
       }
     }
     if constexpr (CHAIN && FIRST) {              // the tables are in flight while the predecessors finish
-      aborted = !chain_wait(*ca, ticket);
+      if (MBOX && n_deps == 0) chain_stamp(*ca, ticket, 1);   // (chain_loop_ahead knows: nothing to wait for, no barrier)
+      else aborted = !chain_wait(*ca, ticket);
       load_own_and_targets();
     }
 #pragma unroll
@@ -1267,20 +1268,57 @@ __device__ __forceinline__ void chain_loop(const ChainArgs& ca, const ChainLaunc
 #ifndef LPMP_MBOX_WPE
 #define LPMP_MBOX_WPE 1
 #endif
+// The same loop for mailbox chains, where a level is a couple of microseconds and what a workgroup needs before it can
+// even request its records — ticket number (an atomic on the far side of the fabric), then the ticket's launch, block and
+// dependency count (three arrays streamed from HBM once per launch: a miss each) — was 3.5 us of round trips in a row per
+// ticket (tools/chain_trace.py: t1 - t0), more than a level.  Here the first thread draws ticket numbers TWO iterations
+// ahead and fetches the fields of the next ticket while the current one is processed: all of it returns during the body and
+// is put down in LDS after it.  (A workgroup runs its tickets in increasing order, so the lowest unfinished ticket of the
+// launch is always one that is running: drawing ahead cannot deadlock.)  Costs registers: not for the joined passes.
+template <class Body>
+__device__ __forceinline__ void chain_loop_ahead(const ChainArgs& ca, const ChainLaunch* __restrict__ launches, Body body) {
+  __shared__ int s_tk[3][4];                       // ticket, launch, block, number of dependencies
+  if (threadIdx.x == 0) {
+    const int t = atomicAdd(ca.next, 1);
+    s_tk[0][0] = t;
+    if (t < ca.n_tickets) { s_tk[0][1] = ca.tk_launch[t]; s_tk[0][2] = ca.tk_block[t]; s_tk[0][3] = ca.dep_off[t + 1] - ca.dep_off[t]; }
+    s_tk[1][0] = atomicAdd(ca.next, 1);
+  }
+  __syncthreads();
+  for (int it = 0;; ++it) {
+    const int cur = it % 3, nx1 = (it + 1) % 3, nx2 = (it + 2) % 3;
+    const int ticket = s_tk[cur][0];
+    if (ticket >= ca.n_tickets) break;
+    int t2 = 0, f_launch = 0, f_block = 0, f_deps = 0;
+    if (threadIdx.x == 0) {
+      t2 = atomicAdd(ca.next, 1);
+      const int t1 = s_tk[nx1][0];
+      if (t1 < ca.n_tickets) { f_launch = ca.tk_launch[t1]; f_block = ca.tk_block[t1]; f_deps = ca.dep_off[t1 + 1] - ca.dep_off[t1]; }
+    }
+    chain_stamp(ca, ticket, 0);                    // ticket in hand
+    const ChainLaunch ln = launches[s_tk[cur][1]];
+    body(ln, (int64_t)s_tk[cur][2], ticket, s_tk[cur][3]);
+    if (threadIdx.x == 0) { s_tk[nx1][1] = f_launch; s_tk[nx1][2] = f_block; s_tk[nx1][3] = f_deps; s_tk[nx2][0] = t2; }
+    chain_publish(ca, ticket);
+    __syncthreads();
+  }
+}
 template <int L, int KMAX, bool VAR, bool NT, bool MBOX>
 __global__ void __launch_bounds__(256, MBOX ? LPMP_MBOX_WPE : 1)
 chain_dense_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, double* __restrict__ dual,
                       const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal, int flags) {
-  chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
-    if constexpr (MBOX) {
+  if constexpr (MBOX) {
+    chain_loop_ahead(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket, int n_deps) {
       dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket,
-                                                           nullptr, 0, ca.mailbox);
-    } else {
+                                                           nullptr, 0, ca.mailbox, n_deps);
+    });
+  } else {
+    chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
       const int hmode = ca.lb_hist ? (ln.pad & 3) : 0;
       dense_pk_body<L, KMAX, VAR, NT, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket,
                                                      hmode ? ca.lb_hist + (int64_t)(ln.pad >> 2) * ca.hist_stride : nullptr, hmode);
-    }
-  });
+    });
+  }
 }
 
 // the generic kernels inside the chain executor (chains of tiny factors: multicut / C5 labeling lists): nothing
