@@ -1,0 +1,270 @@
+"""Lock-step partitioned sweep: several GPUs run THE unpartitioned sweep, not an approximation of it.
+
+multi_gpu.PartitionedSweep gives every part its own sub-problem and reconciles the cut messages in a boundary step; its
+dual bound after n passes stays below the unpartitioned sweep's (1 - 2 % on a random graph).  This module
+does the other thing the level schedule allows: updates of one dependency level commute, so the global
+level-sorted sequence of the reference's sweep (LP::ComputePass, reference include/LP_MP.h:981-1005) can be executed by
+several ranks at once — every rank runs the updates of ITS variables with the GLOBAL weights (LP::get_omega, :412-460,
+computed once on the global structure) level by level, and between two levels the ranks exchange the message vectors the
+next level reads across the cut.  The result is the unpartitioned sweep's, bit for bit, on any number of ranks: the gap
+to the unpartitioned bound is zero by construction, and every step is an iterator-range pass of the reference.
+
+What makes the exchange a plain halo copy: a pairwise factor's dual is [side 0 | side 1] and side s is written ONLY by the
+updates of endpoint s (its receives rewrite its own side, its sends add to its own side), read by endpoint 1 - s.  Both
+ranks of a cut edge hold a copy of the pairwise factor (table and dual) and a never-updated ghost of the remote variable;
+after a level in which endpoint s wrote, its rank ships side s to the other copy.
+
+Levels are merged into SEGMENTS greedily (identically on every rank, from the global structure): a segment ends before the
+first level that reads a cut vector written inside it.  A colour-major grid in row strips: two segments per pass.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import model as M
+from . import synthetic as S
+
+
+@dataclass
+class LockstepPart:
+    rank: int
+    world: int
+    L: int
+    model: M.FlatModel                 # local variables + ghosts (by global index), every pairwise factor touching a local variable
+    vars_global: np.ndarray            # local vector factor -> global variable
+    is_ghost: np.ndarray               # [n local vector factors]
+    edges_global: np.ndarray           # local pairwise factor (in local edge order) -> global edge
+    owned: np.ndarray                  # [n local factors] bool: counted in this rank's share of the lower bound
+    rows: List[List[tuple]]            # [direction][level - 1] = (factors, om_off, om, mk_off, mk) of this rank's updates
+    const_fill: Optional[list] = None
+    dual_fill: Optional[list] = None
+
+
+@dataclass
+class LockstepSchedule:
+    """what every rank computes identically from the global structure"""
+    n_levels: Tuple[int, int]
+    # cut vectors (2 * edge + side) written / read per (direction, level), and who writes / reads a cut vector
+    written: List[List[np.ndarray]]
+    read: List[List[np.ndarray]]
+    writer: np.ndarray                 # [2 * n_edges] rank of endpoint `side` (the only writer of that side)
+    reader: np.ndarray                 # rank of the other endpoint
+    n_edges: int
+    _programs: Dict[int, list] = field(default_factory=dict)
+
+    def program(self, n_passes: int):
+        """steps of n passes: ("run", ((d, level), ...)) and ("halo", vectors to ship: sorted global ids)"""
+        if n_passes in self._programs:
+            return self._programs[n_passes]
+        dirty = np.zeros(2 * self.n_edges, bool)
+        steps, seg = [], []
+        for _ in range(n_passes):
+            for d in (0, 1):
+                for l in range(self.n_levels[d]):
+                    if dirty[self.read[d][l]].any():
+                        steps.append(("run", tuple(seg))); seg = []
+                        steps.append(("halo", np.nonzero(dirty)[0])); dirty[:] = False
+                    seg.append((d, l))
+                    dirty[self.written[d][l]] = True
+        if seg:
+            steps.append(("run", tuple(seg)))
+        if dirty.any():                                 # the copies agree again when the call returns
+            steps.append(("halo", np.nonzero(dirty)[0]))
+        self._programs[n_passes] = steps
+        return steps
+
+
+def _csr_take(off, data, idx):
+    lens = off[idx + 1] - off[idx]
+    first = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pos = np.repeat(off[idx], lens) + (np.arange(int(first[-1])) - np.repeat(first[:-1], lens))
+    return first, data[pos]
+
+
+def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: int, unaries=None, tables=None, potts=None,
+                 only: Optional[int] = None, stream_seed: Optional[int] = None, pairwise: str = "dense"):
+    """Lock-step parts of the MRF synthetic.mrf_model(n_vars, L, edge_i, edge_j, ...) for the partition ``part[v]``.
+    Returns (schedule, parts); ``only``: just that rank's part.  Costs as in multi_gpu.partition_mrf (host arrays, or
+    ``stream_seed``: generated in HBM from the counter stream, fill descriptors in the part)."""
+    from . import engine as E
+    edge_i = np.asarray(edge_i, np.int64); edge_j = np.asarray(edge_j, np.int64); part = np.asarray(part, np.int64)
+    n_edges = edge_i.shape[0]
+    # the global structure (no costs) and everything the reference derives from it
+    if pairwise == "dense":
+        gm = S.mrf_model(n_vars, L, edge_i, edge_j, np.zeros(n_vars * L), device_const=True)
+    else:
+        gm = S.mrf_model(n_vars, L, edge_i, edge_j, np.zeros(n_vars * L), potts=np.zeros(n_edges))
+    gp = E.Plan(gm)
+    g_off, g_ent = gp.msg_lists(gm.n_messages)
+    msg = g_ent // 2                                         # messages of every factor's list; message 2 e + s: edge e, side s
+    writer = np.empty(2 * n_edges, np.int64); writer[0::2] = part[edge_i]; writer[1::2] = part[edge_j]
+    reader = np.empty(2 * n_edges, np.int64); reader[0::2] = part[edge_j]; reader[1::2] = part[edge_i]
+    is_cut_vec = writer != reader
+    per_dir = []
+    n_levels, written, read = [], [], []
+    for d in (M.FORWARD, M.BACKWARD):
+        upd = gp.update_order(d).astype(np.int64)
+        om_off, om = gp.omega(d, mode)
+        mk_off, mk = gp.mask(d, mode)
+        lev = np.maximum(gp.update_levels(d, mode).astype(np.int64), 1)     # (0: no active message; runs with the first level)
+        assert np.all(upd < n_vars), "lock-step parts: only the variables are updated (schedule `left`)"
+        lens = g_off[upd + 1] - g_off[upd]
+        assert np.array_equal(lens, om_off[1:] - om_off[:-1]) and np.array_equal(lens, mk_off[1:] - mk_off[:-1])
+        _, vec_own = _csr_take(g_off, msg, upd)              # per row entry: own-side vector id = the message id (2 e + s)
+        row_of = np.repeat(np.arange(upd.shape[0]), lens)
+        active_w = (om != 0.0) | (mk != 0)
+        active_r = mk != 0
+        cut = is_cut_vec[vec_own]
+        nl = int(lev.max()) if lev.size else 0
+        w_l, r_l = [], []
+        for l in range(1, nl + 1):
+            in_l = lev[row_of] == l
+            w_l.append(np.unique(vec_own[in_l & cut & active_w]))
+            r_l.append(np.unique(vec_own[in_l & cut & active_r] ^ 1))
+        n_levels.append(nl); written.append(w_l); read.append(r_l)
+        per_dir.append((upd, om_off, om, mk_off, mk, lev))
+    sched = LockstepSchedule((n_levels[0], n_levels[1]), written, read, writer, reader, n_edges)
+
+    parts = []
+    for k in (range(world) if only is None else [only]):
+        local = part == k
+        le = np.nonzero(local[edge_i] | local[edge_j])[0]               # every edge touching a local variable, global order
+        vk = np.unique(np.concatenate([np.nonzero(local)[0], edge_i[le], edge_j[le]]))
+        lmap = np.full(n_vars, -1, np.int64); lmap[vk] = np.arange(vk.shape[0])
+        li, lj = lmap[edge_i[le]], lmap[edge_j[le]]
+        ghost = ~local[vk]
+        const_fill = dual_fill = None
+        esz = L * L if pairwise == "dense" else 1
+        if stream_seed is not None:
+            assert pairwise == "dense"
+            m = S.mrf_model(vk.shape[0], L, li, lj, np.zeros(vk.shape[0] * L), device_const=True)
+            const_fill = [("blocks", esz, stream_seed, (n_vars * L + le * esz).astype(np.int64))]
+            dual_fill = [("blocks", L, stream_seed, (vk * L).astype(np.int64))]
+        else:
+            un = np.asarray(unaries, np.float64).reshape(n_vars, L)[vk]
+            if pairwise == "dense":
+                m = S.mrf_model(vk.shape[0], L, li, lj, un, tables=np.asarray(tables, np.float64).reshape(n_edges, L, L)[le])
+            else:
+                m = S.mrf_model(vk.shape[0], L, li, lj, un, potts=np.asarray(potts, np.float64)[le])
+        owned = np.concatenate([~ghost, part[edge_i[le]] == k])        # a pairwise factor counts where its earlier endpoint lives
+        rows = []
+        for (upd, om_off, om, mk_off, mk, lev) in per_dir:
+            mine = local[upd]
+            per_level = []
+            for l in range(1, int(lev.max()) + 1 if lev.size else 1):
+                idx = np.nonzero(mine & (lev == l))[0]
+                fo, o = _csr_take(om_off, om, idx)
+                fm, k_ = _csr_take(mk_off, mk, idx)
+                per_level.append((lmap[upd[idx]].astype(np.int32), fo, o, fm, k_))
+            rows.append(per_level)
+        parts.append(LockstepPart(k, world, L, m, vk, ghost, le, owned, rows, const_fill, dual_fill))
+    return sched, parts
+
+
+def _cat(rows):
+    f = np.concatenate([r[0] for r in rows])
+    def offs(i):
+        out, base = [np.zeros(1, np.int64)], 0
+        for r in rows:
+            out.append(base + r[i][1:]); base += int(r[i][-1])
+        return np.concatenate(out)
+    return f, offs(1), np.concatenate([r[2] for r in rows]), offs(3), np.concatenate([r[4] for r in rows])
+
+
+class LockstepSweep:
+    """one rank of the lock-step sweep.  ``engine``: lp_mp_amd.engine.Engine with the part's model uploaded (or a stand-in
+    with the same methods in CPU tests); ``dual_tensor``: torch view of the engine's dual buffer."""
+
+    def __init__(self, torch, part: LockstepPart, sched: LockstepSchedule, engine, dual_tensor):
+        self.torch, self.part, self.sched, self.engine, self.dual = torch, part, sched, engine, dual_tensor
+        self._sids: Dict[tuple, int] = {}
+        self._halo: Dict[bytes, tuple] = {}
+        p = part
+        n_vec = p.vars_global.shape[0]
+        doff = p.model.dual_offsets()
+        self._pw_off = doff[n_vec:]                                # dual offset of local pairwise factor e (local edge order)
+        self._edge_local = {}                                      # global edge -> local edge, by searchsorted (edges_global is sorted)
+        self.info = {}
+
+    def _schedule(self, seg: tuple) -> int:
+        if seg not in self._sids:
+            rows = [self.part.rows[d][l] for (d, l) in seg]
+            n_sweeps = 1 + sum(1 for a, b in zip(seg[:-1], seg[1:]) if b[0] != a[0] or b[1] < a[1])
+            f, oo, om, mo, mk = _cat(rows)
+            if f.shape[0] == 0:
+                self._sids[seg] = -1
+            else:
+                self._sids[seg] = self.engine.schedule_create(f, oo, om, mo, mk, fuse=n_sweeps > 1)
+                if hasattr(self.engine, "schedule_info"):
+                    self.info[seg] = self.engine.schedule_info(self._sids[seg])
+        return self._sids[seg]
+
+    def run(self, seg: tuple):
+        sid = self._schedule(seg)
+        if sid >= 0:
+            self.engine.schedule_run(sid)
+
+    def _halo_plan(self, vecs: np.ndarray):
+        key = vecs.tobytes()
+        if key not in self._halo:
+            p, s, L = self.part, self.sched, self.part.L
+            def elems(v):                                          # flat dual elements of cut vectors v (global ids), in order
+                le = np.searchsorted(p.edges_global, v // 2)
+                assert np.array_equal(p.edges_global[le], v // 2)
+                base = self._pw_off[le] + (v % 2) * L
+                return (base[:, None] + np.arange(L)[None, :]).reshape(-1)
+            out = vecs[s.writer[vecs] == p.rank]
+            out = out[np.lexsort((out, s.reader[out]))]            # by destination, then vector id
+            inn = vecs[s.reader[vecs] == p.rank]
+            inn = inn[np.lexsort((inn, s.writer[inn]))]            # by source, then vector id
+            dev = self.dual.device
+            self._halo[key] = (self.torch.from_numpy(elems(out)).to(dev), np.bincount(s.reader[out], minlength=p.world).astype(np.int64) * L,
+                               self.torch.from_numpy(elems(inn)).to(dev), np.bincount(s.writer[inn], minlength=p.world).astype(np.int64) * L)
+        return self._halo[key]
+
+    def halo_pack(self, vecs):
+        src, out_counts, _, in_counts = self._halo_plan(vecs)
+        return self.dual[src], out_counts, in_counts
+
+    def halo_unpack(self, vecs, recv):
+        _, _, dst, _ = self._halo_plan(vecs)
+        if dst.shape[0]:
+            self.dual[dst] = recv
+
+    def compute_pass(self, comm, n=1):
+        for step in self.sched.program(n):
+            if step[0] == "run":
+                self.run(step[1])
+            else:
+                send, out_counts, in_counts = self.halo_pack(step[1])
+                self.halo_unpack(step[1], comm.exchange(send, out_counts, in_counts))
+
+    def local_lower_bound(self) -> float:
+        if hasattr(self.engine, "invalidate_lower_bounds"):
+            self.engine.invalidate_lower_bounds()                  # the halo copies edit pairwise duals behind the engine's back
+        flb = np.asarray(self.engine.factor_lower_bounds())
+        return float(flb[self.part.owned].sum())
+
+    def updates_per_pass(self) -> int:
+        return sum(int((r[2] != 0).sum()) + int(r[4].sum()) for d in (0, 1) for r in self.part.rows[d])
+
+
+def run_lockstep(sweeps: List[LockstepSweep], n_passes: int):
+    """all parts inside one process (tests, several parts on one GPU): the all-to-all as in-process row shuffles"""
+    torch = sweeps[0].torch
+    world = len(sweeps)
+    for step in sweeps[0].sched.program(n_passes):
+        if step[0] == "run":
+            for s in sweeps:
+                s.run(step[1])
+            continue
+        packed = [s.halo_pack(step[1]) for s in sweeps]
+        offs = [np.concatenate([[0], np.cumsum(p[1])]) for p in packed]
+        for dst, s in enumerate(sweeps):
+            pieces = [packed[src][0][offs[src][dst]: offs[src][dst + 1]] for src in range(world)]
+            recv = torch.cat(pieces)
+            assert recv.shape[0] == int(packed[dst][2].sum())
+            s.halo_unpack(step[1], recv)

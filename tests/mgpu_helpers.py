@@ -36,6 +36,10 @@ class OracleEngine:
         self.o.set_duals(self.dual)
         return self.o.LowerBound()
 
+    def factor_lower_bounds(self):
+        self.o.set_duals(self.dual)
+        return np.array([self.o.factor_lower_bound(f) for f in range(self.model.n_factors)])
+
 
 def global_replay(global_model, parts, sweeps, n_passes):
     """Runs the partition schedule on the UNPARTITIONED model with the oracle: every ("run", key) step of the parts'
