@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--c4-edges", type=int, default=10_000_000)
     ap.add_argument("--c4-labels", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--schedule", default="boundary", choices=["boundary", "lockstep"],
+                    help="several GPUs: 'boundary' = every part sweeps its own sub-problem, cut messages reconciled in a boundary step "
+                         "(multi_gpu.py; a small dual-bound gap, few exchanges); 'lockstep' = the parts run the unpartitioned sweep level "
+                         "by level with halo copies in between (lockstep.py; gap 0, one exchange per dependent level that reads across the cut)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path even at WORLD_SIZE 1: init_process_group(nccl = RCCL), the partitioned "
                          "sweep with its (empty) all_to_all_single exchanges, device all_reduce — what an N-GPU launch executes "
@@ -131,7 +135,12 @@ def dual_bound_gap_c4(torch, dist, args, mode, world, rank):
     one (same partitioner, same boundary schedule) against its unpartitioned sweep on rank 0"""
     from lp_mp_amd import engine as E, multi_gpu as MG, synthetic as S
     n, m, L, passes = 20000, 100000, args.c4_labels, args.steps
-    sw = MG.GraphSweep(torch, dist, n, m, L, mode, seed=1)
+    if args.schedule == "lockstep":
+        from lp_mp_amd import lockstep as LS
+        sw = LS.LockstepGraph(torch, dist, n, m, L, mode, seed=1)
+        sw.boundary_every, sw.global_cut_fraction = "level that reads across the cut (lock step)", sw.cut_fraction
+    else:
+        sw = MG.GraphSweep(torch, dist, n, m, L, mode, seed=1)
     sw.compute_pass(passes)
     lb_part = sw.lower_bound()
     out = None
@@ -154,7 +163,11 @@ def dual_bound_gap(torch, dist, args, mode, world, rank):
     |LB_unpartitioned| after the same number of passes."""
     from lp_mp_amd import engine as E, multi_gpu as MG, synthetic as S
     g, passes = 128, args.steps
-    sw = MG.StripSweep(torch, dist, g, g, args.labels, args.pairwise, args.order, mode, seed=1, boundary_every="pass")
+    if args.schedule == "lockstep":
+        from lp_mp_amd import lockstep as LS
+        sw = LS.LockstepStrips(torch, dist, g, g, args.labels, args.pairwise, args.order, mode, seed=1)
+    else:
+        sw = MG.StripSweep(torch, dist, g, g, args.labels, args.pairwise, args.order, mode, seed=1, boundary_every="pass")
     sw.compute_pass(passes)
     lb_part = sw.lower_bound()
     out = None
@@ -270,13 +283,19 @@ def main():
     if args.workload == "c4":
         from lp_mp_amd import multi_gpu as MG
         L = args.c4_labels
-        runner = MG.GraphSweep(torch, dist if dist_on else None, args.c4_nodes, args.c4_edges, L, mode, seed=1)
+        if dist_on and args.schedule == "lockstep":
+            from lp_mp_amd import lockstep as LS
+            runner = LS.LockstepGraph(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1)
+            parallelism = (f"{world} parts in lock step (the unpartitioned sweep, {runner.halo_steps_per_pass():.1f} halo exchanges per pass), "
+                           f"{100 * runner.cut_fraction:.1f} % of the edges cut")
+        else:
+            runner = MG.GraphSweep(torch, dist if dist_on else None, args.c4_nodes, args.c4_edges, L, mode, seed=1)
+            parallelism = (f"{world} parts (reverse Cuthill-McKee + balanced KL refinement), {100 * runner.global_cut_fraction:.1f} % of the edges cut, "
+                           f"boundary step every {runner.boundary_every}") if world > 1 else "1 GPU"
         updates_per_pass = runner.global_updates_per_pass
         bytes_per_pass = runner.global_bytes_per_pass
         levels = runner.levels
         eng = runner.engine
-        parallelism = (f"{world} parts (reverse Cuthill-McKee + balanced KL refinement), {100 * runner.global_cut_fraction:.1f} % of the edges cut, "
-                       f"boundary step every {runner.boundary_every}") if world > 1 else "1 GPU"
     elif not dist_on:
         m, const, dual = build_device_grid(torch, H, W, L, args.pairwise, args.order, 1, E, S, stream_ptr)
         setup["model_structure_and_costs_in_hbm_s"] = time.perf_counter() - t_setup0
@@ -295,12 +314,17 @@ def main():
         parallelism = "1 GPU"
     else:
         from lp_mp_amd import multi_gpu as MG
-        runner = MG.StripSweep(torch, dist, H, W, L, args.pairwise, args.order, mode, seed=1, boundary_every="pass")
+        if args.schedule == "lockstep":
+            from lp_mp_amd import lockstep as LS
+            runner = LS.LockstepStrips(torch, dist, H, W, L, args.pairwise, args.order, mode, seed=1)
+            parallelism = f"{world} row strips of {H}x{W} in lock step (the unpartitioned sweep, {runner.halo_steps_per_pass():.1f} halo exchanges per pass)"
+        else:
+            runner = MG.StripSweep(torch, dist, H, W, L, args.pairwise, args.order, mode, seed=1, boundary_every="pass")
+            parallelism = f"{world} row strips of {H}x{W}, cut-edge exchange once per pass"
         updates_per_pass = runner.global_updates_per_pass
         bytes_per_pass = runner.global_bytes_per_pass
         levels = runner.levels
         eng = runner.engine
-        parallelism = f"{world} row strips of {H}x{W}, cut-edge exchange once per pass"
 
     lb0 = runner.lower_bound()
     setup["total_before_first_pass_s"] = time.perf_counter() - t_setup0

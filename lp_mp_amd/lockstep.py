@@ -119,11 +119,13 @@ def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: in
         active_r = mk != 0
         cut = is_cut_vec[vec_own]
         nl = int(lev.max()) if lev.size else 0
-        w_l, r_l = [], []
-        for l in range(1, nl + 1):
-            in_l = lev[row_of] == l
-            w_l.append(np.unique(vec_own[in_l & cut & active_w]))
-            r_l.append(np.unique(vec_own[in_l & cut & active_r] ^ 1))
+
+        def by_level(sel, flip):                             # cut vectors of the selected row entries, grouped by level
+            v, lv = vec_own[sel] ^ flip, lev[row_of[sel]]
+            order = np.argsort(lv, kind="stable")
+            bounds = np.searchsorted(lv[order], np.arange(1, nl + 2))
+            return [np.unique(v[order[bounds[l]: bounds[l + 1]]]) for l in range(nl)]
+        w_l, r_l = by_level(cut & active_w, 0), by_level(cut & active_r, 1)
         n_levels.append(nl); written.append(w_l); read.append(r_l)
         per_dir.append((upd, om_off, om, mk_off, mk, lev))
     sched = LockstepSchedule((n_levels[0], n_levels[1]), written, read, writer, reader, n_edges)
@@ -139,8 +141,10 @@ def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: in
         const_fill = dual_fill = None
         esz = L * L if pairwise == "dense" else 1
         if stream_seed is not None:
-            assert pairwise == "dense"
-            m = S.mrf_model(vk.shape[0], L, li, lj, np.zeros(vk.shape[0] * L), device_const=True)
+            if pairwise == "dense":
+                m = S.mrf_model(vk.shape[0], L, li, lj, np.zeros(vk.shape[0] * L), device_const=True)
+            else:
+                m = S.mrf_model(vk.shape[0], L, li, lj, np.zeros(vk.shape[0] * L), potts=np.zeros(le.shape[0]))
             const_fill = [("blocks", esz, stream_seed, (n_vars * L + le * esz).astype(np.int64))]
             dual_fill = [("blocks", L, stream_seed, (vk * L).astype(np.int64))]
         else:
@@ -152,10 +156,13 @@ def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: in
         owned = np.concatenate([~ghost, part[edge_i[le]] == k])        # a pairwise factor counts where its earlier endpoint lives
         rows = []
         for (upd, om_off, om, mk_off, mk, lev) in per_dir:
-            mine = local[upd]
+            mine = np.nonzero(local[upd])[0]
+            order = mine[np.argsort(lev[mine], kind="stable")]   # by level, sequence order inside a level
+            nl = int(lev.max()) if lev.size else 0
+            bounds = np.searchsorted(lev[order], np.arange(1, nl + 2))
             per_level = []
-            for l in range(1, int(lev.max()) + 1 if lev.size else 1):
-                idx = np.nonzero(mine & (lev == l))[0]
+            for l in range(nl):
+                idx = order[bounds[l]: bounds[l + 1]]
                 fo, o = _csr_take(om_off, om, idx)
                 fm, k_ = _csr_take(mk_off, mk, idx)
                 per_level.append((lmap[upd[idx]].astype(np.int32), fo, o, fm, k_))
@@ -221,8 +228,10 @@ class LockstepSweep:
             inn = vecs[s.reader[vecs] == p.rank]
             inn = inn[np.lexsort((inn, s.writer[inn]))]            # by source, then vector id
             dev = self.dual.device
-            self._halo[key] = (self.torch.from_numpy(elems(out)).to(dev), np.bincount(s.reader[out], minlength=p.world).astype(np.int64) * L,
-                               self.torch.from_numpy(elems(inn)).to(dev), np.bincount(s.writer[inn], minlength=p.world).astype(np.int64) * L)
+            # (a part built from a proxy world, strips_lockstep_part: its ranks are shifted into the true world)
+            shift, world = getattr(p, "rank_shift", 0), getattr(p, "true_world", p.world)
+            self._halo[key] = (self.torch.from_numpy(elems(out)).to(dev), np.bincount(s.reader[out] + shift, minlength=world).astype(np.int64) * L,
+                               self.torch.from_numpy(elems(inn)).to(dev), np.bincount(s.writer[inn] + shift, minlength=world).astype(np.int64) * L)
         return self._halo[key]
 
     def halo_pack(self, vecs):
@@ -268,3 +277,125 @@ def run_lockstep(sweeps: List[LockstepSweep], n_passes: int):
             recv = torch.cat(pieces)
             assert recv.shape[0] == int(packed[dst][2].sum())
             s.halo_unpack(step[1], recv)
+
+
+# ---- drivers (one process per GPU) --------------------------------------------------------------------------------
+def strips_lockstep_part(H: int, W: int, L: int, pairwise: str, order: str, rank: int, world: int, mode: int, seed: int,
+                         proxy: bool = True):
+    """This rank's lock-step part of the (world * H) x W strip grid of multi_gpu.strip_global_edges, costs generated in HBM.
+    The global structure of `world` strips is never built when world > 3: strips are translates of each other, so a strip
+    with a neighbour on both sides looks the same in any world — the part and the schedule come from a 3-strip PROXY
+    (first, interior, last strip) and only the positions in the cost stream and the peer ranks are shifted
+    (tests/test_lockstep.py compares with the parts of the true global structure)."""
+    from . import multi_gpu as MG
+    n_loc, e_int = MG.strip_sizes(H, W)
+    # (only where the level structure is the same in every strip: 2-colour orders.  A row-major order chains its levels
+    # through the strips — the global structure is built then)
+    pw = world if (not proxy or world <= 3 or order != "colour_major") else 3
+    pr = rank if pw == world else (0 if rank == 0 else 2 if rank == world - 1 else 1)
+    ei, ej = MG.strip_global_edges(H, W, pw, order)
+    part_of = np.repeat(np.arange(pw), n_loc)
+    sched, parts = lockstep_mrf(pw * n_loc, L, ei, ej, part_of, pw, mode, only=pr, stream_seed=seed, pairwise=pairwise,
+                                unaries=None if pairwise == "dense" else np.zeros(pw * n_loc * L), potts=None if pairwise == "dense" else np.zeros(ei.shape[0]))
+    p = parts[0]
+    shift = rank - pr                                             # strips between the proxy's and the true position
+    n_true = world * n_loc
+    esz = L * L if pairwise == "dense" else 1
+    var_true = p.vars_global + shift * n_loc
+    edge_true = p.edges_global + shift * (e_int + W)
+    p.const_fill = [("blocks", esz, seed, (n_true * L + edge_true * esz).astype(np.int64))]
+    p.dual_fill = [("blocks", L, seed, (var_true * L).astype(np.int64))]
+    p.rank_shift, p.true_world = shift, world
+    return sched, p
+
+
+class _Driver:
+    def _setup(self, torch, dist, part, sched, mode, fill=True):
+        from . import engine as E
+        from . import multi_gpu as MG
+        self.torch, self.dist, self.part, self.sched = torch, dist, part, sched
+        self.comm = MG.DistComm(dist, torch) if dist is not None and dist.is_initialized() else None
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if self.comm:
+            self.comm._dev = dev
+        m = part.model
+        stream = torch.cuda.current_stream().cuda_stream
+        if fill:
+            self.const = torch.empty(max(int(m.const_sizes().sum()), 2), dtype=torch.float64, device=dev)
+            self.dualt = torch.zeros(int(m.dual_sizes().sum()), dtype=torch.float64, device=dev)
+            if m.const_data is not None and part.const_fill is None:
+                self.const[: m.const_data.shape[0]] = torch.from_numpy(m.const_data).to(dev)
+            MG.fill_device_costs(torch, E, part, self.const, self.dualt, stream)
+        else:
+            self.const = torch.from_numpy(np.ascontiguousarray(m.const_data if m.const_data is not None and m.const_data.size else np.zeros(2))).to(dev)
+            self.dualt = torch.from_numpy(m.dual_data.copy()).to(dev)
+        self.engine = E.Engine(torch.cuda.current_device())
+        self.engine.set_stream(stream)
+        self.engine.upload(m, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt))
+        self.engine.set_reparametrization(mode)
+        self.sweep = LockstepSweep(torch, part, sched, self.engine, self.dualt)
+        # the schedules of the steady state (built here, outside any timed region) and their algorithmic bytes per pass
+        n_probe = 4
+        prog = sched.program(n_probe)
+        by = 0
+        for step in prog:
+            if step[0] == "run" and self.sweep._schedule(step[1]) >= 0:
+                by += self.sweep.info[step[1]]["algorithmic_bytes"]
+        vals = torch.tensor([float(self.sweep.updates_per_pass()), by / n_probe], dtype=torch.float64, device="cpu" if (self.comm is None or self.comm.stage_cpu) else dev)
+        if self.comm:
+            dist.all_reduce(vals)
+        self.global_updates_per_pass = int(vals[0].item())
+        self.global_bytes_per_pass = int(vals[1].item())
+        self.levels = list(sched.n_levels)
+
+    def prepare_passes(self, n):
+        """what depends on the pass count of a call (schedules of its segments, exchange plans): outside a timed region"""
+        for step in self.sched.program(n):
+            if step[0] == "run":
+                self.sweep._schedule(step[1])
+            else:
+                self.sweep._halo_plan(step[1])
+
+    def compute_pass(self, n=1):
+        if self.comm is None:
+            for step in self.sched.program(n):
+                if step[0] == "run":
+                    self.sweep.run(step[1])
+            return
+        self.sweep.compute_pass(self.comm, n)
+
+    def lower_bound(self):
+        lb = self.sweep.local_lower_bound()
+        return self.comm.all_reduce_sum(lb) if self.comm else lb
+
+    def halo_steps_per_pass(self, n=4):
+        return sum(1 for s in self.sched.program(n) if s[0] == "halo") / n
+
+
+class LockstepStrips(_Driver):
+    """bench.py driver: this rank's H x W strip of the (world * H) x W grid, run in lock step with the other strips —
+    the result is the single-GPU sweep of the whole grid, bit for bit."""
+
+    def __init__(self, torch, dist, H, W, L, pairwise, order, mode, seed=1, proxy=True):
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
+        sched, part = strips_lockstep_part(H, W, L, pairwise, order, rank, world, mode, seed, proxy)
+        self._setup(torch, dist, part, sched, mode)
+
+
+class LockstepGraph(_Driver):
+    """the same for the C4-style random graph synthetic.counter_graph_model(n, m, L, seed); every rank derives the global
+    structure from the counter generator (no costs), the partition comes from rank 0"""
+
+    def __init__(self, torch, dist, n, m, L, mode, seed=1, part_of=None):
+        from . import multi_gpu as MG
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
+        ei, ej = S.counter_graph_edges(n, m, seed)
+        if part_of is None:
+            if world > 1:
+                dev = torch.device("cuda", torch.cuda.current_device())
+                part_of = MG.broadcast_partition(torch, dist, n, dev, lambda: MG.graph_partition(n, ei, ej, world))
+            else:
+                part_of = np.zeros(n, np.int64)
+        self.cut_fraction = float((part_of[ei] != part_of[ej]).mean())
+        sched, parts = lockstep_mrf(n, L, ei, ej, part_of, world, mode, only=rank, stream_seed=seed)
+        self._setup(torch, dist, parts[0], sched, mode)

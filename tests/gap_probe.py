@@ -1,13 +1,15 @@
 """Dual-bound gap of the partitioned sweep against the unpartitioned one, on the CPU (oracle-backed engines, lock-stepped
 parts): the experiment behind BOUNDARY_SHARE and the boundary schedule.
     python tests/gap_probe.py [n] [m] [L] [world] [passes] [share,share,...] [every]
+The last line is the LOCK-STEP sweep of the same parts (lp_mp_amd/lockstep.py): the unpartitioned sweep itself, level by
+level with halo copies in between — gap 0 by construction, one exchange per level that reads across the cut.
 GAP_RESERVE=x overrides multi_gpu.BOUNDARY_RESERVE (0: the main sweeps keep nothing back); GAP_VARIANT: experiments."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # lives in tests/: it runs the oracle (test infrastructure)
 import numpy as np
 import torch
-from lp_mp_amd import model as M, multi_gpu as MG, synthetic as S
+from lp_mp_amd import model as M, multi_gpu as MG, synthetic as S, lockstep as LS
 from oracle.binding import Oracle
 from mgpu_helpers import OracleEngine
 
@@ -105,3 +107,13 @@ for share in shares:
     MG.run_lockstep(sweeps, passes)
     lb = sum(s.local_lower_bound() for s in sweeps)
     print(f"  share {share:.3f} every {every}: LB {lb:.3f}  gap {100 * (lb_ref - lb) / abs(lb_ref):.3f} %  ({time.time() - t0:.0f} s)", flush=True)
+
+sched, lparts = LS.lockstep_mrf(n, L, ei, ej, part_of, world, M.REPAM_ANISOTROPIC, g.dual_data[: n * L], g.const_data)
+lsw = []
+for p in lparts:
+    dual = p.model.dual_data.copy()
+    lsw.append(LS.LockstepSweep(torch, p, sched, OracleEngine(p.model, dual), torch.from_numpy(dual)))
+LS.run_lockstep(lsw, passes)
+lb = sum(s.local_lower_bound() for s in lsw)
+n_halo = sum(1 for s in sched.program(passes) if s[0] == "halo")
+print(f"  lock step ({sched.n_levels[0]} + {sched.n_levels[1]} levels per pass, {n_halo / passes:.1f} exchanges per pass): LB {lb:.3f}  gap {100 * (lb_ref - lb) / abs(lb_ref):.3e} %  ({time.time() - t0:.0f} s)", flush=True)

@@ -74,8 +74,9 @@ def test_bench_c4_workload_line():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["boundary", "lockstep"])
 @pytest.mark.parametrize("workload", ["c3", "c4"])
-def test_bench_distributed_branch_on_rccl_at_world_size_one(workload):
+def test_bench_distributed_branch_on_rccl_at_world_size_one(workload, schedule):
     """what an N-GPU launch of bench.py executes first, on the one GPU of the test box: --force-dist takes the multi-GPU
     branch at WORLD_SIZE 1 — init_process_group("nccl") (= RCCL), StripSweep / GraphSweep, all_to_all_single with empty
     splits in every boundary step, device all_reduce for the bound and the timing — and must print the contract line"""
@@ -83,7 +84,7 @@ def test_bench_distributed_branch_on_rccl_at_world_size_one(workload):
     env.pop("LPMP_DIST_BACKEND", None)
     extra = ["--grid", "128"] if workload == "c3" else ["--workload", "c4", "--c4-nodes", "20000", "--c4-edges", "100000"]
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1",
-                                   "--no-cpu-baseline"] + extra, text=True, cwd=ROOT, timeout=900, env=env)
+                                   "--no-cpu-baseline", "--schedule", schedule] + extra, text=True, cwd=ROOT, timeout=900, env=env)
     # the line the driver parses is the last thing on stdout (RCCL's version banner, buffered by C stdio, must not trail it)
     assert out.strip().splitlines()[-1].startswith('{"metric"'), out[-600:]
     d = json.loads([l for l in out.strip().splitlines() if l.startswith('{"metric"')][-1])

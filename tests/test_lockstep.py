@@ -1,0 +1,190 @@
+"""Lock-step partitioned sweep (lp_mp_amd/lockstep.py): several parts run THE unpartitioned sweep — duals and bound of the
+oracle on the unpartitioned model, bit for bit, for any partition.  CPU: oracle-backed engine stand-ins in one process and
+over torch.distributed (gloo, world size 2); GPU: real engines, several parts on the one device of the test box."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from lp_mp_amd import lockstep as LS
+from lp_mp_amd import model as M
+from lp_mp_amd import multi_gpu as MG
+from lp_mp_amd import synthetic as S
+from oracle.binding import Oracle
+from tests.mgpu_helpers import OracleEngine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _graph(n, m, L, world, seed=1):
+    g = S.counter_graph_model(n, m, L, seed)
+    ei = g.m_left[0::2].astype(np.int64); ej = g.m_left[1::2].astype(np.int64)
+    return dict(n_vars=n, L=L, ei=ei, ej=ej, un=g.dual_data[: n * L], tables=g.const_data, potts=None, pairwise="dense",
+                part_of=MG.graph_partition(n, ei, ej, world), world=world)
+
+
+def _strips(H, W, L, world, pairwise, order, seed=1):
+    ei, ej = MG.strip_global_edges(H, W, world, order)
+    un, tables, potts = MG.strip_costs(H, W, L, world, pairwise, seed)
+    return dict(n_vars=world * H * W, L=L, ei=ei, ej=ej, un=un, tables=tables, potts=potts, pairwise=pairwise,
+                part_of=np.repeat(np.arange(world), H * W), world=world)
+
+
+def _global_of(c):
+    return S.mrf_model(c["n_vars"], c["L"], c["ei"], c["ej"], c["un"], tables=c["tables"], potts=c["potts"])
+
+
+def _parts_of(c, mode):
+    return LS.lockstep_mrf(c["n_vars"], c["L"], c["ei"], c["ej"], c["part_of"], c["world"], mode, c["un"], c["tables"], c["potts"], pairwise=c["pairwise"])
+
+
+def _assert_equals_global(c, parts, local_duals, ref):
+    gd, g_off = ref.duals(), ref_offsets(c)
+    for p, d in zip(parts, local_duals):
+        lo = p.model.dual_offsets(); nv = p.vars_global.shape[0]
+        for fl in range(p.model.n_factors):
+            if fl < nv and p.is_ghost[fl]:
+                continue
+            g = int(p.vars_global[fl]) if fl < nv else c["n_vars"] + int(p.edges_global[fl - nv])
+            assert np.array_equal(d[lo[fl]:lo[fl + 1]], gd[g_off[g]:g_off[g + 1]]), (p.rank, fl)
+
+
+def ref_offsets(c):
+    return _global_of(c).dual_offsets()
+
+
+CASES = {
+    "random graph, 4 parts (61 % of the edges cut)": lambda: _graph(400, 1200, 4, 4),
+    "random graph, 7 parts": lambda: _graph(300, 700, 3, 7, seed=3),
+    "colour-major strips, 3 parts": lambda: _strips(8, 8, 3, 3, "dense", "colour_major"),
+    "row-major strips, 3 parts": lambda: _strips(6, 7, 3, 3, "dense", "row_major"),
+    "Potts strips, 4 parts": lambda: _strips(6, 6, 4, 4, "potts", "colour_major"),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("mode", [M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM])
+def test_lockstep_parts_run_the_unpartitioned_sweep(name, mode):
+    c = CASES[name]()
+    ref = Oracle(_global_of(c)); ref.set_reparametrization(mode)
+    sched, parts = _parts_of(c, mode)
+    duals = [p.model.dual_data.copy() for p in parts]
+    sweeps = [LS.LockstepSweep(torch, p, sched, OracleEngine(p.model, d), torch.from_numpy(d)) for p, d in zip(parts, duals)]
+    for n in (1, 2, 3):                                     # separate calls: the copies agree when a call returns
+        ref.ComputePass(n)
+        LS.run_lockstep(sweeps, n)
+        _assert_equals_global(c, parts, duals, ref)
+        lb = sum(s.local_lower_bound() for s in sweeps)
+        assert abs(lb - ref.LowerBound()) <= 1e-12 * max(1.0, abs(ref.LowerBound()))
+    # every edge touching a part's variables is in the part; a pairwise factor is counted once
+    assert sum(int(p.owned.sum()) for p in parts) == c["n_vars"] + c["ei"].shape[0]
+
+
+def test_colour_major_strips_need_two_exchanges_per_pass():
+    c = _strips(8, 8, 3, 4, "dense", "colour_major")
+    sched, _ = _parts_of(c, M.REPAM_ANISOTROPIC)
+    prog = sched.program(6)
+    assert sched.n_levels == (4, 4)
+    assert sum(1 for s in prog if s[0] == "halo") == 2 * 6 + 1          # + the one that closes the call
+    one = _strips(8, 8, 3, 1, "dense", "colour_major")
+    s1, _ = _parts_of(one, M.REPAM_ANISOTROPIC)
+    assert [s[0] for s in s1.program(5)] == ["run"]                      # nothing cut: the whole call is one schedule
+
+
+@pytest.mark.parametrize("world", [4, 6])
+@pytest.mark.parametrize("pairwise,order", [("dense", "colour_major"), ("potts", "colour_major"), ("dense", "row_major")])
+def test_strip_parts_from_the_three_strip_proxy_equal_those_of_the_true_world(world, pairwise, order):
+    """bench.py's strips never build the global structure of `world` strips (strips_lockstep_part): rows, model, cost
+    stream positions, exchange plans and the program must be those of the true global structure"""
+    H, W, L = 6, 6, 3
+    for rank in range(world):
+        got_s, got = LS.strips_lockstep_part(H, W, L, pairwise, order, rank, world, M.REPAM_ANISOTROPIC, 5, proxy=True)
+        ref_s, ref = LS.strips_lockstep_part(H, W, L, pairwise, order, rank, world, M.REPAM_ANISOTROPIC, 5, proxy=False)
+        assert np.array_equal(got.model.m_left, ref.model.m_left) and np.array_equal(got.model.m_right, ref.model.m_right)
+        assert np.array_equal(got.owned, ref.owned) and np.array_equal(got.is_ghost, ref.is_ghost)
+        for a, b in zip(got.const_fill + got.dual_fill, ref.const_fill + ref.dual_fill):
+            assert a[:3] == b[:3] and np.array_equal(a[3], b[3])
+        for d in (0, 1):
+            assert len(got.rows[d]) == len(ref.rows[d])
+            for ra, rb in zip(got.rows[d], ref.rows[d]):
+                assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+        pa, pb = got_s.program(3), ref_s.program(3)
+        assert [(s[0], s[1] if s[0] == "run" else None) for s in pa] == [(s[0], s[1] if s[0] == "run" else None) for s in pb]
+        dummy = torch.zeros(int(ref.model.dual_sizes().sum()), dtype=torch.float64)
+        sa, sb = LS.LockstepSweep(torch, got, got_s, None, dummy), LS.LockstepSweep(torch, ref, ref_s, None, dummy)
+        for xa, xb in zip(pa, pb):
+            if xa[0] == "halo":
+                ha, hb = sa._halo_plan(xa[1]), sb._halo_plan(xb[1])
+                assert torch.equal(ha[0], hb[0]) and torch.equal(ha[2], hb[2])
+                assert np.array_equal(ha[1], hb[1]) and np.array_equal(ha[3], hb[3])
+
+
+WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from lp_mp_amd import model as M, multi_gpu as MG, lockstep as LS, synthetic as S
+from tests.mgpu_helpers import OracleEngine
+from tests.test_lockstep import _graph
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+c = _graph(300, 800, 3, world, seed=2)
+sched, parts = LS.lockstep_mrf(c["n_vars"], c["L"], c["ei"], c["ej"], c["part_of"], world, M.REPAM_ANISOTROPIC, c["un"], c["tables"], only=rank)
+p = parts[0]
+d = p.model.dual_data.copy()
+sw = LS.LockstepSweep(torch, p, sched, OracleEngine(p.model, d), torch.from_numpy(d))
+comm = MG.DistComm(dist, torch)
+sw.compute_pass(comm, 2); sw.compute_pass(comm, 1)
+lb = comm.all_reduce_sum(sw.local_lower_bound())
+np.save(os.path.join({out!r}, f"ls_duals_{{rank}}.npy"), d)
+if rank == 0:
+    np.save(os.path.join({out!r}, "ls_lb.npy"), np.array([lb]))
+dist.destroy_process_group()
+"""
+
+
+def test_two_process_gloo_run_equals_the_unpartitioned_oracle(tmp_path):
+    script = tmp_path / "ls_worker.py"
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29536", str(script)], env=env, cwd=ROOT, timeout=300)
+    c = _graph(300, 800, 3, 2, seed=2)
+    ref = Oracle(_global_of(c)); ref.set_reparametrization(M.REPAM_ANISOTROPIC)
+    ref.ComputePass(3)
+    _, parts = _parts_of(c, M.REPAM_ANISOTROPIC)
+    _assert_equals_global(c, parts, [np.load(tmp_path / f"ls_duals_{k}.npy") for k in range(2)], ref)
+    assert abs(np.load(tmp_path / "ls_lb.npy")[0] - ref.LowerBound()) <= 1e-12 * abs(ref.LowerBound())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,L", [("strips", 32), ("strips", 8), ("graph", 16), ("potts", 8)])
+def test_lockstep_on_device_equals_the_unpartitioned_engine_and_oracle(name, L):
+    """real HIP engines, all parts on the one GPU of the test box: duals of the oracle on the unpartitioned model, bit for bit"""
+    from lp_mp_amd import engine as E
+    c = {"strips": lambda: _strips(12, 10, L, 3, "dense", "colour_major", 5), "graph": lambda: _graph(1500, 6000, L, 4, 2),
+         "potts": lambda: _strips(10, 12, L, 4, "potts", "colour_major", 7)}[name]()
+    gm = _global_of(c)
+    ref = Oracle(gm); ref.set_reparametrization(M.REPAM_ANISOTROPIC)
+    sched, parts = _parts_of(c, M.REPAM_ANISOTROPIC)
+    dev = torch.device("cuda:0")
+    sweeps, tensors = [], []
+    for p in parts:
+        dual = torch.from_numpy(p.model.dual_data.copy()).to(dev)
+        eng = E.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual)
+        eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+        sweeps.append(LS.LockstepSweep(torch, p, sched, eng, dual)); tensors.append(dual)
+    try:
+        for n in (1, 3):
+            ref.ComputePass(n)
+            LS.run_lockstep(sweeps, n)
+            torch.cuda.synchronize()
+            _assert_equals_global(c, parts, [t.cpu().numpy() for t in tensors], ref)
+            lb = sum(s.local_lower_bound() for s in sweeps)
+            assert abs(lb - ref.LowerBound()) <= 1e-9 * max(1.0, abs(ref.LowerBound()))
+    finally:
+        for s in sweeps:
+            s.engine.close()
