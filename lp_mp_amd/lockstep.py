@@ -38,7 +38,7 @@ class LockstepPart:
     is_ghost: np.ndarray               # [n local vector factors]
     edges_global: np.ndarray           # local pairwise factor (in local edge order) -> global edge
     owned: np.ndarray                  # [n local factors] bool: counted in this rank's share of the lower bound
-    rows: List[List[tuple]]            # [direction][level - 1] = (factors, om_off, om, mk_off, mk) of this rank's updates
+    rows: List[List[tuple]]            # [direction][sub-level] = (factors, om_off, om, mk_off, mk) of this rank's updates (sub-level: LockstepSchedule.program)
     const_fill: Optional[list] = None
     dual_fill: Optional[list] = None
 
@@ -56,21 +56,31 @@ class LockstepSchedule:
     _programs: Dict[int, list] = field(default_factory=dict)
 
     def program(self, n_passes: int):
-        """steps of n passes: ("run", ((d, level), ...)) and ("halo", vectors to ship: sorted global ids)"""
+        """steps of n passes: ("run", ((d, sub-level), ...)) and ("halo", vectors to ship: sorted global ids).
+        Sub-level 2 l = the records of level l + 1 that touch a cut edge, 2 l + 1 = the others (they write no cut vector).
+        An exchange is needed before the first sub-level that reads a cut vector written since the last one; it is then
+        moved BACK over the sub-levels that wrote nothing it ships (they read nothing it ships either, or it would have
+        come earlier): on strips of a 2-colour grid that puts it right behind the boundary rows of a colour step, and the
+        bulk of that step lands in the same schedule as the colour's update of the opposite sweep — the two fold."""
         if n_passes in self._programs:
             return self._programs[n_passes]
+        seq = [(d, sl) for _ in range(n_passes) for d in (0, 1) for sl in range(2 * self.n_levels[d])]
         dirty = np.zeros(2 * self.n_edges, bool)
-        steps, seg = [], []
-        for _ in range(n_passes):
-            for d in (0, 1):
-                for l in range(self.n_levels[d]):
-                    if dirty[self.read[d][l]].any():
-                        steps.append(("run", tuple(seg))); seg = []
-                        steps.append(("halo", np.nonzero(dirty)[0])); dirty[:] = False
-                    seg.append((d, l))
-                    dirty[self.written[d][l]] = True
-        if seg:
-            steps.append(("run", tuple(seg)))
+        halos, last = [], 0                             # (position in seq the exchange comes before, vectors)
+        for i, (d, sl) in enumerate(seq):
+            if dirty[self.read[d][sl]].any():
+                pos = i
+                while pos - 1 >= last and self.written[seq[pos - 1][0]][seq[pos - 1][1]].size == 0:
+                    pos -= 1
+                halos.append((pos, np.nonzero(dirty)[0])); dirty[:] = False; last = pos
+            dirty[self.written[d][sl]] = True
+        steps, start = [], 0
+        for pos, vecs in halos:
+            if pos > start:
+                steps.append(("run", tuple(seq[start:pos])))
+            steps.append(("halo", vecs)); start = pos
+        if start < len(seq):
+            steps.append(("run", tuple(seq[start:])))
         if dirty.any():                                 # the copies agree again when the call returns
             steps.append(("halo", np.nonzero(dirty)[0]))
         self._programs[n_passes] = steps
@@ -124,10 +134,15 @@ def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: in
             v, lv = vec_own[sel] ^ flip, lev[row_of[sel]]
             order = np.argsort(lv, kind="stable")
             bounds = np.searchsorted(lv[order], np.arange(1, nl + 2))
-            return [np.unique(v[order[bounds[l]: bounds[l + 1]]]) for l in range(nl)]
+            out = []
+            for l in range(nl):                              # sub-levels: the records that touch a cut edge, then the others
+                out += [np.unique(v[order[bounds[l]: bounds[l + 1]]]), np.zeros(0, np.int64)]
+            return out
         w_l, r_l = by_level(cut & active_w, 0), by_level(cut & active_r, 1)
         n_levels.append(nl); written.append(w_l); read.append(r_l)
-        per_dir.append((upd, om_off, om, mk_off, mk, lev))
+        touches_cut = np.zeros(upd.shape[0], bool)
+        touches_cut[row_of[cut & active_w]] = True
+        per_dir.append((upd, om_off, om, mk_off, mk, lev, touches_cut))
     sched = LockstepSchedule((n_levels[0], n_levels[1]), written, read, writer, reader, n_edges)
 
     parts = []
@@ -155,13 +170,14 @@ def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: in
                 m = S.mrf_model(vk.shape[0], L, li, lj, un, potts=np.asarray(potts, np.float64)[le])
         owned = np.concatenate([~ghost, part[edge_i[le]] == k])        # a pairwise factor counts where its earlier endpoint lives
         rows = []
-        for (upd, om_off, om, mk_off, mk, lev) in per_dir:
+        for (upd, om_off, om, mk_off, mk, lev, touches_cut) in per_dir:
             mine = np.nonzero(local[upd])[0]
-            order = mine[np.argsort(lev[mine], kind="stable")]   # by level, sequence order inside a level
+            sub = 2 * (lev[mine] - 1) + (~touches_cut[mine])      # sub-level: by level, the cut-touching records first
+            order = mine[np.argsort(sub, kind="stable")]          # sequence order inside a sub-level
             nl = int(lev.max()) if lev.size else 0
-            bounds = np.searchsorted(lev[order], np.arange(1, nl + 2))
+            bounds = np.searchsorted(np.sort(sub, kind="stable"), np.arange(0, 2 * nl + 1))
             per_level = []
-            for l in range(nl):
+            for l in range(2 * nl):
                 idx = order[bounds[l]: bounds[l + 1]]
                 fo, o = _csr_take(om_off, om, idx)
                 fm, k_ = _csr_take(mk_off, mk, idx)

@@ -188,3 +188,40 @@ def test_lockstep_on_device_equals_the_unpartitioned_engine_and_oracle(name, L):
     finally:
         for s in sweeps:
             s.engine.close()
+
+
+WORKER_STRIPS = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from lp_mp_amd import model as M, multi_gpu as MG, lockstep as LS
+from tests.mgpu_helpers import OracleEngine, materialise_fills
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+sched, p = LS.strips_lockstep_part(6, 6, 3, "dense", "colour_major", rank, world, M.REPAM_ANISOTROPIC, 5)   # 3-strip proxy, shifted
+materialise_fills(p)
+d = p.model.dual_data.copy()
+sw = LS.LockstepSweep(torch, p, sched, OracleEngine(p.model, d), torch.from_numpy(d))
+comm = MG.DistComm(dist, torch)
+sw.compute_pass(comm, 3)
+lb = comm.all_reduce_sum(sw.local_lower_bound())
+np.save(os.path.join({out!r}, f"st_duals_{{rank}}.npy"), d)
+if rank == 0:
+    np.save(os.path.join({out!r}, "st_lb.npy"), np.array([lb]))
+dist.destroy_process_group()
+"""
+
+
+def test_four_process_gloo_run_of_proxy_built_strips_equals_the_unpartitioned_oracle(tmp_path):
+    """what bench.py --gpus 4 --schedule lockstep does per rank (part and schedule from the 3-strip proxy, cost stream positions
+    and peer ranks shifted into the true world), over torch.distributed: the oracle's sweep of the whole 24 x 6 grid"""
+    script = tmp_path / "st_worker.py"
+    script.write_text(WORKER_STRIPS.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                           "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)], env=env, cwd=ROOT, timeout=600)
+    c = _strips(6, 6, 3, 4, "dense", "colour_major", 5)
+    ref = Oracle(_global_of(c)); ref.set_reparametrization(M.REPAM_ANISOTROPIC)
+    ref.ComputePass(3)
+    _, parts = _parts_of(c, M.REPAM_ANISOTROPIC)
+    _assert_equals_global(c, parts, [np.load(tmp_path / f"st_duals_{k}.npy") for k in range(4)], ref)
+    assert abs(np.load(tmp_path / "st_lb.npy")[0] - ref.LowerBound()) <= 1e-12 * abs(ref.LowerBound())
