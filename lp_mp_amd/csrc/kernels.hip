@@ -1822,12 +1822,15 @@ __device__ __forceinline__ void two_min_merge(double& a1, double& a2) {   // two
 
 // VAR: L is the padded width, the label count (<= L) is read at run time; lanes beyond it carry +inf
 // A: access policy of the duals; CHAIN: called from the chain executor (see dense_pk_body)
-template <int L, bool VAR, int A, bool CHAIN>
+// MBOX: the mailbox form of the chain body (see dense_pk_body and plan.cpp): message vectors between dependent records as
+// tagged granules
+template <int L, bool VAR, int A, bool CHAIN, bool MBOX = false>
 __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, const UpdRec* __restrict__ recs, const Op* __restrict__ ops,
                                               double* __restrict__ dual, const double* __restrict__ cdata, double* __restrict__ lb,
                                               int32_t* __restrict__ primal, int64_t count, int stride, int flags, int64_t block,
-                                              const ChainArgs* ca, int ticket) {
+                                              const ChainArgs* ca, int ticket, unsigned long long* __restrict__ mbox = nullptr, int n_deps = -1) {
   static_assert(!CHAIN || A == ACC_COH, "chain bodies hand results over through relaxed agent-scope flags: every dual access must be an agent-scope (sc1) access");
+  static_assert(!MBOX || (CHAIN && !VAR && MAILBOX_SENDS == 4), "the mailbox belongs to chains of the exact classes; this body forwards 4 receives and holds 4 sends");
   constexpr int GPB = 256 / L;
   constexpr int KR = 4, KS = 4;
   constexpr int PIECES = 3 * (1 + pk_indirect_cap(L));
@@ -1845,7 +1848,10 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
   const int Lr = VAR ? (live ? (int)hdr->d0 : 0) : L;
   const bool vl = live && g < Lr;
   bool aborted = false;
-  if constexpr (CHAIN) aborted = !chain_wait(*ca, ticket);   // a Potts neighbour has no table to request ahead: only the coupling
+  if constexpr (CHAIN) {                        // a Potts neighbour has no table to request ahead: only the coupling
+    if (MBOX && n_deps == 0) chain_stamp(*ca, ticket, 1);
+    else aborted = !chain_wait(*ca, ticket);
+  }
   double theta = vl ? ld_dual<A>(own_g + g) : 0.0;
   double sm[KS];
 #pragma unroll
@@ -1877,12 +1883,23 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
         const Op& o = lop[c + j];
         const int side = (o.info >> 5) & 1;
         msoff[j] = o.peer_dual + (side == 0 ? 0 : Lr) + g;
+        bool boxed = false;
+        if constexpr (MBOX) boxed = (o.info & OP_MAILBOX) != 0;
         if (vl) {
           msv[j] = ld_dual<A>(dual + msoff[j]);
-          mov[j] = ld_dual<A>(dual + o.peer_dual + (side == 0 ? Lr : 0) + g);
+          if (!boxed) mov[j] = ld_dual<A>(dual + o.peer_dual + (side == 0 ? Lr : 0) + g);
         }
         diff[j] = cdata[o.peer_const];
         defer[j] = FW ? o.pad : 0;
+      }
+    }
+    if constexpr (MBOX) {                        // with everything else in flight: the vectors that come by mailbox
+#pragma unroll
+      for (int j = 0; j < KR; ++j) {
+        if (c + j < n_recv) {
+          const Op& o = lop[c + j];
+          if ((o.info & OP_MAILBOX) && vl) { long long row; __builtin_memcpy(&row, &o.omega, 8); mov[j] = mailbox_take(*ca, mbox + row * (2 * L) + 2 * g, aborted); }
+        }
       }
     }
     if constexpr (CHAIN) {                       // every dual awaited before the first store (see dense_pk_body)
@@ -1958,9 +1975,14 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
         else if constexpr (CHAIN) cur = sm[k];
         else cur = preload_ok ? sm[k] : ld_dual<A>(ms + g);
         const double delta = o.omega * snap;
+        bool boxed = false;                          // (see dense_pk_body: the reader sets the peer's tracked bound)
+        if constexpr (MBOX) {
+          boxed = (o.info & OP_MAILBOX) != 0;
+          if (boxed && !(flags & SWEEP_RESIDUAL)) mailbox_put(mbox + o.peer_const * (2 * L) + 2 * g, cur + delta, ca->epoch);
+        }
         st_dual<A>(ms + g, cur + delta);
         theta -= delta;
-        if (g == 0) st_lb<A>(lb + o.peer, LPMP_NAN);
+        if (g == 0 && !boxed) st_lb<A>(lb + o.peer, LPMP_NAN);
       }
     }
     for (int k = KS; k < n_send; ++k) {
@@ -1978,7 +2000,9 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
         double* ms = dual + o.peer_dual + (((o.info >> 5) & 1) ? Lr : 0);
         residual += o.omega;
         const double delta = residual * theta;
-        st_dual<A>(ms + g, ld_dual<A>(ms + g) + delta);
+        const double v = ld_dual<A>(ms + g) + delta;
+        if constexpr (MBOX) { if (k < KS && (o.info & OP_MAILBOX)) mailbox_put(mbox + o.peer_const * (2 * L) + 2 * g, v, ca->epoch); }
+        st_dual<A>(ms + g, v);
         theta -= delta;
       }
     }
@@ -1994,13 +2018,19 @@ sweep_potts_pk_kernel(const Op* __restrict__ packets, const UpdRec* __restrict__
                       int32_t* __restrict__ primal, int64_t count, int stride, int flags) {
   potts_pk_body<L, VAR, NT ? ACC_NT : ACC_PLAIN, false>(packets, recs, ops, dual, cdata, lb, primal, count, stride, flags, (int64_t)blockIdx.x, nullptr, 0);
 }
-template <int L, bool VAR>
+template <int L, bool VAR, bool MBOX>
 __global__ void __launch_bounds__(256)
 chain_potts_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, double* __restrict__ dual,
                       const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal, int flags) {
-  chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
-    potts_pk_body<L, VAR, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket);
-  });
+  if constexpr (MBOX) {
+    chain_loop_ahead(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket, int n_deps) {
+      potts_pk_body<L, VAR, ACC_COH, true, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket, ca.mailbox, n_deps);
+    });
+  } else {
+    chain_loop(ca, launches, [&](const ChainLaunch& ln, int64_t block, int ticket) {
+      potts_pk_body<L, VAR, ACC_COH, true>(ln.packets, ln.recs, ln.ops, dual, cdata, lb, primal, ln.count, ln.stride, flags, block, &ca, ticket);
+    });
+  }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2612,17 +2642,21 @@ bool launch_chain(int kclass, int flags, const void* chain_args, const void* lau
     case KC_DENSE_V16: CHAIN_LAUNCH1(16, 2, true, false); return true;
     case KC_DENSE_V8: CHAIN_LAUNCH1(8, 4, true, false); return true;
     case KC_DENSE_V4: CHAIN_LAUNCH1(4, 4, true, false); return true;
-#define CHAIN_POTTS(LL, VV) do { auto k = chain_potts_pk_kernel<LL, VV>; \
+#define CHAIN_POTTS2(LL, VV, MM) do { auto k = chain_potts_pk_kernel<LL, VV, MM>; \
     hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, dual, cdata, lb, primal, flags); } while (0)
-    case KC_POTTS_32: CHAIN_POTTS(32, false); return true;
-    case KC_POTTS_16: CHAIN_POTTS(16, false); return true;
-    case KC_POTTS_8: CHAIN_POTTS(8, false); return true;
-    case KC_POTTS_4: CHAIN_POTTS(4, false); return true;
+#define CHAIN_POTTS(LL, VV) CHAIN_POTTS2(LL, VV, false)
+#define CHAIN_POTTS_X(LL) do { if (ca.mailbox) CHAIN_POTTS2(LL, false, true); else CHAIN_POTTS2(LL, false, false); } while (0)
+    case KC_POTTS_32: CHAIN_POTTS_X(32); return true;
+    case KC_POTTS_16: CHAIN_POTTS_X(16); return true;
+    case KC_POTTS_8: CHAIN_POTTS_X(8); return true;
+    case KC_POTTS_4: CHAIN_POTTS_X(4); return true;
     case KC_POTTS_V32: CHAIN_POTTS(32, true); return true;
     case KC_POTTS_V16: CHAIN_POTTS(16, true); return true;
     case KC_POTTS_V8: CHAIN_POTTS(8, true); return true;
     case KC_POTTS_V4: CHAIN_POTTS(4, true); return true;
+#undef CHAIN_POTTS_X
 #undef CHAIN_POTTS
+#undef CHAIN_POTTS2
     default: return false;
   }
 #undef CHAIN_LAUNCH

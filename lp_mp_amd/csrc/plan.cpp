@@ -829,7 +829,8 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       std::vector<int8_t> src_k;
       bool any_mbox = false;
       if (!no_mailbox && bands <= 1 && ok) {
-        for (int c = KC_DENSE_4; c <= KC_DENSE_32; ++c) {
+        for (int c = 0; c < KC_COUNT; ++c) {
+          if (!((c >= KC_DENSE_4 && c <= KC_DENSE_32) || (c >= KC_POTTS_4 && c <= KC_POTTS_32))) continue;   // the exact packed classes
           bool el = n_launches_of[c] > 8 && n_launches_of[c] >= chain_min;     // (fewer: plain launches or the banded order)
           for (const auto& lr : out.launches) if (lr.kclass == c && lr.stride <= 0) el = false;
           mbox_class[c] = el; any_mbox = any_mbox || el;

@@ -110,7 +110,10 @@ constexpr int pk_indirect_cap(int labels) { return labels >= 16 ? 32 : labels >=
 // occupancy the dense kernel's registers allow anyway — so the hubs of a random graph of mean degree 10 stay on the packed
 // kernel (as launches of their own on the streaming kernel they cost C4 1.5 of 13.4 ms per pass, profiles/r03_c4b_*).
 // The Potts kernels (more waves per SIMD) keep the smaller slab.
-constexpr int pk_dense_cap(int labels) { return labels == 16 ? 64 : pk_indirect_cap(labels); }
+#ifndef LPMP_PK_DENSE_CAP16          // experiments (tools/build_variant.sh)
+#define LPMP_PK_DENSE_CAP16 64
+#endif
+constexpr int pk_dense_cap(int labels) { return labels == 16 ? LPMP_PK_DENSE_CAP16 : pk_indirect_cap(labels); }
 constexpr int pk_class_cap(int kclass) { return kc_is_dense(kclass) ? pk_dense_cap(kc_width(kclass)) : pk_indirect_cap(kc_width(kclass)); }
 constexpr int32_t UPD_PRELOAD_OK = 1 << 16;   // UpdRec::kind_flags: no send targets a vector a receive writes
 constexpr int32_t UPD_PRIMAL = 1 << 17;       // UpdRec::kind_flags: the factor type has COMPUTE_PRIMAL_SOLUTION

@@ -27,6 +27,9 @@ MODELS = {
     "banded 4 labels, offset 1 (a chain)": lambda: banded_model(900, 4, (1,)),
     "random graph, 8 labels (mailbox and flags mixed)": lambda: S.random_graph_model(3000, 3000, 8, seed=2, compute_primal=True),
     "row-major grid, 16 labels": lambda: S.grid_model(40, 30, 16, order="row_major", seed=5, compute_primal=True),
+    "row-major Potts grid, 8 labels": lambda: S.grid_model(60, 50, 8, pairwise="potts", order="row_major", seed=6, compute_primal=True),
+    "row-major Potts grid, 32 labels": lambda: S.grid_model(30, 40, 32, pairwise="potts", order="row_major", seed=7, compute_primal=True),
+    "random Potts graph, 4 labels (mailbox and flags mixed)": lambda: S.random_graph_model(3000, 3000, 4, seed=2, pairwise="potts", compute_primal=True),
 }
 
 
