@@ -1296,6 +1296,7 @@ __device__ __forceinline__ void chain_loop_ahead(const ChainArgs& ca, const Chai
       if (t1 < ca.n_tickets) { f_launch = ca.tk_launch[t1]; f_block = ca.tk_block[t1]; f_deps = ca.dep_off[t1 + 1] - ca.dep_off[t1]; }
     }
     chain_stamp(ca, ticket, 0);                    // ticket in hand
+    if (ca.trace && threadIdx.x == 0) ca.trace[8 * (int64_t)ticket + 7] = (long long)blockIdx.x;   // ... by this workgroup
     const ChainLaunch ln = launches[s_tk[cur][1]];
     body(ln, (int64_t)s_tk[cur][2], ticket, s_tk[cur][3]);
     if (threadIdx.x == 0) { s_tk[nx1][1] = f_launch; s_tk[nx1][2] = f_block; s_tk[nx1][3] = f_deps; s_tk[nx2][0] = t2; }
@@ -1830,7 +1831,7 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
                                               int32_t* __restrict__ primal, int64_t count, int stride, int flags, int64_t block,
                                               const ChainArgs* ca, int ticket, unsigned long long* __restrict__ mbox = nullptr, int n_deps = -1) {
   static_assert(!CHAIN || A == ACC_COH, "chain bodies hand results over through relaxed agent-scope flags: every dual access must be an agent-scope (sc1) access");
-  static_assert(!MBOX || (CHAIN && !VAR && MAILBOX_SENDS == 4), "the mailbox belongs to chains of the exact classes; this body forwards 4 receives and holds 4 sends");
+  static_assert(!MBOX || (CHAIN && !VAR && MAILBOX_SENDS <= 4), "the mailbox belongs to chains of the exact classes; this body forwards 4 receives and holds 4 sends");
   constexpr int GPB = 256 / L;
   constexpr int KR = 4, KS = 4;
   constexpr int PIECES = 3 * (1 + pk_indirect_cap(L));

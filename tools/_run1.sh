@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_mailbox_gpu.py -x -q -m gpu 2>&1 | tail -3
-timeout 2400 python -m pytest tests/test_fuzz_gpu.py tests/test_primal_gpu.py tests/test_send_rules_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout 600 python tools/chain_trace.py run 1024 32 row_major 2>&1 | tail -2
+mkdir -p gpurun_out; cp /tmp/chain_trace.bin gpurun_out/chain_trace_c3rm.bin

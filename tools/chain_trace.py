@@ -92,6 +92,17 @@ def show(path):
             print("    per ticket: sends issued (both producers) -> inputs landed   :", q(hop))
             print("    per ticket: waiting already when the producers' sends left   :", q(lead), " (negative: not ready yet: %.1f %%)" % (100.0 * np.mean(lead < 0)))
             print("    per ticket: landed -> own sends issued   t6 - t4              :", q(t6 - t4))
+    wg = st.T[7]
+    if wg.any():                                     # mailbox chains stamp the workgroup: how a workgroup spends the launch
+        order = np.lexsort((t0, wg))
+        same = wg[order][1:] == wg[order][:-1]
+        prev, cur = order[:-1][same], order[1:][same]
+        n_wg = len(np.unique(wg))
+        total = float(t3.max() - t0.min()) * n_wg
+        print(f"  {n_wg} workgroups; consecutive tickets of one workgroup are", "%d levels apart (median; p10 %d, p90 %d)" % tuple(np.percentile(tl[cur] - tl[prev], [50, 10, 90])))
+        print("    share of a workgroup's time: start-up t1-t0 %.2f, waiting for inputs t4-t1 %.2f, arithmetic t2-t4 %.2f, publish t3-t2 %.2f, between tickets %.2f"
+              % tuple(float(x.sum()) / total for x in (t1 - t0, t4 - t1, t2 - t4, t3 - t2, t0[cur] - t3[prev])))
+        print("    ticket in hand -> published  t3 - t0 :", q(t3 - t0), "; published -> next ticket in hand :", q(t0[cur] - t3[prev]))
     # critical chain: follow the latest predecessor back from the last ticket
     k = int(np.argmax(t3)); hops = 0; parts = np.zeros(4)
     while True:
