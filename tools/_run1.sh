@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-LPMP_ROT_VERBOSE=1 timeout 900 python bench.py --workload c4 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep -E "table stream|^\{" | cut -c1-200
+timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+bash tools/profile_round.sh r03b --steps 20 --warmup 5 2>&1 | tail -2
