@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-bash tools/profile_round.sh r03b --steps 20 --warmup 5 2>&1 | tail -2
+mkdir -p gpurun_out
+MALLOC_CHECK_=3 timeout 1500 python tests/fuzz_split.py 0 1000000 --minutes 10.5 --families 0123456 --in-process-oracle > gpurun_out/r03_fuzz_soak_last_binaries.log 2>&1
+tail -3 gpurun_out/r03_fuzz_soak_last_binaries.log
+LPMP_CHAIN_MIN=2 LPMP_CHAIN_ALL=1 MALLOC_CHECK_=3 timeout 900 python tests/fuzz_split.py 500000 1000000 --minutes 6 --families 0123456 --in-process-oracle > gpurun_out/r03_fuzz_chains_and_mailbox_forced.log 2>&1
+tail -3 gpurun_out/r03_fuzz_chains_and_mailbox_forced.log
