@@ -857,7 +857,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
                                               unsigned long long* __restrict__ mbox = nullptr, int n_deps = -1) {
   static_assert(!CHAIN || A == ACC_COH, "chain bodies hand results over through relaxed agent-scope flags: every dual access must be an agent-scope (sc1) access");
   static_assert(MAILBOX_SENDS >= 1 && MAILBOX_SENDS <= 4, "plan.hpp: the sends whose fields are held in registers (KS)");
-  static_assert(!MBOX || (CHAIN && !VAR), "the mailbox belongs to chains of the exact dense classes");   // (an instantiation of its own: the joined passes of the headline grid lost 8 % with the mailbox fields in their registers)
+  static_assert(!MBOX || CHAIN, "the mailbox belongs to the chain executor");   // (an instantiation of its own: the joined passes of the headline grid lost 8 % with the mailbox fields in their registers)
   constexpr int G = DenseCfg<L>::G;
   constexpr int CL = L / 2, RPL = 2 * G / L, NL = L / RPL, GPB = 256 / G;
   constexpr int KS = MBOX ? MAILBOX_SENDS : 4;   // sends whose target vectors are prefetched / forwarded
@@ -998,7 +998,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
       if (c + j < n_recv) {
         if constexpr (VAR) {
           if (g < Lr) msv[j] = ld_dual<A>(dual + pdual[j] + roff[j] + g);
-          if (g < (side[j] == 0 ? dC[j] : dR[j])) mov[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? dR[j] : 0) + g);
+          if (!(MBOX && box[j]) && g < (side[j] == 0 ? dC[j] : dR[j])) mov[j] = ld_dual<A>(dual + pdual[j] + (side[j] == 0 ? dR[j] : 0) + g);
         } else if (g < L) {
 #ifdef LPMP_ABLATE_RECV_VEC
           msv[j] = (double)pdual[j] * 1e-300; mov[j] = 0.0;
@@ -1012,7 +1012,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
     if constexpr (MBOX) {                        // ... and, with everything else in flight, the vectors that come by mailbox
 #pragma unroll
       for (int j = 0; j < KMAX; ++j)
-        if (c + j < n_recv && box[j] && g < L) mov[j] = mailbox_take(*ca, box[j] + 2 * g, aborted);
+        if (c + j < n_recv && box[j] && g < (VAR ? (side[j] == 0 ? dC[j] : dR[j]) : L)) mov[j] = mailbox_take(*ca, box[j] + 2 * g, aborted);
     }
     if constexpr (CHAIN && FIRST) {
       // Loads and stores share one counter on this ISA and may complete out of order with respect to each other, so a
@@ -1831,7 +1831,7 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
                                               int32_t* __restrict__ primal, int64_t count, int stride, int flags, int64_t block,
                                               const ChainArgs* ca, int ticket, unsigned long long* __restrict__ mbox = nullptr, int n_deps = -1) {
   static_assert(!CHAIN || A == ACC_COH, "chain bodies hand results over through relaxed agent-scope flags: every dual access must be an agent-scope (sc1) access");
-  static_assert(!MBOX || (CHAIN && !VAR && MAILBOX_SENDS <= 4), "the mailbox belongs to chains of the exact classes; this body forwards 4 receives and holds 4 sends");
+  static_assert(!MBOX || (CHAIN && MAILBOX_SENDS <= 4), "the mailbox belongs to the chain executor; this body forwards 4 receives and holds 4 sends");
   constexpr int GPB = 256 / L;
   constexpr int KR = 4, KS = 4;
   constexpr int PIECES = 3 * (1 + pk_indirect_cap(L));
@@ -2632,6 +2632,7 @@ bool launch_chain(int kclass, int flags, const void* chain_args, const void* lau
 #define CHAIN_LAUNCH1(LL, KK, VV, NTT) CHAIN_LAUNCH2(LL, KK, VV, NTT, false)
   // (a mailbox chain is a deep schedule: latency-bound, no streaming variant)
 #define CHAIN_LAUNCH(LL, KK) do { if (ca.mailbox) CHAIN_LAUNCH2(LL, KK, false, false, true); else if (nt) CHAIN_LAUNCH1(LL, KK, false, true); else CHAIN_LAUNCH1(LL, KK, false, false); } while (0)
+#define CHAIN_LAUNCH_V(LL, KK) do { if (ca.mailbox) CHAIN_LAUNCH2(LL, KK, true, false, true); else CHAIN_LAUNCH1(LL, KK, true, false); } while (0)
   switch (kclass) {
     case KC_GENERIC: { auto k = chain_generic_kernel<64>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<64>::THREADS)), dim3(GenCtx<64>::THREADS), 0, s, ca, ln, dual, cdata, tabs, lb, flags); return true; }
     case KC_SMALL: { auto k = chain_generic_kernel<1>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<1>::THREADS)), dim3(GenCtx<1>::THREADS), 0, s, ca, ln, dual, cdata, tabs, lb, flags); return true; }
@@ -2639,28 +2640,31 @@ bool launch_chain(int kclass, int flags, const void* chain_args, const void* lau
     case KC_DENSE_16: CHAIN_LAUNCH(16, 2); return true;
     case KC_DENSE_8: CHAIN_LAUNCH(8, 4); return true;
     case KC_DENSE_4: CHAIN_LAUNCH(4, 4); return true;
-    case KC_DENSE_V32: CHAIN_LAUNCH1(32, 2, true, false); return true;
-    case KC_DENSE_V16: CHAIN_LAUNCH1(16, 2, true, false); return true;
-    case KC_DENSE_V8: CHAIN_LAUNCH1(8, 4, true, false); return true;
-    case KC_DENSE_V4: CHAIN_LAUNCH1(4, 4, true, false); return true;
+    case KC_DENSE_V32: CHAIN_LAUNCH_V(32, 2); return true;
+    case KC_DENSE_V16: CHAIN_LAUNCH_V(16, 2); return true;
+    case KC_DENSE_V8: CHAIN_LAUNCH_V(8, 4); return true;
+    case KC_DENSE_V4: CHAIN_LAUNCH_V(4, 4); return true;
 #define CHAIN_POTTS2(LL, VV, MM) do { auto k = chain_potts_pk_kernel<LL, VV, MM>; \
     hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets)), dim3(256), 0, s, ca, ln, dual, cdata, lb, primal, flags); } while (0)
 #define CHAIN_POTTS(LL, VV) CHAIN_POTTS2(LL, VV, false)
 #define CHAIN_POTTS_X(LL) do { if (ca.mailbox) CHAIN_POTTS2(LL, false, true); else CHAIN_POTTS2(LL, false, false); } while (0)
+#define CHAIN_POTTS_XV(LL) do { if (ca.mailbox) CHAIN_POTTS2(LL, true, true); else CHAIN_POTTS2(LL, true, false); } while (0)
     case KC_POTTS_32: CHAIN_POTTS_X(32); return true;
     case KC_POTTS_16: CHAIN_POTTS_X(16); return true;
     case KC_POTTS_8: CHAIN_POTTS_X(8); return true;
     case KC_POTTS_4: CHAIN_POTTS_X(4); return true;
-    case KC_POTTS_V32: CHAIN_POTTS(32, true); return true;
-    case KC_POTTS_V16: CHAIN_POTTS(16, true); return true;
-    case KC_POTTS_V8: CHAIN_POTTS(8, true); return true;
-    case KC_POTTS_V4: CHAIN_POTTS(4, true); return true;
+    case KC_POTTS_V32: CHAIN_POTTS_XV(32); return true;
+    case KC_POTTS_V16: CHAIN_POTTS_XV(16); return true;
+    case KC_POTTS_V8: CHAIN_POTTS_XV(8); return true;
+    case KC_POTTS_V4: CHAIN_POTTS_XV(4); return true;
 #undef CHAIN_POTTS_X
+#undef CHAIN_POTTS_XV
 #undef CHAIN_POTTS
 #undef CHAIN_POTTS2
     default: return false;
   }
 #undef CHAIN_LAUNCH
+#undef CHAIN_LAUNCH_V
 #undef CHAIN_LAUNCH1
 #undef CHAIN_LAUNCH2
 }

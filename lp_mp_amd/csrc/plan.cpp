@@ -830,7 +830,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       bool any_mbox = false;
       if (!no_mailbox && bands <= 1 && ok) {
         for (int c = 0; c < KC_COUNT; ++c) {
-          if (!((c >= KC_DENSE_4 && c <= KC_DENSE_32) || (c >= KC_POTTS_4 && c <= KC_POTTS_32))) continue;   // the exact packed classes
+          if (!(c >= KC_DENSE_4 && c <= KC_POTTS_V32)) continue;                   // the packed dense and Potts classes, exact and run-time dims
           // (fewer launches: plain launches, or — a few HBM-sized steps — the banded order below; LPMP_CHAIN_MIN lowers the
           // bar for the randomised tests, which then run the mailbox on every small chain)
           bool el = n_launches_of[c] >= chain_min && !(model_big && n_launches_of[c] <= 8 && !no_auto_bands);

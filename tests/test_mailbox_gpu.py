@@ -29,6 +29,9 @@ MODELS = {
     "row-major grid, 16 labels": lambda: S.grid_model(40, 30, 16, order="row_major", seed=5, compute_primal=True),
     "row-major Potts grid, 8 labels": lambda: S.grid_model(60, 50, 8, pairwise="potts", order="row_major", seed=6, compute_primal=True),
     "row-major Potts grid, 32 labels": lambda: S.grid_model(30, 40, 32, pairwise="potts", order="row_major", seed=7, compute_primal=True),
+    "row-major grid, 21 labels (run-time dims)": lambda: S.grid_model(30, 26, 21, order="row_major", seed=8, compute_primal=True),
+    "row-major Potts grid, 5 labels (run-time dims)": lambda: S.grid_model(44, 50, 5, pairwise="potts", order="row_major", seed=9, compute_primal=True),
+    "banded 3 labels, offsets 1 4 (run-time dims)": lambda: banded_model(500, 3, (1, 4), seed=10),
     "random Potts graph, 4 labels (mailbox and flags mixed)": lambda: S.random_graph_model(3000, 3000, 4, seed=2, pairwise="potts", compute_primal=True),
 }
 

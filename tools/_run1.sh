@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-MALLOC_CHECK_=3 timeout 1500 python tests/fuzz_split.py 0 1000000 --minutes 10.5 --families 0123456 --in-process-oracle > gpurun_out/r03_fuzz_soak_last_binaries.log 2>&1
-tail -3 gpurun_out/r03_fuzz_soak_last_binaries.log
-LPMP_CHAIN_MIN=2 LPMP_CHAIN_ALL=1 MALLOC_CHECK_=3 timeout 900 python tests/fuzz_split.py 500000 1000000 --minutes 6 --families 0123456 --in-process-oracle > gpurun_out/r03_fuzz_chains_and_mailbox_forced.log 2>&1
-tail -3 gpurun_out/r03_fuzz_chains_and_mailbox_forced.log
+timeout 900 python -m pytest tests/test_mailbox_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_engine_gpu.py -x -q -m gpu -k "chain or level or deep or row_major or many or labels" 2>&1 | tail -2
+timeout 300 python tools/chain_probe.py 1024 21 dense 10 2>&1 | tail -1
+timeout 300 python tools/chain_probe.py 1024 7 potts 10 2>&1 | tail -1
