@@ -2636,7 +2636,10 @@ bool launch_chain(int kclass, int flags, const void* chain_args, const void* lau
   switch (kclass) {
     case KC_GENERIC: { auto k = chain_generic_kernel<64>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<64>::THREADS)), dim3(GenCtx<64>::THREADS), 0, s, ca, ln, dual, cdata, tabs, lb, flags); return true; }
     case KC_SMALL: { auto k = chain_generic_kernel<1>; hipLaunchKernelGGL(k, dim3(chain_grid(k, ca.n_tickets, GenCtx<1>::THREADS)), dim3(GenCtx<1>::THREADS), 0, s, ca, ln, dual, cdata, tabs, lb, flags); return true; }
-    case KC_DENSE_32: CHAIN_LAUNCH(32, 2); return true;
+#ifndef LPMP_MBOX_KMAX32           // experiments: receives in flight per record of the 32-label mailbox chain
+#define LPMP_MBOX_KMAX32 2
+#endif
+    case KC_DENSE_32: if (ca.mailbox) CHAIN_LAUNCH2(32, LPMP_MBOX_KMAX32, false, false, true); else CHAIN_LAUNCH(32, 2); return true;
     case KC_DENSE_16: CHAIN_LAUNCH(16, 2); return true;
     case KC_DENSE_8: CHAIN_LAUNCH(8, 4); return true;
     case KC_DENSE_4: CHAIN_LAUNCH(4, 4); return true;
