@@ -102,6 +102,10 @@ def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: in
     from . import engine as E
     edge_i = np.asarray(edge_i, np.int64); edge_j = np.asarray(edge_j, np.int64); part = np.asarray(part, np.int64)
     n_edges = edge_i.shape[0]
+    if part.shape[0] != n_vars or part.min() < 0 or part.max() >= world:
+        raise ValueError("lockstep_mrf: part must name a rank in [0, world) for every variable")
+    if np.bincount(part, minlength=world).min() == 0:
+        raise ValueError("lockstep_mrf: a rank without variables (every rank takes part in every exchange)")
     # the global structure (no costs) and everything the reference derives from it
     if pairwise == "dense":
         gm = S.mrf_model(n_vars, L, edge_i, edge_j, np.zeros(n_vars * L), device_const=True)
@@ -209,7 +213,6 @@ class LockstepSweep:
         n_vec = p.vars_global.shape[0]
         doff = p.model.dual_offsets()
         self._pw_off = doff[n_vec:]                                # dual offset of local pairwise factor e (local edge order)
-        self._edge_local = {}                                      # global edge -> local edge, by searchsorted (edges_global is sorted)
         self.info = {}
 
     def _schedule(self, seg: tuple) -> int:

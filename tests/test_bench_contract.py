@@ -63,6 +63,21 @@ def test_bench_json_line_contract():
 
 
 @pytest.mark.gpu
+def test_bench_row_major_order_runs_the_mailbox_chain():
+    """--order row_major: one level per anti-diagonal, each directional sweep one persistent launch whose records hand their
+    message vectors over through the mailbox; the line carries the same contract, and the bound of the colour-major default
+    at the same pass count is a different one (another sweep order)"""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "128", "--order", "row_major", "--steps", "3",
+                                   "--warmup", "1", "--no-cpu-baseline"], text=True, cwd=ROOT, timeout=600)
+    d = json.loads([l for l in out.strip().splitlines() if l.startswith('{"metric"')][-1])
+    assert d["config"]["levels_per_direction"] == [255, 255] and "row_major" in d["config"]["workload"]
+    assert d["value"] > 0 and d["lower_bound_after"] > d["lower_bound_before"] and d["rounding"]["primal_cost"] >= d["rounding"]["lower_bound"]
+    from lp_mp_amd import engine as E, model as M, synthetic as S
+    ci = E.Plan(S.grid_model(128, 128, 32, order="row_major", device_const=True)).chain_info(-1, M.REPAM_ANISOTROPIC)
+    assert ci["n_chains"] == 1 and ci["mailbox_rows"] == 2 * (2 * 128 * 127)
+
+
+@pytest.mark.gpu
 def test_bench_c4_workload_line():
     """--workload c4 (BASELINE configs[3] in miniature on one GPU): same contract, the random-graph workload named"""
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c4", "--c4-nodes", "20000", "--c4-edges", "100000",

@@ -83,6 +83,27 @@ def test_lockstep_parts_run_the_unpartitioned_sweep(name, mode):
     assert sum(int(p.owned.sum()) for p in parts) == c["n_vars"] + c["ei"].shape[0]
 
 
+def test_isolated_variables_odd_label_counts_and_bad_partitions():
+    """variables without any edge are updated where they live; three labels (run-time-dims classes on the device); a rank
+    without variables is refused"""
+    n, L, world = 60, 3, 3
+    rng = np.random.default_rng(3)
+    ei = rng.integers(0, 40, 90); ej = rng.integers(0, 40, 90)
+    keep = ei != ej
+    e = np.unique(np.stack([np.minimum(ei, ej)[keep], np.maximum(ei, ej)[keep]], 1), axis=0)      # variables 40 .. 59 have no edge
+    c = dict(n_vars=n, L=L, ei=e[:, 0], ej=e[:, 1], un=S.u01(n * L, 4, 0), tables=S.u01(e.shape[0] * L * L, 4, n * L), potts=None,
+             pairwise="dense", part_of=rng.integers(0, world, n), world=world)
+    ref = Oracle(_global_of(c)); ref.set_reparametrization(M.REPAM_ANISOTROPIC2)
+    sched, parts = _parts_of(c, M.REPAM_ANISOTROPIC2)
+    duals = [p.model.dual_data.copy() for p in parts]
+    sweeps = [LS.LockstepSweep(torch, p, sched, OracleEngine(p.model, d), torch.from_numpy(d)) for p, d in zip(parts, duals)]
+    ref.ComputePass(2); LS.run_lockstep(sweeps, 2)
+    _assert_equals_global(c, parts, duals, ref)
+    assert abs(sum(s.local_lower_bound() for s in sweeps) - ref.LowerBound()) <= 1e-12 * max(1.0, abs(ref.LowerBound()))
+    with pytest.raises(ValueError, match="without variables"):
+        LS.lockstep_mrf(n, L, e[:, 0], e[:, 1], np.zeros(n, np.int64), 2, M.REPAM_ANISOTROPIC, c["un"], c["tables"])
+
+
 def test_colour_major_strips_need_two_exchanges_per_pass():
     c = _strips(8, 8, 3, 4, "dense", "colour_major")
     sched, _ = _parts_of(c, M.REPAM_ANISOTROPIC)
