@@ -246,3 +246,40 @@ def test_four_process_gloo_run_of_proxy_built_strips_equals_the_unpartitioned_or
     _, parts = _parts_of(c, M.REPAM_ANISOTROPIC)
     _assert_equals_global(c, parts, [np.load(tmp_path / f"st_duals_{k}.npy") for k in range(4)], ref)
     assert abs(np.load(tmp_path / "st_lb.npy")[0] - ref.LowerBound()) <= 1e-12 * abs(ref.LowerBound())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_lockstep_random_graphs_partitions_and_modes_on_device(seed):
+    """random graph, random (unbalanced, scattered) partition, random label count / pairwise kind / weight mode, separate calls
+    of random length: every part's duals and the summed bound are the oracle's on the unpartitioned model"""
+    from lp_mp_amd import engine as E
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(40, 400)); m = int(rng.integers(n, 4 * n)); L = int(rng.choice([2, 3, 4, 5, 8, 16, 32]))
+    world = int(rng.integers(2, 6)); pairwise = "potts" if rng.uniform() < 0.4 else "dense"
+    mode = [M.REPAM_ANISOTROPIC, M.REPAM_ANISOTROPIC2, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM][int(rng.integers(0, 4))]
+    a = rng.integers(0, n, 2 * m); b = rng.integers(0, n, 2 * m)
+    keep = a != b
+    e = np.unique(np.stack([np.minimum(a, b)[keep], np.maximum(a, b)[keep]], 1), axis=0)[:m]
+    part_of = rng.integers(0, world, n); part_of[:world] = np.arange(world)          # every rank owns something
+    c = dict(n_vars=n, L=L, ei=e[:, 0], ej=e[:, 1], un=S.u01(n * L, seed, 0), pairwise=pairwise, part_of=part_of, world=world,
+             tables=S.u01(e.shape[0] * L * L, seed, n * L) if pairwise == "dense" else None,
+             potts=S.u01(e.shape[0], seed, n * L) if pairwise == "potts" else None)
+    ref = Oracle(_global_of(c)); ref.set_reparametrization(mode)
+    sched, parts = _parts_of(c, mode)
+    dev = torch.device("cuda:0")
+    sweeps, tensors = [], []
+    for p in parts:
+        dual = torch.from_numpy(p.model.dual_data.copy()).to(dev)
+        eng = E.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual); eng.set_reparametrization(mode)
+        sweeps.append(LS.LockstepSweep(torch, p, sched, eng, dual)); tensors.append(dual)
+    try:
+        for k in rng.integers(1, 4, 3):
+            ref.ComputePass(int(k)); LS.run_lockstep(sweeps, int(k)); torch.cuda.synchronize()
+            _assert_equals_global(c, parts, [t.cpu().numpy() for t in tensors], ref)
+            lb = sum(s.local_lower_bound() for s in sweeps)
+            assert abs(lb - ref.LowerBound()) <= 1e-9 * max(1.0, abs(ref.LowerBound())), (seed, lb, ref.LowerBound())
+    finally:
+        for s in sweeps:
+            s.engine.close()
