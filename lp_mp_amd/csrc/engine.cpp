@@ -603,7 +603,11 @@ void upload_schedule(const Schedule& s, DevSchedule& d, hipStream_t stream, bool
       if (c.mailbox_rows > 0) {
         // a granule is valid when its tag is the epoch of the running launch: zeroed once, epochs start at 1
         const size_t bytes = (size_t)c.mailbox_rows * c.mailbox_width * 16;
-        HIP_CHECK(hipMalloc((void**)&dc.mailbox, bytes));
+        if (hipMalloc((void**)&dc.mailbox, bytes) != hipSuccess) {
+          (void)hipGetLastError();
+          throw DeviceError("no device memory for the mailbox of a deep schedule (" + std::to_string(bytes >> 20) +
+                            " MiB: 16 bytes per label and mailbox send); LPMP_NO_MAILBOX=1 plans the same schedule with completion flags only");
+        }
         HIP_CHECK(hipMemsetAsync(dc.mailbox, 0, bytes, stream));
       }
       d.chains.push_back(dc);
