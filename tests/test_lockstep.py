@@ -181,12 +181,15 @@ def test_two_process_gloo_run_equals_the_unpartitioned_oracle(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,L", [("strips", 32), ("strips", 8), ("graph", 16), ("potts", 8)])
+@pytest.mark.parametrize("name,L", [("strips", 32), ("strips", 8), ("graph", 16), ("potts", 8), ("row_major_strips", 16), ("row_major_potts", 5)])
 def test_lockstep_on_device_equals_the_unpartitioned_engine_and_oracle(name, L):
     """real HIP engines, all parts on the one GPU of the test box: duals of the oracle on the unpartitioned model, bit for bit"""
     from lp_mp_amd import engine as E
     c = {"strips": lambda: _strips(12, 10, L, 3, "dense", "colour_major", 5), "graph": lambda: _graph(1500, 6000, L, 4, 2),
-         "potts": lambda: _strips(10, 12, L, 4, "potts", "colour_major", 7)}[name]()
+         "potts": lambda: _strips(10, 12, L, 4, "potts", "colour_major", 7),
+         # deep custom schedules: every segment a chain launch whose records hand over through the mailbox (plan.cpp)
+         "row_major_strips": lambda: _strips(14, 12, L, 3, "dense", "row_major", 9),
+         "row_major_potts": lambda: _strips(12, 14, L, 3, "potts", "row_major", 11)}[name]()
     gm = _global_of(c)
     ref = Oracle(gm); ref.set_reparametrization(M.REPAM_ANISOTROPIC)
     sched, parts = _parts_of(c, M.REPAM_ANISOTROPIC)

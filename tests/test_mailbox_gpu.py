@@ -60,7 +60,7 @@ def test_mailbox_chains_equal_the_oracle(name, monkeypatch):
             tracked = e.lower_bound(); e.invalidate_lower_bounds()
             assert abs(e.lower_bound() - tracked) <= 1e-12 * max(1.0, abs(tracked)), (what, k)
     try:
-        for mode in (M.REPAM_ANISOTROPIC, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM):
+        for mode in (M.REPAM_ANISOTROPIC, M.REPAM_ANISOTROPIC2, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM):
             o.set_reparametrization(mode)
             for e in engines: e.set_reparametrization(mode)
             o.ComputeForwardPass(); o.ComputeBackwardPass()
