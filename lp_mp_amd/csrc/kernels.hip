@@ -927,6 +927,10 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
     for (int m = 32; m >= G; m >>= 1) max_recv = max(max_recv, __shfl_xor(max_recv, m, 64));
   }
   bool aborted = false;
+  // mailbox chains: the tracked bounds of the first chunk's peers are reduced after the sends (the next level waits for those)
+  [[maybe_unused]] double late_pb[KMAX]; [[maybe_unused]] int late_peer[KMAX], late_mode[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) { late_pb[j] = LPMP_INF; late_peer[j] = -1; late_mode[j] = 0; }
 
   // one chunk of up to KMAX receives starting at c; FW: c is a compile-time constant and results may be forwarded;
   // FIRST (chain executor): the tables (constants) are requested, then the predecessors awaited, then the duals read
@@ -1082,6 +1086,9 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
       {
         const bool track = !(FW && defer[j]);     // a deferred receive is followed by a send that dirties the peer
         const bool hist = CHAIN && hmode == HIST_MID;   // ... but its bound at the seam between two passes is this one
+        if constexpr (MBOX && FIRST) {
+          late_pb[j] = pb; late_peer[j] = act ? uni<G>(lop[c + j].peer) : -1; late_mode[j] = track ? 1 : 0;
+        } else
         if (track || hist) {
           pb = vec_min<G, L>(pb);
           if (act && g == 0) {
@@ -1218,6 +1225,19 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
     st_dual<A>(own_g + g, theta);
   }
 #ifndef LPMP_ABLATE_LB_TRACK
+  if constexpr (MBOX) {
+    // (a peer this record also SENDS to ends up stale: the send's mark must be the last word, so its bound is not stored)
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j >= max_recv) break;
+      const double pb = vec_min<G, L>(late_pb[j]);
+      if (late_peer[j] >= 0 && (late_mode[j] & 1) && g == 0) {
+        bool sent = false;
+        for (int k = 0; k < n_send; ++k) if (uni<G>(lop[n_recv + k].peer) == late_peer[j]) sent = true;
+        if (!sent) st_lb<A>(lb + late_peer[j], pb);
+      }
+    }
+  }
   {
     const double ob = vec_min<G, L>(vl ? theta : LPMP_INF);
     if (live && g == 0) {
