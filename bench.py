@@ -41,16 +41,27 @@ def parse():
     ap.add_argument("--c4-edges", type=int, default=10_000_000)
     ap.add_argument("--c4-labels", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--schedule", default="boundary", choices=["boundary", "lockstep"],
-                    help="several GPUs: 'boundary' = every part sweeps its own sub-problem, cut messages reconciled in a boundary step "
-                         "(multi_gpu.py; a small dual-bound gap, few exchanges); 'lockstep' = the parts run the unpartitioned sweep level "
-                         "by level with halo copies in between (lockstep.py; gap 0, one exchange per dependent level that reads across the cut)")
+    ap.add_argument("--schedule", default="auto", choices=["auto", "overlap", "boundary", "lockstep"],
+                    help="several GPUs: 'overlap' (grids in colour-major order; the default there) = every rank holds its strip plus "
+                         "--ghost-rows rows of its neighbours and runs plain joined passes, one exchange per (ghost-rows / 2 - 1) passes: "
+                         "the unpartitioned sweep bit for bit, gap 0 (overlap.py); 'lockstep' = the parts run the unpartitioned sweep level "
+                         "by level with halo copies in between (lockstep.py; gap 0, one exchange per dependent level that reads across the "
+                         "cut; any graph); 'boundary' = every part sweeps its own sub-problem, cut messages reconciled in a boundary step "
+                         "(multi_gpu.py; a small dual-bound gap, few exchanges; the default for --workload c4)")
+    ap.add_argument("--ghost-rows", type=int, default=12, help="overlap schedule: rows of each neighbour a rank holds (even; n passes between exchanges need 2 n + 2)")
+    ap.add_argument("--no-compare-schedules", action="store_true",
+                    help="several GPUs, grid workload: do NOT also run the other schedules (same pass count, after the timed region) for "
+                         "the `schedules` entry of the line")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path even at WORLD_SIZE 1: init_process_group(nccl = RCCL), the partitioned "
                          "sweep with its (empty) all_to_all_single exchanges, device all_reduce — what an N-GPU launch executes "
                          "first, runnable on a 1-GPU box (tests/test_bench_contract.py)")
     ap.add_argument("--cpu-sample-grid", type=int, default=256)
     ap.add_argument("--also-row-major", action="store_true", help="also time the row-major ordering (extra key)")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="--gpus N without a launcher: print the rank processes that WOULD be started (command, environment) as one "
+                         "JSON object and exit; nothing touches a GPU (tests/test_bench_contract.py)")
+    ap.add_argument("--launch-timeout", type=float, default=0.0, help="self-launched ranks: give up after this many seconds (0: never)")
     ap.add_argument("--prewarm-ms", type=float, default=0.0,
                     help="untimed passes (prewarm_ms / 8 of them) before the W warmup steps so that clocks and "
                          "power state have settled; 0 disables")
@@ -157,31 +168,53 @@ def dual_bound_gap_c4(torch, dist, args, mode, world, rank):
     return out
 
 
-def dual_bound_gap(torch, dist, args, mode, world, rank):
+def make_strip_runner(torch, dist, args, schedule, H, mode):
+    """this rank's part of the (world * H) x H strip grid under one of the three multi-GPU schedules"""
+    from lp_mp_amd import multi_gpu as MG
+    if schedule == "overlap":
+        from lp_mp_amd import overlap as OV
+        g = min(args.ghost_rows, H - (H % 2))
+        return OV.OverlapStrips(torch, dist, H, H, args.labels, args.pairwise, mode, seed=1, g=g)
+    if schedule == "lockstep":
+        from lp_mp_amd import lockstep as LS
+        return LS.LockstepStrips(torch, dist, H, H, args.labels, args.pairwise, args.order, mode, seed=1)
+    return MG.StripSweep(torch, dist, H, H, args.labels, args.pairwise, args.order, mode, seed=1, boundary_every="pass")
+
+
+def describe_strip_runner(runner, schedule, world, H, W):
+    if schedule == "overlap":
+        return (f"{world} row strips of {H}x{W} with {runner.part.g} ghost rows per side (rank 0's window: rows {runner.window_rows[0]}..{runner.window_rows[1]}), "
+                f"plain joined passes, one exchange per {runner.sweep.chunk} passes: the unpartitioned sweep of the {world * H}x{W} grid")
+    if schedule == "lockstep":
+        return f"{world} row strips of {H}x{W} in lock step (the unpartitioned sweep, {runner.halo_steps_per_pass():.1f} halo exchanges per pass)"
+    return f"{world} row strips of {H}x{W}, cut-edge exchange once per pass"
+
+
+def dual_bound_gap(torch, dist, args, mode, world, rank, schedule=None):
     """Second half of BASELINE.json's metric.  Same partition schedule, same RCCL exchange, on strips small enough
     that rank 0 can also run the UNPARTITIONED (world*g) x g grid: gap = (LB_unpartitioned - LB_partitioned) /
     |LB_unpartitioned| after the same number of passes."""
     from lp_mp_amd import engine as E, multi_gpu as MG, synthetic as S
     g, passes = 128, args.steps
-    if args.schedule == "lockstep":
-        from lp_mp_amd import lockstep as LS
-        sw = LS.LockstepStrips(torch, dist, g, g, args.labels, args.pairwise, args.order, mode, seed=1)
-    else:
-        sw = MG.StripSweep(torch, dist, g, g, args.labels, args.pairwise, args.order, mode, seed=1, boundary_every="pass")
+    schedule = schedule or args.schedule
+    sw = make_strip_runner(torch, dist, args, schedule, g, mode)
     sw.compute_pass(passes)
     lb_part = sw.lower_bound()
     out = None
     if rank == 0:
-        ei, ej = MG.strip_global_edges(g, g, world, args.order)
-        un, tables, potts = MG.strip_costs(g, g, args.labels, world, args.pairwise, 1)
-        m = S.mrf_model(world * g * g, args.labels, ei, ej, un, tables=tables, potts=potts)
+        if schedule == "overlap":                    # ONE global colour-major order: the single-GPU model of the whole grid
+            m = S.grid_model(world * g, g, args.labels, pairwise=args.pairwise, order="colour_major", seed=1)
+        else:                                        # strip-major order (the strips' own orders one after the other)
+            ei, ej = MG.strip_global_edges(g, g, world, args.order)
+            un, tables, potts = MG.strip_costs(g, g, args.labels, world, args.pairwise, 1)
+            m = S.mrf_model(world * g * g, args.labels, ei, ej, un, tables=tables, potts=potts)
         e = E.Engine(torch.cuda.current_device())
         e.upload(m)
         e.set_reparametrization(mode)
         e.compute_pass(passes)
         lb_ref = e.lower_bound()
         e.close()
-        out = {"dual_bound_gap": (lb_ref - lb_part) / abs(lb_ref), "gap_config": f"{world} strips of {g}x{g}, {passes} passes",
+        out = {"dual_bound_gap": (lb_ref - lb_part) / abs(lb_ref), "gap_config": f"{world} strips of {g}x{g}, {passes} passes, schedule {schedule}",
                "lb_partitioned": lb_part, "lb_unpartitioned": lb_ref}
     sw.engine.close()
     return out
@@ -249,12 +282,103 @@ def cpu_baseline(args, synthetic, M):
             "sample": f"{what}, {passes} passes, oracle/lpmp_oracle.c single thread"}
 
 
+def rank_commands(args, argv, port):
+    """the N rank processes of `python bench.py --gpus N` (no torchrun around it): same arguments, one process per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them"""
+    cmds = []
+    for r in range(args.gpus):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "LPMP_BENCH_SELF_LAUNCHED": "1",
+               "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+        cmds.append({"argv": [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--dry-run-launch"], "env": env})
+    return cmds
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with WORLD_SIZE unset (the shape of the driver's single-GPU command with another N): this
+    process becomes a launcher.  It never imports torch and never touches the GPU (a process that has initialised the GPU
+    must not be replaced or forked into ranks): it starts N children, each of which is one rank on its own device, waits
+    for all of them, relays rank 0's output (the JSON line last) and exits non-zero if any rank does."""
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmds = rank_commands(args, argv, port)
+    if args.dry_run_launch:
+        print(json.dumps({"launcher": "bench.py", "n_ranks": args.gpus, "ranks": cmds}), flush=True)
+        return 0
+    # the extension is compiled ONCE here (hipcc is a child process; no GPU call): the ranks then find a matching stamp
+    from lp_mp_amd import build as B
+    B.build()
+    procs, outs = [], []
+    tmp = tempfile.mkdtemp(prefix="lpmp_bench_")
+    try:
+        for r, c in enumerate(cmds):
+            out = open(os.path.join(tmp, f"rank{r}.out"), "w+")
+            outs.append(out)
+            procs.append(subprocess.Popen(c["argv"], env=dict(os.environ, **c["env"]), stdout=out, stderr=None, cwd=ROOT))
+        t0 = time.time()
+        rc = 0
+        live = set(range(len(procs)))
+        while live and rc == 0:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0:
+                        print(f"bench.py launcher: rank {r} exited with code {code}", file=sys.stderr)
+                        rc = code if code > 0 else 1
+            if args.launch_timeout > 0 and time.time() - t0 > args.launch_timeout and live:
+                print(f"bench.py launcher: ranks {sorted(live)} still running after {args.launch_timeout:.0f} s", file=sys.stderr)
+                rc = 124
+            time.sleep(0.05)
+        for r in live:                                   # a rank failed: the others wait in a collective for ever — end them
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        for r, out in enumerate(outs):
+            out.flush(); out.seek(0)
+            text = out.read()
+            if r == 0:
+                sys.stdout.write(text)
+            elif text.strip():
+                sys.stderr.write(f"[rank {r} stdout]\n{text}")
+        sys.stdout.flush()
+        return rc
+    finally:
+        for out in outs:
+            out.close()
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_run_launch):
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if args.schedule == "auto":
+        args.schedule = "boundary" if args.workload == "c4" else ("overlap" if args.order == "colour_major" else "lockstep")
+    if args.schedule == "overlap" and (args.workload != "c3" or args.order != "colour_major"):
+        print("bench.py: --schedule overlap is for grids in colour-major order (random graphs: lockstep or boundary)", file=sys.stderr)
+        sys.exit(2)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        # the line would claim a GPU count that did not run (n_gpus comes from the process group)
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}: start it as `python bench.py --gpus {args.gpus}` (it launches its own "
+                  f"ranks) or under torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     from lp_mp_amd import build as B
     B.build_on_rank0(rank)                    # rebuilds when the sources changed; the other ranks wait for rank 0
     from lp_mp_amd import engine as E, model as M, synthetic as S
@@ -264,13 +388,27 @@ def main():
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        # "nccl" is RCCL on ROCm; LPMP_DIST_BACKEND=gloo only for smoke runs of this script on a 1-GPU box
-        dist.init_process_group(os.environ.get("LPMP_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        n_dev = torch.cuda.device_count()                 # (counting devices does not initialise the GPU)
+        if n_dev == 0:
+            raise SystemExit("bench.py: no HIP device visible to rank %d (the engine has no CPU path)" % rank)
+        torch.cuda.set_device(local_rank % n_dev)
+        # "nccl" is RCCL on ROCm.  RCCL refuses two ranks on one device, so a box with fewer GPUs than ranks (the 1-GPU test
+        # box: smoke runs of the N-rank path, tests/test_bench_contract.py) falls back to gloo with CPU-staged exchanges —
+        # the line says so (`backend`), and timings of such a run mean nothing
+        backend = os.environ.get("LPMP_DIST_BACKEND") or ("nccl" if n_dev >= int(os.environ.get("LOCAL_WORLD_SIZE", world)) else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        # which device every rank sits on (the line reports it: ranks that share a device are not a scaling measurement)
+        t = torch.zeros(world, dtype=torch.int64, device="cpu" if backend == "gloo" else torch.device("cuda", torch.cuda.current_device()))
+        t[rank] = torch.cuda.current_device()
+        dist.all_reduce(t)
+        launch = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "ranks_seen": dist.get_world_size(),
+                  "devices": [int(x) for x in t.tolist()], "devices_visible": n_dev,
+                  "launcher": "bench.py (self-launched ranks)" if os.environ.get("LPMP_BENCH_SELF_LAUNCHED") else "external (torch.distributed.run)"}
+        if launch["ranks_seen"] != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {launch['ranks_seen']} ranks")
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        launch = {"backend": None, "ranks_seen": 1, "devices": [0], "devices_visible": torch.cuda.device_count(), "launcher": "in-process (1 GPU)"}
 
     mode = M.REPAM_NAMES[args.mode]
     H = W = args.grid
@@ -313,14 +451,8 @@ def main():
         levels = [i["n_levels"] for i in info]
         parallelism = "1 GPU"
     else:
-        from lp_mp_amd import multi_gpu as MG
-        if args.schedule == "lockstep":
-            from lp_mp_amd import lockstep as LS
-            runner = LS.LockstepStrips(torch, dist, H, W, L, args.pairwise, args.order, mode, seed=1)
-            parallelism = f"{world} row strips of {H}x{W} in lock step (the unpartitioned sweep, {runner.halo_steps_per_pass():.1f} halo exchanges per pass)"
-        else:
-            runner = MG.StripSweep(torch, dist, H, W, L, args.pairwise, args.order, mode, seed=1, boundary_every="pass")
-            parallelism = f"{world} row strips of {H}x{W}, cut-edge exchange once per pass"
+        runner = make_strip_runner(torch, dist, args, args.schedule, H, mode)
+        parallelism = describe_strip_runner(runner, args.schedule, world, H, W)
         updates_per_pass = runner.global_updates_per_pass
         bytes_per_pass = runner.global_bytes_per_pass
         levels = runner.levels
@@ -369,6 +501,24 @@ def main():
 
     gap = (dual_bound_gap_c4 if args.workload == "c4" else dual_bound_gap)(torch, dist, args, mode, world, rank) if dist_on else \
         {"dual_bound_gap": 0.0, "gap_config": "1 GPU: the unpartitioned sweep itself"}
+    # the other multi-GPU schedules on the same strips, same pass count (outside the timed region): what the choice costs
+    schedules = None
+    if dist_on and args.workload == "c3" and not args.no_compare_schedules:
+        schedules = {args.schedule: {"ms_per_step": dt / args.steps * 1e3, "dual_bound_gap": gap["dual_bound_gap"] if gap else None, "timed": True}}
+        for other in ("overlap", "lockstep", "boundary"):
+            if other == args.schedule or (other == "overlap" and args.order != "colour_major"):
+                continue
+            r2 = make_strip_runner(torch, dist, args, other, H, mode)
+            dt2 = time_passes(torch, dist, r2, args.steps, args.warmup, 2)
+            t = torch.tensor([dt2], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            lb2 = r2.lower_bound()
+            r2.engine.close()
+            del r2
+            torch.cuda.empty_cache()
+            g2 = dual_bound_gap(torch, dist, args, mode, world, rank, schedule=other)
+            schedules[other] = {"ms_per_step": t.item() / args.steps * 1e3, "dual_bound_gap": g2["dual_bound_gap"] if g2 else None,
+                                "lower_bound_after": lb2, "timed": False}
     out = None
     if rank == 0:
         value = updates_per_pass * args.steps / dt
@@ -385,7 +535,7 @@ def main():
             roof = {"bound": "hbm", "kernel": k["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_launch_ms": avg_ms,
                     "launches": k["launches"], "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
-                    "passes_per_launch": args.steps if chain else None,
+                    "passes_per_launch": args.steps / k["chain_launches"] if chain else None,
                     # `achieved` / `frac` are on the ALGORITHMIC scale (every table once per use, i.e. twice
                     # per pass).  The joined-pass chain launch serves the second read of a table from the 256 MiB
                     # Infinity Cache, so above HBM_STREAM_GBS the algorithmic rate is no longer an HBM rate and may even
@@ -411,7 +561,8 @@ def main():
             "metric": "message updates/sec + dual-bound gap, 32-label grid MRF @1/2/4/8 GPUs" if L == 32 and args.pairwise == "dense" and args.workload == "c3"
                       else "message updates/sec + dual-bound gap, " + ("random sparse graph MRF" if args.workload == "c4" else "grid MRF"),
             "scaling_note": None if args.workload == "c3" else "strong scaling: the graph is fixed, the ranks share it",
-            "value": value, "unit": "msg-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "msg-updates/s", "n_gpus": world, "backend": launch["backend"], "ranks_seen": launch["ranks_seen"],
+            "devices": launch["devices"], "launch": launch, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.workload == "c3" else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"random sparse graph G({args.c4_nodes}, {args.c4_edges}), {L} labels, dense pairwise, {args.mode} weights, "
@@ -424,7 +575,8 @@ def main():
             "setup_s": setup,
             "lower_bound_before": lb0, "lower_bound_after": lb1,
             "oracle_check": oracle_check,
-            "dual_bound_gap": gap["dual_bound_gap"], "dual_bound_gap_detail": gap,
+            "dual_bound_gap": gap["dual_bound_gap"], "dual_bound_gap_detail": gap, "schedule": args.schedule if dist_on else None,
+            "schedules": schedules,
             "kernels": kt,
             "rounding": rounding,
             "roofline": roof,

@@ -28,6 +28,14 @@ class OracleEngine:
         self.o.compute_pass_custom(*self.rows[sid])
         self.dual[:] = self.o.duals()
 
+    def set_reparametrization(self, mode):
+        self.o.set_reparametrization(mode)
+
+    def compute_pass(self, n=1):
+        self.o.set_duals(self.dual)
+        self.o.ComputePass(n)
+        self.dual[:] = self.o.duals()
+
     def schedule_info(self, sid):
         f, oo, om, mo, mk = self.rows[sid]
         return dict(n_levels=0, n_launches=0, n_receives=int(mk.sum()), n_sends=int((om != 0).sum()), algorithmic_bytes=0)
@@ -128,6 +136,8 @@ def materialise_fills(part):
     from lp_mp_amd import synthetic as S
     m = part.model
     for name, fills, size in (("const_data", part.const_fill, int(m.const_sizes().sum())), ("dual_data", part.dual_fill, int(m.dual_sizes().sum()))):
+        if fills is None:                                   # costs already on the host (Potts scalars of overlap.py's windows)
+            continue
         buf = np.zeros(size)
         for f in fills or []:
             if f[0] == "blocks":

@@ -120,3 +120,62 @@ def test_golden_fixture_covers_whatever_pass_count_the_driver_runs():
     assert abs(lb[23] - 346558.6683229103) <= 1e-9 * lb[23] and abs(lb[25] - 346987.1451928538) <= 1e-9 * lb[25]
     assert all(lb[k + 1] >= lb[k] for k in range(48))                                 # dual ascent, pass by pass
     assert len(set(map(int, g["dual_sum_seed1"]))) == 49 and len(set(map(int, g["dual_wsum_seed1"]))) == 49
+
+
+# ---- `python bench.py --gpus N` without a launcher around it (the shape of the driver's command) ----------------------
+def test_launcher_dry_run_names_one_rank_per_gpu():
+    """WORLD_SIZE unset and --gpus 4: bench.py must start 4 rank processes itself.  --dry-run-launch prints what it would
+    start: same arguments, RANK / LOCAL_RANK 0..3, WORLD_SIZE 4, one rendezvous on 127.0.0.1 — and touches no GPU"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "2",
+                                   "--dry-run-launch"], text=True, cwd=ROOT, timeout=120, env=env)
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["n_ranks"] == 4 and len(d["ranks"]) == 4
+    ports = set()
+    for r, c in enumerate(d["ranks"]):
+        assert c["env"]["RANK"] == str(r) and c["env"]["LOCAL_RANK"] == str(r) and c["env"]["WORLD_SIZE"] == "4"
+        assert c["env"]["MASTER_ADDR"] == "127.0.0.1"
+        ports.add(c["env"]["MASTER_PORT"])
+        assert c["argv"][1].endswith("bench.py") and c["argv"][2:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert len(ports) == 1
+
+
+def test_launcher_exits_nonzero_when_a_rank_fails():
+    """no GPU in this container: every self-launched rank stops with "no HIP device"; the launcher must report that with
+    a non-zero exit code and without hanging on the others (on the GPU box the same command runs, test below)"""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "16", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], text=True, cwd=ROOT, timeout=600, env=env, capture_output=True)
+    assert p.returncode != 0 and "no HIP device" in p.stderr and "launcher: rank" in p.stderr
+    assert not any(l.startswith('{"metric"') for l in p.stdout.splitlines())
+
+
+def test_gpus_flag_must_agree_with_the_world_size():
+    """under an external launcher (WORLD_SIZE set) a different --gpus is an error, not a warning: the line would otherwise
+    claim a GPU count that did not run"""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], text=True, cwd=ROOT, timeout=300,
+                       env=env, capture_output=True)
+    assert p.returncode == 2 and "--gpus 8 but WORLD_SIZE 1" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["overlap", "boundary"])
+def test_bench_gpus_2_launches_its_own_ranks(schedule):
+    """`python bench.py --gpus 2` with no launcher around it, on the 1-GPU test box: two rank processes share the device
+    (backend falls back to gloo: RCCL refuses two ranks on one GPU), the line says how many ranks ran and where"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LPMP_DIST_BACKEND")}
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "4", "--warmup", "2",
+                                   "--no-cpu-baseline", "--schedule", schedule], text=True, cwd=ROOT, timeout=1200, env=env)
+    assert out.strip().splitlines()[-1].startswith('{"metric"'), out[-600:]
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["devices"]) == 2 and d["launch"]["launcher"].startswith("bench.py")
+    assert d["backend"] in ("gloo", "rccl (torch.distributed nccl)")
+    assert d["value"] > 0 and d["lower_bound_after"] > d["lower_bound_before"]
+    if schedule == "overlap":
+        assert abs(d["dual_bound_gap"]) <= 1e-12       # the exact schedule: the unpartitioned sweep's bound
+    else:
+        assert 0 <= d["dual_bound_gap"] < 0.01
