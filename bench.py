@@ -503,8 +503,18 @@ def main():
         {"dual_bound_gap": 0.0, "gap_config": "1 GPU: the unpartitioned sweep itself"}
     # the other multi-GPU schedules on the same strips, same pass count (outside the timed region): what the choice costs
     schedules = None
+    peak_bytes = torch.cuda.max_memory_allocated()
     if dist_on and args.workload == "c3" and not args.no_compare_schedules:
         schedules = {args.schedule: {"ms_per_step": dt / args.steps * 1e3, "dual_bound_gap": gap["dual_bound_gap"] if gap else None, "timed": True}}
+        # (the timed runner's 18.5 GB go first: N ranks may share one device in a smoke run)
+        eng.close()
+        for name in ("const", "dualt", "sweep", "engine"):
+            if hasattr(runner, name):
+                setattr(runner, name, None)
+        eng = runner = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
         for other in ("overlap", "lockstep", "boundary"):
             if other == args.schedule or (other == "overlap" and args.order != "colour_major"):
                 continue
@@ -572,7 +582,7 @@ def main():
                        "levels_per_direction": levels, "msg_updates_per_pass": updates_per_pass,
                        "algorithmic_bytes_per_pass": bytes_per_pass},
             "pass_algorithmic_GBps": bytes_per_pass * args.steps / dt / 1e9,
-            "setup_s": setup,
+            "setup_s": setup, "peak_device_memory_GB_rank0": peak_bytes / 1e9,
             "lower_bound_before": lb0, "lower_bound_after": lb1,
             "oracle_check": oracle_check,
             "dual_bound_gap": gap["dual_bound_gap"], "dual_bound_gap_detail": gap, "schedule": args.schedule if dist_on else None,

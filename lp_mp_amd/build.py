@@ -69,6 +69,11 @@ MGPU_SOURCES = [os.path.join(ROOT, "tools", "mgpu_rccl_driver.cpp"), os.path.joi
                 os.path.join(ROOT, "include", "lpmp_engine.h"), os.path.join(ROOT, "include", "lpmp_model.h")]
 
 
+def have_rccl() -> bool:
+    """the RCCL development files the C++ multi-GPU host needs"""
+    return any(os.path.exists(os.path.join(d, "rccl", "rccl.h")) for d in ("/opt/rocm/include", "/usr/include"))
+
+
 def build_mgpu_driver(force: bool = False) -> str:
     """tools/mgpu_rccl_driver.cpp -> build/mgpu_rccl_driver (links liblpmp_engine.so and RCCL; hipcc only for its include
     and library paths — the file is plain host C++).  Stamped with a source hash like the library."""

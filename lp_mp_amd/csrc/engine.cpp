@@ -373,7 +373,7 @@ struct lpmp_engine {
     double* d_hist = nullptr; size_t hist_cap = 0;   // (n - 1) rows of per-factor bounds
     double* d_hpart = nullptr; size_t hpart_cap = 0; // partial sums of those rows
     bool snap_lb_stale = false;
-    int64_t batches = 0, passes_launched = 0, passes_used = 0, rollbacks = 0;
+    int64_t batches = 0, passes_launched = 0, passes_used = 0, rollbacks = 0, alloc_failures = 0;
     void release() {
       for (double** p : {&d_snap, &d_hist, &d_hpart}) if (*p) { (void)hipFree(*p); *p = nullptr; }
       snap_cap = hist_cap = hpart_cap = 0; n = pos = 0; mode = -1; run_len = learned = last_batch = 0; lb_ready = false;
@@ -941,19 +941,26 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
     }
     rc.dev_bytes = lds.size() * sizeof(ChainLaunchDev) + (tk_launch.size() + tk_block.size() + dep_off.size() + dep.size() + (size_t)N + 1) * sizeof(int32_t);
     evict_for(rc.dev_bytes);
-    e->rot_cache_bytes += rc.dev_bytes;
     auto up = [&](auto*& dst, const auto& v) {
       using T = std::remove_reference_t<decltype(*dst)>;
       HIP_CHECK(hipMalloc((void**)&dst, std::max<size_t>(1, v.size()) * sizeof(T)));
       if (!v.empty()) h2d(dst, v.data(), v.size() * sizeof(T), e->stream);
     };
     auto& dc = rc.dc;
-    up(dc.launches, lds); up(dc.tk_launch, tk_launch); up(dc.tk_block, tk_block); up(dc.dep_off, dep_off); up(dc.dep, dep);
-    dc.tickets = (int32_t)N; dc.kclass = ri.kclass;
-    HIP_CHECK(hipMalloc((void**)&dc.done, (size_t)N * sizeof(int32_t)));
-    HIP_CHECK(hipMalloc((void**)&dc.next, sizeof(int32_t)));
-    HIP_CHECK(hipMemsetAsync(dc.done, 0, (size_t)N * sizeof(int32_t), e->stream));
-    HIP_CHECK(hipStreamSynchronize(e->stream));
+    try {
+      up(dc.launches, lds); up(dc.tk_launch, tk_launch); up(dc.tk_block, tk_block); up(dc.dep_off, dep_off); up(dc.dep, dep);
+      dc.tickets = (int32_t)N; dc.kclass = ri.kclass;
+      HIP_CHECK(hipMalloc((void**)&dc.done, (size_t)N * sizeof(int32_t)));
+      HIP_CHECK(hipMalloc((void**)&dc.next, sizeof(int32_t)));
+      HIP_CHECK(hipMemsetAsync(dc.done, 0, (size_t)N * sizeof(int32_t), e->stream));
+      HIP_CHECK(hipStreamSynchronize(e->stream));
+    } catch (...) {
+      // nothing half-built stays behind: the entry goes (a later call tries again), the bytes were never counted
+      for (void* p : {(void*)dc.launches, (void*)dc.tk_launch, (void*)dc.tk_block, (void*)dc.dep_off, (void*)dc.dep, (void*)dc.done, (void*)dc.next}) if (p) (void)hipFree(p);
+      e->rot_chain[mode].erase(n);
+      throw;
+    }
+    e->rot_cache_bytes += rc.dev_bytes;
     rc.n_steps = n_steps;
     if (verbose)
       std::fprintf(stderr, "lpmp: %d passes as one launch: %lld tickets, %d bands, lag %d, depth %d; built and uploaded in %.0f ms\n", n, (long long)N, bands, lag, depth, since());
@@ -1231,6 +1238,9 @@ int lpmp_create(int device, lpmp_engine** out) {
 void lpmp_destroy(lpmp_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  // a BORROWED dual buffer (LPMP_MEM_DEVICE) outlives the engine: an open batch of passes that ran ahead of the caller must
+  // not stay in it
+  if (e->plan && !e->own_dual && e->spec.n > 0) { try { settle(e); } catch (const std::exception& ex) { std::fprintf(stderr, "lpmp_destroy: could not roll back passes that ran ahead: %s\n", ex.what()); } }
   (void)hipStreamSynchronize(e->stream);
   for (auto& p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->event_pool) (void)hipEventDestroy(ev);
@@ -1264,8 +1274,9 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
   return guarded([&] {
     if (!e || !m) throw std::runtime_error("null argument");
     HIP_CHECK(hipSetDevice(e->device));
+    if (e->plan && !e->own_dual && e->spec.n > 0) settle(e);   // the caller keeps the old model's (borrowed) dual buffer: leave it at the caller's pass
     HIP_CHECK(hipStreamSynchronize(e->stream));
-    { const int d = e->spec.max_depth; e->release_model(); e->spec.max_depth = d; }   // (an open speculative batch dies with the old model)
+    { const int d = e->spec.max_depth; e->release_model(); e->spec.max_depth = d; }   // (an open speculative batch in an engine-owned buffer dies with the old model)
     auto pl = std::make_unique<lpmp_plan>();
     pl->p.build(*m);
     const Plan& p = pl->p;
@@ -1323,6 +1334,12 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
     e->lb_all_stale = true;
     e->plan = std::move(pl);
     e->plan->p.force_generic = e->rtype == LPMP_RTYPE_ADAPTIVE;
+    {   // mailbox budget of every schedule planned for this model: half of what the device has left now (LPMP_MAILBOX_MB overrides)
+      size_t free_b = 0, total_b = 0;
+      if (const char* v = std::getenv("LPMP_MAILBOX_MB")) e->plan->p.mailbox_budget_bytes = (int64_t)std::atoll(v) << 20;
+      else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) e->plan->p.mailbox_budget_bytes = (int64_t)(free_b / 2);
+      else (void)hipGetLastError();
+    }
     try { check_rtype(e, e->rtype); } catch (...) { e->release_model(); throw; }
   });
 }
@@ -1508,25 +1525,33 @@ static bool spec_start_batch(lpmp_engine* e, int depth) {
   depth = std::min(depth, 32);
   if (!rotation_chain(e, e->mode, depth)) return false;
   const size_t nd = (size_t)e->plan->p.f_doff[e->plan->p.nf], nf = (size_t)e->plan->p.nf;
-  auto grow = [&](double*& p, size_t& cap, size_t want) {
-    if (want <= cap) return;
+  // (an allocation that fails switches speculation OFF for this engine — the plain pass needs none of these buffers — instead
+  // of making every lpmp_compute_pass(e, 1) fail on a model that solves fine without: snapshot = all duals + tracked bounds)
+  auto grow = [&](double*& p, size_t& cap, size_t want) -> bool {
+    if (want <= cap) return true;
     HIP_CHECK(hipStreamSynchronize(e->stream));
     if (p) { HIP_CHECK(hipFree(p)); p = nullptr; cap = 0; }
-    HIP_CHECK(hipMalloc((void**)&p, want * sizeof(double)));
+    if (hipMalloc((void**)&p, want * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
     cap = want;
+    return true;
   };
-  grow(sp.d_snap, sp.snap_cap, nd + nf);
-  grow(sp.d_hist, sp.hist_cap, (size_t)(std::min(sp.max_depth, 32) - 1) * nf);
-  grow(sp.d_hpart, sp.hpart_cap, (size_t)(std::min(sp.max_depth, 32) - 1) * 1024);
+  if (!grow(sp.d_snap, sp.snap_cap, nd + nf) || !grow(sp.d_hist, sp.hist_cap, (size_t)(std::min(sp.max_depth, 32) - 1) * nf) ||
+      !grow(sp.d_hpart, sp.hpart_cap, (size_t)(std::min(sp.max_depth, 32) - 1) * 1024)) {
+    sp.release();
+    sp.max_depth = 0;
+    ++sp.alloc_failures;
+    return false;
+  }
   HIP_CHECK(hipMemcpyAsync(sp.d_snap, e->d_dual, nd * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
   HIP_CHECK(hipMemcpyAsync(sp.d_snap + nd, e->d_lb, nf * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
   sp.snap_lb_stale = e->lb_all_stale;
   if (!run_rotation_chain(e, e->mode, depth, sp.d_hist)) return false;
+  // the device is `depth` passes ahead from here on: the batch is open BEFORE anything else can fail, so that settle() rolls back
+  sp.n = depth; sp.pos = 0; sp.mode = e->mode; sp.lb_ready = false; sp.last_batch = depth;
+  ++sp.batches; sp.passes_launched += depth;
   int64_t nb, per; lb_sum_blocks((int64_t)nf, nb, per);
   for (int i = 0; i < depth - 1; ++i) launch_sum_stage(sp.d_hist + (size_t)i * nf, sp.d_hpart + (size_t)i * 1024, (int64_t)nf, per, nb, e->stream);
   HIP_CHECK(hipGetLastError());
-  sp.n = depth; sp.pos = 0; sp.mode = e->mode; sp.lb_ready = false; sp.last_batch = depth;
-  ++sp.batches; sp.passes_launched += depth;
   return true;
 }
 static void check_chain(lpmp_engine* e);

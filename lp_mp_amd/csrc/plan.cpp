@@ -881,6 +881,25 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
           }
         }
       }
+      if (any_mbox && mailbox_budget_bytes >= 0) {
+        // rows of a class <= its receives with a mailbox source (every row is polled by at least one of them): a class whose
+        // mailbox would not fit the budget keeps its completion flags — decided HERE, before any dependency is dropped
+        std::vector<int64_t> rows_upper(KC_COUNT, 0);
+        for (size_t li = 0; li < out.launches.size(); ++li) {
+          const auto& lr = out.launches[li];
+          if (!mbox_class[lr.kclass]) continue;
+          for (int64_t i = lr.begin; i < lr.end; ++i) {
+            const UpdRec& r = out.recs[i];
+            for (int j = 0; j < r.n_recv; ++j) if (src_rec[r.op_begin + j] >= 0) ++rows_upper[lr.kclass];
+          }
+        }
+        int64_t left = mailbox_budget_bytes;
+        for (int c = 0; c < KC_COUNT; ++c) {
+          if (!mbox_class[c]) continue;
+          const int64_t bytes = rows_upper[c] * (int64_t)kc_width(c) * 16;
+          if (bytes > left) mbox_class[c] = 0; else left -= bytes;
+        }
+      }
       // replay the sequence: who touched each factor last
       std::vector<int32_t> toucher(nf, -1);
       std::vector<std::vector<std::pair<int32_t, int32_t>>> edges(KC_COUNT);     // per class: (ticket, predecessor ticket)

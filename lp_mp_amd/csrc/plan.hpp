@@ -216,6 +216,10 @@ struct Plan {
   } part;
   bool any_batch = false;        // some message op has a static batch send (lpmp_msg_flags)
   bool force_generic = false;    // schedule every update on the generic kernels (adaptive sends)
+  // device memory a schedule's mailbox may take (16 bytes per label and mailbox send; C3 row-major: 2 GB): the engine sets it
+  // from the free memory of its device, and a class whose mailbox would not fit is planned with completion flags only
+  // (-1: no limit)
+  int64_t mailbox_budget_bytes = -1;
 
   // throws std::runtime_error on invalid input (the reference throws too, LP_MP.h:458)
   void build(const lpmp_model& m);

@@ -333,6 +333,7 @@ class Engine:
         if getattr(self, "h", None):
             self.L.lpmp_destroy(self.h)
             self.h = None
+            self._keep = None          # the caller-owned device buffers the engine borrowed may go now
 
     def __del__(self):
         self.close()

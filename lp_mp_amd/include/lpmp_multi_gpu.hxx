@@ -23,7 +23,15 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <poll.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <chrono>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -135,24 +143,76 @@ struct rccl_world {
   hipStream_t stream = nullptr;
   double* d_scalar = nullptr;
   int rank_of(int part) const { return part / parts_per_rank; }
-  // id_file: where rank 0 leaves the ncclUniqueId for the others (a shared path, e.g. /tmp/lpmp_nccl_<MASTER_PORT>)
-  void init(int rank_, int world_, int parts_per_rank_, const std::string& id_file, hipStream_t s) {
+  // The ncclUniqueId travels over a TCP connection to rank 0 on MASTER_ADDR : MASTER_PORT (the rendezvous every launcher
+  // names), not through a file: nothing is left behind that a later launch on the same port could mistake for its own id
+  // (a stale id makes ncclCommInitRank wait for ever), and every wait here is bounded (timeout_s).
+  static void send_all(int fd, const void* p, size_t n) {
+    const char* c = (const char*)p;
+    while (n > 0) { const ssize_t k = ::send(fd, c, n, MSG_NOSIGNAL); if (k <= 0) throw std::runtime_error("rccl_world: sending the ncclUniqueId failed"); c += k; n -= (size_t)k; }
+  }
+  static void recv_all(int fd, void* p, size_t n) {
+    char* c = (char*)p;
+    while (n > 0) { const ssize_t k = ::recv(fd, c, n, 0); if (k <= 0) throw std::runtime_error("rccl_world: receiving the ncclUniqueId failed"); c += k; n -= (size_t)k; }
+  }
+  struct id_packet { uint64_t magic; int32_t world, rank; ncclUniqueId id; };
+  static constexpr uint64_t ID_MAGIC = 0x4C504D5052434349ULL;   // "LPMPRCCI"
+  static void hand_out_id(ncclUniqueId& id, int rank, int world, const std::string& addr, int port, double timeout_s) {
+    if (world <= 1) return;
+    sockaddr_in sa{}; sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);
+    if (inet_pton(AF_INET, addr.c_str(), &sa.sin_addr) != 1) throw std::runtime_error("rccl_world: MASTER_ADDR must be an IPv4 address (e.g. 127.0.0.1), got " + addr);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto left = [&] { return timeout_s - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    if (rank == 0) {
+      const int ls = ::socket(AF_INET, SOCK_STREAM, 0); if (ls < 0) throw std::runtime_error("rccl_world: socket()");
+      int one = 1; (void)setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+      sockaddr_in any = sa; any.sin_addr.s_addr = htonl(INADDR_ANY);
+      if (::bind(ls, (sockaddr*)&any, sizeof(any)) != 0 || ::listen(ls, world) != 0) { ::close(ls); throw std::runtime_error("rccl_world: cannot listen on port " + std::to_string(port)); }
+      std::vector<char> served((size_t)world, 0);
+      for (int got = 0; got < world - 1;) {
+        pollfd pf{ls, POLLIN, 0};
+        const double l = left();
+        if (l <= 0 || ::poll(&pf, 1, (int)std::min(l * 1000.0, 1000.0)) < 0) { if (l <= 0) { ::close(ls); throw std::runtime_error("rccl_world: timed out waiting for " + std::to_string(world - 1 - got) + " rank(s) to fetch the ncclUniqueId"); } continue; }
+        if (!(pf.revents & POLLIN)) continue;
+        const int fd = ::accept(ls, nullptr, nullptr); if (fd < 0) continue;
+        timeval tv{5, 0}; (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+        id_packet hello{};
+        try {
+          recv_all(fd, &hello, offsetof(id_packet, id));
+          // a connection that is not one of this launch's ranks (wrong magic / world, a rank seen before) gets nothing
+          if (hello.magic == ID_MAGIC && hello.world == world && hello.rank > 0 && hello.rank < world && !served[(size_t)hello.rank]) {
+            id_packet out{ID_MAGIC, world, 0, id};
+            send_all(fd, &out, sizeof(out));
+            served[(size_t)hello.rank] = 1; ++got;
+          }
+        } catch (const std::exception&) {}
+        ::close(fd);
+      }
+      ::close(ls);
+    } else {
+      for (;;) {
+        const int fd = ::socket(AF_INET, SOCK_STREAM, 0); if (fd < 0) throw std::runtime_error("rccl_world: socket()");
+        if (::connect(fd, (sockaddr*)&sa, sizeof(sa)) == 0) {
+          timeval tv{(long)std::max(1.0, left()), 0}; (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+          id_packet hello{ID_MAGIC, world, rank, {}}, in{};
+          try {
+            send_all(fd, &hello, offsetof(id_packet, id));
+            recv_all(fd, &in, sizeof(in));
+            ::close(fd);
+            if (in.magic != ID_MAGIC || in.world != world) throw std::runtime_error("rccl_world: " + addr + ":" + std::to_string(port) + " is not this launch's rank 0");
+            id = in.id;
+            return;
+          } catch (const std::exception&) { ::close(fd); if (left() <= 0) throw; }
+        } else ::close(fd);
+        if (left() <= 0) throw std::runtime_error("rccl_world: no rank 0 on " + addr + ":" + std::to_string(port) + " within " + std::to_string((int)timeout_s) + " s");
+        struct timespec ts{0, 20000000}; nanosleep(&ts, nullptr);
+      }
+    }
+  }
+  void init(int rank_, int world_, int parts_per_rank_, const std::string& master_addr, int master_port, hipStream_t s, double timeout_s = 120.0) {
     rank = rank_; world = world_; parts_per_rank = parts_per_rank_; stream = s;
     ncclUniqueId id;
-    if (rank == 0) {
-      nccl_ok(ncclGetUniqueId(&id), "ncclGetUniqueId");
-      if (world > 1) {
-        const std::string tmp = id_file + ".tmp";
-        FILE* f = std::fopen(tmp.c_str(), "wb"); if (!f) throw std::runtime_error("cannot write " + tmp);
-        std::fwrite(&id, sizeof(id), 1, f); std::fclose(f);
-        if (std::rename(tmp.c_str(), id_file.c_str()) != 0) throw std::runtime_error("cannot publish " + id_file);
-      }
-    } else {
-      FILE* f = nullptr;
-      for (int tries = 0; tries < 6000 && !f; ++tries) { f = std::fopen(id_file.c_str(), "rb"); if (!f) { struct timespec ts{0, 10000000}; nanosleep(&ts, nullptr); } }
-      if (!f || std::fread(&id, sizeof(id), 1, f) != 1) throw std::runtime_error("no ncclUniqueId in " + id_file);
-      std::fclose(f);
-    }
+    if (rank == 0) nccl_ok(ncclGetUniqueId(&id), "ncclGetUniqueId");
+    hand_out_id(id, rank, world, master_addr, master_port, timeout_s);
     nccl_ok(ncclCommInitRank(&comm, world, id, rank), "ncclCommInitRank");
     hip_ok(hipMalloc((void**)&d_scalar, 2 * sizeof(double)), "hipMalloc");
   }

@@ -127,15 +127,29 @@ def graph_local_part(n: int, m: int, L: int, rank: int, world: int, seed: int = 
     return partition_mrf(n, L, ei, ej, part, world, only=rank, stream_seed=seed)[0]
 
 
+_HOST_GROUP = {}
+
+
+def host_group(dist):
+    """a gloo group beside the RCCL one, for host-side hand-offs: a rank waiting in it for rank 0's host work (the partitioner:
+    the better part of a minute at 2 M variables, more on a loaded box) does not sit inside an RCCL kernel under the NCCL
+    watchdog (10 minutes by default), and its wait has a timeout of its own (an hour)"""
+    if dist.get_backend() == "gloo":
+        return None                                        # the default group already is one
+    key = dist.get_world_size()
+    if key not in _HOST_GROUP:
+        import datetime
+        _HOST_GROUP[key] = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=1))
+    return _HOST_GROUP[key]
+
+
 def broadcast_partition(torch, dist, n: int, device, compute) -> np.ndarray:
-    """the partition of a multi-process run: rank 0 calls ``compute()`` (minutes of host work at 2 M variables), the others
-    receive the result — one 8 n-byte broadcast instead of N identical partitioner runs"""
+    """the partition of a multi-process run: rank 0 calls ``compute()`` (host work), the others receive the result — one
+    8 n-byte broadcast over the host group instead of N identical partitioner runs"""
     rank = dist.get_rank()
     t = torch.from_numpy(np.ascontiguousarray(compute(), np.int64)) if rank == 0 else torch.empty(n, dtype=torch.int64)
-    if dist.get_backend() != "gloo":
-        t = t.to(device)
-    dist.broadcast(t, 0)
-    return t.cpu().numpy()
+    dist.broadcast(t, 0, group=host_group(dist))
+    return t.numpy()
 
 
 def partition_model(gm: M.FlatModel, part: np.ndarray, world: int) -> List[LocalPart]:

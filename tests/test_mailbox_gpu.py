@@ -120,3 +120,54 @@ def test_mailbox_tags_survive_many_runs_and_new_duals():
             os.environ.pop("LPMP_NO_MAILBOX", None)
     for a, b in zip(res[None], res["1"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["row-major grid, 16 labels", "row-major Potts grid, 8 labels", "banded 32 labels, offsets 1 2 3 4"])
+def test_mailbox_planned_schedule_on_the_launch_by_launch_paths(name, monkeypatch):
+    """the mailbox plan edits the PACKET copies of the ops it covers (plan.hpp OP_MAILBOX: a send's peer_const, the bits of a
+    receive's omega).  The same packets are read by the plain kernels whenever such a schedule runs launch by launch — per-launch
+    kernel timing, LPMP_NO_CHAIN=1 (hipGraph replay), primal passes: those bodies must not read the edited fields.  Duals of the
+    oracle on each of these paths."""
+    m = MODELS[name]()
+    monkeypatch.delenv("LPMP_NO_MAILBOX", raising=False)
+    assert E.Plan(m).chain_info(M.FORWARD, M.REPAM_ANISOTROPIC)["mailbox_rows"] > 0
+    o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    timed = E.Engine(0); timed.upload(m); timed.set_reparametrization(M.REPAM_ANISOTROPIC)
+    monkeypatch.setenv("LPMP_NO_CHAIN", "1")
+    nochain = E.Engine(0); nochain.upload(m); nochain.set_reparametrization(M.REPAM_ANISOTROPIC)
+    monkeypatch.delenv("LPMP_NO_CHAIN")
+    try:
+        timed.enable_kernel_timing(True)
+        for n in (1, 2):
+            o.ComputePass(n); timed.compute_pass(n); nochain.compute_pass(n)
+            assert np.array_equal(timed.download_duals(), o.duals()) and np.array_equal(nochain.download_duals(), o.duals())
+        o.ComputeForwardPass(); timed.forward_pass(); nochain.forward_pass()
+        assert np.array_equal(timed.download_duals(), o.duals()) and np.array_equal(nochain.download_duals(), o.duals())
+        timed.enable_kernel_timing(False)
+        kt = timed.kernel_timing()
+        assert sum(v["launches"] for v in kt.values()) > 9 and all(v["chain_launches"] == 0 for v in kt.values())   # launch by launch indeed
+        o.ComputePassAndPrimal(7); timed.compute_pass_and_primal(7); nochain.compute_pass_and_primal(7)
+        assert np.array_equal(timed.download_duals(), o.duals()) and np.array_equal(nochain.download_duals(), o.duals())
+        assert np.array_equal(timed.download_primal(), o.primal())
+    finally:
+        timed.close(); nochain.close()
+
+
+def test_mailbox_that_does_not_fit_the_device_is_planned_away(monkeypatch):
+    """16 bytes per label and mailbox send (C3 row-major: 2 GB).  The engine gives every schedule of a model a budget (half of
+    the device memory free at upload; LPMP_MAILBOX_MB overrides): a class whose rows would not fit keeps its completion flags
+    instead of failing at upload — same duals, more dependencies"""
+    m = MODELS["row-major grid, 16 labels"]()
+    monkeypatch.delenv("LPMP_NO_MAILBOX", raising=False)
+    o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    monkeypatch.setenv("LPMP_MAILBOX_MB", "0")
+    tight = E.Engine(0); tight.upload(m); tight.set_reparametrization(M.REPAM_ANISOTROPIC)
+    monkeypatch.delenv("LPMP_MAILBOX_MB")
+    roomy = E.Engine(0); roomy.upload(m); roomy.set_reparametrization(M.REPAM_ANISOTROPIC)
+    try:
+        ct, cr = tight.plan.chain_info(M.FORWARD, M.REPAM_ANISOTROPIC), roomy.plan.chain_info(M.FORWARD, M.REPAM_ANISOTROPIC)
+        assert ct["n_chains"] == 1 and ct["mailbox_rows"] == 0 and cr["mailbox_rows"] > 0 and ct["n_dependencies"] > cr["n_dependencies"]
+        o.ComputePass(3); tight.compute_pass(3); roomy.compute_pass(3)
+        assert np.array_equal(tight.download_duals(), o.duals()) and np.array_equal(roomy.download_duals(), o.duals())
+    finally:
+        tight.close(); roomy.close()

@@ -538,8 +538,10 @@ def test_cpp_rccl_driver_equals_the_python_partitioned_sweep(tmp_path, pairwise,
     against lp_mp_amd/multi_gpu.py's lock-stepped PartitionedSweep on the same strips: duals bit-identical part by part"""
     from lp_mp_amd import build as B, engine as E
     H, W, passes = 10, 12, 3
+    if not B.have_rccl():
+        pytest.skip("no <rccl/rccl.h> on this box")
     exe = B.build_mgpu_driver()
-    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LPMP_NCCL_ID_FILE=str(tmp_path / "nccl_id"))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.check_output([exe, "--H", str(H), "--W", str(W), "--L", str(L), "--pairwise", pairwise, "--order", order,
                                    "--passes", str(passes), "--parts-per-rank", str(parts), "--boundary", every,
                                    "--out", str(tmp_path / "duals")], text=True, env=env, timeout=600)
@@ -567,3 +569,90 @@ def test_cpp_rccl_driver_equals_the_python_partitioned_sweep(tmp_path, pairwise,
     assert line["lower_bound_after"] > line["lower_bound_before"]
     for e in engines:
         e.close()
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_nccl_unique_id_is_handed_out_over_tcp_not_through_a_file(tmp_path):
+    """rccl_world::hand_out_id (lpmp_multi_gpu.hxx): rank 0 serves the ncclUniqueId on MASTER_ADDR : port to exactly the ranks
+    of this launch — three rank processes here, no GPU and no RCCL call involved; a connection with a wrong greeting (another
+    program, a rank of another launch) gets nothing and does not use up a slot; a rank without a rank 0 gives up after its
+    timeout instead of waiting for ever; nothing is left on disk that a later launch could mistake for its own id"""
+    import socket
+    import struct
+    import time
+    from lp_mp_amd import build as B
+    if not B.have_rccl():
+        pytest.skip("no <rccl/rccl.h> on this box")
+    B.build()
+    exe = str(tmp_path / "test_id_handout")
+    subprocess.check_call([B.hipcc(), "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "lp_mp_amd", "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "test_id_handout.cpp"), "-L", B.CSRC, "-llpmp_engine", "-lrccl", "-Wl,-rpath," + B.CSRC])
+    port, world = _free_port(), 3
+    procs = [subprocess.Popen([exe, str(r), str(world), str(port), "60"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (1, 0)]
+    # an intruder: connects, sends a greeting of the right length with the wrong magic, must receive nothing
+    deadline = time.time() + 30
+    while True:
+        try:
+            sk = socket.create_connection(("127.0.0.1", port), timeout=2)
+            break
+        except OSError:
+            assert time.time() < deadline
+            time.sleep(0.05)
+    sk.sendall(struct.pack("<Qii", 0x1234, world, 2))
+    sk.settimeout(5)
+    try:
+        assert sk.recv(256) == b""
+    except socket.timeout:
+        pass
+    sk.close()
+    procs.append(subprocess.Popen([exe, "2", str(world), str(port), "60"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    ids = {o[0].strip() for o in outs}
+    assert len(ids) == 1 and len(next(iter(ids))) == 256 and next(iter(ids)) != "00" * 128
+    # no rank 0 at all: bounded wait
+    t0 = time.time()
+    r = subprocess.run([exe, "1", "2", str(_free_port()), "2"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "no rank 0" in r.stderr and time.time() - t0 < 30
+    src = open(os.path.join(ROOT, "lp_mp_amd", "include", "lpmp_multi_gpu.hxx")).read()
+    assert "fopen" not in src and "/tmp/" not in src
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_driver_two_processes_on_one_gpu_fail_or_agree(tmp_path):
+    """two rank PROCESSES of the C++ RCCL driver (the multi-process path: id hand-out over TCP, ncclCommInitRank at world 2).
+    On the 1-GPU test box RCCL refuses two ranks on one device — the run must then end with an error from both ranks within
+    its timeout (no hang on a stale id); on a box with two GPUs it must equal the Python partitioned sweep like the
+    single-process run above"""
+    from lp_mp_amd import build as B
+    if not B.have_rccl():
+        pytest.skip("no <rccl/rccl.h> on this box")
+    exe = B.build_mgpu_driver()
+    port = _free_port()
+    H, W, L, passes = 10, 12, 16, 3
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NCCL_DEBUG="WARN")
+        procs.append(subprocess.Popen([exe, "--H", str(H), "--W", str(W), "--L", str(L), "--passes", str(passes), "--out", str(tmp_path / "duals")],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("the two-process RCCL driver hung")
+    if torch.cuda.device_count() < 2:
+        assert all(p.returncode != 0 for p in procs), outs      # RCCL: two ranks on one device
+        return
+    assert all(p.returncode == 0 for p in procs), outs
+    import json
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["lower_bound_after"] > line["lower_bound_before"]

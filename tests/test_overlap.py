@@ -211,3 +211,63 @@ def test_overlapped_strips_with_the_joined_pass_chain_forced(monkeypatch):
     finally:
         for s in sweeps:
             s.engine.close()
+
+
+@pytest.mark.gpu
+def test_full_size_windows_equal_one_engine_on_the_whole_grid():
+    """BASELINE configs[2] per rank, two ranks: the two 1024 x 1024 windows (12 ghost rows, costs generated in HBM from the global
+    stream, the joined-pass chain launch of 5 passes between exchanges) against ONE engine on the whole 2048 x 1024 grid: every
+    owned dual bit-identical after 5 + 2 passes (compared on the device), same bound.  (That single engine is the oracle's equal
+    at 1024 x 1024: test_what_bench_times_against_the_oracle_at_full_size.)"""
+    from lp_mp_amd import engine as E, multi_gpu as MG
+    H = W = 1024; L = 32; world = 2; g = 12
+    dev = torch.device("cuda:0")
+    if torch.cuda.get_device_properties(0).total_memory < 100e9:
+        pytest.skip("needs ~80 GB of device memory")
+    stream = torch.cuda.current_stream().cuda_stream
+    # the whole grid on one engine
+    gm = S.grid_model(world * H, W, L, order="colour_major", seed=1, device_const=True, unaries=np.zeros(world * H * W * L))
+    n_g, E_g = world * H * W, gm.n_factors - world * H * W
+    gconst = torch.empty(E_g * L * L, dtype=torch.float64, device=dev)
+    gdual = torch.zeros(n_g * L + E_g * 2 * L, dtype=torch.float64, device=dev)
+    E.synth_fill(gconst.data_ptr(), gconst.numel(), 1, n_g * L, stream)
+    E.synth_fill(gdual.data_ptr(), n_g * L, 1, 0, stream)
+    torch.cuda.synchronize()
+    ge = E.Engine(0); ge.set_stream(stream)
+    ge.upload(gm, const_dev=gconst.data_ptr(), dual_dev=gdual.data_ptr(), keep=(gconst, gdual))
+    ge.set_reparametrization(M.REPAM_ANISOTROPIC)
+    sweeps, keep = [], []
+    try:
+        for r in range(world):
+            p = OV.strip_window_part(H, W, L, "dense", r, world, g, 1)
+            m = p.model
+            const = torch.empty(int(m.const_sizes().sum()), dtype=torch.float64, device=dev)
+            dual = torch.zeros(int(m.dual_sizes().sum()), dtype=torch.float64, device=dev)
+            MG.fill_device_costs(torch, E, p, const, dual, stream)
+            e = E.Engine(0); e.set_stream(stream)
+            e.upload(m, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual))
+            e.set_reparametrization(M.REPAM_ANISOTROPIC)
+            sweeps.append(OV.OverlapSweep(torch, p, e, dual)); keep.append((const, dual))
+        assert sweeps[0].chunk == 5
+        goff = torch.from_numpy(gm.dual_offsets()).to(dev)
+        for n in (5, 2):
+            ge.compute_pass(n)
+            OV.run_overlapped(sweeps, n)
+            torch.cuda.synchronize()
+            for s, (_, dual) in zip(sweeps, keep):
+                p = s.part
+                lo = torch.from_numpy(p.model.dual_offsets()).to(dev)
+                nv = p.vars_global.shape[0]
+                own_v = torch.from_numpy(np.nonzero(p.owned[:nv])[0]).to(dev)
+                own_e = torch.from_numpy(np.nonzero(p.owned[nv:])[0]).to(dev)
+                gv = torch.from_numpy(p.vars_global).to(dev)[own_v]
+                gedge = torch.from_numpy(p.edges_global).to(dev)[own_e]
+                ar = torch.arange(L, device=dev); ar2 = torch.arange(2 * L, device=dev)
+                assert torch.equal(dual[(lo[own_v][:, None] + ar).reshape(-1)], gdual[(goff[gv][:, None] + ar).reshape(-1)])
+                assert torch.equal(dual[(lo[nv + own_e][:, None] + ar2).reshape(-1)], gdual[(goff[n_g + gedge][:, None] + ar2).reshape(-1)])
+            lb, lbg = sum(s.local_lower_bound() for s in sweeps), ge.lower_bound()
+            assert abs(lb - lbg) <= 1e-12 * abs(lbg)
+    finally:
+        ge.close()
+        for s in sweeps:
+            s.engine.close()

@@ -51,8 +51,9 @@ int main(int argc, char** argv) {
     hipStream_t stream = nullptr;
     hip_ok(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
     rccl_world w;
-    const char* idf = std::getenv("LPMP_NCCL_ID_FILE");
-    w.init(rank, world, ppr, idf ? idf : "/tmp/lpmp_nccl_id_" + std::to_string(env_int("MASTER_PORT", 29500)), stream);
+    const char* addr = std::getenv("MASTER_ADDR");
+    // (the id hand-out takes the port next to MASTER_PORT: a torch.distributed store of the same launch may hold that one)
+    w.init(rank, world, ppr, addr && *addr ? addr : "127.0.0.1", env_int("LPMP_NCCL_ID_PORT", env_int("MASTER_PORT", 29500) + 1), stream);
 
     const int n_parts = world * ppr;
     std::vector<std::unique_ptr<part_sweep>> own;
