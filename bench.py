@@ -56,7 +56,7 @@ def parse():
                     help="take the multi-GPU code path even at WORLD_SIZE 1: init_process_group(nccl = RCCL), the partitioned "
                          "sweep with its (empty) all_to_all_single exchanges, device all_reduce — what an N-GPU launch executes "
                          "first, runnable on a 1-GPU box (tests/test_bench_contract.py)")
-    ap.add_argument("--cpu-sample-grid", type=int, default=256)
+    ap.add_argument("--cpu-sample-grid", type=int, default=512)
     ap.add_argument("--also-row-major", action="store_true", help="also time the row-major ordering (extra key)")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="--gpus N without a launcher: print the rank processes that WOULD be started (command, environment) as one "
@@ -275,11 +275,24 @@ def cpu_baseline(args, synthetic, M):
         o.ComputePass(1)
         passes += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or passes >= 50:
+        if dt > 12.0 or passes >= 50:
             break
     r1, s1 = o.counters()
     return {"value": (r1 - r0 + s1 - s0) / dt, "unit": "msg-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{what}, {passes} passes, oracle/lpmp_oracle.c single thread"}
+            "sample": f"{what}, {passes} passes, oracle/lpmp_oracle.c single thread", "seconds": dt,
+            "host_cpu": host_cpu_model(), "host_cores_available": os.cpu_count()}
+
+
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def rank_commands(args, argv, port):
@@ -406,6 +419,15 @@ def main():
                   "launcher": "bench.py (self-launched ranks)" if os.environ.get("LPMP_BENCH_SELF_LAUNCHED") else "external (torch.distributed.run)"}
         if launch["ranks_seen"] != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {launch['ranks_seen']} ranks")
+        launch["persistent_launches"] = True
+        if len(set(launch["devices"])) < world:
+            # ranks that SHARE a device (smoke runs on the 1-GPU box): the persistent chain launches assume that resident
+            # workgroups keep running, which a device time-sliced between processes does not give them (kernels.hip, chain
+            # executor: about every third 8-rank run stalled until its wait bound) — one launch per step instead
+            os.environ["LPMP_NO_CHAIN"] = "1"
+            os.environ["LPMP_NO_BLOCKED_PASSES"] = "1"
+            launch["persistent_launches"] = False
+            launch["note"] = "ranks share a device: persistent launches off, timings mean nothing"
     else:
         torch.cuda.set_device(0)
         launch = {"backend": None, "ranks_seen": 1, "devices": [0], "devices_visible": torch.cuda.device_count(), "launcher": "in-process (1 GPU)"}
@@ -489,15 +511,38 @@ def main():
     # reference solver.hxx:387-397) and LP::EvaluatePrimal
     rounding = None
     if not dist_on and args.workload == "c3":
-        eng.compute_pass_and_primal(args.steps + args.warmup)      # first call builds the label-propagation lists
+        # what a DEFAULT MpRoundingSolver run executes on every 5th iteration (standard_visitor.hxx:37,172-185): the visitor
+        # switches to roundingReparametrization = damped_uniform (every message received and sent in EACH direction:
+        # 2x the message updates of an anisotropic pass), then forward-and-primal, EvaluatePrimal,
+        # backward-and-primal, EvaluatePrimal
+        it = args.steps + args.warmup
+        eng.set_reparametrization(M.REPAM_NAMES["damped_uniform"])
+        eng.compute_pass_and_primal(it)                            # first call builds the schedules and the label-propagation lists
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        eng.compute_pass_and_primal(args.steps + args.warmup + 1)
+        eng.forward_pass_and_primal(it + 1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        cost_f = eng.evaluate_primal()
+        t2 = time.perf_counter()
+        eng.backward_pass_and_primal(it + 1)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
         cost = eng.evaluate_primal()
-        rounding = {"ms_pass_and_primal": (t1 - t0) * 1e3, "ms_evaluate_primal": (time.perf_counter() - t1) * 1e3,
-                    "primal_cost": cost, "lower_bound": eng.lower_bound()}
+        t4 = time.perf_counter()
+        info_r = [eng.plan.schedule_info(d, M.REPAM_NAMES["damped_uniform"]) for d in (0, 1)]
+        rounding = {"mode": "damped_uniform", "ms_forward_pass_and_primal": (t1 - t0) * 1e3, "ms_backward_pass_and_primal": (t3 - t2) * 1e3,
+                    "ms_pass_and_primal": (t1 - t0 + t3 - t2) * 1e3, "ms_evaluate_primal": (t4 - t3) * 1e3,
+                    "msg_updates_per_pass": sum(i["n_receives"] + i["n_sends"] for i in info_r),
+                    "primal_cost_after_forward": cost_f, "primal_cost": cost, "lower_bound": eng.lower_bound()}
+        eng.set_reparametrization(mode)
+        # (the same under the weights of the timed passes, as rounds 1-3 reported it)
+        eng.compute_pass_and_primal(it + 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.compute_pass_and_primal(it + 3)
+        torch.cuda.synchronize()
+        rounding["ms_pass_and_primal_" + args.mode] = (time.perf_counter() - t0) * 1e3
 
     gap = (dual_bound_gap_c4 if args.workload == "c4" else dual_bound_gap)(torch, dist, args, mode, world, rank) if dist_on else \
         {"dual_bound_gap": 0.0, "gap_config": "1 GPU: the unpartitioned sweep itself"}

@@ -48,6 +48,9 @@ enum lpmp_mem { LPMP_MEM_HOST = 0, LPMP_MEM_DEVICE = 1 };
 
 const char* lpmp_last_error(void);
 const char* lpmp_version(void);
+/* 0 for the product library.  1 / 2: an experimental build of tools/build_variant.sh (2: with LPMP_ABLATE_* switches that
+   remove work from the kernels and compute wrong results) — never what lp_mp_amd/build.py produces. */
+int lpmp_experiment_build(void);
 
 /* ---- host-only analysis (no GPU needed) -------------------------------------------------------
  * Replaces LP::SortFactors (include/LP_MP.h:730-797), LP::get_omega (:412-460) and the weight

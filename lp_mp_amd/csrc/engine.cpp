@@ -3,6 +3,8 @@
 // entry point needs a HIP device and fails with LPMP_ERR_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -116,7 +118,16 @@ struct ChainArgsHost {
   const int32_t* tk_block; int32_t n_tickets; int32_t epoch; long long* trace;
   double* lb_hist; int64_t hist_stride;     // per-pass bound rows of a joined-pass launch (kernels.hip, ChainArgs)
   unsigned long long* mailbox;              // or nullptr
+  long long timeout_ticks;                  // bound of every wait, ticks of the 100 MHz s_memrealtime clock
+  int32_t per_begin, per_len, per_count, per_launch_shift, per_row_shift;   // periodic ticket lists (kernels.hip, ChainArgs)
+  int32_t ring;                             // slots of done[] when it is a ring (0: one flag per ticket)
 };
+constexpr int CHAIN_GEN_BITS = 8;           // kernels.hip
+constexpr int CHAIN_ABORT_WORDS = 16;       // abort word + what the first wait that gave up was waiting for (kernels.hip, chain_abort)
+static long long chain_timeout_ticks() {    // LPMP_CHAIN_TIMEOUT_S (default 20 s)
+  static const long long v = [] { const char* e = std::getenv("LPMP_CHAIN_TIMEOUT_S"); const double s = e ? std::atof(e) : 20.0; return (long long)(std::max(0.001, s) * 1e8); }();
+  return v;
+}
 constexpr int HIST_END = 1, HIST_MID = 2;   // kernels.hip
 
 struct ClassTiming { double ms = 0; int64_t launches = 0, factors = 0, receives = 0, bytes = 0, chain_launches = 0; };
@@ -357,7 +368,13 @@ struct lpmp_engine {
   bool use_chain = true;          // deep single-class schedules as one persistent launch (LPMP_NO_CHAIN=1: graph replay)
   int32_t* d_chain_abort = nullptr; bool chain_ran = false;
   // joined passes as one persistent launch: expansions of RotationInfo, by mode and pass count
-  struct RotChain { DevSchedule::DevChain dc; int n_steps = 0; int64_t factors = 0, recv = 0, bytes = 0; uint64_t last_use = 0; size_t dev_bytes = 0; };
+  struct RotChain {
+    DevSchedule::DevChain dc; int n_steps = 0; int64_t factors = 0, recv = 0, bytes = 0; uint64_t last_use = 0; size_t dev_bytes = 0;
+    // periodic form (rotation_chain): dc holds the TEMPLATE of n_tmpl passes whose tickets [per_begin, per_begin + per_len) are
+    // one group of `depth` steps that an n-pass launch executes 1 + (n - n_tmpl) / (depth / 2) times; per_* sums: one period
+    bool periodic = false; int n_tmpl = 0, depth = 0; int32_t per_begin = 0, per_len = 0, ring = 0;
+    int64_t per_factors = 0, per_recv = 0, per_bytes = 0;
+  };
   // the ticket lists of a pass count are device memory (C3, 32 passes: ~350 MB): the cache of built chains is bounded in
   // BYTES over all modes (default 2 GiB, LPMP_CHAIN_CACHE_MB; least recently used first), lpmp_chain_cache_bytes reports it
   uint64_t rot_clock = 0;
@@ -500,7 +517,7 @@ struct Staging {
 // small device-written host words (partial sums, counters, flags): one pinned block per engine, taken from a pool
 // and given back at destroy — no pinned allocation / free per uploaded model or per engine.  The pools are per thread
 // and bounded: beyond POOL_MAX idle entries a returned block is freed / a returned stream destroyed.
-constexpr size_t PINNED_WORDS_BYTES = 8 * 1024 + 128;
+constexpr size_t PINNED_WORDS_BYTES = 8 * 1024 + 256;   // 1024 partial sums, then words at +0 (stale counter), +64 (primal flag), +128 ... (chain abort report)
 constexpr size_t POOL_MAX = 8;
 struct PinnedPool {
   std::vector<char*> free_blocks;
@@ -701,7 +718,17 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
 // -> launch map and the dependency lists: tools/chain_trace.py turns them into the latency budget of DESIGN.md 6
 struct ChainTrace {
   long long* d = nullptr; int32_t n = 0;
-  static const char* path() { static const char* p = std::getenv("LPMP_CHAIN_TRACE"); return p; }
+  // ("%p" in the path: this process's id — several ranks on one box)
+  static const char* path() {
+    static const std::string p = [] {
+      const char* e = std::getenv("LPMP_CHAIN_TRACE");
+      std::string s = e ? e : "";
+      const size_t k = s.find("%p");
+      if (k != std::string::npos) s.replace(k, 2, std::to_string((long long)getpid()));
+      return s;
+    }();
+    return p.empty() ? nullptr : p.c_str();
+  }
   long long* begin(int32_t n_tickets, hipStream_t s) {
     if (!path()) return nullptr;
     n = n_tickets;
@@ -709,9 +736,12 @@ struct ChainTrace {
     HIP_CHECK(hipMemsetAsync(d, 0, (size_t)8 * n * sizeof(long long), s));
     return d;
   }
-  template <class DC> void end(const DC& c, hipStream_t s) {
+  template <class DC> void end(const DC& c, hipStream_t s, const int32_t* d_abort = nullptr) {
     if (!d) return;
     HIP_CHECK(hipStreamSynchronize(s));
+    // the dump of a run in which a wait gave up is kept under its own name (later runs do not overwrite it)
+    std::string out = path();
+    if (d_abort) { int32_t a = 0; HIP_CHECK(hipMemcpy(&a, d_abort, sizeof(a), hipMemcpyDeviceToHost)); if (a) out += ".aborted"; }
     std::vector<long long> st((size_t)8 * n);
     std::vector<int32_t> tl((size_t)n), off((size_t)n + 1);
     HIP_CHECK(hipMemcpy(st.data(), d, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
@@ -720,7 +750,7 @@ struct ChainTrace {
     std::vector<int32_t> dep((size_t)off[n]);
     if (!dep.empty()) HIP_CHECK(hipMemcpy(dep.data(), c.dep, dep.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     (void)hipFree(d); d = nullptr;
-    if (FILE* f = std::fopen(path(), "wb")) {
+    if (FILE* f = std::fopen(out.c_str(), "wb")) {
       const int64_t hdr[2] = {n, off[n]};
       std::fwrite(hdr, sizeof(hdr), 1, f);
       std::fwrite(st.data(), sizeof(long long), st.size(), f);
@@ -745,7 +775,7 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
     for (const auto& c : s.chains) if (kc_width(c.kclass) == 0) chain_ok = false;
   }
   if (chain_ok) {
-    if (!e->d_chain_abort) { HIP_CHECK(hipMalloc((void**)&e->d_chain_abort, sizeof(int32_t))); HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, sizeof(int32_t), e->stream)); }
+    if (!e->d_chain_abort) { HIP_CHECK(hipMalloc((void**)&e->d_chain_abort, CHAIN_ABORT_WORDS * sizeof(int32_t))); HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, CHAIN_ABORT_WORDS * sizeof(int32_t), e->stream)); }
     // UpdateFactorPrimal always sends 'shared' (issue_launches)
     const int rule = e->primal_pass ? SWEEP_PRIMAL : e->rtype == LPMP_RTYPE_RESIDUAL ? SWEEP_RESIDUAL : e->rtype == LPMP_RTYPE_ADAPTIVE ? SWEEP_ADAPTIVE : 0;
     // classes are independent of each other (plan.cpp): the plain launches first, then one persistent launch per class
@@ -775,10 +805,10 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
       }
       HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
       ChainTrace tr;
-      const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream), nullptr, 0, c.mailbox};
+      const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream), nullptr, 0, c.mailbox, chain_timeout_ticks(), 0, 0, 0, 0, 0, 0};
       if (!launch_chain(c.kclass, rule | (c.banded ? 0 : e->nt_flag), &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->d_primal, e->stream))
         throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
-      tr.end(c, e->stream);
+      tr.end(c, e->stream, e->d_chain_abort);
     }
     HIP_CHECK(hipGetLastError());
     e->chain_ran = true;
@@ -821,11 +851,24 @@ void check_rows(int64_t n, const int64_t* om_off, const double* om, const int64_
 // 256 MiB Infinity Cache (every table is needed by both of its endpoints, i.e. by consecutive steps).  Only the order
 // changes: the dependency flags keep every result identical to the sequential sweeps.  Returns nullptr when the model
 // does not qualify (then the steps run as one launch each).
-lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
-  auto it = e->rot_chain[mode].find(n);
+// Calls of n > ROT_EXPLICIT_MAX passes use a PERIODIC template instead of explicit lists: with `depth` even the groups of
+// `depth` steps from the second one on are all alike — K, W, K, W with the same bands in the same order, their dependencies
+// the same offsets into themselves and into the group before — so the lists of a template call (prologue = the first two
+// groups, ONE more group = the period, then the tail: T, or K W T for an odd pass count) describe every pass count of that
+// parity: the kernel maps ticket t to (template ticket, copy of the period) (kernels.hip, chain_ticket_ref), and the
+// completion flags are a ring of a few groups.  Host work, upload and device memory of an n-pass launch no longer depend on n.
+constexpr int ROT_EXPLICIT_MAX = 7;
+lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n_call) {
+  const int depth = std::max(1, e->rot_depth);
+  // template: groups 0, 1 (prologue), 2 (the period) and a tail as long as the call's: r = (2 n + 1) mod depth steps
+  const int tail = depth % 2 == 0 ? (2 * n_call + 1) % depth : 0;
+  const int n_template = (3 * depth + tail - 1) / 2;
+  const bool periodic = depth % 2 == 0 && n_call > ROT_EXPLICIT_MAX && n_call >= n_template && !std::getenv("LPMP_ROT_EXPLICIT");
+  const int n = periodic ? n_template : n_call;
+  const int key = periodic ? -tail : n_call;
+  auto it = e->rot_chain[mode].find(key);
   if (it != e->rot_chain[mode].end()) { it->second.last_use = ++e->rot_clock; return it->second.n_steps > 0 ? &it->second : nullptr; }
-  // bound the cache in bytes: drop the least recently used built chains (of any mode) until the new one fits (about 11 MB
-  // per pass at C3); the stream is drained first
+  // bound the cache in bytes: drop the least recently used built chains (of any mode) until the new one fits; the stream is drained first
   auto evict_for = [&](size_t need) {
     bool drained = false;
     while (e->rot_cache_bytes + need > e->rot_cache_limit) {
@@ -841,13 +884,13 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
       vm->erase(victim);
     }
   };
-  lpmp_engine::RotChain& rc = e->rot_chain[mode][n];           // n_steps == 0: tried, not possible
+  lpmp_engine::RotChain& rc = e->rot_chain[mode][key];           // n_steps == 0: tried, not possible
   rc.last_use = ++e->rot_clock;
   const RotationInfo& ri = e->plan->rot[mode];
   const bool verbose = std::getenv("LPMP_ROT_VERBOSE") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-  auto no = [&](const char* why) -> lpmp_engine::RotChain* { if (verbose) std::fprintf(stderr, "lpmp: %d passes stay one launch per step: %s\n", n, why); return nullptr; };
+  auto no = [&](const char* why) -> lpmp_engine::RotChain* { if (verbose) std::fprintf(stderr, "lpmp: %d passes stay one launch per step: %s\n", n_call, why); return nullptr; };
   if (!ri.valid) return no("the pass does not have the H, W, K, T shape of one packed class");
   const int n_steps = 2 * n + 1;
   std::vector<int> tmpl(n_steps), kind(n_steps, -1);
@@ -875,12 +918,14 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
   // reuse (1024:3:5 5.67, 1024:3:6 6.37), lag 2 leaves the waiting workgroups less slack (1024:2:4 5.24)
   int bands = e->rot_bands;
   if (bands <= 0) bands = (int)std::max<int64_t>(1, std::min<int64_t>(ri.t[1].nb, ri.t[1].bytes / ((int64_t)16 << 20)));
-  const int depth = std::max(1, e->rot_depth);
   std::vector<int32_t> new_of((size_t)N), tk_launch((size_t)N), tk_block((size_t)N);
+  std::vector<int64_t> group_begin;                                 // first ticket of every group of `depth` steps
   auto band_begin = [](int64_t b, int64_t nb, int64_t bands_) { return (b * nb + bands_ - 1) / bands_; };   // first block of band b
   for (int lag = std::max(1, e->rot_lag); lag <= 16; ++lag) {
     int64_t at = 0;
+    group_begin.clear();
     for (int s0 = 0; s0 < n_steps; s0 += depth) {
+      group_begin.push_back(at);
       const int d = std::min(depth, n_steps - s0);
       for (int64_t tau = 0; tau < bands + (int64_t)lag * (d - 1); ++tau)
         for (int sd = 0; sd < d; ++sd) {
@@ -893,6 +938,7 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
           }
         }
     }
+    group_begin.push_back(at);
     if (at != N) throw std::runtime_error("rotation chain: ticket count");
     if (verbose) std::fprintf(stderr, "lpmp:   %d passes, lag %d: order after %.0f ms\n", n, lag, since());
     // every predecessor must come earlier
@@ -927,19 +973,49 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
       }
     }
     if (verbose) std::fprintf(stderr, "lpmp:   dependency lists after %.0f ms (%zu)\n", since(), dep.size());
+    int32_t ring = 0;
+    if (periodic) {
+      // the template is [group 0][group 1][group 2 = the period][tail]; what the kernel's map relies on, checked here:
+      // groups 1 and 2 are the same tickets in the same order, the period's and the tail's dependencies all lie in the
+      // group before the period or later (they move with the copy), the prologue's before the period
+      if (group_begin.size() != 5) throw std::runtime_error("rotation chain: template groups");
+      const int64_t g1 = group_begin[1], g2 = group_begin[2], g3 = group_begin[3], P = g3 - g2;
+      bool fine = g2 - g1 == P;
+      for (int64_t t = g2; t < g3 && fine; ++t) {
+        fine = tk_launch[t] == tk_launch[t - P] + depth && tk_block[t] == tk_block[t - P];
+        for (int64_t q = dep_off[t]; q < dep_off[t + 1] && fine; ++q) fine = dep[q] >= g1;
+      }
+      for (int64_t t = g3; t < N && fine; ++t) for (int64_t q = dep_off[t]; q < dep_off[t + 1] && fine; ++q) fine = dep[q] >= g2;
+      for (int64_t t = 0; t < g2 && fine; ++t) for (int64_t q = dep_off[t]; q < dep_off[t + 1] && fine; ++q) fine = dep[q] < g2;
+      // (group 2's dependencies into group 1 must be what a later copy's are into the copy before it: same relative offsets
+      // as group 1's own... group 1 reaches into group 0, whose order differs, so that cannot be compared — the step kinds
+      // of groups >= 2 are identical by construction: kind[s] depends on the parity of s only from s = 3 on)
+      if (!fine) throw std::runtime_error("rotation chain: the template is not periodic");
+      rc.per_begin = (int32_t)g2; rc.per_len = (int32_t)P;
+      // flags: a ring of three groups — a dependency reaches at most into the group before, and a ticket may only publish
+      // into a slot whose previous occupant (a ring earlier) has published (kernels.hip, chain_wait)
+      ring = (int32_t)(3 * P);
+      if ((int64_t)48 * (int64_t)(2 * P) / ring + 64 >= (1 << CHAIN_GEN_BITS)) throw std::runtime_error("rotation chain: ring too small for its generation counter");
+    }
     std::vector<ChainLaunchDev> lds;
     for (int s = 0; s < n_steps; ++s) {
       const auto& t = ri.t[tmpl[s]];
       const DevSchedule& ds = t.sched == 0 ? e->sched_pass[mode] : e->sched_bf[mode];
       // per-pass bound rows (only written when the launch is given rows: speculative batches): W of pass i (step 2 i + 1)
       // and K after pass i (step 2 i + 2) write row i, for the passes i = 0 ... n - 2 that have a seam behind them
+      // (periodic template: the tail's last W is the last W of ANY call of this parity)
       int32_t hist = 0;
       if (tmpl[s] == 1 && (s - 1) / 2 < n - 1) hist = HIST_END | (((s - 1) / 2) << 2);
       if (tmpl[s] == 2) hist = HIST_MID | (((s - 2) / 2) << 2);
       lds.push_back({t.lr.stride > 0 ? ds.packets + t.lr.pk_begin : nullptr, ds.recs + t.lr.begin, ds.ops, t.lr.end - t.lr.begin, t.lr.stride, hist});
       rc.factors += t.factors; rc.recv += t.recv; rc.bytes += t.bytes;
+      if (periodic && s >= 2 * depth && s < 3 * depth) { rc.per_factors += t.factors; rc.per_recv += t.recv; rc.per_bytes += t.bytes; }
     }
-    rc.dev_bytes = lds.size() * sizeof(ChainLaunchDev) + (tk_launch.size() + tk_block.size() + dep_off.size() + dep.size() + (size_t)N + 1) * sizeof(int32_t);
+    // (periodic: the kernel looks a ticket's launch up at its TEMPLATE step — the steps of a later copy of the period are the
+    // same K / W launches, and the tail's the same K, W, T; only the bound row in `pad` moves with the copy, depth / 2 rows
+    // per copy — so this table, too, is the template's whatever the call's pass count)
+    const size_t n_done = periodic ? (size_t)ring : (size_t)N;
+    rc.dev_bytes = lds.size() * sizeof(ChainLaunchDev) + (tk_launch.size() + tk_block.size() + dep_off.size() + dep.size() + n_done + 1) * sizeof(int32_t);
     evict_for(rc.dev_bytes);
     auto up = [&](auto*& dst, const auto& v) {
       using T = std::remove_reference_t<decltype(*dst)>;
@@ -950,20 +1026,21 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n) {
     try {
       up(dc.launches, lds); up(dc.tk_launch, tk_launch); up(dc.tk_block, tk_block); up(dc.dep_off, dep_off); up(dc.dep, dep);
       dc.tickets = (int32_t)N; dc.kclass = ri.kclass;
-      HIP_CHECK(hipMalloc((void**)&dc.done, (size_t)N * sizeof(int32_t)));
+      HIP_CHECK(hipMalloc((void**)&dc.done, n_done * sizeof(int32_t)));
       HIP_CHECK(hipMalloc((void**)&dc.next, sizeof(int32_t)));
-      HIP_CHECK(hipMemsetAsync(dc.done, 0, (size_t)N * sizeof(int32_t), e->stream));
+      HIP_CHECK(hipMemsetAsync(dc.done, 0, n_done * sizeof(int32_t), e->stream));
       HIP_CHECK(hipStreamSynchronize(e->stream));
     } catch (...) {
       // nothing half-built stays behind: the entry goes (a later call tries again), the bytes were never counted
       for (void* p : {(void*)dc.launches, (void*)dc.tk_launch, (void*)dc.tk_block, (void*)dc.dep_off, (void*)dc.dep, (void*)dc.done, (void*)dc.next}) if (p) (void)hipFree(p);
-      e->rot_chain[mode].erase(n);
+      e->rot_chain[mode].erase(key);
       throw;
     }
     e->rot_cache_bytes += rc.dev_bytes;
-    rc.n_steps = n_steps;
+    rc.n_steps = n_steps; rc.periodic = periodic; rc.n_tmpl = n; rc.depth = depth; rc.ring = ring;
     if (verbose)
-      std::fprintf(stderr, "lpmp: %d passes as one launch: %lld tickets, %d bands, lag %d, depth %d; built and uploaded in %.0f ms\n", n, (long long)N, bands, lag, depth, since());
+      std::fprintf(stderr, "lpmp: %d passes as one launch%s: %lld tickets, %d bands, lag %d, depth %d; built and uploaded in %.0f ms\n", n,
+                   periodic ? " (periodic template)" : "", (long long)N, bands, lag, depth, since());
     return &rc;
   }
   return no("no band order keeps the dependencies backwards");
@@ -973,20 +1050,30 @@ bool run_rotation_chain(lpmp_engine* e, int mode, int n, double* lb_hist = nullp
   if (!e->use_chain || !e->use_blocked_passes || e->primal_pass || e->rtype != LPMP_RTYPE_SHARED) return false;
   lpmp_engine::RotChain* rc = rotation_chain(e, mode, n);
   if (!rc) return false;
-  if (!e->d_chain_abort) { HIP_CHECK(hipMalloc((void**)&e->d_chain_abort, sizeof(int32_t))); HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, sizeof(int32_t), e->stream)); }
+  if (!e->d_chain_abort) { HIP_CHECK(hipMalloc((void**)&e->d_chain_abort, CHAIN_ABORT_WORDS * sizeof(int32_t))); HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, CHAIN_ABORT_WORDS * sizeof(int32_t), e->stream)); }
   auto& c = rc->dc;
   HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
+  // periodic template: the period runs once in the template and `extra` more times in this call
+  const int extra = rc->periodic ? (n - rc->n_tmpl) / (rc->depth / 2) : 0;
+  if (rc->periodic && (extra < 0 || rc->n_tmpl + extra * (rc->depth / 2) != n)) throw std::runtime_error("rotation chain: pass count does not fit the template");
+  if (rc->periodic && c.epoch >= (1 << (31 - CHAIN_GEN_BITS)) - 2) {   // the epoch shares the flag word with the generation: start over
+    HIP_CHECK(hipMemsetAsync(c.done, 0, (size_t)rc->ring * sizeof(int32_t), e->stream));
+    c.epoch = 0;
+  }
   ChainTrace tr;
-  const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream),
-                         lb_hist, lb_hist ? e->plan->p.nf : 0, nullptr};
+  const int32_t n_tickets = c.tickets + extra * rc->per_len;
+  const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, n_tickets, ++c.epoch, rc->periodic ? nullptr : tr.begin(c.tickets, e->stream),
+                         lb_hist, lb_hist ? e->plan->p.nf : 0, nullptr, chain_timeout_ticks(),
+                         rc->periodic ? rc->per_begin : 0, rc->periodic ? rc->per_len : 0, rc->periodic ? 1 + extra : 0, 0,
+                         rc->periodic ? rc->depth / 2 : 0, rc->periodic ? rc->ring : 0};
   hipEvent_t a = nullptr, b = nullptr;
   if (e->timing) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, e->stream)); }
   // (plain table loads, not the streaming policy: the second reader of a table is meant to find it in the Infinity Cache)
   if (!launch_chain(c.kclass, 0, &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, nullptr, e->stream)) throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
-  tr.end(c, e->stream);
+  if (!rc->periodic) tr.end(c, e->stream, e->d_chain_abort);
   if (e->timing) {
     HIP_CHECK(hipEventRecord(b, e->stream));
-    e->pending.push_back({a, b, c.kclass, rc->factors, rc->recv, rc->bytes});
+    e->pending.push_back({a, b, c.kclass, rc->factors + extra * rc->per_factors, rc->recv + extra * rc->per_recv, rc->bytes + extra * rc->per_bytes});
     e->ct[c.kclass].chain_launches++;
   }
   HIP_CHECK(hipGetLastError());
@@ -1884,13 +1971,21 @@ int lpmp_schedule_destroy(lpmp_engine* e, int id) {
 // the chain executor bounds every wait; a run that gave up leaves the duals half updated and must not pass silently
 static void check_chain(lpmp_engine* e) {
   if (!e->chain_ran || !e->d_chain_abort) return;
-  int32_t* h = (int32_t*)(e->pinned + 8 * 1024 + 96);
-  HIP_CHECK(hipMemcpyAsync(h, e->d_chain_abort, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  int32_t* h = (int32_t*)(e->pinned + 8 * 1024 + 128);
+  static_assert(8 * 1024 + 128 + CHAIN_ABORT_WORDS * 4 <= PINNED_WORDS_BYTES, "pinned block");
+  HIP_CHECK(hipMemcpyAsync(h, e->d_chain_abort, CHAIN_ABORT_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
   HIP_CHECK(hipStreamSynchronize(e->stream));
   e->chain_ran = false;
-  if (*h != 0) {
-    HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, sizeof(int32_t), e->stream));
-    throw DeviceError("chain executor: a dependency wait timed out; the duals are in an undefined state (LPMP_NO_CHAIN=1 selects graph replay)");
+  if (h[0] != 0) {
+    std::string what;
+    if (h[1] != 0) {
+      const long long now = (long long)(((unsigned long long)(unsigned)h[7] << 32) | (unsigned)h[6]), t0 = (long long)(((unsigned long long)(unsigned)h[9] << 32) | (unsigned)h[8]);
+      what = h[3] == -2 ? " (a mailbox granule, tag seen " + std::to_string(h[4]) + ", epoch " + std::to_string(h[5])
+                        : " (ticket " + std::to_string(h[2]) + " waited for ticket " + std::to_string(h[3]) + ": flag word " + std::to_string(h[4]) + ", epoch " + std::to_string(h[5]);
+      what += ", " + std::to_string((double)(now - t0) * 1e-8) + " s, " + std::to_string(h[10]) + " tickets drawn)";
+    }
+    HIP_CHECK(hipMemsetAsync(e->d_chain_abort, 0, CHAIN_ABORT_WORDS * sizeof(int32_t), e->stream));
+    throw DeviceError("chain executor: a dependency wait timed out" + what + "; the duals are in an undefined state (LPMP_NO_CHAIN=1 selects graph replay, LPMP_CHAIN_TIMEOUT_S the bound)");
   }
 }
 

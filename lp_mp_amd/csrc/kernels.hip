@@ -20,6 +20,28 @@
 
 #include "plan.hpp"
 
+// The LPMP_ABLATE_* switches below REMOVE work from the kernel bodies (loads, reductions, bound tracking) to price it
+// (tools/build_variant.sh, EXPERIMENTS.md): such a build computes WRONG duals.  They are only accepted together with
+// LPMP_EXPERIMENT_BUILD, which tools/build_variant.sh sets and lp_mp_amd/build.py never does; the product library
+// additionally exports lpmp_experiment_build() == 0 (tests/test_product_isolation.py).
+#if (defined(LPMP_ABLATE_TABLE) || defined(LPMP_ABLATE_RECV_VEC) || defined(LPMP_ABLATE_SEND_VEC) || defined(LPMP_ABLATE_REDUCE) || \
+     defined(LPMP_ABLATE_LB_TRACK)) && !defined(LPMP_EXPERIMENT_BUILD)
+#error "LPMP_ABLATE_* builds compute wrong results: they need -DLPMP_EXPERIMENT_BUILD (tools/build_variant.sh) and must never be the product library"
+#endif
+#if defined(LPMP_ABLATE_TABLE) || defined(LPMP_ABLATE_RECV_VEC) || defined(LPMP_ABLATE_SEND_VEC) || defined(LPMP_ABLATE_REDUCE) || defined(LPMP_ABLATE_LB_TRACK)
+#define LPMP_ANY_ABLATION 1
+#else
+#define LPMP_ANY_ABLATION 0
+#endif
+extern "C" int lpmp_experiment_build(void) {
+#ifdef LPMP_EXPERIMENT_BUILD
+  return 1 + LPMP_ANY_ABLATION;     // 1: an experimental build (tuning knobs only), 2: with ablations (wrong results)
+#else
+  static_assert(LPMP_ANY_ABLATION == 0, "ablations in a product build");
+  return 0;
+#endif
+}
+
 namespace lpmp {
 
 #define LPMP_INF (__builtin_inf())
@@ -81,6 +103,15 @@ template <int A> __device__ __forceinline__ void st_lb(double* p, double v) {
 // only ever waits for lower tickets, and those are held by workgroups that are already running, so the scheme needs
 // no assumption about residency or dispatch order.  Every wait is bounded: on a timeout the launch sets an abort word
 // and drains, and the host reports an error instead of hanging the device.
+// What it DOES assume: the workgroups that are resident keep running — the device is this process's.  When several
+// processes oversubscribe one device, its scheduler time-slices their queues XCD by XCD: workgroups of this launch that
+// hold tickets can be switched out on one XCD for as long as another process's persistent launch runs there, while the
+// workgroups on the other XCDs poll for those tickets — and that other launch may be waiting the same way for an XCD this
+// one occupies.  Measured (round 4, 8 rank processes sharing the one GPU of the test box, profiles/r04_8rank_stall_*):
+// about every third run stalled until the bound below ended it, every load and barrier of the stalled workgroups frozen
+// for exactly as long, neither slower polls nor a read-modify-write publish changed it.  One process per device (what the
+// engine is built for) never has this; drivers that put several ranks on one device for smoke runs switch the
+// persistent launches off (bench.py; LPMP_NO_CHAIN=1 LPMP_NO_BLOCKED_PASSES=1).
 struct ChainArgs {
   const int32_t* dep_off;    // [n_tickets + 1]
   const int32_t* dep;        // predecessor tickets
@@ -97,7 +128,22 @@ struct ChainArgs {
   double* lb_hist; int64_t hist_stride;
   // launches with CHAIN_LAUNCH_MAILBOX (plan.cpp): rows of L granule pairs, see mailbox_put / mailbox_take
   unsigned long long* mailbox;
+  // bound of every wait in ticks of s_memrealtime (100 MHz; engine.cpp: 20 s, LPMP_CHAIN_TIMEOUT_S).  Time, not a number of
+  // polls: a device shared by several processes (N ranks of a smoke run on one GPU) serves a poll an order of magnitude
+  // slower, and a count of polls that means seconds on an idle device was reached there by waits that were merely slow
+  long long timeout_ticks;
+  // PERIODIC ticket lists (the joined passes of lpmp_compute_pass(n), engine.cpp rotation_chain): the arrays above describe
+  // a TEMPLATE — prologue tickets [0, per_begin), ONE period of per_len tickets, epilogue — and the launch executes the
+  // period per_count times: ticket t of the launch is template ticket t - q * per_len of copy q = min((t - per_begin) /
+  // per_len, per_count - 1) (0 in the prologue); its launch is the template's + q * per_launch_shift (every copy is a group
+  // of as many steps later), its dependencies the template's + q * per_len, its bound row the template's + q * per_row_shift.
+  // per_len == 0: plain lists.  Host work and device memory of an n-pass launch are then independent of n.
+  int32_t per_begin, per_len, per_count, per_launch_shift, per_row_shift;
+  // ring > 0: done[] has `ring` slots, ticket t publishes {epoch, t / ring} into slot t % ring AFTER ticket t - ring has
+  // published there (one more dependency of t), and a waiter accepts any generation >= the one it needs
+  int32_t ring;
 };
+constexpr int CHAIN_GEN_BITS = 8;            // low bits of a ring slot: generation t / ring (< 256); the rest: the epoch
 // debugging (LPMP_LEVEL_TRACE, engine.cpp): time stamps of the first levels of a level-loop launch, 8 slots per level
 __device__ long long* g_level_trace = nullptr;
 constexpr int LEVEL_TRACE_MAX = 4000;
@@ -123,21 +169,64 @@ struct ChainLaunch { const Op* packets; const UpdRec* recs; const Op* ops; int64
 //   HIST_MID  (a K step)  the updated factor's bound after its receives, before its sends, and the bound of every
 //                         pairwise factor it receives from, right after that receive
 constexpr int HIST_END = 1, HIST_MID = 2;
-constexpr int CHAIN_SPIN_LIMIT = 1 << 22;   // polls of one dependency before giving up (seconds)
-
+// a wait gives up when it has lasted ChainArgs::timeout_ticks (the clock is first read after 1024 polls: short waits never
+// read it) or when another wait of the launch has given up
+__device__ __forceinline__ bool chain_wait_expired(const ChainArgs& ca, int spins, long long& t0, bool& own) {
+  own = false;
+  if ((spins & 1023) != 0) return false;
+  if (__hip_atomic_load(ca.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+  const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+  if (spins == 1024) { t0 = now; return false; }
+  own = now - t0 > ca.timeout_ticks;
+  return own;
+}
+// Pause between two polls of a flag or granule: short while the wait is young (a hand-over between dependent levels is a
+// couple of microseconds and every pause adds to it); a wait that has lasted a quarter of a millisecond is a wait for
+// something that is far from done, and polls it every few microseconds only.
+__device__ __forceinline__ void chain_poll_pause(int spins) {
+  if (spins < 256) __builtin_amdgcn_s_sleep(1);
+  else if (spins < 512) __builtin_amdgcn_s_sleep(8);
+  else __builtin_amdgcn_s_sleep(64);
+}
+// the wait that gives up FIRST says what it was waiting for (abort_flag[1 ...]: engine.cpp puts it into the error message)
+__device__ __forceinline__ void chain_abort(const ChainArgs& ca, bool own, int ticket, int dep, int seen, long long t0) {
+  if (own && atomicCAS(ca.abort_flag + 1, 0, 1) == 0) {
+    const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+    ca.abort_flag[2] = ticket; ca.abort_flag[3] = dep; ca.abort_flag[4] = seen; ca.abort_flag[5] = ca.epoch;
+    ca.abort_flag[6] = (int)(unsigned)now; ca.abort_flag[7] = (int)(now >> 32); ca.abort_flag[8] = (int)(unsigned)t0; ca.abort_flag[9] = (int)(t0 >> 32);
+    ca.abort_flag[10] = __hip_atomic_load(ca.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __hip_atomic_store(ca.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// template ticket and copy of a ticket of a periodic launch (ChainArgs::per_*)
+struct TicketRef { int idx, copy; };
+__device__ __forceinline__ TicketRef chain_ticket_ref(const ChainArgs& ca, int ticket) {
+  if (ca.per_len == 0 || ticket < ca.per_begin) return {ticket, 0};
+  const int q = min((ticket - ca.per_begin) / ca.per_len, ca.per_count - 1);
+  return {ticket - q * ca.per_len, q};
+}
+__device__ __forceinline__ bool chain_flag_set(const ChainArgs& ca, int dep_ticket) {
+  if (ca.ring == 0) return __hip_atomic_load(ca.done + dep_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ca.epoch;
+  const int v = __hip_atomic_load(ca.done + dep_ticket % ca.ring, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (v >> CHAIN_GEN_BITS) == ca.epoch && (v & ((1 << CHAIN_GEN_BITS) - 1)) >= dep_ticket / ca.ring;
+}
 // all threads of the workgroup; returns false when the run was aborted
 __device__ __forceinline__ bool chain_wait(const ChainArgs& ca, int ticket) {
   __shared__ int s_bad;
   if (threadIdx.x == 0) s_bad = 0;
   __syncthreads();
-  const int b = ca.dep_off[ticket], e = ca.dep_off[ticket + 1];
-  for (int i = b + (int)threadIdx.x; i < e; i += (int)blockDim.x) {
-    const int32_t* flag = ca.done + ca.dep[i];
-    int spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ca.epoch) {
-      __builtin_amdgcn_s_sleep(1);
-      if (((++spins) & 1023) == 0 && (spins >= CHAIN_SPIN_LIMIT || __hip_atomic_load(ca.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        __hip_atomic_store(ca.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const TicketRef tr = chain_ticket_ref(ca, ticket);
+  const int b = ca.dep_off[tr.idx], e = ca.dep_off[tr.idx + 1];
+  const int shift = tr.copy * ca.per_len;
+  // ring: the slot this ticket will publish into must hold its previous occupant's completion (ticket - ring)
+  const int extra = (ca.ring > 0 && ticket >= ca.ring) ? 1 : 0;
+  for (int i = b + (int)threadIdx.x; i < e + extra; i += (int)blockDim.x) {
+    const int d = i < e ? ca.dep[i] + shift : ticket - ca.ring;
+    int spins = 0; long long t0 = 0; bool own;
+    while (!chain_flag_set(ca, d)) {
+      chain_poll_pause(spins);
+      if (chain_wait_expired(ca, ++spins, t0, own)) {
+        chain_abort(ca, own, ticket, d, __hip_atomic_load(ca.done + (ca.ring ? d % ca.ring : d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t0);
         s_bad = 1;
         break;
       }
@@ -161,7 +250,10 @@ __device__ __forceinline__ void chain_publish(const ChainArgs& ca, int ticket) {
   chain_stamp(ca, ticket, 2);                      // body done, stores issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(ca.done + ticket, ca.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    if (ca.ring == 0) __hip_atomic_store(ca.done + ticket, ca.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(ca.done + ticket % ca.ring, (ca.epoch << CHAIN_GEN_BITS) | (ticket / ca.ring), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   chain_stamp(ca, ticket, 3);                      // published
 }
 
@@ -199,6 +291,7 @@ __device__ __forceinline__ double mailbox_take(const ChainArgs& ca, const unsign
     b[i] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (i + 1 < LPMP_MBOX_PIPE) __builtin_amdgcn_s_sleep(LPMP_MBOX_GAP);
   }
+  long long t0 = 0;
   for (int spins = 0;;) {
     if ((unsigned)(a[0] >> 32) == tag && (unsigned)(b[0] >> 32) == tag) return __hiloint2double((int)(unsigned)b[0], (int)(unsigned)a[0]);
 #pragma unroll
@@ -206,14 +299,20 @@ __device__ __forceinline__ double mailbox_take(const ChainArgs& ca, const unsign
     a[LPMP_MBOX_PIPE - 1] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     b[LPMP_MBOX_PIPE - 1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
+  long long t0 = 0;
   for (int spins = 0;;) {
     const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag) return __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+#if LPMP_MBOX_SLEEP == 1
+    chain_poll_pause(spins);
+#else
     __builtin_amdgcn_s_sleep(LPMP_MBOX_SLEEP);
 #endif
-    if (((++spins) & 1023) == 0 && (spins >= CHAIN_SPIN_LIMIT || __hip_atomic_load(ca.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-      __hip_atomic_store(ca.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    bool own;
+    if (chain_wait_expired(ca, ++spins, t0, own)) {
+      chain_abort(ca, own, -1, -2, (int)(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32), t0);   // a mailbox granule
       bad = true;
       return 0.0;
     }
@@ -1278,8 +1377,10 @@ __device__ __forceinline__ void chain_loop(const ChainArgs& ca, const ChainLaunc
     if (ticket >= ca.n_tickets) break;
     if (threadIdx.x == 0) s_ticket[(it + 1) & 1] = atomicAdd(ca.next, 1);
     chain_stamp(ca, ticket, 0);                    // ticket in hand
-    const ChainLaunch ln = launches[ca.tk_launch[ticket]];
-    body(ln, (int64_t)ca.tk_block[ticket], ticket);
+    const TicketRef tr = chain_ticket_ref(ca, ticket);
+    ChainLaunch ln = launches[ca.tk_launch[tr.idx] + tr.copy * ca.per_launch_shift];
+    if (ln.pad & 3) ln.pad += (tr.copy * ca.per_row_shift) << 2;      // joined passes: bound row of this copy's pass (HIST_* | row << 2)
+    body(ln, (int64_t)ca.tk_block[tr.idx], ticket);
     chain_publish(ca, ticket);
     __syncthreads();                               // s_ticket[(it + 1) & 1] is written, the LDS of the body is free again
   }

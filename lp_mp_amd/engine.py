@@ -37,7 +37,7 @@ KERNEL_NAMES = ["sweep_generic_kernel<64>", "sweep_dense_pk_kernel<4, 4, false",
 MEM_HOST, MEM_DEVICE = 0, 1
 
 EXPORTS = [
-    "lpmp_last_error", "lpmp_version", "lpmp_plan_create", "lpmp_plan_destroy", "lpmp_plan_n_factors",
+    "lpmp_last_error", "lpmp_version", "lpmp_experiment_build", "lpmp_plan_create", "lpmp_plan_destroy", "lpmp_plan_n_factors",
     "lpmp_plan_n_updated", "lpmp_plan_get_order", "lpmp_plan_get_update_order", "lpmp_plan_omega_nnz",
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
     "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_custom_schedule_info", "lpmp_plan_schedule_classes", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_plan_pass_rotates", "lpmp_plan_chain_info", "lpmp_plan_mailbox_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",

@@ -6,7 +6,10 @@
 // this file is not needed.
 #pragma once
 
+#include <cstdio>
 #include <typeinfo>
+
+#include <unistd.h>
 
 #include "LP_gpu.hxx"
 
@@ -28,6 +31,7 @@ class StandardVisitor {
       else if (k == "--minDualImprovementInterval") minDualImprovementInterval_ = std::stoul(v);
       else if (k == "--standardReparametrization") standardReparametrization_ = LPReparametrizationModeConvert(v);
       else if (k == "--roundingReparametrization") roundingReparametrization_ = LPReparametrizationModeConvert(v);
+      else if (k == "--maxMemory") maxMemory_ = std::stoul(v);
       else if (k == "-v") verbosity_ = std::stoul(v);
     }
   }
@@ -40,13 +44,18 @@ class StandardVisitor {
   LpControl visit(const LpControl c, const REAL lowerBound, const REAL primalBound) {
     lowerBound_.push_back(lowerBound);
     const INDEX timeElapsed = (INDEX)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - beginTime_).count();
-    if ((c.computePrimal || c.computeLowerBound) && verbosity_ >= 1)
-      std::cout << "iteration = " << curIter_ << ", lower bound = " << lowerBound << ", time elapsed = " << timeElapsed / 1000 << "." << (timeElapsed % 1000) / 10 << "s\n";
+    if ((c.computePrimal || c.computeLowerBound) && verbosity_ >= 1) {   // standard_visitor.hxx:116-128
+      std::cout << "iteration = " << curIter_;
+      if (c.computeLowerBound) std::cout << ", lower bound = " << lowerBound;
+      if (c.computePrimal) std::cout << ", upper bound = " << primalBound;
+      std::cout << ", time elapsed = " << timeElapsed / 1000 << "." << (timeElapsed % 1000) / 10 << "s\n";
+    }
     curIter_++; remainingIter_--;
     LpControl ret;
     if (remainingIter_ == 0) { ret.end = true; return ret; }
     if (primalBound <= lowerBound + eps) { ret.end = true; return ret; }
     if (timeout_ != std::numeric_limits<INDEX>::max() && timeElapsed / 1000 >= timeout_) remainingIter_ = std::min(INDEX(1), remainingIter_);
+    if (maxMemory_ > 0 && maxMemory_ < host_memory_used_mb()) remainingIter_ = std::min(INDEX(1), remainingIter_);   // --maxMemory, :152-160
     // (the reference compares as soon as curIter_ >= interval, standard_visitor.hxx:163-165, and on the first such visit
     // indexes lowerBound_[size - 1 - interval] with size == interval: out of bounds, covered there only by a debug
     // assert.  Deliberate deviation: start comparing one visit later, when that entry exists.)
@@ -64,7 +73,7 @@ class StandardVisitor {
   // mode of `c`: the solver may run them as ONE device call and replay the visits afterwards (same visits, same
   // arguments, same returned controls).  1 whenever anything could intervene (a timeout is checked per visit).
   INDEX quiet_iterations(const LpControl c) const {
-    if (c.end || c.error || c.computeLowerBound || c.computePrimal || timeout_ != std::numeric_limits<INDEX>::max()) return 1;
+    if (c.end || c.error || c.computeLowerBound || c.computePrimal || timeout_ != std::numeric_limits<INDEX>::max() || maxMemory_ > 0) return 1;
     INDEX n = 1;
     for (INDEX j = 1; j + 1 < remainingIter_; ++j) {            // the control visit j returns (see visit())
       const INDEX it = curIter_ + j;
@@ -79,7 +88,14 @@ class StandardVisitor {
     if (verbosity_ >= 1) std::cout << "final lower bound = " << lower_bound << ", upper bound = " << upper_bound << "\n";
   }
   const std::vector<REAL>& lower_bound_history() const { return lowerBound_; }
+  // resident set of this process in MB (what the reference's memory_used() reports; the model itself lives in HBM here)
+  static INDEX host_memory_used_mb() {
+    long pages = 0, rss = 0;
+    if (FILE* f = std::fopen("/proc/self/statm", "r")) { if (std::fscanf(f, "%ld %ld", &pages, &rss) != 2) rss = 0; std::fclose(f); }
+    return (INDEX)((double)rss * (double)sysconf(_SC_PAGESIZE) / (1024.0 * 1024.0));
+  }
  private:
+  INDEX maxMemory_ = 0;
   INDEX maxIter_ = 1000, remainingIter_ = 0, curIter_ = 0, timeout_ = std::numeric_limits<INDEX>::max();
   INDEX primalComputationInterval_ = 5, primalComputationStart_ = 1, lowerBoundComputationInterval_ = 1;
   INDEX minDualImprovementInterval_ = 10, verbosity_ = 0;

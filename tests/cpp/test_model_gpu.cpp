@@ -6,6 +6,7 @@
 // usage: test_model_gpu [--host-only]   (host-only: construction + counts, no device call)
 #include <cmath>
 #include <cstring>
+#include <sstream>
 #include <iostream>
 #include <stdexcept>
 
@@ -86,6 +87,32 @@ static void add_pairwise(MRF& lp, typename FMC_SRMP::UnaryFactor* u1, typename F
 
 int main(int argc, char** argv) {
   const bool host_only = argc > 1 && std::strcmp(argv[1], "--host-only") == 0;
+  {   // ---- StandardVisitor: the iteration line and the --maxMemory stop (reference standard_visitor.hxx:116-128, 152-160) ----
+    std::ostringstream line;
+    std::streambuf* was = std::cout.rdbuf(line.rdbuf());
+    StandardVisitor v({"--maxIter", "100", "-v", "1"});
+    int dummy = 0;
+    LpControl c = v.begin(dummy);
+    c = v.visit(c, 1.0, 9.0);                               // a plain iteration: bound only
+    LpControl p = c; p.computePrimal = true; p.computeLowerBound = true;
+    (void)v.visit(p, 2.0, 7.5);                             // a rounding iteration: bound and primal
+    std::cout.rdbuf(was);
+    const std::string out = line.str();
+    test(out.find("iteration = 0, lower bound = 1, time elapsed") != std::string::npos);
+    test(out.find("iteration = 1, lower bound = 2, upper bound = 7.5, time elapsed") != std::string::npos);
+    StandardVisitor m({"--maxIter", "100", "--maxMemory", "1"});   // 1 MB: less than any process here uses
+    c = m.begin(dummy);
+    c = m.visit(c, 1.0, 9.0);
+    test(!c.end && c.computePrimal && c.computeLowerBound);   // one iteration remaining: the rounding one
+    c = m.visit(c, 2.0, 9.0);
+    test(c.end);
+    StandardVisitor roomy({"--maxIter", "100", "--maxMemory", "100000000"});
+    c = roomy.begin(dummy);
+    c = roomy.visit(c, 1.0, 9.0);
+    test(!c.end && c.computePrimal);                           // iteration 1 is a rounding iteration by the interval rule only
+    c = roomy.visit(c, 2.0, 9.0);
+    test(!c.end && !c.computePrimal);
+  }
   {   // ---- test/test_model.cpp ----
     Solver<LP<test_FMC>, StandardVisitor> s;
     auto& lp = s.GetLP();

@@ -164,13 +164,21 @@ def test_joined_passes_as_one_blocked_chain_launch(pairwise, L, H, W, bands, lag
         e.upload(m); e.set_reparametrization(M.REPAM_ANISOTROPIC)
         assert e.plan.pass_rotates(M.REPAM_ANISOTROPIC)
         e.prepare_passes(5)
-        for n in (1, 5, 2, 1, 9, 70):                      # 70: slices of 32 + 32 + 6 passes, one launch each
+        cache = {}
+        for n in (1, 5, 2, 1, 9, 70, 8, 12, 20, 31, 13, 32):   # 70: slices of 32 + 32 + 6 passes, one launch each
             e.enable_kernel_timing(True)
             e.compute_pass(n); o.ComputePass(n)
             kt = e.kernel_timing(); e.reset_kernel_timing(); e.enable_kernel_timing(False)
             assert all(v["kernel"].startswith("chain_") and v["chain_launches"] == (n + 31) // 32 for v in kt.values()), kt
             assert np.array_equal(e.download_duals(), o.duals()), (n,)
             assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+            cache[n] = e.chain_cache_bytes()
+        if depth % 2 == 0:
+            # calls of more than 7 passes run from a periodic template (prologue, ONE period, tail; engine.cpp rotation_chain):
+            # ticket lists and flags of a launch do not grow with its pass count — 12, 20 and 32 passes (the same tail) added
+            # nothing to what 8 had built, 31 and 13 nothing to what 9 had (depth 4; depth 2 has one tail for all)
+            assert cache[12] == cache[8] and cache[20] == cache[8], cache
+            assert cache[13] == cache[31] == cache[32], cache
         flb = e.factor_lower_bounds()
         assert np.max(np.abs(flb - np.array([o.factor_lower_bound(f) for f in range(m.n_factors)]))) <= DUAL_ATOL
     finally:

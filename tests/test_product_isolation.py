@@ -51,3 +51,17 @@ def test_bench_uses_the_oracle_only_in_the_cpu_baseline_leg():
         if isinstance(node, ast.FunctionDef):
             uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(node))
             assert uses == (node.name in ("build", "smoke")), node.name
+
+
+def test_product_library_is_not_an_experiment_build():
+    """tools/build_variant.sh builds the same sources with tuning knobs and LPMP_ABLATE_* switches (the latter compute wrong
+    duals).  kernels.hip refuses the switches without LPMP_EXPERIMENT_BUILD, lp_mp_amd/build.py never sets it, and the library
+    says which it is"""
+    from lp_mp_amd import build as B, engine as E
+    assert not any("ABLATE" in f or "EXPERIMENT" in f for f in B.FLAGS)
+    assert E.lib().lpmp_experiment_build() == 0
+    src = open(os.path.join(ROOT, "lp_mp_amd", "csrc", "kernels.hip")).read()
+    used = set(re.findall(r"LPMP_ABLATE_[A-Z_0-9]+", src))
+    guard = src[: src.index("namespace lpmp {")]
+    assert used and all(m in guard for m in used), used - set(re.findall(r"LPMP_ABLATE_[A-Z_0-9]+", guard))
+    assert "#error" in guard and "LPMP_EXPERIMENT_BUILD" in guard

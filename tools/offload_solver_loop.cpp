@@ -6,7 +6,14 @@
 // The adapter lets the engine run passes ahead of the loop (lpmp_set_speculation); the loop is run with that on and off and
 // the two bound histories are compared (they must be identical).
 //
-//   offload_solver_loop [--grid 512] [--labels 32] [--iterations 60] [--warm 24]
+// --rounding 1: the DEFAULT cycle of MpRoundingSolver under StandardVisitor (include/solver.hxx:387-397,
+// include/visitors/standard_visitor.hxx:37,172-185): every primalComputationInterval-th (5th) iteration runs
+//   set_reparametrization(damped_uniform); ComputeForwardPassAndPrimal(iter); RegisterPrimal(); ComputeBackwardPassAndPrimal(iter);
+//   RegisterPrimal();  [RegisterPrimal = EvaluatePrimal, + CheckPrimalConsistency when the cost improved: solver.hxx:320-337]
+// the others the anisotropic ComputePass; LowerBound() after every iteration.  Reported: mean ms per iteration of the cycle and
+// of each kind of iteration; the bound / primal-cost history with and without passes running ahead must be identical.
+//
+//   offload_solver_loop [--grid 512] [--labels 32] [--iterations 60] [--warm 24] [--rounding 0|1]
 // Build: g++ -std=c++17 -O2 -I lp_mp_amd/include -I tests/cpp tools/offload_solver_loop.cpp -L lp_mp_amd/csrc -llpmp_engine -Wl,-rpath,$PWD/lp_mp_amd/csrc
 #include <algorithm>
 #include <chrono>
@@ -58,11 +65,12 @@ struct FMC_MRF {
 static double u01(uint64_t& st) { st = st * 6364136223846793005ULL + 1442695040888963407ULL; return (double)(st >> 11) / 9007199254740992.0; }
 
 int main(int argc, char** argv) {
-  int G = 512, L = 32, iters = 60, warm = 24;
+  int G = 512, L = 32, iters = 60, warm = 24, rounding = 0;
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string a = argv[i];
     if (a == "--grid") G = std::atoi(argv[i + 1]); else if (a == "--labels") L = std::atoi(argv[i + 1]);
     else if (a == "--iterations") iters = std::atoi(argv[i + 1]); else if (a == "--warm") warm = std::atoi(argv[i + 1]);
+    else if (a == "--rounding") rounding = std::atoi(argv[i + 1]);
   }
   try {
     using LP_device = lpmp_offload::offloaded<LP_MP::LP<FMC_MRF>>;
@@ -89,13 +97,35 @@ int main(int argc, char** argv) {
       if (r + 1 < G) edge(r * G + cc, (r + 1) * G + cc);
     }
     lp.Begin();
+    std::size_t iter = 0;                                    // Solver::iter: grows over the whole solve (the primal time stamps follow it)
+    std::size_t iter_base = 0;                               // the second configuration continues the stamps of the first (they must not decrease)
+    double best_primal = std::numeric_limits<double>::infinity();
+    double ms_plain = 0, ms_round = 0; int n_plain = 0, n_round = 0;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto register_primal = [&](std::vector<double>* hist) {   // Solver::RegisterPrimal, solver.hxx:320-337
+      const double cost = lp.EvaluatePrimal();
+      if (hist) hist->push_back(cost);
+      if (cost < best_primal && lp.CheckPrimalConsistency()) best_primal = cost;
+    };
     auto run = [&](int n, std::vector<double>* hist) {
       const auto t0 = std::chrono::steady_clock::now();
-      for (int it = 0; it < n; ++it) {                       // Solver::Solve: PreIterate, Iterate, PostIterate (computeLowerBound)
-        lp.set_reparametrization(LP_MP::LPReparametrizationMode::Anisotropic);
-        lp.ComputePass((std::size_t)it);
+      for (int it = 0; it < n; ++it, ++iter) {               // Solver::Solve: PreIterate, Iterate, PostIterate (computeLowerBound)
+        // StandardVisitor::visit: curIter_ >= primalComputationStart_ (1) && (curIter_ - 1) % primalComputationInterval_ (5) == 0
+        const bool primal = rounding && iter >= 1 && (iter - 1) % 5 == 0;
+        const double t_it = now_ms();
+        if (primal) {
+          lp.set_reparametrization(LP_MP::LPReparametrizationMode::DampedUniform);
+          lp.ComputeForwardPassAndPrimal(iter_base + iter);
+          register_primal(hist);
+          lp.ComputeBackwardPassAndPrimal(iter_base + iter);
+          register_primal(hist);
+        } else {
+          lp.set_reparametrization(LP_MP::LPReparametrizationMode::Anisotropic);
+          lp.ComputePass(iter);
+        }
         const double lb = lp.LowerBound();
         if (hist) hist->push_back(lb);
+        (primal ? ms_round : ms_plain) += now_ms() - t_it; ++(primal ? n_round : n_plain);
       }
       return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / n;
     };
@@ -105,20 +135,25 @@ int main(int argc, char** argv) {
     lpmp_engine* e = lp.engine();
     std::vector<double> start((size_t)lpmp_dual_size(e));
     lpmp_offload::check(lpmp_download_duals(e, start.data()));
-    double ms[2]; std::vector<double> hist[2]; int64_t stats[2][4];
+    double ms[2], kind_ms[2][2]; std::vector<double> hist[2]; int64_t stats[2][4];
     for (int k = 0; k < 2; ++k) {
       lp.set_speculation(k == 0 ? 0 : 16);
       lpmp_offload::check(lpmp_upload_duals(e, start.data()));
       (void)lp.LowerBound();
+      iter_base += iter; iter = 0; best_primal = std::numeric_limits<double>::infinity();
       run(warm, &hist[k]);                                   // builds the ticket lists of the batch sizes, warms the clocks
+      ms_plain = ms_round = 0; n_plain = n_round = 0;
       ms[k] = run(iters, &hist[k]);
+      kind_ms[k][0] = n_plain ? ms_plain / n_plain : 0; kind_ms[k][1] = n_round ? ms_round / n_round : 0;
       lpmp_offload::check(lpmp_speculation_stats(e, &stats[k][0], &stats[k][1], &stats[k][2], &stats[k][3]));
     }
     const bool same = hist[0] == hist[1];
     std::printf("{\"tool\": \"offload_solver_loop\", \"grid\": %d, \"labels\": %d, \"iterations\": %d, \"lower_bound_start\": %.17g, \"lower_bound_end\": %.17g, "
                 "\"ms_per_iteration_every_call_as_it_comes\": %.4f, \"ms_per_iteration_passes_running_ahead\": %.4f, "
+                "\"rounding_cycle\": %s, \"ms_plain_iteration\": [%.4f, %.4f], \"ms_rounding_iteration\": [%.4f, %.4f], \"best_primal_cost\": %.17g, "
                 "\"bound_history_identical\": %s, \"batches\": %lld, \"passes_launched\": %lld, \"passes_used\": %lld, \"rollbacks\": %lld}\n",
-                G, L, iters, lb0, hist[1].back(), ms[0], ms[1], same ? "true" : "false",
+                G, L, iters, lb0, hist[1].back(), ms[0], ms[1], rounding ? "true" : "false", kind_ms[0][0], kind_ms[1][0], kind_ms[0][1], kind_ms[1][1],
+                best_primal, same ? "true" : "false",
                 (long long)(stats[1][0] - stats[0][0]), (long long)(stats[1][1] - stats[0][1]), (long long)(stats[1][2] - stats[0][2]), (long long)(stats[1][3] - stats[0][3]));
     lp.End();
     return same ? 0 : 1;
