@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--c4-nodes", type=int, default=2_000_000)
     ap.add_argument("--c4-edges", type=int, default=10_000_000)
     ap.add_argument("--c4-labels", type=int, default=16)
+    ap.add_argument("--c4-order", default="colour_major", choices=["colour_major", "index"],
+                    help="--workload c4 --schedule lockstep: variable order of the random graph (colour_major: one dependent level per colour, "
+                         "18 exchanges per pass instead of 60; the boundary schedule and the 1-GPU line keep the generator's index order)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schedule", default="auto", choices=["auto", "overlap", "boundary", "lockstep"],
                     help="several GPUs: 'overlap' (grids in colour-major order; the default there) = every rank holds its strip plus "
@@ -49,6 +52,9 @@ def parse():
                          "cut; any graph); 'boundary' = every part sweeps its own sub-problem, cut messages reconciled in a boundary step "
                          "(multi_gpu.py; a small dual-bound gap, few exchanges; the default for --workload c4)")
     ap.add_argument("--ghost-rows", type=int, default=12, help="overlap schedule: rows of each neighbour a rank holds (even; n passes between exchanges need 2 n + 2)")
+    ap.add_argument("--rows-layout", default="auto", choices=["auto", "on", "off"],
+                    help="dense pairwise factors as [table | m1 | m2] rows of an engine-private buffer (lpmp_set_rows_layout): one burst per "
+                         "receive instead of a table and two single lines elsewhere.  auto: on for --workload c4 on one GPU")
     ap.add_argument("--no-compare-schedules", action="store_true",
                     help="several GPUs, grid workload: do NOT also run the other schedules (same pass count, after the timed region) for "
                          "the `schedules` entry of the line")
@@ -146,10 +152,12 @@ def dual_bound_gap_c4(torch, dist, args, mode, world, rank):
     one (same partitioner, same boundary schedule) against its unpartitioned sweep on rank 0"""
     from lp_mp_amd import engine as E, multi_gpu as MG, synthetic as S
     n, m, L, passes = 20000, 100000, args.c4_labels, args.steps
+    rank_of = None
     if args.schedule == "lockstep":
         from lp_mp_amd import lockstep as LS
-        sw = LS.LockstepGraph(torch, dist, n, m, L, mode, seed=1)
+        sw = LS.LockstepGraph(torch, dist, n, m, L, mode, seed=1, order=args.c4_order)
         sw.boundary_every, sw.global_cut_fraction = "level that reads across the cut (lock step)", sw.cut_fraction
+        rank_of = sw.rank_of
     else:
         sw = MG.GraphSweep(torch, dist, n, m, L, mode, seed=1)
     sw.compute_pass(passes)
@@ -157,7 +165,7 @@ def dual_bound_gap_c4(torch, dist, args, mode, world, rank):
     out = None
     if rank == 0:
         e = E.Engine(torch.cuda.current_device())
-        e.upload(S.counter_graph_model(n, m, L, 1))
+        e.upload(S.counter_graph_model(n, m, L, 1, rank=rank_of))
         e.set_reparametrization(mode)
         e.compute_pass(passes)
         lb_ref = e.lower_bound()
@@ -445,11 +453,12 @@ def main():
         L = args.c4_labels
         if dist_on and args.schedule == "lockstep":
             from lp_mp_amd import lockstep as LS
-            runner = LS.LockstepGraph(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1)
-            parallelism = (f"{world} parts in lock step (the unpartitioned sweep, {runner.halo_steps_per_pass():.1f} halo exchanges per pass), "
+            runner = LS.LockstepGraph(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1, order=args.c4_order)
+            parallelism = (f"{world} parts in lock step (the unpartitioned sweep in {args.c4_order} variable order, {runner.halo_steps_per_pass():.1f} halo exchanges per pass), "
                            f"{100 * runner.cut_fraction:.1f} % of the edges cut")
         else:
-            runner = MG.GraphSweep(torch, dist if dist_on else None, args.c4_nodes, args.c4_edges, L, mode, seed=1)
+            rows = (not dist_on) and args.rows_layout != "off"
+            runner = MG.GraphSweep(torch, dist if dist_on else None, args.c4_nodes, args.c4_edges, L, mode, seed=1, rows_layout=rows)
             parallelism = (f"{world} parts (reverse Cuthill-McKee + balanced KL refinement), {100 * runner.global_cut_fraction:.1f} % of the edges cut, "
                            f"boundary step every {runner.boundary_every}") if world > 1 else "1 GPU"
         updates_per_pass = runner.global_updates_per_pass
@@ -462,7 +471,7 @@ def main():
         t1 = time.perf_counter()
         eng = E.Engine(torch.cuda.current_device())
         eng.set_stream(stream_ptr)
-        eng.upload(m, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual))
+        eng.upload(m, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual), rows_layout=args.rows_layout == "on")
         eng.set_reparametrization(mode)
         eng.synchronize()
         setup["plan_schedules_upload_s"] = time.perf_counter() - t1   # ordering, weights, level schedule, op lists -> HBM
@@ -481,6 +490,7 @@ def main():
         eng = runner.engine
 
     lb0 = runner.lower_bound()
+    eng_rows = bool(getattr(eng, "rows_layout", False))
     setup["total_before_first_pass_s"] = time.perf_counter() - t_setup0
     t1 = time.perf_counter()
     if hasattr(runner, "prepare_passes"):            # ticket lists of the joined-pass chain launches (depends on the pass count)
@@ -497,6 +507,7 @@ def main():
     # number of passes are compared with the state the timed passes left in HBM
     oracle_check = None
     if not dist_on and args.workload == "c3":
+        eng.synchronize()                            # (rows layout: the packed dual buffer is written out here)
         oracle_check = golden_check(torch, args, dual, lb1)
 
     # roofline leg: the same passes again with every launch bracketed by HIP events on the engine's stream
@@ -624,6 +635,7 @@ def main():
                                     "index order" if args.workload == "c4" else
                                     f"{H}x{W} grid per GPU, {L} labels, {args.pairwise} pairwise, {args.mode} weights, {args.order} order"),
                        "parallelism": parallelism,
+                       "pairwise_layout": "rows [table | m1 | m2], engine-private" if eng_rows else "packed (tables / serialize_dual order)",
                        "levels_per_direction": levels, "msg_updates_per_pass": updates_per_pass,
                        "algorithmic_bytes_per_pass": bytes_per_pass},
             "pass_algorithmic_GBps": bytes_per_pass * args.steps / dt / 1e9,

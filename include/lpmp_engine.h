@@ -232,7 +232,17 @@ int64_t lpmp_dual_size(const lpmp_engine* e);
 /* serialize_dual + save_archive / load_archive (include/serialization.hxx:228-424): packed duals */
 int lpmp_download_duals(lpmp_engine* e, double* host_out);
 int lpmp_upload_duals(lpmp_engine* e, const double* host_in);
-void* lpmp_device_duals(lpmp_engine* e);   /* device pointer of the packed duals (for zero-copy exchange) */
+void* lpmp_device_duals(lpmp_engine* e);   /* device pointer of the packed duals (for zero-copy exchange); with the rows layout
+                                              the dense pairwise factors' vectors are written out to it first, and the rows are
+                                              refreshed from it before the next pass (the caller is assumed to write it) */
+/* Rows layout (engine-private): from the NEXT lpmp_upload_model on, every dense pairwise factor lives on the device
+ * as one contiguous row [table | m1 | m2] of a buffer of the engine's own, so that the three reads of a receive are one burst
+ * (random graphs: C4).  The packed dual array — serialize_dual order, reference factors_messages.hxx:3196-3223 — stays the format
+ * of every call that hands duals over (lpmp_download_duals / lpmp_upload_duals / lpmp_device_duals / lpmp_synchronize with a
+ * borrowed buffer / the lpmp_boundary_* offsets): the message vectors are copied between the two at those calls, never inside a
+ * pass.  Costs the tables a second time in device memory; passes that run ahead of the caller (lpmp_set_speculation) stay off. */
+int lpmp_set_rows_layout(lpmp_engine* e, int on);
+int lpmp_rows_layout(const lpmp_engine* e);   /* 1 if the uploaded model uses it */
 
 const lpmp_plan* lpmp_engine_plan(const lpmp_engine* e);
 lpmp_plan* lpmp_engine_plan_mut(lpmp_engine* e);

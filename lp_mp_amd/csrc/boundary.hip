@@ -85,6 +85,9 @@ extern "C" {
 void* lpmp_engine_stream(lpmp_engine* e);      // engine.cpp
 int lpmp_set_last_error(const char* msg);      // engine.cpp
 int lpmp_boundary_enter(lpmp_engine* e);       // engine.cpp: the engine's device current, speculative passes settled, no aborted chain run behind
+void* lpmp_engine_dual_base(lpmp_engine* e);   // engine.cpp: the dual base pointer the device offsets are relative to
+int64_t lpmp_engine_device_dual_offset(lpmp_engine* e, int64_t packed_off);   // engine.cpp: a packed dual offset as a device offset (rows layout)
+int lpmp_boundary_leave(lpmp_engine* e);       // engine.cpp: duals were written through device offsets
 
 #define B_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { lpmp_set_last_error((std::string(#x) + ": " + hipGetErrorString(e_)).c_str()); return LPMP_ERR_DEVICE; } } while (0)
 
@@ -95,7 +98,7 @@ static int boundary_create(lpmp_engine* e, int64_t n_out, const int64_t* out_dua
   std::unique_ptr<lpmp_boundary> b(new lpmp_boundary());
   std::vector<BVec> ov((size_t)n_out);
   int64_t at = 0;
-  for (int64_t i = 0; i < n_out; ++i) { ov[i] = {out_dual_off[i], at, out_len[i], 0}; at += out_len[i]; }
+  for (int64_t i = 0; i < n_out; ++i) { ov[i] = {lpmp_engine_device_dual_offset(e, out_dual_off[i]), at, out_len[i], 0}; at += out_len[i]; }
   b->n_out = n_out; b->out_doubles = at;
   // incoming messages arrive in exchange order (buffer offsets by prefix sum); in_order lists them grouped by variable,
   // inside a variable in the order its message list holds them
@@ -107,7 +110,8 @@ static int boundary_create(lpmp_engine* e, int64_t n_out, const int64_t* out_dua
     const int64_t m = in_order[k];
     if (m < 0 || m >= n_in) { lpmp_set_last_error("boundary: in_order out of range"); return LPMP_ERR_INVALID; }
     seq[k] = {in_buf[m], in_omega[m]};
-    if (vars.empty() || vars.back().dual_off != in_dual_off[m]) vars.push_back({in_dual_off[m], in_len[m], (int32_t)k, 0, 0});
+    const int64_t dev_off = lpmp_engine_device_dual_offset(e, in_dual_off[m]);
+    if (vars.empty() || vars.back().dual_off != dev_off) vars.push_back({dev_off, in_len[m], (int32_t)k, 0, 0});
     if (vars.back().len != in_len[m]) { lpmp_set_last_error("boundary: messages of one variable differ in length"); return LPMP_ERR_INVALID; }
     vars.back().n++;
   }
@@ -140,25 +144,25 @@ int lpmp_boundary_pack(lpmp_engine* e, lpmp_boundary* b, double* send_dev) {
   if (!e || !b || (b->n_out > 0 && !send_dev)) { lpmp_set_last_error("bad argument"); return LPMP_ERR_INVALID; }
   if (const int rc = lpmp_boundary_enter(e)) return rc;
   if (b->n_out > 0) hipLaunchKernelGGL(boundary_pack_kernel, dim3((unsigned)((b->n_out + 3) / 4)), dim3(256), 0, (hipStream_t)lpmp_engine_stream(e),
-                                       b->d_out, b->n_out, (double*)lpmp_device_duals(e), send_dev);
+                                       b->d_out, b->n_out, (double*)lpmp_engine_dual_base(e), send_dev);
   B_TRY(hipGetLastError());
-  return lpmp_invalidate_lower_bounds(e);
+  return lpmp_boundary_leave(e);
 }
 int lpmp_boundary_reply(lpmp_engine* e, lpmp_boundary* b, const double* recv_dev, double* reply_dev) {
   if (!e || !b || (b->n_vars > 0 && (!recv_dev || !reply_dev))) { lpmp_set_last_error("bad argument"); return LPMP_ERR_INVALID; }
   if (const int rc = lpmp_boundary_enter(e)) return rc;
   if (b->n_vars > 0) hipLaunchKernelGGL(boundary_reply_kernel, dim3((unsigned)((b->n_vars + 3) / 4)), dim3(256), 0, (hipStream_t)lpmp_engine_stream(e),
-                                        b->d_vars, b->d_seq, b->n_vars, (double*)lpmp_device_duals(e), recv_dev, reply_dev);
+                                        b->d_vars, b->d_seq, b->n_vars, (double*)lpmp_engine_dual_base(e), recv_dev, reply_dev);
   B_TRY(hipGetLastError());
-  return lpmp_invalidate_lower_bounds(e);
+  return lpmp_boundary_leave(e);
 }
 int lpmp_boundary_fold(lpmp_engine* e, lpmp_boundary* b, const double* back_dev) {
   if (!e || !b || (b->n_out > 0 && !back_dev)) { lpmp_set_last_error("bad argument"); return LPMP_ERR_INVALID; }
   if (const int rc = lpmp_boundary_enter(e)) return rc;
   if (b->n_out > 0) hipLaunchKernelGGL(boundary_fold_kernel, dim3((unsigned)((b->n_out + 3) / 4)), dim3(256), 0, (hipStream_t)lpmp_engine_stream(e),
-                                       b->d_out, b->n_out, (double*)lpmp_device_duals(e), back_dev);
+                                       b->d_out, b->n_out, (double*)lpmp_engine_dual_base(e), back_dev);
   B_TRY(hipGetLastError());
-  return lpmp_invalidate_lower_bounds(e);
+  return lpmp_boundary_leave(e);
 }
 
 // out[b * block_len + i] = u01(seed, first[b] + i): the cost blocks of a scattered subset of a global stream (a rank's

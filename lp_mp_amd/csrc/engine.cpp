@@ -40,6 +40,8 @@ void launch_factor_lb(const void* recs, const double* dual, const double* cdata,
 bool launch_dense_lb(int L, const void* recs, const double* dual, const double* cdata, double* out, int64_t first, int64_t count, hipStream_t s);
 void launch_sum_stage(const double* in, double* out, int64_t n, int64_t per_block, int64_t n_blocks, hipStream_t s);
 void launch_synth_fill(double* out, int64_t n, uint64_t seed, uint64_t first, hipStream_t s);
+void launch_rows_copy(const void* recs, int64_t n, const double* cdata, double* dual, double* rows, int what, hipStream_t s);
+struct RowRecHost { int64_t dual_off, const_off, row_off; int32_t d0, d1; };
 int generic_max_dual();
 int generic_max_adaptive_sends();
 struct LbRecHost { int64_t dual_off; int64_t const_off; int32_t d0, d1; int32_t kind_flags; int32_t pad; };
@@ -120,6 +122,7 @@ struct ChainArgsHost {
   unsigned long long* mailbox;              // or nullptr
   long long timeout_ticks;                  // bound of every wait, ticks of the 100 MHz s_memrealtime clock
   int32_t per_begin, per_len, per_count, per_launch_shift, per_row_shift;   // periodic ticket lists (kernels.hip, ChainArgs)
+  int32_t hist_rows;                        // rows of lb_hist the launch may write
   int32_t ring;                             // slots of done[] when it is a ring (0: one flag per ticket)
 };
 constexpr int CHAIN_GEN_BITS = 8;           // kernels.hip
@@ -345,6 +348,11 @@ struct lpmp_engine {
   uint64_t primal_t = 0;          // primal_access_ of every factor a primal pass touches (they move together)
   bool have_primal = false;
   bool primal_pass = false;       // the launches being issued belong to an ...AndPrimal pass
+  // rows layout (kernels.hip, rows_copy_kernel): dense pairwise factors live as [table | m1 | m2] rows of d_rows; the packed
+  // dual array keeps the vector factors and is the format of every call that hands duals over.  packed_stale: the rows hold
+  // newer message vectors than the packed array; rows_stale: the packed array was (or may have been) written by the caller
+  bool want_rows = false, rows = false, packed_stale = false, rows_stale = false;
+  double* d_rows = nullptr; RowRecHost* d_rowrecs = nullptr; int64_t n_rowrecs = 0;
   int nt_flag = 0;                // SWEEP_NT when tables + duals are far larger than L2 + Infinity Cache
   bool model_big = false;         // tables + duals > 1 GiB: only then is an Infinity-Cache ticket order worth a chain launch
   struct LbRun { int cls; int64_t first, count; };
@@ -440,6 +448,9 @@ struct lpmp_engine {
     if (own_const && d_const) (void)hipFree(d_const);
     d_dual = nullptr; d_const = nullptr; own_dual = own_const = false;
     if (d_tabs) { (void)hipFree(d_tabs); d_tabs = nullptr; }
+    if (d_rows) { (void)hipFree(d_rows); d_rows = nullptr; }
+    if (d_rowrecs) { (void)hipFree(d_rowrecs); d_rowrecs = nullptr; }
+    rows = packed_stale = rows_stale = false; n_rowrecs = 0;
     if (d_lbrecs) { (void)hipFree(d_lbrecs); d_lbrecs = nullptr; }
     if (d_lb) { (void)hipFree(d_lb); d_lb = nullptr; }
     if (d_part) { (void)hipFree(d_part); d_part = nullptr; }
@@ -805,7 +816,7 @@ void run_schedule(lpmp_engine* e, DevSchedule& s) {
       }
       HIP_CHECK(hipMemsetAsync(c.next, 0, sizeof(int32_t), e->stream));
       ChainTrace tr;
-      const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream), nullptr, 0, c.mailbox, chain_timeout_ticks(), 0, 0, 0, 0, 0, 0};
+      const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, c.tickets, ++c.epoch, tr.begin(c.tickets, e->stream), nullptr, 0, c.mailbox, chain_timeout_ticks(), 0, 0, 0, 0, 0, 0, 0};
       if (!launch_chain(c.kclass, rule | (c.banded ? 0 : e->nt_flag), &ca, c.launches, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->d_primal, e->stream))
         throw DeviceError("chain executor: no kernel for class " + std::to_string(c.kclass));
       tr.end(c, e->stream, e->d_chain_abort);
@@ -1005,7 +1016,9 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n_call) {
       // and K after pass i (step 2 i + 2) write row i, for the passes i = 0 ... n - 2 that have a seam behind them
       // (periodic template: the tail's last W is the last W of ANY call of this parity)
       int32_t hist = 0;
-      if (tmpl[s] == 1 && (s - 1) / 2 < n - 1) hist = HIST_END | (((s - 1) / 2) << 2);
+      // (periodic template: every W carries its row — whether it has a seam behind it depends on the call, and the kernel drops
+      // rows >= ChainArgs::hist_rows)
+      if (tmpl[s] == 1 && ((s - 1) / 2 < n - 1 || periodic)) hist = HIST_END | (((s - 1) / 2) << 2);
       if (tmpl[s] == 2) hist = HIST_MID | (((s - 2) / 2) << 2);
       lds.push_back({t.lr.stride > 0 ? ds.packets + t.lr.pk_begin : nullptr, ds.recs + t.lr.begin, ds.ops, t.lr.end - t.lr.begin, t.lr.stride, hist});
       rc.factors += t.factors; rc.recv += t.recv; rc.bytes += t.bytes;
@@ -1065,7 +1078,7 @@ bool run_rotation_chain(lpmp_engine* e, int mode, int n, double* lb_hist = nullp
   const ChainArgsHost ca{c.dep_off, c.dep, c.done, c.next, e->d_chain_abort, c.tk_launch, c.tk_block, n_tickets, ++c.epoch, rc->periodic ? nullptr : tr.begin(c.tickets, e->stream),
                          lb_hist, lb_hist ? e->plan->p.nf : 0, nullptr, chain_timeout_ticks(),
                          rc->periodic ? rc->per_begin : 0, rc->periodic ? rc->per_len : 0, rc->periodic ? 1 + extra : 0, 0,
-                         rc->periodic ? rc->depth / 2 : 0, rc->periodic ? rc->ring : 0};
+                         rc->periodic ? rc->depth / 2 : 0, lb_hist ? n - 1 : 0, rc->periodic ? rc->ring : 0};
   hipEvent_t a = nullptr, b = nullptr;
   if (e->timing) { a = e->get_event(); b = e->get_event(); HIP_CHECK(hipEventRecord(a, e->stream)); }
   // (plain table loads, not the streaming policy: the second reader of a table is meant to find it in the Infinity Cache)
@@ -1090,6 +1103,14 @@ void require_mode(const lpmp_engine* e) {
 }  // namespace
 
 static void settle(lpmp_engine* e);          // speculative passes: make the device state the caller's state (below)
+// rows layout: bring the side that is about to be read up to date (stream-ordered copies of the message vectors)
+static void rows_refresh(lpmp_engine* e) {   // packed duals -> rows, before anything computes on the rows
+  if (e->rows && e->rows_stale) { launch_rows_copy(e->d_rowrecs, e->n_rowrecs, e->d_const, e->d_dual, e->d_rows, 1, e->stream); HIP_CHECK(hipGetLastError()); e->rows_stale = false; }
+}
+static void rows_flush(lpmp_engine* e) {     // rows -> packed duals, before the packed array is handed to anybody
+  if (e->rows && e->packed_stale) { launch_rows_copy(e->d_rowrecs, e->n_rowrecs, e->d_const, e->d_dual, e->d_rows, 2, e->stream); HIP_CHECK(hipGetLastError()); e->packed_stale = false; }
+}
+static void begin_compute(lpmp_engine* e) { rows_refresh(e); if (e->rows) e->packed_stale = true; }
 
 extern "C" {
 
@@ -1317,6 +1338,7 @@ int lpmp_create(int device, lpmp_engine** out) {
     if (const char* v = std::getenv("LPMP_ROT_LAG")) e->rot_lag = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LPMP_ROT_DEPTH")) e->rot_depth = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LPMP_CHAIN_CACHE_MB")) e->rot_cache_limit = (size_t)std::max(1, std::atoi(v)) << 20;
+    if (const char* v = std::getenv("LPMP_ROWS_LAYOUT")) e->want_rows = std::atoi(v) != 0;                             // as lpmp_set_rows_layout
     if (const char* v = std::getenv("LPMP_SPECULATION")) e->spec.max_depth = std::min(32, std::max(0, std::atoi(v)));   // as lpmp_set_speculation
     *out = e.release();
   });
@@ -1391,6 +1413,37 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
       e->own_dual = true;
       h2d(e->d_dual, m->dual_data, (size_t)n_dual * sizeof(double), e->stream);
     }
+    if (e->want_rows && e->d_const) {
+      // rows layout: every dense pairwise factor becomes one row [table | m1 | m2] of a private buffer; its device offsets
+      // (relative to the const / dual base pointers, which the kernels add them to) point there from now on
+      std::vector<RowRecHost> rr;
+      int64_t at = 0;
+      for (int64_t f = 0; f < p.nf; ++f)
+        if (p.f_kind[f] == LPMP_F_PAIRWISE_DENSE) {
+          rr.push_back({p.f_doff[f], p.f_coff[f], at, p.f_dim0[f], p.f_dim1[f]});
+          at += ((int64_t)p.f_dim0[f] * p.f_dim1[f] + p.f_dim0[f] + p.f_dim1[f] + 1) / 2 * 2;      // rows start 16-byte aligned
+        }
+      if (!rr.empty()) {
+        HIP_CHECK(hipMalloc((void**)&e->d_rows, (size_t)at * sizeof(double)));
+        if ((((uintptr_t)e->d_rows - (uintptr_t)e->d_const) % 16) != 0 || (((uintptr_t)e->d_rows - (uintptr_t)e->d_dual) % 8) != 0)
+          throw std::runtime_error("rows layout: buffers are not aligned to each other");
+        HIP_CHECK(hipMalloc((void**)&e->d_rowrecs, rr.size() * sizeof(RowRecHost)));
+        h2d(e->d_rowrecs, rr.data(), rr.size() * sizeof(RowRecHost), e->stream);
+        e->n_rowrecs = (int64_t)rr.size();
+        launch_rows_copy(e->d_rowrecs, e->n_rowrecs, e->d_const, e->d_dual, e->d_rows, 0, e->stream);
+        HIP_CHECK(hipGetLastError());
+        const int64_t c_shift = (int64_t)(((intptr_t)e->d_rows - (intptr_t)e->d_const) / 8), d_shift = (int64_t)(((intptr_t)e->d_rows - (intptr_t)e->d_dual) / 8);
+        pl->p.dev_coff.assign(p.f_coff.begin(), p.f_coff.end()); pl->p.dev_doff.assign(p.f_doff.begin(), p.f_doff.end());
+        size_t k = 0;
+        for (int64_t f = 0; f < p.nf; ++f)
+          if (p.f_kind[f] == LPMP_F_PAIRWISE_DENSE) {
+            pl->p.dev_coff[f] = c_shift + rr[k].row_off;
+            pl->p.dev_doff[f] = d_shift + rr[k].row_off + (int64_t)p.f_dim0[f] * p.f_dim1[f];
+            ++k;
+          }
+        e->rows = true; e->packed_stale = false; e->rows_stale = false;
+      }
+    }
     if (!p.tab_data.empty()) {
       HIP_CHECK(hipMalloc((void**)&e->d_tabs, p.tab_data.size() * sizeof(int32_t)));
       h2d(e->d_tabs, p.tab_data.data(), p.tab_data.size() * sizeof(int32_t), e->stream);
@@ -1398,12 +1451,12 @@ int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int du
     // lower-bound records, in factor order, and runs of factors the streaming dense kernel can take
     std::vector<LbRecHost> lb(p.nf);
     auto lb_class = [&](int64_t f) {
-      if (p.f_kind[f] == LPMP_F_PAIRWISE_DENSE && p.f_dim0[f] == p.f_dim1[f] && (p.f_coff[f] % 2) == 0 &&
+      if (p.f_kind[f] == LPMP_F_PAIRWISE_DENSE && p.f_dim0[f] == p.f_dim1[f] && (p.coff(f) % 2) == 0 &&
           (p.f_dim0[f] == 8 || p.f_dim0[f] == 16 || p.f_dim0[f] == 32)) return p.f_dim0[f];
       return 0;
     };
     for (int64_t f = 0; f < p.nf; ++f) {
-      lb[f] = {p.f_doff[f], p.f_kind[f] == LPMP_F_VECTOR ? -1 : p.f_coff[f], p.f_dim0[f], p.f_dim1[f], p.f_kind[f] | (p.f_flags[f] << 4), 0};
+      lb[f] = {p.doff(f), p.f_kind[f] == LPMP_F_VECTOR ? -1 : p.coff(f), p.f_dim0[f], p.f_dim1[f], p.f_kind[f] | (p.f_flags[f] << 4), 0};
       const int c = lb_class(f);
       if (e->lb_runs.empty() || e->lb_runs.back().cls != c) e->lb_runs.push_back({c, f, 1}); else e->lb_runs.back().count++;
     }
@@ -1513,10 +1566,10 @@ static void ensure_partition_schedule(lpmp_engine* e, int rtype) {
 }
 
 int lpmp_compute_forward_pass(lpmp_engine* e) {
-  return guarded([&] { require_mode(e); HIP_CHECK(hipSetDevice(e->device)); settle(e); run_schedule(e, e->sched[0][e->mode]); });
+  return guarded([&] { require_mode(e); HIP_CHECK(hipSetDevice(e->device)); settle(e); begin_compute(e); run_schedule(e, e->sched[0][e->mode]); });
 }
 int lpmp_compute_backward_pass(lpmp_engine* e) {
-  return guarded([&] { require_mode(e); HIP_CHECK(hipSetDevice(e->device)); settle(e); run_schedule(e, e->sched[1][e->mode]); });
+  return guarded([&] { require_mode(e); HIP_CHECK(hipSetDevice(e->device)); settle(e); begin_compute(e); run_schedule(e, e->sched[1][e->mode]); });
 }
 static void compute_plain_passes(lpmp_engine* e, int n) {   // ComputeForwardPass(); ComputeBackwardPass(); n times
   if (e->use_fused) {
@@ -1665,7 +1718,7 @@ static bool spec_lower_bound(lpmp_engine* e, double* out) {
 }
 static bool spec_usable(const lpmp_engine* e) {
   return e->spec.max_depth >= 2 && e->rtype == LPMP_RTYPE_SHARED && e->use_fused && e->use_rotation && e->use_chain &&
-         e->use_blocked_passes && e->use_lb_tracking && !e->timing;
+         e->use_blocked_passes && e->use_lb_tracking && !e->timing && !e->rows;
 }
 
 int lpmp_set_speculation(lpmp_engine* e, int max_passes_ahead) {
@@ -1692,6 +1745,7 @@ int lpmp_compute_pass(lpmp_engine* e, int n) {   // LP::ComputePass, LP_MP.h:869
   return guarded([&] {
     require_mode(e);
     HIP_CHECK(hipSetDevice(e->device));
+    begin_compute(e);
     if (n == 1 && e->spec.max_depth >= 2) {
       auto& sp = e->spec;
       if (sp.n > 0) {
@@ -1803,6 +1857,7 @@ static void run_primal_sweep(lpmp_engine* e, int d, uint64_t t) {
   require_mode(e);
   HIP_CHECK(hipSetDevice(e->device));
   settle(e);
+  begin_compute(e);
   ensure_primal(e);
   // the reference asserts primal_access_ <= timestamp (factors_messages.hxx:3304); in a release build a smaller
   // stamp lowers primal_access_ of the rounded factors only and later passes depend on the update order
@@ -1854,6 +1909,7 @@ int lpmp_evaluate_primal(lpmp_engine* e, double* cost) {
     ensure_primal(e);
     if (!primal_consistent(e)) { *cost = std::numeric_limits<double>::infinity(); return; }
     const int64_t nf = e->plan->p.nf;
+    rows_refresh(e);
     launch_primal_cost(e->d_lbrecs, e->d_dual, e->d_const, e->d_primal, e->d_pcost, nf, e->stream);
     int64_t nb = std::min<int64_t>(1024, (nf + 255) / 256);
     const int64_t per = (nf + nb - 1) / nb;
@@ -1895,6 +1951,7 @@ int lpmp_compute_pass_custom(lpmp_engine* e, int64_t n, const int32_t* factors, 
     check_rows(n, om_off, om, mk_off, mk);
     HIP_CHECK(hipSetDevice(e->device));
     settle(e);
+    begin_compute(e);
     Schedule s;
     static const double dz = 0; static const uint8_t uz = 0;
     e->plan->p.make_schedule(factors, n, om_off, om ? om : &dz, mk_off, mk ? mk : &uz, s);
@@ -1945,6 +2002,7 @@ int lpmp_schedule_run(lpmp_engine* e, int id) {
       throw StateError("this schedule was prepared under another send rule (adaptive sends run on other kernels): create it again");
     HIP_CHECK(hipSetDevice(e->device));
     settle(e);
+    begin_compute(e);
     run_schedule(e, d);
   });
 }
@@ -1991,6 +2049,7 @@ static void check_chain(lpmp_engine* e) {
 
 static void compute_factor_lbs(lpmp_engine* e) {
   check_chain(e);
+  rows_refresh(e);
   if (e->use_lb_tracking && !e->lb_all_stale) {
     // the sweep kernels kept d_lb current except for the entries they marked NaN: recompute only those
     const int64_t nf = e->plan->p.nf;
@@ -2049,6 +2108,8 @@ int lpmp_synchronize(lpmp_engine* e) {
     if (!e) throw std::runtime_error("null engine");
     HIP_CHECK(hipSetDevice(e->device));
     settle(e);                                  // after this call the (possibly borrowed) dual buffer holds the caller's state
+    rows_flush(e);
+    if (e->rows && !e->own_dual) e->rows_stale = true;   // ... and the caller may write it: the rows are refreshed before the next pass
     HIP_CHECK(hipStreamSynchronize(e->stream));
     if (e->timing) e->drain_timing();
     check_chain(e);
@@ -2079,6 +2140,7 @@ int lpmp_download_duals(lpmp_engine* e, double* out) {
     HIP_CHECK(hipSetDevice(e->device));
     settle(e);
     check_chain(e);
+    rows_flush(e);
     d2h(out, e->d_dual, (size_t)lpmp_dual_size(e) * sizeof(double), e->stream);
   });
 }
@@ -2089,13 +2151,40 @@ int lpmp_upload_duals(lpmp_engine* e, const double* in) {
     HIP_CHECK(hipSetDevice(e->device));
     settle(e);
     h2d(e->d_dual, in, (size_t)lpmp_dual_size(e) * sizeof(double), e->stream);
+    if (e->rows) { e->rows_stale = true; e->packed_stale = false; }
     e->lb_all_stale = true;
   });
 }
 int lpmp_invalidate_lower_bounds(lpmp_engine* e) {
-  return guarded([&] { require_model(e); settle(e); e->lb_all_stale = true; });
+  // (the caller says it wrote the packed dual array behind the engine's back: with the rows layout, what it wrote there for
+  // a dense pairwise factor replaces the row's vectors — after what the rows hold has been written out, so that everything
+  // the caller did not touch survives)
+  return guarded([&] { require_model(e); settle(e); if (e->rows) { rows_flush(e); e->rows_stale = true; } e->lb_all_stale = true; });
 }
-void* lpmp_device_duals(lpmp_engine* e) { return e ? e->d_dual : nullptr; }
+// The packed dual array (serialize_dual order) on the device.  With the rows layout the dense pairwise factors' vectors are
+// written out to it first (stream-ordered on the engine's stream), and the caller is assumed to write it: the rows are
+// refreshed from it before the next pass — callers that only read may say so by not calling this between passes.
+void* lpmp_device_duals(lpmp_engine* e) {
+  if (!e) return nullptr;
+  if (e->rows) { try { (void)hipSetDevice(e->device); rows_flush(e); e->rows_stale = true; } catch (const std::exception& ex) { g_error = ex.what(); return nullptr; } }
+  return e->d_dual;
+}
+// internal (boundary.hip): the base pointer itself, and where a packed dual offset lives on the device
+void* lpmp_engine_dual_base(lpmp_engine* e) { return e ? e->d_dual : nullptr; }
+int64_t lpmp_engine_device_dual_offset(lpmp_engine* e, int64_t packed_off) {
+  if (!e || !e->plan || e->plan->p.dev_doff.empty()) return packed_off;
+  const Plan& p = e->plan->p;
+  const int64_t f = (int64_t)(std::upper_bound(p.f_doff.begin(), p.f_doff.end(), packed_off) - p.f_doff.begin()) - 1;
+  if (f < 0 || f >= p.nf) return packed_off;
+  return p.dev_doff[f] + (packed_off - p.f_doff[f]);
+}
+int lpmp_boundary_leave(lpmp_engine* e) {      // a boundary kernel wrote duals through device offsets: only the tracked bounds are stale
+  return guarded([&] { require_model(e); e->lb_all_stale = true; if (e->rows) e->packed_stale = true; });
+}
+int lpmp_set_rows_layout(lpmp_engine* e, int on) {
+  return guarded([&] { if (!e) throw std::runtime_error("null engine"); e->want_rows = on != 0; });
+}
+int lpmp_rows_layout(const lpmp_engine* e) { return e && e->rows ? 1 : 0; }
 void* lpmp_engine_stream(lpmp_engine* e) { return e ? (void*)e->stream : nullptr; }
 const lpmp_plan* lpmp_engine_plan(const lpmp_engine* e) { return e ? e->plan.get() : nullptr; }
 lpmp_plan* lpmp_engine_plan_mut(lpmp_engine* e) { return e ? e->plan.get() : nullptr; }

@@ -139,6 +139,9 @@ struct ChainArgs {
   // of as many steps later), its dependencies the template's + q * per_len, its bound row the template's + q * per_row_shift.
   // per_len == 0: plain lists.  Host work and device memory of an n-pass launch are then independent of n.
   int32_t per_begin, per_len, per_count, per_launch_shift, per_row_shift;
+  // rows of lb_hist the launch may write (an n-pass call has n - 1 seams): a W step of a periodic template carries a row
+  // even when, in a call that ends right behind it, it is the LAST step before T and has no seam behind it
+  int32_t hist_rows;
   // ring > 0: done[] has `ring` slots, ticket t publishes {epoch, t / ring} into slot t % ring AFTER ticket t - ring has
   // published there (one more dependency of t), and a waiter accepts any generation >= the one it needs
   int32_t ring;
@@ -1379,7 +1382,10 @@ __device__ __forceinline__ void chain_loop(const ChainArgs& ca, const ChainLaunc
     chain_stamp(ca, ticket, 0);                    // ticket in hand
     const TicketRef tr = chain_ticket_ref(ca, ticket);
     ChainLaunch ln = launches[ca.tk_launch[tr.idx] + tr.copy * ca.per_launch_shift];
-    if (ln.pad & 3) ln.pad += (tr.copy * ca.per_row_shift) << 2;      // joined passes: bound row of this copy's pass (HIST_* | row << 2)
+    if (ln.pad & 3) {                                                  // joined passes: bound row of this copy's pass (HIST_* | row << 2)
+      ln.pad += (tr.copy * ca.per_row_shift) << 2;
+      if ((ln.pad >> 2) >= ca.hist_rows) ln.pad = 0;
+    }
     body(ln, (int64_t)ca.tk_block[tr.idx], ticket);
     chain_publish(ca, ticket);
     __syncthreads();                               // s_ticket[(it + 1) & 1] is written, the LDS of the body is free again
@@ -2831,6 +2837,30 @@ void launch_primal_check(const PrimalLink* links, int64_t n, const int32_t* prim
 }
 void launch_primal_cost(const void* recs, const double* dual, const double* cdata, const int32_t* primal, double* out, int64_t count, hipStream_t s) {
   if (count > 0) hipLaunchKernelGGL(primal_cost_kernel, blocks256(count), dim3(256), 0, s, (const LbRec*)recs, dual, cdata, primal, out, count);
+}
+
+// ---- rows layout (engine.cpp): a dense pairwise factor's table and its two message vectors in ONE contiguous row ----------
+// [T (d0 x d1) | m1 (d0) | m2 (d1)] of an engine-private buffer, so that a receive's three reads are one burst (a random
+// graph's receives otherwise touch a 2-KiB table and two single 128-byte lines somewhere else: C4).  The packed
+// arrays stay the boundary's format (serialize_dual order); these copies move between the two.
+//   what 0: build a row (table from the packed constants, vectors from the packed duals)
+//   what 1: packed duals -> rows (vectors only)      what 2: rows -> packed duals (vectors only)
+struct RowRec { int64_t dual_off, const_off, row_off; int32_t d0, d1; };
+__global__ void __launch_bounds__(256)
+rows_copy_kernel(const RowRec* __restrict__ recs, int64_t n, const double* __restrict__ cdata, double* __restrict__ dual, double* __restrict__ rows, int what) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  const RowRec r = recs[i];
+  const int nt = r.d0 * r.d1, nm = r.d0 + r.d1;
+  double* row = rows + r.row_off;
+  if (what == 0) for (int x = lane; x < nt; x += 64) row[x] = cdata[r.const_off + x];
+  if (what == 2) { for (int x = lane; x < nm; x += 64) dual[r.dual_off + x] = row[nt + x]; }
+  else { for (int x = lane; x < nm; x += 64) row[nt + x] = dual[r.dual_off + x]; }
+}
+void launch_rows_copy(const void* recs, int64_t n, const double* cdata, double* dual, double* rows, int what, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(rows_copy_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, (const RowRec*)recs, n, cdata, dual, rows, what);
 }
 
 void launch_sum_stage(const double* in, double* out, int64_t n, int64_t per_block, int64_t n_blocks, hipStream_t s) {

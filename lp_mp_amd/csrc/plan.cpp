@@ -465,7 +465,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       const auto& mt = mtypes[m_type[e.msg]];
       const int32_t peer = e.adjacent;
       Op op{};
-      op.peer_dual = f_doff[peer];
+      op.peer_dual = doff(peer);
       op.omega = w;
       op.peer = peer;
       op.len = f_dim0[m_left[e.msg]];
@@ -474,8 +474,8 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       int side = 0, imp = 0;
       if (mt.kind == LPMP_M_UNARY_PAIRWISE) {
         side = mt.param;
-        op.peer_const = e.role == 0 ? f_coff[peer] : -1;
-        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && f_dim0[peer] == own_d0 && f_dim1[peer] == own_d0 && (f_coff[peer] % 2) == 0)) all_dense[o] = 0;
+        op.peer_const = e.role == 0 ? coff(peer) : -1;
+        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && f_dim0[peer] == own_d0 && f_dim1[peer] == own_d0 && (coff(peer) % 2) == 0)) all_dense[o] = 0;
         if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == own_d0)) all_potts[o] = 0;
         if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && (side == 0 ? f_dim0[peer] : f_dim1[peer]) == own_d0)) var_dense[o] = 0;
         if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == own_d0 && f_dim1[peer] == own_d0)) var_potts[o] = 0;
@@ -615,8 +615,8 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       if (!is_rec(u)) continue;
       const int32_t f = uf[u];
       UpdRec r{};
-      r.dual_off = f_doff[f];
-      r.const_off = f_kind[f] == LPMP_F_VECTOR ? -1 : f_coff[f];
+      r.dual_off = doff(f);
+      r.const_off = f_kind[f] == LPMP_F_VECTOR ? -1 : coff(f);
       r.d0 = f_dim0[f]; r.d1 = f_dim1[f];
       r.op_begin = (int32_t)op_start[u];
       r.n_recv = (int16_t)n_recv_of[u]; r.n_send = (int16_t)n_send_of[u];

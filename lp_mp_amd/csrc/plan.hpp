@@ -220,6 +220,12 @@ struct Plan {
   // from the free memory of its device, and a class whose mailbox would not fit is planned with completion flags only
   // (-1: no limit)
   int64_t mailbox_budget_bytes = -1;
+  // Engine-private placement of factors on the device (engine.cpp, rows layout): where a factor's constants start relative
+  // to the const base pointer and its duals relative to the dual base pointer, in doubles — possibly in ANOTHER allocation
+  // (the kernels only ever form base + offset).  Empty: the packed offsets f_coff / f_doff.  Sizes always come from f_*.
+  std::vector<int64_t> dev_coff, dev_doff;
+  int64_t coff(int64_t f) const { return dev_coff.empty() ? f_coff[f] : dev_coff[f]; }
+  int64_t doff(int64_t f) const { return dev_doff.empty() ? f_doff[f] : dev_doff[f]; }
 
   // throws std::runtime_error on invalid input (the reference throws too, LP_MP.h:458)
   void build(const lpmp_model& m);

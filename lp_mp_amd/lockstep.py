@@ -54,9 +54,10 @@ class LockstepSchedule:
     reader: np.ndarray                 # rank of the other endpoint
     n_edges: int
     _programs: Dict[int, list] = field(default_factory=dict)
+    _halo_ids: Dict[bytes, int] = field(default_factory=dict)     # distinct exchanges (sets of vectors) of all programs -> small integer
 
     def program(self, n_passes: int):
-        """steps of n passes: ("run", ((d, sub-level), ...)) and ("halo", vectors to ship: sorted global ids).
+        """steps of n passes: ("run", ((d, sub-level), ...)) and ("halo", vectors to ship: sorted global ids, id of that set).
         Sub-level 2 l = the records of level l + 1 that touch a cut edge, 2 l + 1 = the others (they write no cut vector).
         An exchange is needed before the first sub-level that reads a cut vector written since the last one; it is then
         moved BACK over the sub-levels that wrote nothing it ships (they read nothing it ships either, or it would have
@@ -74,15 +75,18 @@ class LockstepSchedule:
                     pos -= 1
                 halos.append((pos, np.nonzero(dirty)[0])); dirty[:] = False; last = pos
             dirty[self.written[d][sl]] = True
+        def halo(vecs):                                 # (the id is what a rank's exchange plans are kept under: a step of a pass
+            hid = self._halo_ids.setdefault(vecs.tobytes(), len(self._halo_ids))   # must not hash its vector list every time)
+            return ("halo", vecs, hid)
         steps, start = [], 0
         for pos, vecs in halos:
             if pos > start:
                 steps.append(("run", tuple(seq[start:pos])))
-            steps.append(("halo", vecs)); start = pos
+            steps.append(halo(vecs)); start = pos
         if start < len(seq):
             steps.append(("run", tuple(seq[start:])))
         if dirty.any():                                 # the copies agree again when the call returns
-            steps.append(("halo", np.nonzero(dirty)[0]))
+            steps.append(halo(np.nonzero(dirty)[0]))
         self._programs[n_passes] = steps
         return steps
 
@@ -208,7 +212,7 @@ class LockstepSweep:
     def __init__(self, torch, part: LockstepPart, sched: LockstepSchedule, engine, dual_tensor):
         self.torch, self.part, self.sched, self.engine, self.dual = torch, part, sched, engine, dual_tensor
         self._sids: Dict[tuple, int] = {}
-        self._halo: Dict[bytes, tuple] = {}
+        self._halo: Dict[int, tuple] = {}
         p = part
         n_vec = p.vars_global.shape[0]
         doff = p.model.dual_offsets()
@@ -233,8 +237,9 @@ class LockstepSweep:
         if sid >= 0:
             self.engine.schedule_run(sid)
 
-    def _halo_plan(self, vecs: np.ndarray):
-        key = vecs.tobytes()
+    def _halo_plan(self, vecs: np.ndarray, key: Optional[int] = None):
+        if key is None:
+            key = self.sched._halo_ids.setdefault(vecs.tobytes(), len(self.sched._halo_ids))
         if key not in self._halo:
             p, s, L = self.part, self.sched, self.part.L
             def elems(v):                                          # flat dual elements of cut vectors v (global ids), in order
@@ -253,12 +258,12 @@ class LockstepSweep:
                                self.torch.from_numpy(elems(inn)).to(dev), np.bincount(s.writer[inn] + shift, minlength=world).astype(np.int64) * L)
         return self._halo[key]
 
-    def halo_pack(self, vecs):
-        src, out_counts, _, in_counts = self._halo_plan(vecs)
+    def halo_pack(self, vecs, key=None):
+        src, out_counts, _, in_counts = self._halo_plan(vecs, key)
         return self.dual[src], out_counts, in_counts
 
-    def halo_unpack(self, vecs, recv):
-        _, _, dst, _ = self._halo_plan(vecs)
+    def halo_unpack(self, vecs, recv, key=None):
+        _, _, dst, _ = self._halo_plan(vecs, key)
         if dst.shape[0]:
             self.dual[dst] = recv
 
@@ -267,8 +272,8 @@ class LockstepSweep:
             if step[0] == "run":
                 self.run(step[1])
             else:
-                send, out_counts, in_counts = self.halo_pack(step[1])
-                self.halo_unpack(step[1], comm.exchange(send, out_counts, in_counts))
+                send, out_counts, in_counts = self.halo_pack(step[1], step[2])
+                self.halo_unpack(step[1], comm.exchange(send, out_counts, in_counts), step[2])
 
     def local_lower_bound(self) -> float:
         if hasattr(self.engine, "invalidate_lower_bounds"):
@@ -289,13 +294,13 @@ def run_lockstep(sweeps: List[LockstepSweep], n_passes: int):
             for s in sweeps:
                 s.run(step[1])
             continue
-        packed = [s.halo_pack(step[1]) for s in sweeps]
+        packed = [s.halo_pack(step[1], step[2]) for s in sweeps]
         offs = [np.concatenate([[0], np.cumsum(p[1])]) for p in packed]
         for dst, s in enumerate(sweeps):
             pieces = [packed[src][0][offs[src][dst]: offs[src][dst + 1]] for src in range(world)]
             recv = torch.cat(pieces)
             assert recv.shape[0] == int(packed[dst][2].sum())
-            s.halo_unpack(step[1], recv)
+            s.halo_unpack(step[1], recv, step[2])
 
 
 # ---- drivers (one process per GPU) --------------------------------------------------------------------------------
@@ -373,7 +378,7 @@ class _Driver:
             if step[0] == "run":
                 self.sweep._schedule(step[1])
             else:
-                self.sweep._halo_plan(step[1])
+                self.sweep._halo_plan(step[1], step[2])
 
     def compute_pass(self, n=1):
         if self.comm is None:
@@ -403,16 +408,29 @@ class LockstepStrips(_Driver):
 
 class LockstepGraph(_Driver):
     """the same for the C4-style random graph synthetic.counter_graph_model(n, m, L, seed); every rank derives the global
-    structure from the counter generator (no costs), the partition comes from rank 0"""
+    structure from the counter generator (no costs), the partition comes from rank 0.
+    ``order``: "colour_major" (default) renames the variables by ordering.colour_major_order first — one dependent level per
+    colour (9 per directional sweep on the C4 shape instead of 30), i.e. 18 exchanges per pass instead of 60; "index": the
+    generator's own order.  The order is part of the problem (another order is another, equally valid sweep): the
+    unpartitioned sweep the result equals bit for bit is the one of counter_graph_model(..., rank=self.rank_of)."""
 
-    def __init__(self, torch, dist, n, m, L, mode, seed=1, part_of=None):
+    def __init__(self, torch, dist, n, m, L, mode, seed=1, part_of=None, order="colour_major"):
         from . import multi_gpu as MG
-        rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
-        ei, ej = S.counter_graph_edges(n, m, seed)
+        from . import ordering as O
+        on = dist is not None and dist.is_initialized()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+        self.order = order
+        self.rank_of = None
+        if order == "colour_major":
+            compute = lambda: O.colour_major_order(n, *S.counter_graph_edges(n, m, seed), seed=seed)
+            # (a colouring of 2 M variables / 10 M edges is a minute of numpy: once, on rank 0)
+            self.rank_of = MG.broadcast_partition(torch, dist, n, None, compute) if on and world > 1 else compute()
+        elif order != "index":
+            raise ValueError(order)
+        ei, ej = S.counter_graph_edges(n, m, seed, self.rank_of)
         if part_of is None:
             if world > 1:
-                dev = torch.device("cuda", torch.cuda.current_device())
-                part_of = MG.broadcast_partition(torch, dist, n, dev, lambda: MG.graph_partition(n, ei, ej, world))
+                part_of = MG.broadcast_partition(torch, dist, n, None, lambda: MG.graph_partition(n, ei, ej, world))
             else:
                 part_of = np.zeros(n, np.int64)
         self.cut_fraction = float((part_of[ei] != part_of[ej]).mean())

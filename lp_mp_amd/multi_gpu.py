@@ -827,10 +827,12 @@ class GraphSweep:
     graphs cut most of their edges under any balanced partition, so the boundary step runs after every directional
     sweep (boundary_every="sweep")."""
 
-    def __init__(self, torch, dist, n, m, L, mode, seed=1, omega_b=None, boundary_every=None):
+    def __init__(self, torch, dist, n, m, L, mode, seed=1, omega_b=None, boundary_every=None, rows_layout=None):
         from . import engine as E
         self.torch, self.dist = torch, dist
         self.comm = DistComm(dist, torch) if dist is not None and dist.is_initialized() else None
+        if rows_layout and self.comm is not None and self.comm.world > 1:
+            raise ValueError("rows layout: the partitioned sweep indexes the packed dual buffer between passes")
         rank, world = (self.comm.rank, self.comm.world) if self.comm else (0, 1)
         dev = torch.device("cuda", torch.cuda.current_device())
         if self.comm:
@@ -847,7 +849,7 @@ class GraphSweep:
         fill_device_costs(torch, E, part, self.const, self.dualt, stream)
         self.engine = E.Engine(torch.cuda.current_device())
         self.engine.set_stream(stream)
-        self.engine.upload(mdl, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt))
+        self.engine.upload(mdl, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt), rows_layout=rows_layout)
         n_cut = int(part.out_ghost.shape[0] + part.in_unary.shape[0])
         self.cut_fraction = n_cut / max(1, int(mdl.n_messages) // 2 + int(part.in_unary.shape[0]))
         if boundary_every is None:                       # few cut edges: once per pass (fused sweeps); many: every sweep

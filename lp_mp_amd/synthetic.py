@@ -37,21 +37,26 @@ def u64(n: int, seed: int, first: int = 0) -> np.ndarray:
     return z
 
 
-def counter_graph_edges(n: int, m: int, seed: int):
+def counter_graph_edges(n: int, m: int, seed: int, rank: Optional[np.ndarray] = None):
     """C4 (BASELINE.json configs[3]) structure from the counter generator alone, so that every rank of a partitioned
     run derives the same edge list without any communication: edge e joins a = h(2e) mod n and b = a + 1 + h(2e+1) mod
     (n - 1) (never a self loop); returned as (min, max) in edge order.  Uniform random edges; the expected handful of
-    repeated pairs at m << n^2 / 2 are kept (two pairwise factors between the same variables are a valid model)."""
+    repeated pairs at m << n^2 / 2 are kept (two pairwise factors between the same variables are a valid model).
+    ``rank``: the same graph with its variables renamed (variable v becomes rank[v]) — e.g. ordering.colour_major_order,
+    which turns the 30 dependent levels per sweep of the index order into one level per colour."""
     h = u64(2 * m, seed ^ 0x5DEECE66D, 0)
     a = (h[0::2] % np.uint64(n)).astype(np.int64)
     b = (a + 1 + (h[1::2] % np.uint64(n - 1)).astype(np.int64)) % n
+    if rank is not None:
+        rank = np.asarray(rank, np.int64)
+        a, b = rank[a], rank[b]
     return np.minimum(a, b), np.maximum(a, b)
 
 
-def counter_graph_model(n: int, m: int, L: int, seed: int = 1, device_const: bool = False) -> M.FlatModel:
+def counter_graph_model(n: int, m: int, L: int, seed: int = 1, device_const: bool = False, rank: Optional[np.ndarray] = None) -> M.FlatModel:
     """the unpartitioned C4-style model over counter_graph_edges: unaries u01 stream [0, n L), table of edge e at
     [n L + e L^2, ...) — the layout the per-rank generator of multi_gpu.graph_local_part reproduces piecewise"""
-    i, j = counter_graph_edges(n, m, seed)
+    i, j = counter_graph_edges(n, m, seed, rank)
     un = u01(n * L, seed, 0)
     if device_const:
         return mrf_model(n, L, i, j, un, device_const=True)

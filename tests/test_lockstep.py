@@ -19,8 +19,12 @@ from tests.mgpu_helpers import OracleEngine
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _graph(n, m, L, world, seed=1):
-    g = S.counter_graph_model(n, m, L, seed)
+def _graph(n, m, L, world, seed=1, colour_major=False):
+    rank = None
+    if colour_major:                                  # LockstepGraph's default: the variables renamed colour by colour
+        from lp_mp_amd import ordering as O
+        rank = O.colour_major_order(n, *S.counter_graph_edges(n, m, seed), seed=seed)
+    g = S.counter_graph_model(n, m, L, seed, rank=rank)
     ei = g.m_left[0::2].astype(np.int64); ej = g.m_left[1::2].astype(np.int64)
     return dict(n_vars=n, L=L, ei=ei, ej=ej, un=g.dual_data[: n * L], tables=g.const_data, potts=None, pairwise="dense",
                 part_of=MG.graph_partition(n, ei, ej, world), world=world)
@@ -59,6 +63,7 @@ def ref_offsets(c):
 CASES = {
     "random graph, 4 parts (61 % of the edges cut)": lambda: _graph(400, 1200, 4, 4),
     "random graph, 7 parts": lambda: _graph(300, 700, 3, 7, seed=3),
+    "random graph in colour-major order, 5 parts": lambda: _graph(400, 1300, 4, 5, seed=4, colour_major=True),
     "colour-major strips, 3 parts": lambda: _strips(8, 8, 3, 3, "dense", "colour_major"),
     "row-major strips, 3 parts": lambda: _strips(6, 7, 3, 3, "dense", "row_major"),
     "Potts strips, 4 parts": lambda: _strips(6, 6, 4, 4, "potts", "colour_major"),
@@ -286,3 +291,16 @@ def test_lockstep_random_graphs_partitions_and_modes_on_device(seed):
     finally:
         for s in sweeps:
             s.engine.close()
+
+
+def test_colour_major_order_cuts_the_exchanges_of_a_random_graph():
+    """LockstepGraph's default variable order (ordering.colour_major_order): one dependent level per colour, so the sweep
+    needs an exchange per colour instead of one per level of the generator's index order"""
+    n, m, L, world = 3000, 15000, 4, 4
+    counts = {}
+    for cm in (False, True):
+        c = _graph(n, m, L, world, seed=2, colour_major=cm)
+        sched, _ = _parts_of(c, M.REPAM_ANISOTROPIC)
+        counts[cm] = (sched.n_levels, sum(1 for s in sched.program(4) if s[0] == "halo") / 4)
+    assert counts[True][0][0] < counts[False][0][0] / 2 and counts[True][1] < counts[False][1] / 2, counts
+    assert counts[True][1] <= 2 * max(counts[True][0]) + 1

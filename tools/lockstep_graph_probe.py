@@ -1,7 +1,9 @@
 """C4-shaped random graph on ONE GPU, `parts` parts as separate engines stepped in process (no RCCL): the lock-step sweep
 (lockstep.py: the unpartitioned sweep itself) against the partitioned sweep with boundary steps (multi_gpu.py) and the
 unpartitioned engine — ms per pass and part, exchanges per pass, dual-bound gap after `passes` passes.
-    python tools/lockstep_graph_probe.py [n] [m] [labels] [parts] [passes]"""
+    python tools/lockstep_graph_probe.py [n] [m] [labels] [parts] [passes] [colour_major|index]
+The lock-step sweep and its unpartitioned reference run in the given variable order (default colour_major: one level per colour);
+the boundary-step schedule keeps the generator's index order (its own reference too)."""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,13 +14,22 @@ m = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 parts = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 passes = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+order = sys.argv[6] if len(sys.argv) > 6 else "colour_major"
 mode = M.REPAM_ANISOTROPIC
 torch.cuda.set_device(0)
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream().cuda_stream
-ei, ej = S.counter_graph_edges(n, m, 1)
-part_of = MG.graph_partition(n, ei, ej, parts)
-out = {"n": n, "m": m, "labels": L, "parts": parts, "passes": passes, "cut_fraction": round(float((part_of[ei] != part_of[ej]).mean()), 4)}
+ei0, ej0 = S.counter_graph_edges(n, m, 1)
+part0 = MG.graph_partition(n, ei0, ej0, parts)
+rank_of = None
+if order == "colour_major":
+    from lp_mp_amd import ordering as O
+    t0 = time.perf_counter(); rank_of = O.colour_major_order(n, ei0, ej0, seed=1); t_order = time.perf_counter() - t0
+ei, ej = S.counter_graph_edges(n, m, 1, rank_of)
+part_of = part0 if rank_of is None else MG.graph_partition(n, ei, ej, parts)
+out = {"n": n, "m": m, "labels": L, "parts": parts, "passes": passes, "order": order, "cut_fraction": round(float((part_of[ei] != part_of[ej]).mean()), 4)}
+if rank_of is not None:
+    out["ordering_s"] = round(t_order, 2)
 
 def timed(run):
     run(); torch.cuda.synchronize()                      # builds the schedules
@@ -35,16 +46,25 @@ def device_part(p):
     e.set_reparametrization(mode)
     return e, dual, const
 
-# the unpartitioned engine: 2 x passes passes (the timed call follows the warm-up call, as below)
-g = S.counter_graph_model(n, m, L, 1, device_const=True)
-const0 = torch.empty(m * L * L, dtype=torch.float64, device=dev)
-dual0 = torch.zeros(n * L + m * 2 * L, dtype=torch.float64, device=dev)
-E.synth_fill(const0.data_ptr(), const0.numel(), 1, n * L, stream); E.synth_fill(dual0.data_ptr(), n * L, 1, 0, stream); torch.cuda.synchronize()
-e0 = E.Engine(0); e0.set_stream(stream); e0.upload(g, const_dev=const0.data_ptr(), dual_dev=dual0.data_ptr(), keep=(const0, dual0)); e0.set_reparametrization(mode)
-e0.compute_pass(passes); lb_mid = e0.lower_bound()
-t0 = time.perf_counter(); e0.compute_pass(passes); e0.synchronize(); out["unpartitioned_ms_per_pass"] = round((time.perf_counter() - t0) / passes * 1e3, 3)
-lb_ref = e0.lower_bound(); e0.close(); del const0, dual0
-
+# the unpartitioned engines: 2 x passes passes (the timed call follows the warm-up call, as below)
+def unpartitioned(rank):
+    g = S.counter_graph_model(n, m, L, 1, device_const=True, rank=rank)
+    const0 = torch.empty(m * L * L, dtype=torch.float64, device=dev)
+    dual0 = torch.zeros(n * L + m * 2 * L, dtype=torch.float64, device=dev)
+    E.synth_fill(const0.data_ptr(), const0.numel(), 1, n * L, stream); E.synth_fill(dual0.data_ptr(), n * L, 1, 0, stream); torch.cuda.synchronize()
+    e0 = E.Engine(0); e0.set_stream(stream); e0.upload(g, const_dev=const0.data_ptr(), dual_dev=dual0.data_ptr(), keep=(const0, dual0)); e0.set_reparametrization(mode)
+    info = [e0.plan.schedule_info(d, mode)["n_levels"] for d in (0, 1)]
+    e0.compute_pass(passes)
+    t0 = time.perf_counter(); e0.compute_pass(passes); e0.synchronize(); ms = (time.perf_counter() - t0) / passes * 1e3
+    lb = e0.lower_bound(); e0.close()
+    return ms, lb, info
+ms_i, lb_index, lev_i = unpartitioned(None)
+out["unpartitioned_index_order"] = {"ms_per_pass": round(ms_i, 3), "levels": lev_i, "lb": lb_index}
+if rank_of is not None:
+    ms_c, lb_ref, lev_c = unpartitioned(rank_of)
+    out["unpartitioned_" + order] = {"ms_per_pass": round(ms_c, 3), "levels": lev_c, "lb": lb_ref}
+else:
+    lb_ref = lb_index
 t0 = time.perf_counter()
 sched, lparts = LS.lockstep_mrf(n, L, ei, ej, part_of, parts, mode, stream_seed=1)
 out["lockstep_setup_s"] = round(time.perf_counter() - t0, 1)
@@ -60,13 +80,12 @@ out["lockstep"] = {"ms_per_pass_and_part": round(ms / parts, 3), "exchanges_per_
 for s in sw: s.engine.close()
 del sw, keep
 
-pparts = MG.partition_mrf(n, L, ei, ej, part_of, parts, only=None, stream_seed=1)
+pparts = MG.partition_mrf(n, L, ei0, ej0, part0, parts, only=None, stream_seed=1)
 sw, keep = [], []
 for p in pparts:
     e, dual, const = device_part(p); keep.append((dual, const))
     sw.append(MG.PartitionedSweep(torch, p, e, dual, mode, None, "sweep", MG.BOUNDARY_RESERVE))
 ms = timed(lambda: MG.run_lockstep(sw, passes))
 lb = sum(s.local_lower_bound() for s in sw)
-out["boundary_steps"] = {"ms_per_pass_and_part": round(ms / parts, 3), "exchanges_per_pass": 4, "gap_percent": 100 * (lb_ref - lb) / abs(lb_ref), "lb": lb}
-out["lb_unpartitioned"] = lb_ref
+out["boundary_steps"] = {"ms_per_pass_and_part": round(ms / parts, 3), "exchanges_per_pass": 4, "order": "index", "gap_percent": 100 * (lb_index - lb) / abs(lb_index), "lb": lb}
 print(json.dumps(out))
