@@ -591,8 +591,8 @@ void d2h(void* dst, const void* src, size_t bytes, hipStream_t stream) {
   }
 }
 
-template <class T>
-void fill_device(T*& dst, size_t& cap, const std::vector<T>& src, hipStream_t stream) {
+template <class T, class V>
+void fill_device(T*& dst, size_t& cap, const V& src, hipStream_t stream) {
   if (src.size() > cap) {
     if (dst) { HIP_CHECK(hipFree(dst)); dst = nullptr; cap = 0; }
     const size_t n = src.size() + src.size() / 4 + 16;

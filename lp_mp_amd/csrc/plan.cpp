@@ -10,10 +10,33 @@
 #include <limits>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 
 namespace lpmp {
 
 namespace {
+
+// Contiguous chunks of [0, n) on up to LPMP_PLAN_THREADS (default: the hardware's, at most 16) threads; small ranges run on the
+// caller's thread.  The analysis below is a handful of linear passes over millions of updates: the two that build the
+// op records and the packets are independent per update / per record.  An exception of any chunk is rethrown.
+template <class F>
+void parallel_chunks(int64_t n, int64_t min_per_thread, F&& f) {
+  static const int max_threads = [] {
+    const char* e = std::getenv("LPMP_PLAN_THREADS");
+    const int hw = (int)std::thread::hardware_concurrency();
+    return std::max(1, e ? std::atoi(e) : std::min(16, hw > 0 ? hw : 1));
+  }();
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(max_threads, n / std::max<int64_t>(1, min_per_thread)));
+  if (nt <= 1) { f((int64_t)0, n, 0); return; }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err((size_t)nt);
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      try { f(n * t / nt, n * (t + 1) / nt, t); } catch (...) { err[(size_t)t] = std::current_exception(); }
+    });
+  for (auto& x : th) x.join();
+  for (auto& e : err) if (e) std::rethrow_exception(e);
+}
 
 // message_passing_schedule -> what each side does (reference factors_messages.hxx:1530-1545)
 struct SchedCaps { bool to_left, to_right, from_left, from_right; };
@@ -394,6 +417,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   }
   lap_("rows");
   std::vector<int32_t> last_level(nf, 0), last_toucher(nf, -1), last_update_of(nf, -1);
+  std::vector<int32_t> nr_of_u(N, 0), ns_of_u(N, 0);            // active receives / sends of every single update (its own, not the owner's sum)
   int32_t max_level = 0;
   std::vector<int32_t> touched;
   for (int64_t u = 0; u < N; ++u) {
@@ -413,6 +437,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
         if (active || (ftype_primal[f_type[f]] && f_kind[f] != LPMP_F_VECTOR)) touched.push_back(e.adjacent);
       }
     }
+    nr_of_u[u] = nr; ns_of_u[u] = ns;
     int32_t lv = 0;
     for (int32_t g : touched) lv = std::max(lv, last_level[g]);
     const int32_t prev = last_update_of[f];
@@ -446,8 +471,13 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   std::vector<int64_t> op_start(N + 1, 0);
   for (int64_t u = 0; u < N; ++u) op_start[u + 1] = op_start[u] + (owner[u] == u ? n_recv_of[u] + n_send_of[u] : 0);
   if (op_start[N] > std::numeric_limits<int32_t>::max()) fail("too many active message operations for one schedule");
-  std::vector<Op> ops(op_start[N]);
-  std::vector<int32_t> cur_r(N, 0), cur_s(N, 0);
+  OpVec ops((size_t)op_start[N]);                   // (every slot is written below: the counts are the same walk over the rows)
+  // where every update writes inside its owner's op range: receives of the members in sequence order, then the sends
+  std::vector<int32_t> r_at(N, 0), s_at(N, 0);
+  {
+    std::vector<int32_t> cur_r(N, 0), cur_s(N, 0);
+    for (int64_t u = 0; u < N; ++u) { const int32_t o = owner[u]; r_at[u] = cur_r[o]; cur_r[o] += nr_of_u[u]; s_at[u] = cur_s[o]; cur_s[o] += ns_of_u[u]; }
+  }
   std::vector<int64_t> rec_bytes(N, 0);
   std::vector<uint8_t> all_dense(N, 1), all_potts(N, 1);     // exact classes: every peer L x L, L the own label count
   std::vector<uint8_t> var_dense(N, 1), var_potts(N, 1);     // padded classes: runtime dims
@@ -455,11 +485,18 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   std::vector<uint8_t> small_ok(N, 1);                       // lane-per-factor class: every size <= SMALL_MAXD
   std::vector<uint8_t> pw_right(N, 1);                       // updated dense pairwise factor, every op unary-pairwise with the factor on the right
   std::vector<int32_t> max_dim(N, 0);                        // largest peer table dim of the record
-  for (int64_t u = 0; u < N; ++u) {
+  std::vector<int64_t> alg_bytes_of_thread(64, 0);
+  // (several updates may share an owner record — folded sweeps — and land on different threads: the per-owner flags only
+  // ever go from 1 to 0, sums and maxima are atomic)
+  auto clear_flag = [](uint8_t& x) { __atomic_store_n(&x, (uint8_t)0, __ATOMIC_RELAXED); };
+  auto atomic_max = [](int32_t& x, int32_t v) { int32_t cur = __atomic_load_n(&x, __ATOMIC_RELAXED); while (cur < v && !__atomic_compare_exchange_n(&x, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} };
+  parallel_chunks(N, 65536, [&](int64_t u_begin, int64_t u_end, int thread) {
+  int64_t alg_local = 0;
+  for (int64_t u = u_begin; u < u_end; ++u) {
     const int32_t f = uf[u];
     const int32_t o = owner[u];
     const int32_t own_d0 = f_dim0[f];
-    if (f_doff[f + 1] - f_doff[f] > SMALL_MAXD) small_ok[o] = 0;   // also for a record without any op (COMPUTE_PRIMAL types)
+    if (f_doff[f + 1] - f_doff[f] > SMALL_MAXD) clear_flag(small_ok[o]);   // also for a record without any op (COMPUTE_PRIMAL types)
     Op* base = ops.data() + op_start[o];
     auto fill = [&](const MsgEntry& e, double w) {
       const auto& mt = mtypes[m_type[e.msg]];
@@ -475,15 +512,15 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       if (mt.kind == LPMP_M_UNARY_PAIRWISE) {
         side = mt.param;
         op.peer_const = e.role == 0 ? coff(peer) : -1;
-        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && f_dim0[peer] == own_d0 && f_dim1[peer] == own_d0 && (coff(peer) % 2) == 0)) all_dense[o] = 0;
-        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == own_d0)) all_potts[o] = 0;
-        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && (side == 0 ? f_dim0[peer] : f_dim1[peer]) == own_d0)) var_dense[o] = 0;
-        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == own_d0 && f_dim1[peer] == own_d0)) var_potts[o] = 0;
-        max_dim[o] = std::max(max_dim[o], std::max(f_dim0[peer], f_dim1[peer]));
+        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && f_dim0[peer] == own_d0 && f_dim1[peer] == own_d0 && (coff(peer) % 2) == 0)) clear_flag(all_dense[o]);
+        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == own_d0)) clear_flag(all_potts[o]);
+        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_DENSE && (side == 0 ? f_dim0[peer] : f_dim1[peer]) == own_d0)) clear_flag(var_dense[o]);
+        if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && f_kind[peer] == LPMP_F_PAIRWISE_POTTS && f_dim0[peer] == own_d0 && f_dim1[peer] == own_d0)) clear_flag(var_potts[o]);
+        atomic_max(max_dim[o], std::max(f_dim0[peer], f_dim1[peer]));
         if (!(f_kind[f] == LPMP_F_VECTOR && e.role == 0 && (f_kind[peer] == LPMP_F_PAIRWISE_DENSE || f_kind[peer] == LPMP_F_PAIRWISE_POTTS) &&
-              (side == 0 ? f_dim0[peer] : f_dim1[peer]) == own_d0)) up_any[o] = 0;
+              (side == 0 ? f_dim0[peer] : f_dim1[peer]) == own_d0)) clear_flag(up_any[o]);
       } else {
-        all_dense[o] = all_potts[o] = var_dense[o] = var_potts[o] = up_any[o] = 0;
+        clear_flag(all_dense[o]); clear_flag(all_potts[o]); clear_flag(var_dense[o]); clear_flag(var_potts[o]); clear_flag(up_any[o]);
         if (mt.kind == LPMP_M_LABELING) {
           op.peer_const = tab_off[mt.param];
           op.pd1 = tab_nleft[mt.param];
@@ -492,9 +529,9 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       }
       op.info = mt.kind | (e.role << 4) | (side << 5) | (imp << 6) | ((f_flags[peer] & LPMP_FF_IMPLICIT_ORIGIN) ? 1 << 7 : 0) | (f_kind[peer] << 8) |
                 ((mt.flags & LPMP_MF_IMPROVEMENT) ? OP_HAS_IMPROVEMENT : 0);
-      if (std::max(op.len, std::max(op.pd0, op.pd1)) > SMALL_MAXD || f_doff[f + 1] - f_doff[f] > SMALL_MAXD) small_ok[o] = 0;
+      if (std::max(op.len, std::max(op.pd0, op.pd1)) > SMALL_MAXD || f_doff[f + 1] - f_doff[f] > SMALL_MAXD) clear_flag(small_ok[o]);
       if (!(mt.kind == LPMP_M_UNARY_PAIRWISE && e.role == 1 && f_kind[f] != LPMP_F_VECTOR && f_kind[peer] == LPMP_F_VECTOR &&
-            f_dim1[f] > 0 && op.len == (side == 0 ? f_dim0[f] : f_dim1[f]))) pw_right[o] = 0;
+            f_dim1[f] > 0 && op.len == (side == 0 ? f_dim0[f] : f_dim1[f]))) clear_flag(pw_right[o]);
       return op;
     };
     // algorithmic bytes, counted per update as the reference executes it: own dual read + written
@@ -510,13 +547,14 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       return 16 * (int64_t)op.pd0;
     };
     int64_t ks = 0, kr = 0, bytes = 0, n_act = 0;
+    int32_t at_r = r_at[u], at_s = n_recv_of[o] + s_at[u];
     for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
       const MsgEntry& e = fm[j];
-      if (e.receives && umk[u][kr++]) { Op op = fill(e, 1.0); bytes += op_bytes(op, true); base[cur_r[o]++] = op; ++n_act; }
+      if (e.receives && umk[u][kr++]) { Op op = fill(e, 1.0); bytes += op_bytes(op, true); base[at_r++] = op; ++n_act; }
     }
     for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
       const MsgEntry& e = fm[j];
-      if (e.sends) { const double w = uom[u][ks++]; if (w != 0.0) { Op op = fill(e, w); bytes += op_bytes(op, false); base[n_recv_of[o] + cur_s[o]++] = op; ++n_act; } }
+      if (e.sends) { const double w = uom[u][ks++]; if (w != 0.0) { Op op = fill(e, w); bytes += op_bytes(op, false); base[at_s++] = op; ++n_act; } }
     }
     if (n_act > 0) bytes += 16 * (f_doff[f + 1] - f_doff[f]);
     // an updated dense pairwise factor reads its own table once to compute the min-marginals it sends
@@ -525,9 +563,12 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       for (int64_t j = 0; j < ks; ++j) if (uom[u][j] != 0.0) { sends_any = true; break; }
       if (sends_any) bytes += 8 * (int64_t)f_dim0[f] * f_dim1[f];
     }
-    rec_bytes[o] += bytes;
-    out.alg_bytes += bytes;
+    __atomic_fetch_add(&rec_bytes[o], bytes, __ATOMIC_RELAXED);
+    alg_local += bytes;
   }
+  alg_bytes_of_thread[(size_t)thread] = alg_local;
+  });
+  for (int64_t b : alg_bytes_of_thread) out.alg_bytes += b;
   lap_("ops");
   // Records with two receives, or two sends, into ONE vector (duplicate messages between the same two factors) need an
   // op-by-op kernel: the packed kernels request a record's vectors before reducing.  They get a class of their own
@@ -667,19 +708,14 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   lap_("sorted");
   // flags of the fast-class records, kept in recs / ops themselves (packets are plain copies)
   static_assert(sizeof(UpdRec) == sizeof(Op), "a packet slot holds either record");
+  int64_t pk_total = 0;                      // packet slots of all packed launches (the array is allocated once, below)
   for (auto& lr : out.launches) {
     if (kc_is_pw(lr.kclass)) {               // updated pairwise factors: plain packets (no preload / forwarding flags)
       int kmax = 0;
       for (int64_t i = lr.begin; i < lr.end; ++i) kmax = std::max<int>(kmax, out.recs[i].n_recv + out.recs[i].n_send);
       lr.stride = 1 + kmax;
-      lr.pk_begin = (int64_t)out.packets.size();
-      out.packets.resize(out.packets.size() + (size_t)(lr.end - lr.begin) * lr.stride);
-      for (int64_t i = lr.begin; i < lr.end; ++i) {
-        Op* slot = out.packets.data() + lr.pk_begin + (i - lr.begin) * lr.stride;
-        const UpdRec& r = out.recs[i];
-        std::memcpy(slot, &r, sizeof(Op));
-        for (int k = 0; k < r.n_recv + r.n_send; ++k) slot[1 + k] = out.ops[r.op_begin + k];
-      }
+      lr.pk_begin = pk_total;
+      pk_total += (lr.end - lr.begin) * lr.stride;
       continue;
     }
     if (lr.kclass == KC_SMALL) {
@@ -722,49 +758,65 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       // (the streaming dense kernel works op by op, so duplicates and any op count are fine for it)
       if (!ok) { lr.kclass = KC_DENSE_BIG; continue; }
     }
-    int kmax = 0;
-    bool dup_recv = false;
-    for (int64_t i = lr.begin; i < lr.end; ++i) {
-      UpdRec& r = out.recs[i];
-      Op* o = out.ops.data() + r.op_begin;
-      kmax = std::max<int>(kmax, r.n_recv + r.n_send);
-      auto same = [&](int a, int b) { return o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1); };
-      bool preload_ok = true;   // a send may be requested early unless a receive of this update writes the same vector
-      for (int a = 0; a < r.n_recv && preload_ok; ++a)
-        for (int b = r.n_recv; b < r.n_recv + r.n_send; ++b)
-          if (same(a, b)) { preload_ok = false; break; }
-      if (preload_ok) r.kind_flags |= UPD_PRELOAD_OK;
-      // two receives, or two sends, into one vector (duplicate messages between the same two factors)
-      for (int a = 0; a < r.n_recv && !dup_recv; ++a)
-        for (int a2 = a + 1; a2 < r.n_recv; ++a2) if (same(a, a2)) { dup_recv = true; break; }
-      for (int b = r.n_recv; b < r.n_recv + r.n_send && !dup_recv; ++b)
-        for (int b2 = b + 1; b2 < r.n_recv + r.n_send; ++b2) if (same(b, b2)) { dup_recv = true; break; }
-      // register forwarding: send b targets the vector receive a (one of the first 4) has just rewritten ->
-      // the receive keeps its result in a register (pad = 1: no store) and the send reads it from there
-      // (pad = a + 1); at most one send per receive, and only if no other receive/send touches that vector
-      for (int b = r.n_recv; b < r.n_recv + r.n_send && b - r.n_recv < 4; ++b) {
-        int hit = -1, n_hit = 0, n_send_same = 0;
-        for (int a = 0; a < r.n_recv; ++a) if (same(a, b)) { hit = a; ++n_hit; }
-        for (int b2 = r.n_recv; b2 < r.n_recv + r.n_send; ++b2) if (same(b2, b)) ++n_send_same;
-        if (n_hit == 1 && n_send_same == 1 && hit < 4) { o[hit].pad = 1; o[b].pad = hit + 1; }
+    // flags of the records (independent of each other: chunks of the launch on several threads), then the packet stride
+    const int64_t n_lr = lr.end - lr.begin;
+    std::vector<int> kmax_of(64, 0); std::vector<uint8_t> dup_of(64, 0);
+    parallel_chunks(n_lr, 32768, [&](int64_t c0, int64_t c1, int thread) {
+      int kmax_l = 0; bool dup_l = false;
+      for (int64_t i = lr.begin + c0; i < lr.begin + c1; ++i) {
+        UpdRec& r = out.recs[i];
+        Op* o = out.ops.data() + r.op_begin;
+        kmax_l = std::max<int>(kmax_l, r.n_recv + r.n_send);
+        auto same = [&](int a, int b) { return o[a].peer_dual == o[b].peer_dual && ((o[a].info >> 5) & 1) == ((o[b].info >> 5) & 1); };
+        bool preload_ok = true;   // a send may be requested early unless a receive of this update writes the same vector
+        for (int a = 0; a < r.n_recv && preload_ok; ++a)
+          for (int b = r.n_recv; b < r.n_recv + r.n_send; ++b)
+            if (same(a, b)) { preload_ok = false; break; }
+        if (preload_ok) r.kind_flags |= UPD_PRELOAD_OK;
+        // two receives, or two sends, into one vector (duplicate messages between the same two factors)
+        for (int a = 0; a < r.n_recv && !dup_l; ++a)
+          for (int a2 = a + 1; a2 < r.n_recv; ++a2) if (same(a, a2)) { dup_l = true; break; }
+        for (int b = r.n_recv; b < r.n_recv + r.n_send && !dup_l; ++b)
+          for (int b2 = b + 1; b2 < r.n_recv + r.n_send; ++b2) if (same(b, b2)) { dup_l = true; break; }
+        // register forwarding: send b targets the vector receive a (one of the first 4) has just rewritten ->
+        // the receive keeps its result in a register (pad = 1: no store) and the send reads it from there
+        // (pad = a + 1); at most one send per receive, and only if no other receive/send touches that vector
+        for (int b = r.n_recv; b < r.n_recv + r.n_send && b - r.n_recv < 4; ++b) {
+          int hit = -1, n_hit = 0, n_send_same = 0;
+          for (int a = 0; a < r.n_recv; ++a) if (same(a, b)) { hit = a; ++n_hit; }
+          for (int b2 = r.n_recv; b2 < r.n_recv + r.n_send; ++b2) if (same(b2, b)) ++n_send_same;
+          if (n_hit == 1 && n_send_same == 1 && hit < 4) { o[hit].pad = 1; o[b].pad = hit + 1; }
+        }
       }
-    }
+      kmax_of[(size_t)thread] = kmax_l; dup_of[(size_t)thread] = dup_l;
+    });
+    int kmax = 0; bool dup_recv = false;
+    for (int t = 0; t < 64; ++t) { kmax = std::max(kmax, kmax_of[(size_t)t]); dup_recv = dup_recv || dup_of[(size_t)t]; }
     if (dup_recv) continue;                  // only the op-by-op kernels are safe for that: stride stays 0
     if (kmax > PK_MAX_OPS) {                 // too many ops for a packet: indirect mode if they fit the LDS slab
       if (kmax <= pk_class_cap(lr.kclass)) lr.stride = -1;
       continue;
     }
     lr.stride = 1 + kmax;
-    lr.pk_begin = (int64_t)out.packets.size();
-    out.packets.resize(out.packets.size() + (size_t)(lr.end - lr.begin) * lr.stride);
-    for (int64_t i = lr.begin; i < lr.end; ++i) {
-      Op* slot = out.packets.data() + lr.pk_begin + (i - lr.begin) * lr.stride;
-      const UpdRec& r = out.recs[i];
-      std::memcpy(slot, &r, sizeof(Op));
-      for (int k = 0; k < r.n_recv + r.n_send; ++k) slot[1 + k] = out.ops[r.op_begin + k];
-    }
+    lr.pk_begin = pk_total;                  // (filled below, when the size of the whole array is known)
+    pk_total += n_lr * lr.stride;
   }
-
+  lap_("pk-flags");
+  // packets: ONE allocation, never zero-filled (every slot is written: the record, its ops, zeros behind them)
+  out.packets.resize((size_t)pk_total);
+  for (const auto& lr : out.launches) {
+    if (lr.stride <= 0) continue;
+    parallel_chunks(lr.end - lr.begin, 32768, [&](int64_t c0, int64_t c1, int) {
+      for (int64_t i = lr.begin + c0; i < lr.begin + c1; ++i) {
+        Op* slot = out.packets.data() + lr.pk_begin + (i - lr.begin) * lr.stride;
+        const UpdRec& r = out.recs[i];
+        std::memcpy(slot, &r, sizeof(Op));
+        const int n = r.n_recv + r.n_send;
+        for (int k = 0; k < n; ++k) slot[1 + k] = out.ops[r.op_begin + k];
+        if (n + 1 < lr.stride) std::memset((void*)(slot + 1 + n), 0, (size_t)(lr.stride - 1 - n) * sizeof(Op));
+      }
+    });
+  }
   lap_("packets");
   // ---- chain plans: a deep schedule becomes persistent launches (kernels.hip, chain executor), one per kernel class.
   // Dependencies: update u must see the results of the last earlier update that touched u's factor or a factor u

@@ -10,7 +10,10 @@
 //                  :1489-1505 (full receive mask)
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/lpmp_model.h"
@@ -170,10 +173,22 @@ constexpr int kc_block_records(int kclass) {
 constexpr bool kc_chain_capable(int kclass) { return (kclass >= KC_DENSE_4 && kclass <= KC_POTTS_V32) || kclass == KC_GENERIC || kclass == KC_SMALL; }
 constexpr int64_t CHAIN_MIN_LAUNCHES = 9;   // shorter schedules run as plain launches
 
+// vectors of op records are hundreds of megabytes at the headline size and every element is written right after the
+// allocation: default-initialise (= leave alone) instead of zero-filling them first
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U> struct rebind { using other = default_init_allocator<U>; };
+  default_init_allocator() = default;
+  template <class U> default_init_allocator(const default_init_allocator<U>&) noexcept {}
+  template <class U> void construct(U* p) { ::new (static_cast<void*>(p)) U; }
+  template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+using OpVec = std::vector<Op, default_init_allocator<Op>>;
+
 struct Schedule {             // executable form of one (factor list, omega, mask) sweep
   std::vector<UpdRec> recs;   // sorted by (level, kclass)
-  std::vector<Op> ops;
-  std::vector<Op> packets;            // packed launches: [UpdRec | Op x (stride-1)] per factor
+  OpVec ops;
+  OpVec packets;                      // packed launches: [UpdRec | Op x (stride-1)] per factor
   std::vector<LevelRange> launches;   // in execution order
   int64_t n_levels = 0;
   int64_t n_recv = 0, n_send = 0;     // active receives / sends = message updates per sweep
