@@ -168,7 +168,7 @@ struct lpmp_plan {
   }
 };
 
-static void plan_pass_schedule(lpmp_plan* pl, int mode) {
+static void plan_pass_schedule(lpmp_plan* pl, int mode, bool chains = true) {
   if (pl->have_pass[mode]) return;
   pl->p.ensure_weights(mode);
   std::vector<Plan::Segment> segs;
@@ -177,7 +177,7 @@ static void plan_pass_schedule(lpmp_plan* pl, int mode) {
     const auto& mk = pl->p.mask[d][mode];
     segs.push_back({pl->p.upd[d].data(), (int64_t)pl->p.upd[d].size(), om.off.data(), om.data.data(), mk.off.data(), mk.data.data()});
   }
-  pl->p.make_schedule(segs, true, pl->pass_cache[mode]);
+  pl->p.make_schedule(segs, true, pl->pass_cache[mode], chains);
   pl->have_pass[mode] = true;
 }
 
@@ -238,7 +238,7 @@ static void plan_rotation(lpmp_plan* pl, int mode) {
     segs.push_back({pl->p.upd[d].data(), (int64_t)pl->p.upd[d].size(), om.off.data(), om.data.data(), mk.off.data(), mk.data.data()});
   }
   Schedule& bf = pl->bf_cache[mode];
-  pl->p.make_schedule(segs, true, bf);
+  pl->p.make_schedule(segs, true, bf, false);
   // K (middle step of backward+forward) must be exactly "receives of T, then sends of H" factor by factor, and W
   // (middle step of forward+backward) exactly "receives of T', then sends of H'": then H, W, (K, W)^(n-1), T executes
   // the same receives and sends as n unfused passes, in an order that differs only between independent updates
@@ -290,21 +290,27 @@ static void plan_rotation_chain(lpmp_plan* pl, int mode) {
   for (int kind = 0; kind < 6; ++kind) {
     const Schedule& s = *sch[X[kind]];
     const LevelRange& lr = *lrs[X[kind]];
-    std::vector<std::vector<std::pair<int8_t, int32_t>>> per((size_t)ri.t[X[kind]].nb);
-    for (int64_t i = lr.begin; i < lr.end; ++i) {
-      const UpdRec& r = s.recs[i];
-      auto& dst = per[(size_t)((i - lr.begin) / ri.gpb)];
-      auto visit = [&](int32_t g) {
-        if (touch[Y1[kind]][g] >= 0) dst.emplace_back((int8_t)1, touch[Y1[kind]][g]);
-        else if (Y2[kind] >= 0 && touch[Y2[kind]][g] >= 0) dst.emplace_back((int8_t)2, touch[Y2[kind]][g]);
-      };
-      visit(r.factor);
-      for (int q = 0; q < r.n_recv + r.n_send; ++q) visit(s.ops[r.op_begin + q].peer);
-    }
+    // (blocks are independent: chunks of them on several threads, see plan.hpp parallel_blocks)
+    const int64_t nbk = ri.t[X[kind]].nb;
+    std::vector<std::vector<std::pair<int8_t, int32_t>>> per((size_t)nbk);
+    parallel_blocks(nbk, 4096, [&](int64_t b0, int64_t b1) {
+      for (int64_t b = b0; b < b1; ++b) {
+        auto& dst = per[(size_t)b];
+        for (int64_t i = lr.begin + b * ri.gpb; i < std::min<int64_t>(lr.end, lr.begin + (b + 1) * ri.gpb); ++i) {
+          const UpdRec& r = s.recs[i];
+          auto visit = [&](int32_t g) {
+            if (touch[Y1[kind]][g] >= 0) dst.emplace_back((int8_t)1, touch[Y1[kind]][g]);
+            else if (Y2[kind] >= 0 && touch[Y2[kind]][g] >= 0) dst.emplace_back((int8_t)2, touch[Y2[kind]][g]);
+          };
+          visit(r.factor);
+          for (int q = 0; q < r.n_recv + r.n_send; ++q) visit(s.ops[r.op_begin + q].peer);
+        }
+        std::sort(dst.begin(), dst.end());
+        dst.erase(std::unique(dst.begin(), dst.end()), dst.end());
+      }
+    });
     ri.off[kind].assign(1, 0);
     for (auto& v : per) {
-      std::sort(v.begin(), v.end());
-      v.erase(std::unique(v.begin(), v.end()), v.end());
       for (const auto& d : v) { ri.delta[kind].push_back(d.first); ri.block[kind].push_back(d.second); }
       ri.off[kind].push_back((int64_t)ri.block[kind].size());
     }
@@ -674,9 +680,22 @@ void ensure_device_schedules(lpmp_engine* e, int mode) {
 
 void ensure_pass_schedule(lpmp_engine* e, int mode) {
   if (e->have_pass[mode]) return;
-  plan_pass_schedule(e->plan.get(), mode);
+  const bool timed_ = std::getenv("LPMP_PLAN_TIMES") != nullptr;
+  auto t_last_ = std::chrono::steady_clock::now();
+  auto lap_ = [&](const char* what) { if (!timed_) return; const auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "lpmp: pass schedule %-28s %.0f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last_).count()); t_last_ = now; };
+  // (a three-level pass is the shape whose passes join: its own chain plan is only built if the joins do not check out)
+  plan_pass_schedule(e->plan.get(), mode, false);
+  lap_("forward+backward planned");
+  plan_rotation(e->plan.get(), mode);
+  lap_("backward+forward planned, joins checked");
+  if (!e->plan->rotation_ok[mode] && e->plan->pass_cache[mode].n_levels == 3) {
+    e->plan->have_pass[mode] = false;
+    plan_pass_schedule(e->plan.get(), mode, true);
+    lap_("forward+backward planned again, with its chain plan");
+  }
   check_generic_limits(e->plan->p, e->plan->pass_cache[mode]);
   upload_schedule(e->plan->pass_cache[mode], e->sched_pass[mode], e->stream);
+  lap_("... uploaded");
   // LPMP_LAUNCH_LOG=<file> (profiling aid): one line per launch of the fused pass in execution order — level, class, records,
   // receives, sends, algorithmic bytes, packet stride — to lay beside the durations of a kernel trace (tools/launch_rates.py)
   if (const char* path = std::getenv("LPMP_LAUNCH_LOG")) {
@@ -687,11 +706,12 @@ void ensure_pass_schedule(lpmp_engine* e, int mode) {
       std::fclose(f);
     }
   }
-  plan_rotation(e->plan.get(), mode);
   e->rotation_ok[mode] = e->plan->rotation_ok[mode];
   if (e->rotation_ok[mode]) {
     upload_schedule(e->plan->bf_cache[mode], e->sched_bf[mode], e->stream);
+    lap_("... uploaded");
     plan_rotation_chain(e->plan.get(), mode);
+    lap_("block relations of the steps");
     e->plan->bf_cache[mode] = Schedule();
   }
   // the host copy is only needed for its summary

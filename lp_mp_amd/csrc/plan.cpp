@@ -376,7 +376,7 @@ void Plan::ensure_weights(int mode) {
 // from the state after the receives" is exactly what running u1 then u2 computes, and the factor's dual
 // makes one round trip instead of two (2-colour grids: the receive level of the forward sweep and the
 // send level of the backward sweep are the same factors).
-void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out) const {
+void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out, bool chains) const {
   out = Schedule();
   const bool timed_ = std::getenv("LPMP_PLAN_TIMES") != nullptr;
   auto t_last_ = std::chrono::steady_clock::now();
@@ -818,6 +818,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     });
   }
   lap_("packets");
+  if (!chains && max_level == 3) return;
   // ---- chain plans: a deep schedule becomes persistent launches (kernels.hip, chain executor), one per kernel class.
   // Dependencies: update u must see the results of the last earlier update that touched u's factor or a factor u
   // touches — the same relation the levels were computed from.  Classes are separate launches and cannot wait for each

@@ -9,10 +9,13 @@
 //   weights        include/LP_MP.h:1232-1415 (anisotropic), :1086-1154 (anisotropic2), :1422-1449 (uniform),
 //                  :1489-1505 (full receive mask)
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <exception>
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -175,6 +178,21 @@ constexpr int64_t CHAIN_MIN_LAUNCHES = 9;   // shorter schedules run as plain la
 
 // vectors of op records are hundreds of megabytes at the headline size and every element is written right after the
 // allocation: default-initialise (= leave alone) instead of zero-filling them first
+// contiguous chunks of [0, n) on a few threads (host analysis of models with millions of factors; plan.cpp has the same for
+// its own loops): f(begin, end); exceptions are rethrown on the caller's thread
+template <class F>
+inline void parallel_blocks(int64_t n, int64_t min_per_thread, F&& f) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, hw ? hw : 1), n / std::max<int64_t>(1, min_per_thread)));
+  if (nt <= 1) { f((int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err((size_t)nt);
+  for (int64_t t = 0; t < nt; ++t)
+    th.emplace_back([&, t] { try { f(n * t / nt, n * (t + 1) / nt); } catch (...) { err[(size_t)t] = std::current_exception(); } });
+  for (auto& x : th) x.join();
+  for (auto& e : err) if (e) std::rethrow_exception(e);
+}
+
 template <class T>
 struct default_init_allocator : std::allocator<T> {
   template <class U> struct rebind { using other = default_init_allocator<U>; };
@@ -249,7 +267,10 @@ struct Plan {
   // one sweep: a factor list with one omega row and one receive-mask row per listed factor
   struct Segment { const int32_t* factors; int64_t n; const int64_t* om_off; const double* om; const int64_t* mk_off; const uint8_t* mk; };
   // turn a sequence of sweeps into levels/records/ops; fuse: fold back-to-back updates of one factor (plan.cpp)
-  void make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out) const;
+  // chains = false: a schedule of exactly three levels (the shape whose consecutive passes the engine joins into its own
+  // persistent launch, engine.cpp rotation_chain) gets no chain plan of its own — a third of the planning time at the
+  // headline size for lists the joined launch never reads
+  void make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out, bool chains = true) const;
   void make_schedule(const int32_t* factors, int64_t n, const int64_t* om_off, const double* om,
                      const int64_t* mk_off, const uint8_t* mk, Schedule& out) const;
   int64_t row_sends(int32_t f) const;
