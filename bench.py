@@ -386,7 +386,8 @@ def main():
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_run_launch):
         sys.exit(launch_ranks(args, sys.argv[1:]))
     if args.schedule == "auto":
-        args.schedule = "boundary" if args.workload == "c4" else ("overlap" if args.order == "colour_major" else "lockstep")
+        # (overlap: 2-colour grids with an even number of rows per strip; anything else that must be exact runs in lock step)
+        args.schedule = "boundary" if args.workload == "c4" else ("overlap" if args.order == "colour_major" and args.grid % 2 == 0 else "lockstep")
     if args.schedule == "overlap" and (args.workload != "c3" or args.order != "colour_major"):
         print("bench.py: --schedule overlap is for grids in colour-major order (random graphs: lockstep or boundary)", file=sys.stderr)
         sys.exit(2)
