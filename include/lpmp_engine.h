@@ -201,6 +201,9 @@ int lpmp_factor_lower_bounds(lpmp_engine* e, double* out /*[n_factors], host*/);
  * a pass is a sum over an array.  Call this after changing duals behind the engine's back (writes through
  * lpmp_device_duals or a borrowed dual buffer): the next lpmp_lower_bound recomputes every factor. */
 int lpmp_invalidate_lower_bounds(lpmp_engine* e);
+/* How many per-factor bounds the last lpmp_lower_bound / lpmp_factor_lower_bounds had to recompute from the duals (the sweep
+ * kernels keep the others current: DESIGN.md 5); the number of factors when it recomputed everything, -1 before the first. */
+int64_t lpmp_lower_bound_recomputed(const lpmp_engine* e);
 int lpmp_synchronize(lpmp_engine* e);
 /* diagnostic: 1 when the uploaded model is streamed with non-temporal loads / stores (tables + duals above 1 GiB, i.e.
  * far larger than L2 + Infinity Cache; LPMP_NT=0/1 in the environment overrides), else 0; -1 without a model */

@@ -344,6 +344,7 @@ struct lpmp_engine {
   int32_t* d_stale = nullptr; unsigned long long* d_stale_n = nullptr; unsigned long long* h_stale_n = nullptr;
   bool lb_all_stale = true;
   bool use_lb_tracking = true;
+  int64_t last_lb_recomputed = -1;   // factor bounds the last evaluation had to recompute (-1: none evaluated yet)
   // primal rounding: the factors' primal_ members, the lazily initialised set, the message links
   int32_t* d_primal = nullptr;
   PrimalInit* d_pinit = nullptr; int64_t n_pinit = 0;
@@ -2081,9 +2082,11 @@ static void compute_factor_lbs(lpmp_engine* e) {
     if (n_stale <= nf / 8) {
       launch_factor_lb_list(e->d_lbrecs, e->d_dual, e->d_const, e->d_lb, e->d_stale, n_stale, e->stream);
       HIP_CHECK(hipGetLastError());
+      e->last_lb_recomputed = n_stale;
       return;
     }
   }
+  e->last_lb_recomputed = e->plan->p.nf;
   for (const auto& r : e->lb_runs) {
     if (r.cls == 0 || !launch_dense_lb(r.cls, e->d_lbrecs, e->d_dual, e->d_const, e->d_lb, r.first, r.count, e->stream))
       launch_factor_lb(e->d_lbrecs + r.first, e->d_dual, e->d_const, e->d_lb + r.first, r.count, e->stream);
@@ -2205,6 +2208,7 @@ int lpmp_set_rows_layout(lpmp_engine* e, int on) {
   return guarded([&] { if (!e) throw std::runtime_error("null engine"); e->want_rows = on != 0; });
 }
 int lpmp_rows_layout(const lpmp_engine* e) { return e && e->rows ? 1 : 0; }
+int64_t lpmp_lower_bound_recomputed(const lpmp_engine* e) { return e ? e->last_lb_recomputed : -1; }
 void* lpmp_engine_stream(lpmp_engine* e) { return e ? (void*)e->stream : nullptr; }
 const lpmp_plan* lpmp_engine_plan(const lpmp_engine* e) { return e ? e->plan.get() : nullptr; }
 lpmp_plan* lpmp_engine_plan_mut(lpmp_engine* e) { return e ? e->plan.get() : nullptr; }

@@ -1217,9 +1217,27 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
     if (live && g == 0 && (uni<G>(hdr->kind_flags) & UPD_PRIMAL)) store_label(primal, uni<G>(hdr->factor), Lr, lab);
   }
 #ifndef LPMP_ABLATE_LB_TRACK
-  if constexpr (CHAIN) {
-    if (hmode == HIST_MID) { const double mb = vec_min<G, L>(vl ? theta : LPMP_INF); if (live && g == 0) st_lb<A>(lbh + uni<G>(hdr->factor), mb); }
+  // Bound of a pairwise peer after a SEND that follows this record's receive through the same vector (plan.cpp marks the pair:
+  // Op::pad of the send = index of that receive + 1).  The receive left m_s = -q (q[a] = min_b T[a][b] + m_o[b], up to the
+  // rounding of m_s - (m_s + q)), nothing else of the peer moved since, and the send adds omega * theta_snap: the peer's
+  // bound min_a (m_s[a] + q[a]) is omega * min_a theta_snap[a] up to ~1e-16 of |q| per factor (sums of millions of them
+  // stay below 1e-12 of the bound).  In the weight modes in which every message is received and then sent (uniform /
+  // damped_uniform: the rounding iterations of MpRoundingSolver) this keeps EVERY pairwise bound tracked, and
+  // LP::LowerBound after such a pass is a sum instead of a scan of all tables (C3: 0.04 instead of 3.2 ms).
+  // (parked in LDS — lds_q is free once the receives are done, and only the lane that wrote it reads it back: a register
+  // held across the send loops takes the 32-label chain body from 167 to 170 VGPRs, i.e. from 3 to 2 waves per SIMD)
+  {
+    const double snap_min_v = vec_min<G, L>(vl ? theta : LPMP_INF);
+    if (g == 0) lds_q[grp][0] = snap_min_v;
+    if constexpr (CHAIN) {   // joined passes: the factor's own bound at the seam between two passes is this minimum too
+      if (hmode == HIST_MID) { if (live && g == 0) st_lb<A>(lbh + uni<G>(hdr->factor), snap_min_v); }
+    }
   }
+  const bool send_bounds = !(flags & SWEEP_RESIDUAL);   // (the residual rule adds to the sent vectors once more)
+#define LPMP_SNAP_MIN (lds_q[grp][0])
+#else
+  const bool send_bounds = false;
+#define LPMP_SNAP_MIN 0.0
 #endif
   if (vl && !aborted) {
     const double snap = theta;
@@ -1246,7 +1264,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
 #ifndef LPMP_ABLATE_LB_TRACK
           // a vector that goes to the mailbox has a reader later in this launch, which sets the peer's tracked bound itself
           // — and is not ordered after THIS store, so it is left out
-          if (g == 0 && !(MBOX && s_box[k])) st_lb<A>(lb + s_peer[k], LPMP_NAN);
+          if (g == 0 && !(MBOX && s_box[k])) st_lb<A>(lb + s_peer[k], fw > 0 && send_bounds ? s_om[k] * LPMP_SNAP_MIN : LPMP_NAN);
 #endif
         }
       }
@@ -1268,7 +1286,7 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
           st_dual<A>(ms + g, cur + delta);
           theta -= delta;
 #ifndef LPMP_ABLATE_LB_TRACK
-          if (g == 0) st_lb<A>(lb + uni<G>(o.peer), LPMP_NAN);
+          if (g == 0) st_lb<A>(lb + uni<G>(o.peer), fw > 0 && send_bounds ? o.omega * LPMP_SNAP_MIN : LPMP_NAN);
 #endif
         }
       }
@@ -1428,8 +1446,10 @@ __device__ __forceinline__ void chain_loop_ahead(const ChainArgs& ca, const Chai
     __syncthreads();
   }
 }
+// (the exact 32-label body needs 167-171 VGPRs depending on small things: three waves per SIMD are asked for, so that it stays
+// at the 170 that allows them — the joined passes of the headline grid lose 8 % at two)
 template <int L, int KMAX, bool VAR, bool NT, bool MBOX>
-__global__ void __launch_bounds__(256, MBOX ? LPMP_MBOX_WPE : 1)
+__global__ void __launch_bounds__(256, MBOX ? LPMP_MBOX_WPE : (L == 32 && !VAR ? 3 : 1))
 chain_dense_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, double* __restrict__ dual,
                       const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal, int flags) {
   if constexpr (MBOX) {
@@ -2074,6 +2094,9 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
     const int lab = group_argmin<L, L>(theta, vl, g);
     if (live && g == 0 && (hdr->kind_flags & UPD_PRIMAL)) store_label(primal, hdr->factor, Lr, lab);
   }
+  // (see dense_pk_body: the bound of a peer after a send that follows this record's receive through the same vector)
+  const double snap_min = vec_min<L, L>(vl ? theta : LPMP_INF);
+  const bool send_bounds = !(flags & SWEEP_RESIDUAL);
   if (vl && !aborted) {
     const double snap = theta;
     if constexpr (CHAIN) {                          // no load inside the send loop (see dense_pk_body)
@@ -2107,7 +2130,7 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
         }
         st_dual<A>(ms + g, cur + delta);
         theta -= delta;
-        if (g == 0 && !boxed) st_lb<A>(lb + o.peer, LPMP_NAN);
+        if (g == 0 && !boxed) st_lb<A>(lb + o.peer, fw > 0 && send_bounds ? o.omega * snap_min : LPMP_NAN);
       }
     }
     for (int k = KS; k < n_send; ++k) {

@@ -37,7 +37,7 @@ KERNEL_NAMES = ["sweep_generic_kernel<64>", "sweep_dense_pk_kernel<4, 4, false",
 MEM_HOST, MEM_DEVICE = 0, 1
 
 EXPORTS = [
-    "lpmp_last_error", "lpmp_version", "lpmp_experiment_build", "lpmp_set_rows_layout", "lpmp_rows_layout", "lpmp_plan_create", "lpmp_plan_destroy", "lpmp_plan_n_factors",
+    "lpmp_last_error", "lpmp_version", "lpmp_experiment_build", "lpmp_set_rows_layout", "lpmp_rows_layout", "lpmp_lower_bound_recomputed", "lpmp_plan_create", "lpmp_plan_destroy", "lpmp_plan_n_factors",
     "lpmp_plan_n_updated", "lpmp_plan_get_order", "lpmp_plan_get_update_order", "lpmp_plan_omega_nnz",
     "lpmp_plan_mask_nnz", "lpmp_plan_get_omega", "lpmp_plan_get_mask", "lpmp_plan_get_msg_lists",
     "lpmp_plan_anisotropic_weights", "lpmp_plan_schedule_info", "lpmp_plan_custom_schedule_info", "lpmp_plan_schedule_classes", "lpmp_plan_get_update_levels", "lpmp_plan_pass_schedule_info", "lpmp_plan_pass_rotates", "lpmp_plan_chain_info", "lpmp_plan_mailbox_info", "lpmp_create", "lpmp_destroy", "lpmp_set_stream",
@@ -143,6 +143,9 @@ def lib():
             L.lpmp_speculation_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
             L.lpmp_chain_cache_bytes.restype = C.c_int64
             L.lpmp_chain_cache_bytes.argtypes = [C.c_void_p]
+        if hasattr(L, "lpmp_lower_bound_recomputed"):
+            L.lpmp_lower_bound_recomputed.restype = C.c_int64
+            L.lpmp_lower_bound_recomputed.argtypes = [C.c_void_p]
         if hasattr(L, "lpmp_set_rows_layout"):
             L.lpmp_set_rows_layout.argtypes = [C.c_void_p, C.c_int]
             L.lpmp_rows_layout.argtypes = [C.c_void_p]
@@ -358,6 +361,10 @@ class Engine:
         self.model = model
         _chk(self.L.lpmp_upload_model(self.h, C.addressof(cs), MEM_DEVICE if const_dev is not None else MEM_HOST,
                                       MEM_DEVICE if dual_dev is not None else MEM_HOST))
+
+    def lower_bound_recomputed(self) -> int:
+        """per-factor bounds the last lower_bound() had to recompute (the rest were tracked by the sweep kernels)"""
+        return int(self.L.lpmp_lower_bound_recomputed(self.h))
 
     @property
     def rows_layout(self) -> bool:

@@ -1049,3 +1049,33 @@ def test_updated_pairwise_factors_rectangular_tables(eng):
         _check(eng, m, mode, 3)
     cls = eng.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC)
     assert sum(v for k, v in cls.items() if k.startswith("pairwise")) > 0
+
+
+@pytest.mark.parametrize("pairwise,L", [("dense", 32), ("dense", 16), ("potts", 8), ("dense", 21)])
+def test_bounds_stay_tracked_through_uniform_weight_passes(pairwise, L):
+    """uniform / damped_uniform (the rounding iterations of MpRoundingSolver): every message is received and then sent by the same
+    record, so a pairwise factor's last touch is a SEND — its bound after that send is omega * min(theta_snapshot) up to rounding
+    (kernels.hip, dense_pk_body), and LP::LowerBound after such a pass is a sum over tracked values, not a scan of all tables"""
+    m = S.grid_model(24, 26, L, pairwise=pairwise, order="colour_major", seed=L, compute_primal=True)
+    o = Oracle(m)
+    e = E.Engine(0)
+    try:
+        e.upload(m)
+        for mode in (M.REPAM_DAMPED_UNIFORM, M.REPAM_UNIFORM, M.REPAM_ANISOTROPIC):
+            o.set_reparametrization(mode); e.set_reparametrization(mode)
+            e.lower_bound()                                  # everything evaluated once
+            for n in (1, 2):
+                o.ComputePass(n); e.compute_pass(n)
+                lb = e.lower_bound()
+                assert e.lower_bound_recomputed() == 0, (mode, n, e.lower_bound_recomputed())
+                assert abs(lb - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+                e.invalidate_lower_bounds()
+                assert abs(e.lower_bound() - lb) <= 1e-12 * max(1.0, abs(lb)) and e.lower_bound_recomputed() == m.n_factors
+        # a rounding pass under damped_uniform, then the bound: still nothing to recompute
+        o.set_reparametrization(M.REPAM_DAMPED_UNIFORM); e.set_reparametrization(M.REPAM_DAMPED_UNIFORM)
+        o.ComputePassAndPrimal(9); e.compute_pass_and_primal(9)
+        lb = e.lower_bound()
+        assert e.lower_bound_recomputed() == 0 and abs(lb - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+        assert np.array_equal(e.download_duals(), o.duals())
+    finally:
+        e.close()

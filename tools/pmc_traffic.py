@@ -29,7 +29,12 @@ def main():
     w = per_launch(write_csv, "WRITE_SIZE", kernel)
     if len(sys.argv) > 6 and int(sys.argv[6]) > 0:
         f, w = f[:-int(sys.argv[6])], w[:-int(sys.argv[6])]
-    if len(sys.argv) > 5:
+    if len(sys.argv) > 5 and int(sys.argv[5]) == 0:
+        # last_n = 0: the LARGEST launch of the kernel (the timed multi-pass chain launch: other legs of bench.py launch the
+        # same kernel for single sweeps)
+        k = max(range(len(f)), key=lambda i: f[i])
+        f, w = [f[k]], [w[k]]
+    elif len(sys.argv) > 5:
         f, w = f[-int(sys.argv[5]):], w[-int(sys.argv[5]):]
     assert f and w and len(f) == len(w), (len(f), len(w))
     by = [(2.0 * a + b) * 1024.0 for a, b in zip(f, w)]

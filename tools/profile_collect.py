@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/profile_collect.py TAG [kernel substring] [last_n skip_tail] — summaries of tools/profile_round.sh's runs
+"""tools/profile_collect.py TAG [kernel substring] [last_n skip_tail] [workload] (last_n = 0: the largest launch of the kernel) — summaries of tools/profile_round.sh's runs
 (gpurun_out/prof_TAG/) written into profiles/:
   TAG_bench_c3_default.json, TAG_bench_c3_under_rocprof.json   bench lines (plain / under the kernel trace)
   TAG_bench_c3_kernel_stats.csv                                per-kernel calls / total / average of the kernel trace
@@ -51,7 +51,7 @@ d["note"] = ("FETCH_SIZE / WRITE_SIZE are the L2's fabric-side request counters:
 json.dump(d, open(pj, "w"))
 c = sqlite3.connect(db("stats"))
 v = [r[0] for r in c.execute("select duration from kernels where name like ? order by start", ("%" + kernel + "%",))]
-leg = v[:len(v) - skip_tail][-last_n:]
+leg = v[:len(v) - skip_tail][-last_n:] if last_n > 0 else [max(v)]          # last_n = 0: the longest launch (the timed multi-pass chain launch)
 print(json.dumps({"plain_ms_per_step": plain["ms_per_step"], "plain_frac": plain["roofline"]["frac"], "oracle_check": plain.get("oracle_check"),
                   "under_rocprof_in_bench_avg_launch_ms": prof["roofline"]["avg_launch_ms"],
                   "rocprof_kernel_trace_avg_ms_same_launches": sum(leg) / len(leg) / 1e6, "launches": len(leg)}))
