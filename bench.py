@@ -181,7 +181,7 @@ def make_strip_runner(torch, dist, args, schedule, H, mode):
     from lp_mp_amd import multi_gpu as MG
     if schedule == "overlap":
         from lp_mp_amd import overlap as OV
-        g = min(args.ghost_rows, H - (H % 2))
+        g = max(4, min(args.ghost_rows, H - (H % 2)))
         return OV.OverlapStrips(torch, dist, H, H, args.labels, args.pairwise, mode, seed=1, g=g)
     if schedule == "lockstep":
         from lp_mp_amd import lockstep as LS

@@ -1226,14 +1226,16 @@ __device__ __forceinline__ void dense_pk_body(const Op* __restrict__ packets, co
   // LP::LowerBound after such a pass is a sum instead of a scan of all tables (C3: 0.04 instead of 3.2 ms).
   // (parked in LDS — lds_q is free once the receives are done, and only the lane that wrote it reads it back: a register
   // held across the send loops takes the 32-label chain body from 167 to 170 VGPRs, i.e. from 3 to 2 waves per SIMD)
-  {
+  // Not in the mailbox bodies: there a record is a link of a latency-bound chain, and the reduction (+ 2-3 % per level,
+  // measured) buys nothing — deep schedules are not what a rounding iteration's bound waits for.
+  if constexpr (!MBOX) {
     const double snap_min_v = vec_min<G, L>(vl ? theta : LPMP_INF);
     if (g == 0) lds_q[grp][0] = snap_min_v;
     if constexpr (CHAIN) {   // joined passes: the factor's own bound at the seam between two passes is this minimum too
       if (hmode == HIST_MID) { if (live && g == 0) st_lb<A>(lbh + uni<G>(hdr->factor), snap_min_v); }
     }
   }
-  const bool send_bounds = !(flags & SWEEP_RESIDUAL);   // (the residual rule adds to the sent vectors once more)
+  const bool send_bounds = !MBOX && !(flags & SWEEP_RESIDUAL);   // (the residual rule adds to the sent vectors once more)
 #define LPMP_SNAP_MIN (lds_q[grp][0])
 #else
   const bool send_bounds = false;
@@ -2095,8 +2097,9 @@ __device__ __forceinline__ void potts_pk_body(const Op* __restrict__ packets, co
     if (live && g == 0 && (hdr->kind_flags & UPD_PRIMAL)) store_label(primal, hdr->factor, Lr, lab);
   }
   // (see dense_pk_body: the bound of a peer after a send that follows this record's receive through the same vector)
-  const double snap_min = vec_min<L, L>(vl ? theta : LPMP_INF);
-  const bool send_bounds = !(flags & SWEEP_RESIDUAL);
+  double snap_min = 0.0;
+  if constexpr (!MBOX) snap_min = vec_min<L, L>(vl ? theta : LPMP_INF);
+  const bool send_bounds = !MBOX && !(flags & SWEEP_RESIDUAL);
   if (vl && !aborted) {
     const double snap = theta;
     if constexpr (CHAIN) {                          // no load inside the send loop (see dense_pk_body)

@@ -93,8 +93,8 @@ def strip_window_part(H: int, W: int, L: int, pairwise: str, rank: int, world: i
     """rank's window of the (world * H) x W grid of synthetic.grid_model(world * H, W, L, pairwise, "colour_major", seed).
     ``costs``: host arrays of the GLOBAL model (tests: {"unaries": [n, L], "tables": [E, L, L] or "potts": [E]}); else the
     costs are generated in HBM from the counter stream (fill descriptors, multi_gpu.fill_device_costs)."""
-    if g % 2 or g < 2:
-        raise ValueError("overlap: the ghost depth must be even and at least 2 (the window keeps the global colouring)")
+    if g % 2 or g < 4:
+        raise ValueError("overlap: the ghost depth must be even (the window keeps the global colouring) and at least 4 (one pass between exchanges needs 4 rows)")
     if H % 2:
         raise ValueError("overlap: strips need an even number of rows (every window starts on an even global row)")
     if world > 1 and g > H:
@@ -158,7 +158,9 @@ def _u01_at(pos: np.ndarray, seed: int) -> np.ndarray:
 def max_passes_between_exchanges(g: int) -> int:
     """what is wrong at the rim of a window moves two rows per pass (one per directional sweep); the outermost row is wrong
     from the first update on and one more row of margin keeps the cut edge's far side exact: g >= 2 n + 2"""
-    return max(1, (g - 2) // 2)
+    if g < 4:
+        raise ValueError("overlap: fewer than 4 ghost rows allow no pass at all between two exchanges")
+    return (g - 2) // 2
 
 
 class OverlapSweep:

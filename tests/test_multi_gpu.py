@@ -656,3 +656,57 @@ def test_cpp_rccl_driver_two_processes_on_one_gpu_fail_or_agree(tmp_path):
     import json
     line = json.loads(outs[0][0].strip().splitlines()[-1])
     assert line["lower_bound_after"] > line["lower_bound_before"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pairwise,L,H,W,parts,ghost,chunk", [("dense", 16, 12, 10, 2, 6, 0), ("dense", 32, 12, 9, 3, 6, 1), ("potts", 8, 16, 12, 3, 8, 2),
+                                                               ("dense", 8, 8, 7, 4, 8, 0)])
+def test_cpp_rccl_driver_overlap_schedule_equals_the_python_overlap_sweep_and_the_oracle(tmp_path, pairwise, L, H, W, parts, ghost, chunk):
+    """tools/mgpu_rccl_driver.cpp --schedule overlap (lp_mp_amd/include/lpmp_overlap.hxx: windows with ghost rows, plain
+    lpmp_compute_pass calls, ghost rows refreshed by ncclSend / ncclRecv of contiguous ranges of the packed duals) at world 1 with
+    several parts on the one GPU — through RCCL to self — against lp_mp_amd/overlap.py on the same windows: every part's WHOLE dual
+    array bit-identical (ghost rows included: both end a call with an exchange), and the owned rows against the oracle on the
+    unpartitioned grid"""
+    from lp_mp_amd import build as B, engine as E, overlap as OV
+    from oracle.binding import Oracle
+    if not B.have_rccl():
+        pytest.skip("no <rccl/rccl.h> on this box")
+    passes = 5
+    exe = B.build_mgpu_driver()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.check_output([exe, "--H", str(H), "--W", str(W), "--L", str(L), "--pairwise", pairwise, "--passes", str(passes),
+                                   "--parts-per-rank", str(parts), "--schedule", "overlap", "--ghost-rows", str(ghost), "--chunk", str(chunk),
+                                   "--out", str(tmp_path / "duals")], text=True, env=env, timeout=600)
+    import json
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["schedule"] == "overlap" and line["passes_between_exchanges"] == (chunk or (ghost - 2) // 2)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    sweeps, tensors = [], []
+    for k in range(parts):
+        p = OV.strip_window_part(H, W, L, pairwise, k, parts, ghost, 1)
+        m = p.model
+        const = torch.empty(max(int(m.const_sizes().sum()), 2), dtype=torch.float64, device=dev)
+        dual = torch.zeros(int(m.dual_sizes().sum()), dtype=torch.float64, device=dev)
+        if m.const_data is not None and p.const_fill is None and m.const_data.size:
+            const[: m.const_data.shape[0]] = torch.from_numpy(m.const_data).to(dev)
+        MG.fill_device_costs(torch, E, p, const, dual, stream)
+        eng = E.Engine(0); eng.set_stream(stream)
+        eng.upload(m, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual))
+        eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+        sweeps.append(OV.OverlapSweep(torch, p, eng, dual, chunk or None)); tensors.append(dual)
+    try:
+        lb0 = sum(s.local_lower_bound() for s in sweeps)
+        OV.run_overlapped(sweeps, passes)
+        torch.cuda.synchronize()
+        lb1 = sum(s.local_lower_bound() for s in sweeps)
+        for k in range(parts):
+            got = np.fromfile(tmp_path / f"duals.{k}.bin", dtype=np.float64)
+            assert np.array_equal(got, tensors[k].cpu().numpy()), k
+        assert abs(line["lower_bound_before"] - lb0) <= 1e-9 * abs(lb0) and abs(line["lower_bound_after"] - lb1) <= 1e-9 * abs(lb1)
+        gm = S.grid_model(parts * H, W, L, pairwise=pairwise, order="colour_major", seed=1)
+        o = Oracle(gm); o.set_reparametrization(M.REPAM_ANISOTROPIC); o.ComputePass(passes)
+        assert abs(line["lower_bound_after"] - o.LowerBound()) <= 1e-9 * abs(o.LowerBound())
+    finally:
+        for s in sweeps:
+            s.engine.close()

@@ -86,11 +86,13 @@ def test_ghost_depth_is_what_the_pass_count_needs():
     passes than that are refused — and would be wrong: forced, the owned rows differ from the unpartitioned sweep"""
     H, W, L, world = 8, 6, 3, 3
     gm, costs = _global(H, W, L, world, "dense", seed=2)
-    assert [OV.max_passes_between_exchanges(g) for g in (2, 4, 6, 12, 22)] == [1, 1, 2, 5, 10]
+    assert [OV.max_passes_between_exchanges(g) for g in (4, 6, 12, 22)] == [1, 2, 5, 10]
+    with pytest.raises(ValueError, match="at least 4"):
+        OV.strip_window_part(H, W, L, "dense", 0, world, 2, costs=costs)
     parts = [OV.strip_window_part(H, W, L, "dense", r, world, 4, costs=costs) for r in range(world)]
     with pytest.raises(ValueError, match="ghost rows"):
         _cpu_sweeps(parts, M.REPAM_ANISOTROPIC, chunk=2)
-    for bad in (3, 5):
+    for bad in (5, 7):
         with pytest.raises(ValueError, match="even"):
             OV.strip_window_part(H, W, L, "dense", 0, world, bad, costs=costs)
     with pytest.raises(ValueError, match="even number of rows"):
@@ -269,5 +271,32 @@ def test_full_size_windows_equal_one_engine_on_the_whole_grid():
             assert abs(lb - lbg) <= 1e-12 * abs(lbg)
     finally:
         ge.close()
+        for s in sweeps:
+            s.engine.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_overlapped_strips_random_shapes_modes_and_chunks_on_device(seed):
+    """random strip height / width (odd widths too), label count, pairwise kind, number of strips, ghost depth, passes between
+    exchanges (any value the depth allows) and weight mode; separate calls of random length: owned duals and the summed bound are
+    the oracle's on the whole grid"""
+    rng = np.random.default_rng(500 + seed)
+    world = int(rng.integers(2, 6)); g = 2 * int(rng.integers(2, 6))
+    H = 2 * int(rng.integers(max(1, g // 2), 9)); W = int(rng.integers(2, 14))
+    L = int(rng.choice([2, 3, 4, 5, 8, 16, 21, 32])); pairwise = "potts" if rng.uniform() < 0.35 else "dense"
+    mode = [M.REPAM_ANISOTROPIC, M.REPAM_ANISOTROPIC2, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM][int(rng.integers(0, 4))]
+    chunk = int(rng.integers(1, OV.max_passes_between_exchanges(g) + 1))
+    gm, costs = _global(H, W, L, world, pairwise, seed=seed)
+    ref = Oracle(gm); ref.set_reparametrization(mode)
+    parts = [OV.strip_window_part(H, W, L, pairwise, r, world, g, costs=costs) for r in range(world)]
+    sweeps, tensors = _device_sweeps(parts, mode, chunk)
+    try:
+        for n in rng.integers(1, 6, 3):
+            ref.ComputePass(int(n)); OV.run_overlapped(sweeps, int(n)); torch.cuda.synchronize()
+            _assert_owned_equal_global(gm, parts, [t.cpu().numpy() for t in tensors], ref)
+            lb = sum(s.local_lower_bound() for s in sweeps)
+            assert abs(lb - ref.LowerBound()) <= 1e-9 * max(1.0, abs(ref.LowerBound())), (seed, lb, ref.LowerBound())
+    finally:
         for s in sweeps:
             s.engine.close()

@@ -7,6 +7,9 @@
 //
 //   mgpu_rccl_driver [--H 64] [--W 64] [--L 8] [--pairwise dense|potts] [--order colour_major|row_major] [--passes 4]
 //                    [--parts-per-rank 1] [--boundary pass|sweep] [--mode 0] [--out PREFIX] [--time K]
+//                    [--schedule boundary|overlap] [--ghost-rows 12] [--chunk 0]
+// --schedule overlap (lpmp_overlap.hxx): the EXACT schedule for colour-major grids — every part a window with ghost rows of the
+// global (n_parts * H) x W grid, plain lpmp_compute_pass calls, one exchange per (ghost-rows / 2 - 1) passes (or --chunk).
 //
 // Prints one JSON line on rank 0 (lower bound before / after, msg-updates/s when --time is given); with --out every part's
 // packed duals go to PREFIX.<part>.bin (tests/test_multi_gpu.py compares them with lp_mp_amd/multi_gpu.py's run).
@@ -19,7 +22,7 @@
 #include <string>
 #include <vector>
 
-#include "../lp_mp_amd/include/lpmp_multi_gpu.hxx"
+#include "../lp_mp_amd/include/lpmp_overlap.hxx"
 
 using namespace lpmp_mgpu;
 
@@ -27,7 +30,8 @@ static int env_int(const char* name, int dflt) { const char* v = std::getenv(nam
 
 int main(int argc, char** argv) {
   int H = 64, W = 64, L = 8, passes = 4, ppr = 1, mode = LPMP_REPAM_ANISOTROPIC, timed = 0;
-  bool potts = false, colour = true, every_pass = true;
+  bool potts = false, colour = true, every_pass = true, overlap = false;
+  int ghost = 12, chunk = 0;
   std::string out;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -38,6 +42,8 @@ int main(int argc, char** argv) {
     else if (a == "--pairwise") potts = std::string(next()) == "potts";
     else if (a == "--order") colour = std::string(next()) == "colour_major";
     else if (a == "--boundary") every_pass = std::string(next()) == "pass";
+    else if (a == "--schedule") overlap = std::string(next()) == "overlap";
+    else if (a == "--ghost-rows") ghost = std::atoi(next()); else if (a == "--chunk") chunk = std::atoi(next());
     else if (a == "--out") out = next();
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
@@ -56,6 +62,47 @@ int main(int argc, char** argv) {
     w.init(rank, world, ppr, addr && *addr ? addr : "127.0.0.1", env_int("LPMP_NCCL_ID_PORT", env_int("MASTER_PORT", 29500) + 1), stream);
 
     const int n_parts = world * ppr;
+    if (overlap) {
+      if (!colour) throw std::runtime_error("--schedule overlap is for colour-major grids");
+      std::vector<std::unique_ptr<window_sweep>> own;
+      std::vector<window_sweep*> parts;
+      for (int k = 0; k < ppr; ++k) {
+        own.emplace_back(new window_sweep());
+        own.back()->build(strip_window(H, W, L, potts, rank * ppr + k, n_parts, ghost, 1), device, stream, mode);
+        parts.push_back(own.back().get());
+      }
+      const double lb0 = overlap_lower_bound(parts, w);
+      overlap_compute_pass(parts, w, passes, chunk);
+      const double lb1 = overlap_lower_bound(parts, w);
+      if (!out.empty())
+        for (window_sweep* p : parts) {
+          const std::vector<double> d = p->download_duals();
+          const std::string path = out + "." + std::to_string(p->wm.part) + ".bin";
+          FILE* f = std::fopen(path.c_str(), "wb");
+          if (!f || std::fwrite(d.data(), sizeof(double), d.size(), f) != d.size()) throw std::runtime_error("cannot write " + path);
+          std::fclose(f);
+        }
+      double ms_per_pass = 0;
+      if (timed > 0) {
+        (void)w.all_reduce_sum(0.0);
+        const auto t0 = std::chrono::steady_clock::now();
+        overlap_compute_pass(parts, w, timed, chunk);
+        (void)w.all_reduce_sum(0.0);
+        ms_per_pass = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
+      }
+      if (rank == 0) {
+        const double E = (double)n_parts * H * (W - 1) + ((double)n_parts * H - 1) * W;       // edges of the whole grid: 4 E message updates per anisotropic pass
+        std::printf("{\"driver\": \"mgpu_rccl_driver (C++ host, C ABI + RCCL)\", \"schedule\": \"overlap\", \"world\": %d, \"parts\": %d, \"grid_per_part\": [%d, %d], "
+                    "\"labels\": %d, \"pairwise\": \"%s\", \"ghost_rows\": %d, \"passes_between_exchanges\": %d, \"passes\": %d, \"lower_bound_before\": %.17g, "
+                    "\"lower_bound_after\": %.17g", world, n_parts, H, W, L, potts ? "potts" : "dense", ghost, chunk > 0 ? chunk : (ghost - 2) / 2, passes, lb0, lb1);
+        if (timed > 0) std::printf(", \"ms_per_pass\": %.6f, \"msg_updates_per_s\": %.6g", ms_per_pass, 4.0 * E / (ms_per_pass * 1e-3));
+        std::printf("}\n");
+      }
+      own.clear();
+      w.destroy();
+      (void)hipStreamDestroy(stream);
+      return 0;
+    }
     std::vector<std::unique_ptr<part_sweep>> own;
     std::vector<part_sweep*> parts;
     for (int k = 0; k < ppr; ++k) {
