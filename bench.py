@@ -429,7 +429,7 @@ def main():
         if launch["ranks_seen"] != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {launch['ranks_seen']} ranks")
         launch["persistent_launches"] = True
-        if len(set(launch["devices"])) < world:
+        if len(set(launch["devices"])) < world and not os.environ.get("LPMP_BENCH_KEEP_PERSISTENT"):   # (tools/shared_device_stall_probe.sh keeps them on)
             # ranks that SHARE a device (smoke runs on the 1-GPU box): the persistent chain launches assume that resident
             # workgroups keep running, which a device time-sliced between processes does not give them (kernels.hip, chain
             # executor: about every third 8-rank run stalled until its wait bound) — one launch per step instead

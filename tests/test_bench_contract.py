@@ -89,12 +89,14 @@ def test_bench_c4_workload_line():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("schedule", ["boundary", "lockstep"])
+@pytest.mark.parametrize("schedule", ["overlap", "boundary", "lockstep"])
 @pytest.mark.parametrize("workload", ["c3", "c4"])
 def test_bench_distributed_branch_on_rccl_at_world_size_one(workload, schedule):
     """what an N-GPU launch of bench.py executes first, on the one GPU of the test box: --force-dist takes the multi-GPU
     branch at WORLD_SIZE 1 — init_process_group("nccl") (= RCCL), StripSweep / GraphSweep, all_to_all_single with empty
     splits in every boundary step, device all_reduce for the bound and the timing — and must print the contract line"""
+    if workload == "c4" and schedule == "overlap":
+        pytest.skip("the overlap schedule is for grids")
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
     env.pop("LPMP_DIST_BACKEND", None)
     extra = ["--grid", "128"] if workload == "c3" else ["--workload", "c4", "--c4-nodes", "20000", "--c4-edges", "100000"]

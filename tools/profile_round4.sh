@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4 profiles, batch A: C3 and C4 bench lines plain / under the kernel trace / under the two PMC passes, probes, multi-rank smokes
+# tools/profile_round4.sh — round 4 on the GPU box: C3 and C4 bench lines plain / under the kernel trace / under the two PMC passes, the overlap and lock-step probes, the solver cycle, N ranks on the one GPU (everything under gpurun_out/; profile_collect.py + copies go into profiles/)
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
