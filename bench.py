@@ -147,13 +147,14 @@ def pmc_traffic(kernel_name, args):
     return b, os.path.relpath(files[-1], ROOT)
 
 
-def dual_bound_gap_c4(torch, dist, args, mode, world, rank):
+def dual_bound_gap_c4(torch, dist, args, mode, world, rank, schedule=None):
     """the same for the C4 workload: a 20 000-node / 100 000-edge graph of the same generator, partitioned like the big
     one (same partitioner, same boundary schedule) against its unpartitioned sweep on rank 0"""
     from lp_mp_amd import engine as E, multi_gpu as MG, synthetic as S
     n, m, L, passes = 20000, 100000, args.c4_labels, args.steps
     rank_of = None
-    if args.schedule == "lockstep":
+    schedule = schedule or args.schedule
+    if schedule == "lockstep":
         from lp_mp_amd import lockstep as LS
         sw = LS.LockstepGraph(torch, dist, n, m, L, mode, seed=1, order=args.c4_order)
         sw.boundary_every, sw.global_cut_fraction = "level that reads across the cut (lock step)", sw.cut_fraction
@@ -573,7 +574,7 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         for other in ("overlap", "lockstep", "boundary"):
-            if other == args.schedule or (other == "overlap" and args.order != "colour_major"):
+            if other == args.schedule or (other == "overlap" and (args.order != "colour_major" or args.grid % 2)):
                 continue
             r2 = make_strip_runner(torch, dist, args, other, H, mode)
             dt2 = time_passes(torch, dist, r2, args.steps, args.warmup, 2)
@@ -586,6 +587,33 @@ def main():
             g2 = dual_bound_gap(torch, dist, args, mode, world, rank, schedule=other)
             schedules[other] = {"ms_per_step": t.item() / args.steps * 1e3, "dual_bound_gap": g2["dual_bound_gap"] if g2 else None,
                                 "lower_bound_after": lb2, "timed": False}
+    if dist_on and args.workload == "c4" and not args.no_compare_schedules:
+        # C4: the exact schedule (lock step, colour-major variable order) beside the boundary-step one, same graph size
+        from lp_mp_amd import multi_gpu as MG, lockstep as LS
+        schedules = {args.schedule: {"ms_per_step": dt / args.steps * 1e3, "dual_bound_gap": gap["dual_bound_gap"] if gap else None, "timed": True}}
+        eng.close()
+        for name in ("const", "dualt", "sweep", "engine"):
+            if hasattr(runner, name):
+                setattr(runner, name, None)
+        eng = runner = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        other = "boundary" if args.schedule == "lockstep" else "lockstep"
+        r2 = (MG.GraphSweep(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1) if other == "boundary" else
+              LS.LockstepGraph(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1, order=args.c4_order))
+        dt2 = time_passes(torch, dist, r2, args.steps, args.warmup, 2)
+        t = torch.tensor([dt2], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lb2 = r2.lower_bound()
+        r2.engine.close()
+        del r2
+        torch.cuda.empty_cache()
+        g2 = dual_bound_gap_c4(torch, dist, args, mode, world, rank, schedule=other)
+        schedules[other] = {"ms_per_step": t.item() / args.steps * 1e3, "dual_bound_gap": g2["dual_bound_gap"] if g2 else None,
+                            "lower_bound_after": lb2, "timed": False,
+                            "note": "lock step runs the sweep of the colour-major variable order, the boundary-step schedule that of the index order: "
+                                    "different (equally valid) sweeps, each gap is against its own unpartitioned sweep" if args.c4_order == "colour_major" else None}
     out = None
     if rank == 0:
         value = updates_per_pass * args.steps / dt
