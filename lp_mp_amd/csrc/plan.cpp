@@ -107,6 +107,9 @@ int64_t Plan::row_receives(int32_t f) const {
 }
 
 void Plan::build(const lpmp_model& m) {
+  const bool timed_ = std::getenv("LPMP_PLAN_TIMES") != nullptr;
+  auto t_last_ = std::chrono::steady_clock::now();
+  auto lap_ = [&](const char* what) { if (!timed_) return; const auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "lpmp: plan build %-10s %.0f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last_).count()); t_last_ = now; };
   if (m.n_ftypes <= 0 || m.n_factors <= 0) fail("model has no factors");
   if (m.n_factors > std::numeric_limits<int32_t>::max() || m.n_messages > std::numeric_limits<int32_t>::max() / 2)
     fail("model too large for 32-bit factor/message indices");
@@ -179,6 +182,7 @@ void Plan::build(const lpmp_model& m) {
     if (ok && mt.kind == LPMP_M_MINNORM) ok = f_kind[r] == LPMP_F_VECTOR && f_dim0[r] == f_dim0[l];
     if (!ok) fail("message " + std::to_string(i) + ": factors do not fit the message type");
   }
+  lap_("checks");
 
   // ---- per-factor message lists: dispatcher order = left-role types in MessageList order, then right-role
   std::vector<int32_t> rank_l(n_mtypes), rank_r(n_mtypes);
@@ -201,7 +205,9 @@ void Plan::build(const lpmp_model& m) {
     }
   }
   updated.assign(nf, 0);
-  for (int64_t f = 0; f < nf; ++f) {
+  lap_("msg lists");
+  parallel_chunks(nf, 65536, [&](int64_t f_begin, int64_t f_end, int) {
+  for (int64_t f = f_begin; f < f_end; ++f) {
     Tmp* b = tmp.data() + fm_off[f];
     Tmp* e = tmp.data() + fm_off[f + 1];
     std::stable_sort(b, e, [](const Tmp& x, const Tmp& y) { return x.rank < y.rank; });
@@ -229,15 +235,20 @@ void Plan::build(const lpmp_model& m) {
     }
     updated[f] = upd_f;
   }
+  });
+  lap_("dispatch");
 
   // ---- orderings
   const int32_t* rels[2] = {m.rel_fwd, m.rel_bwd};
   const int64_t nrels[2] = {m.n_rel_fwd, m.n_rel_bwd};
-  for (int d = 0; d < 2; ++d) {
-    order[d] = reference_topological_order(nf, rels[d], nrels[d]);
-    upd[d].clear();
-    for (int32_t f : order[d]) if (updated[f]) upd[d].push_back(f);
-  }
+  parallel_chunks(2, 1, [&](int64_t d_begin, int64_t d_end, int) {       // the two directions are independent
+    for (int64_t d = d_begin; d < d_end; ++d) {
+      order[d] = reference_topological_order(nf, rels[d], nrels[d]);
+      upd[d].clear();
+      for (int32_t f : order[d]) if (updated[f]) upd[d].push_back(f);
+    }
+  });
+  lap_("orderings");
 }
 
 // rows for the updated members of a list (reference allocate_omega / allocate_receive_mask)

@@ -112,9 +112,9 @@ def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: in
         raise ValueError("lockstep_mrf: a rank without variables (every rank takes part in every exchange)")
     # the global structure (no costs) and everything the reference derives from it
     if pairwise == "dense":
-        gm = S.mrf_model(n_vars, L, edge_i, edge_j, np.zeros(n_vars * L), device_const=True)
+        gm = S.mrf_model(n_vars, L, edge_i, edge_j, None, device_const=True, device_dual=True)
     else:
-        gm = S.mrf_model(n_vars, L, edge_i, edge_j, np.zeros(n_vars * L), potts=np.zeros(n_edges))
+        gm = S.mrf_model(n_vars, L, edge_i, edge_j, None, potts=np.zeros(n_edges), device_dual=True)
     gp = E.Plan(gm)
     g_off, g_ent = gp.msg_lists(gm.n_messages)
     msg = g_ent // 2                                         # messages of every factor's list; message 2 e + s: edge e, side s
@@ -165,9 +165,9 @@ def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: in
         esz = L * L if pairwise == "dense" else 1
         if stream_seed is not None:
             if pairwise == "dense":
-                m = S.mrf_model(vk.shape[0], L, li, lj, np.zeros(vk.shape[0] * L), device_const=True)
+                m = S.mrf_model(vk.shape[0], L, li, lj, None, device_const=True, device_dual=True)
             else:
-                m = S.mrf_model(vk.shape[0], L, li, lj, np.zeros(vk.shape[0] * L), potts=np.zeros(le.shape[0]))
+                m = S.mrf_model(vk.shape[0], L, li, lj, None, potts=np.zeros(le.shape[0]), device_dual=True)
             const_fill = [("blocks", esz, stream_seed, (n_vars * L + le * esz).astype(np.int64))]
             dual_fill = [("blocks", L, stream_seed, (vk * L).astype(np.int64))]
         else:

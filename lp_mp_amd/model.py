@@ -175,6 +175,7 @@ class ModelBuilder:
         self._part = []
         self.constant = 0.0
         self.skip_const = False  # True: const tables live only on the device (see Engine.upload)
+        self.skip_dual = False   # True: so do the duals (upload(dual_dev=...)): no host copy of them is built
 
     # -- labeling match tables (reference labeling_list_factor.hxx:384-402) ------------------
     def add_labeling_table(self, left_labelings, right_labelings, indices) -> int:
@@ -196,15 +197,20 @@ class ModelBuilder:
                         np.full(n, dim0, np.int32), np.full(n, dim1, np.int32)))
         if const is not None:
             self._const.append(np.ascontiguousarray(const, np.float64).reshape(-1))
-        self._dual.append(np.ascontiguousarray(dual, np.float64).reshape(-1))
+        if not self.skip_dual:
+            self._dual.append(np.ascontiguousarray(dual, np.float64).reshape(-1))
         self._nf += n
         return ids
 
-    def add_vector_factors(self, ftype: int, costs, implicit_origin: bool = False) -> np.ndarray:
-        """UnarySimplexFactor / labeling_factor / test_factor; ``costs`` is [n, dim]."""
-        costs = np.atleast_2d(np.asarray(costs, np.float64))
-        return self._add_factors(costs.shape[0], ftype, F_VECTOR, FF_IMPLICIT_ORIGIN if implicit_origin else 0,
-                                 costs.shape[1], 0, None, costs)
+    def add_vector_factors(self, ftype: int, costs, implicit_origin: bool = False, shape=None) -> np.ndarray:
+        """UnarySimplexFactor / labeling_factor / test_factor; ``costs`` is [n, dim] (None with skip_dual: ``shape`` = (n, dim))."""
+        if costs is None:
+            assert self.skip_dual and shape is not None
+            n, dim = shape
+        else:
+            costs = np.atleast_2d(np.asarray(costs, np.float64))
+            n, dim = costs.shape
+        return self._add_factors(n, ftype, F_VECTOR, FF_IMPLICIT_ORIGIN if implicit_origin else 0, dim, 0, None, costs)
 
     def add_dense_pairwise(self, ftype: int, tables=None, n: Optional[int] = None, dims=None) -> np.ndarray:
         """PairwiseSimplexFactor; ``tables`` is [n, d0, d1] (row-major) or None with skip_const."""
@@ -216,13 +222,13 @@ class ModelBuilder:
         else:
             assert self.skip_const and n is not None and dims is not None
             d0, d1 = dims
-        return self._add_factors(n, ftype, F_PAIRWISE_DENSE, 0, d0, d1, tables, np.zeros((n, d0 + d1)))
+        return self._add_factors(n, ftype, F_PAIRWISE_DENSE, 0, d0, d1, tables, None if self.skip_dual else np.zeros((n, d0 + d1)))
 
     def add_potts_pairwise(self, ftype: int, n_labels: int, diffs) -> np.ndarray:
         """pairwise_potts_factor(n_labels, diff)."""
         diffs = np.atleast_1d(np.asarray(diffs, np.float64))
         n = diffs.shape[0]
-        return self._add_factors(n, ftype, F_PAIRWISE_POTTS, 0, n_labels, n_labels, diffs, np.zeros((n, 2 * n_labels)))
+        return self._add_factors(n, ftype, F_PAIRWISE_POTTS, 0, n_labels, n_labels, diffs, None if self.skip_dual else np.zeros((n, 2 * n_labels)))
 
     # -- messages / relations ------------------------------------------------------------------------
     def add_messages(self, mtype: int, left, right) -> np.ndarray:
@@ -274,7 +280,7 @@ class ModelBuilder:
             f_flags=cat([c[2] for c in self._f], np.uint8), f_dim0=cat([c[3] for c in self._f], np.int32),
             f_dim1=cat([c[4] for c in self._f], np.int32),
             const_data=None if self.skip_const else cat(self._const, np.float64),
-            dual_data=cat(self._dual, np.float64),
+            dual_data=None if self.skip_dual else cat(self._dual, np.float64),
             m_type=cat([c[0] for c in self._m], np.int32), m_left=cat([c[1] for c in self._m], np.int32),
             m_right=cat([c[2] for c in self._m], np.int32),
             rel_fwd=cat(self._rel_fwd, np.int32, (0, 2)).astype(np.int32).reshape(-1, 2),

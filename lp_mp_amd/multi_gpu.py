@@ -93,7 +93,7 @@ def partition_mrf(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, p
         lj[cut] = lv.shape[0] + np.arange(n_ghost)
         const_fill = dual_fill = None
         if stream_seed is not None:
-            m = S.mrf_model(lv.shape[0] + n_ghost, L, li, lj, np.zeros((lv.shape[0] + n_ghost) * L), device_const=True)
+            m = S.mrf_model(lv.shape[0] + n_ghost, L, li, lj, None, device_const=True, device_dual=True)
             const_fill = [("blocks", L * L, stream_seed, (n_vars * L + le * (L * L)).astype(np.int64))]
             dual_fill = [("blocks", L, stream_seed, (lv * L).astype(np.int64))]
         else:

@@ -98,18 +98,20 @@ def grid_edges(H: int, W: int) -> Tuple[np.ndarray, np.ndarray]:
 
 def mrf_model(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, unaries: np.ndarray,
               tables: Optional[np.ndarray] = None, potts: Optional[np.ndarray] = None,
-              device_const: bool = False, compute_primal: bool = False) -> M.FlatModel:
+              device_const: bool = False, compute_primal: bool = False, device_dual: bool = False) -> M.FlatModel:
     """MRF over variables 0..n_vars-1 (already in variable order) with edges (i<j required).
     ``compute_primal``: the unary FactorContainer's COMPUTE_PRIMAL_SOLUTION flag (as in LP_MP-MRF's FMC_SRMP);
     needed for the ...AndPrimal passes.
     ``tables`` [E,L,L] (T[e,a,b]: a = label of i) or ``potts`` [E] diffs. With ``device_const`` the dense
-    tables are not materialised on the host (they are generated in HBM; see Engine.upload)."""
+    tables are not materialised on the host (they are generated in HBM; see Engine.upload); with ``device_dual`` neither are the
+    duals (``unaries`` is ignored: the caller fills the device buffer it hands to Engine.upload)."""
     edge_i = np.asarray(edge_i, np.int64)
     edge_j = np.asarray(edge_j, np.int64)
     assert np.all(edge_i < edge_j)
     b = M.ModelBuilder(2, mrf_mtypes(), [1, 0] if compute_primal else None)
     b.skip_const = device_const
-    u = b.add_vector_factors(0, np.asarray(unaries, np.float64).reshape(n_vars, L))
+    b.skip_dual = device_dual
+    u = b.add_vector_factors(0, None, shape=(n_vars, L)) if device_dual else b.add_vector_factors(0, np.asarray(unaries, np.float64).reshape(n_vars, L))
     E = edge_i.shape[0]
     if potts is not None:
         assert not device_const

@@ -78,6 +78,24 @@ def test_lockstep_parts_equal_oracle_replay_on_global_model(pairwise, order, wor
     assert lb > lb0 and lb <= ref.LowerBound() + 0.2 * abs(ref.LowerBound())
 
 
+def test_parts_generated_from_the_cost_stream_hold_no_host_copy_of_costs_or_duals():
+    """the C4 parts (costs generated in HBM) are structure only: at 2 M / 10 M a host copy of the duals alone is 2.8 GB of zeros
+    built and concatenated per rank; sizes, offsets and the host analysis do not depend on it"""
+    from lp_mp_amd import engine as E
+    n, m, L = 300, 900, 4
+    part = MG.graph_local_part(n, m, L, 0, 1, seed=1)
+    mdl = part.model
+    assert mdl.dual_data is None and mdl.const_data is None
+    ref = S.counter_graph_model(n, m, L, 1)
+    assert int(mdl.dual_sizes().sum()) == ref.dual_data.shape[0] and int(mdl.const_sizes().sum()) == ref.const_data.shape[0]
+    assert np.array_equal(mdl.m_left, ref.m_left) and np.array_equal(mdl.m_right, ref.m_right) and np.array_equal(mdl.rel_fwd, ref.rel_fwd)
+    pa, pb = E.Plan(mdl), E.Plan(ref)
+    for d in (0, 1):
+        assert np.array_equal(pa.order(d), pb.order(d)) and np.array_equal(pa.update_order(d), pb.update_order(d))
+        oa, ob = pa.omega(d, M.REPAM_ANISOTROPIC), pb.omega(d, M.REPAM_ANISOTROPIC)
+        assert np.array_equal(oa[0], ob[0]) and np.array_equal(oa[1], ob[1])
+
+
 def test_random_graph_general_partition_with_multi_cut_unaries():
     # random sparse graph, random 3-way split: unaries with several cut edges exercise the rounds
     n, m_edges, L, world = 40, 120, 3, 3
