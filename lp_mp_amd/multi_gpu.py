@@ -280,16 +280,17 @@ def refine_partition(adj, part: np.ndarray, world: int, rounds: int = 30, imbala
     adjacency with edge multiplicities).  Per round: gain of moving v to the part holding most of its neighbours;
     a pseudo-random half of the variables with positive gain is considered (neighbours moving at once could undo each
     other), best gains first, as long as the target part has room."""
-    from scipy.sparse import csr_matrix
+    adj = adj.tocsr()
     n = adj.shape[0]
     part = part.copy()
     cap = int(np.ceil(n / world * (1.0 + imbalance)))
     idx = np.arange(n)
+    row_w = np.repeat(idx, np.diff(adj.indptr)) * world               # directed edges v -> u: slot of v's counters
+    col, mult = adj.indices.astype(np.int64), adj.data.astype(np.float64)
     with np.errstate(over="ignore"):
         coin = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)) >> np.uint64(40)
     for r in range(rounds):
-        onehot = csr_matrix((np.ones(n, np.float32), (idx, part)), shape=(n, world))
-        cnt = np.asarray((adj @ onehot).todense())                       # neighbours of v in every part
+        cnt = np.bincount(row_w + part[col], weights=mult, minlength=n * world).reshape(n, world)   # neighbours of v in every part
         cur = cnt[idx, part]
         best = np.argmax(cnt, axis=1)
         gain = cnt[idx, best] - cur

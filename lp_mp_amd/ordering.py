@@ -13,33 +13,26 @@ import numpy as np
 
 
 def two_colouring(n: int, ei: np.ndarray, ej: np.ndarray):
-    """colours in {0,1} if the graph is bipartite, else None (BFS depth parity per component)."""
+    """colours in {0,1} if the graph is bipartite, else None.  One connected-components call on the bipartite double cover
+    (vertices (v, 0) = v and (v, 1) = n + v, an edge u - v becomes (u, 0) - (v, 1) and (u, 1) - (v, 0)): the graph is bipartite iff
+    no v has both copies in one component, and then "which copy of v lies in the component labelled first" is a proper
+    colouring in which the first vertex of every component of the graph gets colour 0 (= BFS depth parity from that vertex)."""
     from scipy.sparse import coo_matrix
-    from scipy.sparse.csgraph import breadth_first_order, connected_components
-    a = coo_matrix((np.ones(ei.shape[0], np.int8), (ei, ej)), shape=(n, n)).tocsr()
-    a = a + a.T
-    n_comp, comp = connected_components(a, directed=False)
-    depth = np.zeros(n, np.int64)
-    seen = np.zeros(n, bool)
-    # one BFS per component root; components are usually few (1 for grids)
-    roots = np.full(n_comp, -1, np.int64)
-    first = np.unique(comp, return_index=True)[1]
-    roots[comp[first]] = first
-    for r in roots:
-        order, pred = breadth_first_order(a, int(r), directed=False, return_predecessors=True)
-        d = np.zeros(n, np.int64)
-        for v in order[1:]:                      # BFS order: the predecessor's depth is final when v is reached
-            d[v] = d[pred[v]] + 1
-        depth[order] = d[order]
-        seen[order] = True
-    col = depth & 1
-    return col if np.all(col[ei] != col[ej]) else None
+    from scipy.sparse.csgraph import connected_components
+    ei = np.asarray(ei, np.int64); ej = np.asarray(ej, np.int64)
+    rows = np.concatenate([ei, ei + n]); cols = np.concatenate([ej + n, ej])
+    cover = coo_matrix((np.ones(rows.shape[0], np.int8), (rows, cols)), shape=(2 * n, 2 * n)).tocsr()
+    _, comp = connected_components(cover, directed=False)
+    if np.any(comp[:n] == comp[n:]):
+        return None
+    return (comp[:n] > comp[n:]).astype(np.int64)
 
 
 def greedy_colouring(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0) -> np.ndarray:
     """Luby / Jones-Plassmann style parallel greedy colouring with numpy: in every round the uncoloured vertices that
     beat all their uncoloured neighbours (random priorities) take the smallest colour their neighbours do not use.
-    At most 63 colours (max degree < 63 is plenty for sparse MRFs)."""
+    At most 63 colours (max degree < 63 is plenty for sparse MRFs).  A round looks only at the directed edges whose
+    first end is still uncoloured (most vertices are coloured in the first few rounds)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     prio = rng.permutation(n)
     colour = np.full(n, -1, np.int64)
@@ -48,12 +41,15 @@ def greedy_colouring(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0) -> n
         un = colour < 0
         if not un.any():
             return colour
-        both = un[a] & un[b]
+        live = un[a]
+        if not live.all():
+            a, b = a[live], b[live]
+        unb = un[b]
         loser = np.zeros(n, bool)
-        loser[a[both & (prio[a] < prio[b])]] = True
+        loser[a[unb & (prio[a] < prio[b])]] = True
         cand = un & ~loser
         used = np.zeros(n, np.uint64)
-        m = cand[a] & ~un[b]                                            # coloured neighbours of candidates
+        m = cand[a] & ~unb                                              # coloured neighbours of candidates
         if m.any():
             np.bitwise_or.at(used, a[m], np.uint64(1) << colour[b[m]].astype(np.uint64))
         free = ~used[cand]
