@@ -14,6 +14,11 @@ updates of endpoint s (its receives rewrite its own side, its sends add to its o
 ranks of a cut edge hold a copy of the pairwise factor (table and dual) and a never-updated ghost of the remote variable;
 after a level in which endpoint s wrote, its rank ships side s to the other copy.
 
+The same holds for any model whose messages all have the `left` schedule (lockstep_model: multicut triplets, C5's labeling-list
+factors, mixed label counts): the unit shipped is the slice of a higher factor's dual one message writes — one side of a pairwise
+factor, the WHOLE dual of a labeling-list factor (every message into it rewrites all of it, so such a write also needs the other
+ranks' last writes first) — and it goes to every other rank that holds a copy of that factor.
+
 Levels are merged into SEGMENTS greedily (identically on every rank, from the global structure): a segment ends before the
 first level that reads a cut vector written inside it.  A colour-major grid in row strips: two segments per pass.
 """
@@ -41,18 +46,25 @@ class LockstepPart:
     rows: List[List[tuple]]            # [direction][sub-level] = (factors, om_off, om, mk_off, mk) of this rank's updates (sub-level: LockstepSchedule.program)
     const_fill: Optional[list] = None
     dual_fill: Optional[list] = None
+    # the exchange units this part holds a copy of: global vector id (ascending), first element in the local dual array, length
+    vec_ids: Optional[np.ndarray] = None
+    vec_start: Optional[np.ndarray] = None
+    vec_len: Optional[np.ndarray] = None
+    factors_global: Optional[np.ndarray] = None   # lockstep_model: local factor -> global factor
 
 
 @dataclass
 class LockstepSchedule:
     """what every rank computes identically from the global structure"""
     n_levels: Tuple[int, int]
-    # cut vectors (2 * edge + side) written / read per (direction, level), and who writes / reads a cut vector
+    # cut vectors (one per message: an MRF's 2 * edge + side) written / read per (direction, level), who writes a vector and
+    # which other ranks hold a copy of it
     written: List[List[np.ndarray]]
     read: List[List[np.ndarray]]
-    writer: np.ndarray                 # [2 * n_edges] rank of endpoint `side` (the only writer of that side)
-    reader: np.ndarray                 # rank of the other endpoint
-    n_edges: int
+    writer: np.ndarray                 # [n_vecs] rank of the message's left factor (the only writer of that slice)
+    dest_off: np.ndarray               # [n_vecs + 1] CSR: the other ranks holding the vector's factor (an MRF: the other endpoint's rank, if it differs)
+    dest: np.ndarray
+    n_vecs: int
     _programs: Dict[int, list] = field(default_factory=dict)
     _halo_ids: Dict[bytes, int] = field(default_factory=dict)     # distinct exchanges (sets of vectors) of all programs -> small integer
 
@@ -66,7 +78,7 @@ class LockstepSchedule:
         if n_passes in self._programs:
             return self._programs[n_passes]
         seq = [(d, sl) for _ in range(n_passes) for d in (0, 1) for sl in range(2 * self.n_levels[d])]
-        dirty = np.zeros(2 * self.n_edges, bool)
+        dirty = np.zeros(self.n_vecs, bool)
         halos, last = [], 0                             # (position in seq the exchange comes before, vectors)
         for i, (d, sl) in enumerate(seq):
             if dirty[self.read[d][sl]].any():
@@ -151,7 +163,8 @@ def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: in
         touches_cut = np.zeros(upd.shape[0], bool)
         touches_cut[row_of[cut & active_w]] = True
         per_dir.append((upd, om_off, om, mk_off, mk, lev, touches_cut))
-    sched = LockstepSchedule((n_levels[0], n_levels[1]), written, read, writer, reader, n_edges)
+    dest_off = np.concatenate([[0], np.cumsum(is_cut_vec)]).astype(np.int64)
+    sched = LockstepSchedule((n_levels[0], n_levels[1]), written, read, writer, dest_off, reader[is_cut_vec], 2 * n_edges)
 
     parts = []
     for k in (range(world) if only is None else [only]):
@@ -191,7 +204,155 @@ def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: in
                 fm, k_ = _csr_take(mk_off, mk, idx)
                 per_level.append((lmap[upd[idx]].astype(np.int32), fo, o, fm, k_))
             rows.append(per_level)
-        parts.append(LockstepPart(k, world, L, m, vk, ghost, le, owned, rows, const_fill, dual_fill))
+        pw_off = m.dual_offsets()[vk.shape[0]: vk.shape[0] + le.shape[0]]      # dual offset of local pairwise factor e (local edge order)
+        parts.append(LockstepPart(k, world, L, m, vk, ghost, le, owned, rows, const_fill, dual_fill,
+                                  vec_ids=(2 * le[:, None] + np.arange(2)[None, :]).reshape(-1), vec_start=(pw_off[:, None] + L * np.arange(2)[None, :]).reshape(-1),
+                                  vec_len=np.full(2 * le.shape[0], L, np.int64)))
+    return sched, parts
+
+
+def lockstep_model(gm: M.FlatModel, part, world: int, mode: int, only: Optional[int] = None):
+    """Lock-step parts of ANY model whose messages all have the `left` schedule and whose factors are either variables (left
+    factor of their messages, or no message at all) or higher factors (right factor), with unary-pairwise or labeling messages —
+    what multi_gpu.partition_model accepts.  ``part[f]``: rank of variable f (ignored for higher factors).  Returns
+    (schedule, parts) like lockstep_mrf; the parts run the unpartitioned sweep of ``gm`` bit for bit.
+    A part holds its variables, every higher factor touching one of them with ALL its messages, and never-updated ghosts of the
+    remote variables behind those; factors and messages keep the global relative order (message lists of a local variable are
+    the global ones).  A higher factor counts in the bound where its lowest-numbered variable lives."""
+    from . import engine as E
+    part = np.asarray(part, np.int64)
+    nf, nm = gm.n_factors, gm.n_messages
+    ml, mr = gm.m_left.astype(np.int64), gm.m_right.astype(np.int64)
+    for t in gm.mtypes:
+        if t.schedule != M.SCHED_LEFT or t.kind not in (M.M_UNARY_PAIRWISE, M.M_LABELING):
+            raise ValueError("lockstep_model: only `left`-schedule unary-pairwise / labeling messages")
+    is_right = np.zeros(nf, bool); is_right[mr] = True
+    is_left = np.zeros(nf, bool); is_left[ml] = True
+    if np.any(is_left & is_right):
+        raise ValueError("lockstep_model: a factor is both left and right of messages")
+    is_var = ~is_right
+    if part.shape[0] != nf or part[is_var].min() < 0 or part[is_var].max() >= world:
+        raise ValueError("lockstep_model: part must name a rank in [0, world) for every variable")
+    if np.bincount(part[is_var], minlength=world).min() == 0:
+        raise ValueError("lockstep_model: a rank without variables (every rank takes part in every exchange)")
+    gp = E.Plan(gm)
+    g_off, g_ent = gp.msg_lists(nm)
+    msg_of_entry = g_ent // 2
+    # the slice of its higher factor's dual a message writes: side `param` of a pairwise factor, all of a labeling-list factor
+    kind = np.array([t.kind for t in gm.mtypes], np.int64)[gm.m_type]
+    side = np.array([t.param for t in gm.mtypes], np.int64)[gm.m_type]
+    d0 = gm.f_dim0[mr].astype(np.int64)
+    d1 = np.where(gm.f_kind[mr] == M.F_PAIRWISE_POTTS, d0, gm.f_dim1[mr].astype(np.int64))
+    up = kind == M.M_UNARY_PAIRWISE
+    v_off = np.where(up & (side == 1), d0, 0)
+    v_len = np.where(up, np.where(side == 1, d1, d0), gm.dual_sizes()[mr])
+    whole = ~up
+    writer = part[ml]
+    # ranks holding a copy of higher factor r: those of its variables; a vector goes to all of them but its writer
+    by_r = np.argsort(mr, kind="stable")
+    sib_off = np.concatenate([[0], np.cumsum(np.bincount(mr, minlength=nf))]).astype(np.int64)      # messages of every factor as a right factor
+    sib = by_r
+    hold = np.unique(mr * world + writer)                      # (r, rank) pairs
+    hold_off = np.concatenate([[0], np.cumsum(np.bincount(hold // world, minlength=nf))]).astype(np.int64)
+    hold_rank = hold % world
+    first, q = _csr_take(hold_off, hold_rank, mr)              # per message: the holders of its factor
+    kq = np.repeat(np.arange(nm), np.diff(first))
+    far = q != writer[kq]
+    dest = q[far]
+    dest_off = np.concatenate([[0], np.cumsum(np.bincount(kq[far], minlength=nm))]).astype(np.int64)
+    is_cut_vec = np.diff(dest_off) > 0
+
+    per_dir = []
+    n_levels, written, read = [], [], []
+    for d in (M.FORWARD, M.BACKWARD):
+        upd = gp.update_order(d).astype(np.int64)
+        om_off, om = gp.omega(d, mode)
+        mk_off, mk = gp.mask(d, mode)
+        lev = np.maximum(gp.update_levels(d, mode).astype(np.int64), 1)
+        if np.any(is_right[upd]):
+            raise ValueError("lockstep_model: only variables may be updated (a higher factor computes a primal or sends)")
+        lens = g_off[upd + 1] - g_off[upd]
+        assert np.array_equal(lens, om_off[1:] - om_off[:-1]) and np.array_equal(lens, mk_off[1:] - mk_off[:-1])
+        _, k_own = _csr_take(g_off, msg_of_entry, upd)        # per row entry: its message
+        row_of = np.repeat(np.arange(upd.shape[0]), lens)
+        writes = (om != 0.0) | (mk != 0)
+        reads = (mk != 0) | (writes & whole[k_own])           # a write into a labeling-list factor rewrites all of it
+        nl = int(lev.max()) if lev.size else 0
+
+        def by_level(v, lv):
+            order = np.argsort(lv, kind="stable")
+            bounds = np.searchsorted(lv[order], np.arange(1, nl + 2))
+            out = []
+            for l in range(nl):                              # sub-levels: the records that touch a cut vector, then the others
+                out += [np.unique(v[order[bounds[l]: bounds[l + 1]]]), np.zeros(0, np.int64)]
+            return out
+        sel_w = writes & is_cut_vec[k_own]
+        w_l = by_level(k_own[sel_w], lev[row_of[sel_w]])
+        # what an entry reads across the cut: the vectors of its factor's other messages written on another rank
+        rd = np.nonzero(reads)[0]
+        f2, k2 = _csr_take(sib_off, sib, mr[k_own[rd]])
+        e2 = np.repeat(rd, np.diff(f2))
+        remote = writer[k2] != writer[k_own[e2]]
+        r_l = by_level(k2[remote], lev[row_of[e2[remote]]])
+        n_levels.append(nl); written.append(w_l); read.append(r_l)
+        touches_cut = np.zeros(upd.shape[0], bool)
+        touches_cut[row_of[sel_w]] = True
+        per_dir.append((upd, om_off, om, mk_off, mk, lev, touches_cut))
+    sched = LockstepSchedule((n_levels[0], n_levels[1]), written, read, writer, dest_off, dest, nm)
+
+    first_var = np.full(nf, nf, np.int64)
+    np.minimum.at(first_var, mr, ml)
+    owner = np.where(is_right, part[np.minimum(first_var, nf - 1)], part)
+    coff, doff = gm.const_offsets(), gm.dual_offsets()
+
+    def take(data, off, idx):
+        if data is None:
+            return None
+        _, out = _csr_take(off, data, idx)
+        return np.ascontiguousarray(out)
+
+    parts = []
+    for k in (range(world) if only is None else [only]):
+        local = is_var & (part == k)
+        in_r = np.zeros(nf, bool); in_r[mr[local[ml]]] = True             # higher factors touching a local variable
+        mk_sel = np.nonzero(in_r[mr])[0]                                   # all their messages, global order
+        keep = local | in_r
+        keep[ml[mk_sel]] = True                                            # + ghosts of the remote variables behind them
+        fk = np.nonzero(keep)[0]
+        lmap = np.full(nf, -1, np.int64); lmap[fk] = np.arange(fk.shape[0])
+        ghost = is_var[fk] & ~local[fk]
+
+        def map_rel(rel):
+            rel = np.asarray(rel, np.int64).reshape(-1, 2)
+            a, b = lmap[rel[:, 0]], lmap[rel[:, 1]]
+            ok = (a >= 0) & (b >= 0)
+            return np.ascontiguousarray(np.stack([a[ok], b[ok]], 1).astype(np.int32)).reshape(-1, 2)
+        m = M.FlatModel(
+            n_ftypes=gm.n_ftypes, ftype_computes_primal=gm.ftype_computes_primal, mtypes=gm.mtypes,
+            tab_off=gm.tab_off, tab_data=gm.tab_data, tab_nleft=gm.tab_nleft,
+            f_type=np.ascontiguousarray(gm.f_type[fk]), f_kind=np.ascontiguousarray(gm.f_kind[fk]), f_flags=np.ascontiguousarray(gm.f_flags[fk]),
+            f_dim0=np.ascontiguousarray(gm.f_dim0[fk]), f_dim1=np.ascontiguousarray(gm.f_dim1[fk]),
+            const_data=take(gm.const_data, coff, fk), dual_data=take(gm.dual_data, doff, fk),
+            m_type=np.ascontiguousarray(gm.m_type[mk_sel]), m_left=lmap[ml[mk_sel]].astype(np.int32), m_right=lmap[mr[mk_sel]].astype(np.int32),
+            rel_fwd=map_rel(gm.rel_fwd), rel_bwd=map_rel(gm.rel_bwd), constant=gm.constant if k == 0 else 0.0)
+        owned = owner[fk] == k
+        rows = []
+        for (upd, om_off, om, mk_off, mk, lev, touches_cut) in per_dir:
+            mine = np.nonzero(local[upd])[0]
+            sub = 2 * (lev[mine] - 1) + (~touches_cut[mine])
+            order = mine[np.argsort(sub, kind="stable")]
+            nl = int(lev.max()) if lev.size else 0
+            bounds = np.searchsorted(np.sort(sub, kind="stable"), np.arange(0, 2 * nl + 1))
+            per_level = []
+            for l in range(2 * nl):
+                idx = order[bounds[l]: bounds[l + 1]]
+                fo, o = _csr_take(om_off, om, idx)
+                fm, k_ = _csr_take(mk_off, mk, idx)
+                per_level.append((lmap[upd[idx]].astype(np.int32), fo, o, fm, k_))
+            rows.append(per_level)
+        ldoff = m.dual_offsets()
+        parts.append(LockstepPart(k, world, 0, m, fk[is_var[fk]], ghost[is_var[fk]], np.zeros(0, np.int64), owned, rows,
+                                  vec_ids=mk_sel, vec_start=ldoff[lmap[mr[mk_sel]]] + v_off[mk_sel], vec_len=v_len[mk_sel], factors_global=fk))
     return sched, parts
 
 
@@ -213,10 +374,6 @@ class LockstepSweep:
         self.torch, self.part, self.sched, self.engine, self.dual = torch, part, sched, engine, dual_tensor
         self._sids: Dict[tuple, int] = {}
         self._halo: Dict[int, tuple] = {}
-        p = part
-        n_vec = p.vars_global.shape[0]
-        doff = p.model.dual_offsets()
-        self._pw_off = doff[n_vec:]                                # dual offset of local pairwise factor e (local edge order)
         self.info = {}
 
     def _schedule(self, seg: tuple) -> int:
@@ -241,21 +398,30 @@ class LockstepSweep:
         if key is None:
             key = self.sched._halo_ids.setdefault(vecs.tobytes(), len(self.sched._halo_ids))
         if key not in self._halo:
-            p, s, L = self.part, self.sched, self.part.L
-            def elems(v):                                          # flat dual elements of cut vectors v (global ids), in order
-                le = np.searchsorted(p.edges_global, v // 2)
-                assert np.array_equal(p.edges_global[le], v // 2)
-                base = self._pw_off[le] + (v % 2) * L
-                return (base[:, None] + np.arange(L)[None, :]).reshape(-1)
-            out = vecs[s.writer[vecs] == p.rank]
-            out = out[np.lexsort((out, s.reader[out]))]            # by destination, then vector id
-            inn = vecs[s.reader[vecs] == p.rank]
-            inn = inn[np.lexsort((inn, s.writer[inn]))]            # by source, then vector id
+            p, s = self.part, self.sched
+            lens = s.dest_off[vecs + 1] - s.dest_off[vecs]
+            _, q = _csr_take(s.dest_off, s.dest, vecs)             # (vector, rank holding another copy of it) pairs
+            v = np.repeat(vecs, lens)
+            at = np.searchsorted(p.vec_ids, v)
+            at[at >= p.vec_ids.shape[0]] = 0
+            here = p.vec_ids[at] == v if p.vec_ids.shape[0] else np.zeros(v.shape[0], bool)     # the vectors this part holds
+            src = s.writer[v]
+
+            def plan(sel, peer):                                   # flat dual elements of the selected pairs, by peer, then vector id
+                idx = np.nonzero(sel)[0]
+                idx = idx[np.lexsort((v[idx], peer[idx]))]
+                assert here[idx].all()
+                start, ln = p.vec_start[at[idx]], p.vec_len[at[idx]]
+                first = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+                el = np.repeat(start, ln) + (np.arange(int(first[-1])) - np.repeat(first[:-1], ln))
+                return el, peer[idx], ln
             dev = self.dual.device
             # (a part built from a proxy world, strips_lockstep_part: its ranks are shifted into the true world)
             shift, world = getattr(p, "rank_shift", 0), getattr(p, "true_world", p.world)
-            self._halo[key] = (self.torch.from_numpy(elems(out)).to(dev), np.bincount(s.reader[out] + shift, minlength=world).astype(np.int64) * L,
-                               self.torch.from_numpy(elems(inn)).to(dev), np.bincount(s.writer[inn] + shift, minlength=world).astype(np.int64) * L)
+            count = lambda peer, ln: np.bincount(peer + shift, weights=ln, minlength=world).astype(np.int64)
+            out_el, out_peer, out_len = plan(src == p.rank, q)
+            in_el, in_peer, in_len = plan(q == p.rank, src)
+            self._halo[key] = (self.torch.from_numpy(out_el).to(dev), count(out_peer, out_len), self.torch.from_numpy(in_el).to(dev), count(in_peer, in_len))
         return self._halo[key]
 
     def halo_pack(self, vecs, key=None):
@@ -436,3 +602,15 @@ class LockstepGraph(_Driver):
         self.cut_fraction = float((part_of[ei] != part_of[ej]).mean())
         sched, parts = lockstep_mrf(n, L, ei, ej, part_of, world, mode, only=rank, stream_seed=seed)
         self._setup(torch, dist, parts[0], sched, mode)
+
+
+class LockstepModel(_Driver):
+    """one rank of the lock-step sweep of an arbitrary `left`-schedule model (lockstep_model): C5's grid + labeling-list factors,
+    multicut triplets, ...  Every rank holds ``global_model`` on the host (structure and costs) and takes its own part of it;
+    ``part_of[f]``: rank of variable f (e.g. multi_gpu.graph_partition_model, computed once and broadcast)."""
+
+    def __init__(self, torch, dist, global_model: M.FlatModel, part_of, mode):
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
+        sched, parts = lockstep_model(global_model, part_of, world, mode, only=rank)
+        self._setup(torch, dist, parts[0], sched, mode, fill=False)
+

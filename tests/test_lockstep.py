@@ -88,6 +88,40 @@ def test_lockstep_parts_run_the_unpartitioned_sweep(name, mode):
     assert sum(int(p.owned.sum()) for p in parts) == c["n_vars"] + c["ei"].shape[0]
 
 
+@pytest.mark.parametrize("name", ["mixed_mrf", "multicut", "c5"])
+@pytest.mark.parametrize("world,mode", [(2, M.REPAM_ANISOTROPIC), (3, M.REPAM_DAMPED_UNIFORM), (4, M.REPAM_ANISOTROPIC2)])
+def test_lockstep_parts_of_any_left_schedule_model_run_the_unpartitioned_sweep(name, world, mode):
+    """lockstep_model: ragged label counts, mixed dense / Potts edges, labeling-list factors with three and four variables (the
+    whole dual of such a factor is one exchange unit and goes to every other rank holding it): duals of every copy and the bound
+    equal the oracle's on the unpartitioned model, random partitions of the variables"""
+    from tests.test_multi_gpu import _general_models
+    gm = _general_models()[name]
+    rng = np.random.default_rng(11 + world)
+    is_right = np.zeros(gm.n_factors, bool); is_right[gm.m_right] = True
+    part_of = rng.integers(0, world, gm.n_factors)
+    part_of[np.nonzero(~is_right)[0][:world]] = np.arange(world)           # every rank has a variable
+    ref = Oracle(gm); ref.set_reparametrization(mode)
+    sched, parts = LS.lockstep_model(gm, part_of, world, mode)
+    assert sum(int(p.owned.sum()) for p in parts) == gm.n_factors
+    assert max(int(np.diff(sched.dest_off).max()), 0) >= 1 and (name == "mixed_mrf" or world == 2 or int(np.diff(sched.dest_off).max()) >= 2)
+    duals = [p.model.dual_data.copy() for p in parts]
+    sweeps = [LS.LockstepSweep(torch, p, sched, OracleEngine(p.model, d), torch.from_numpy(d)) for p, d in zip(parts, duals)]
+    g_off = gm.dual_offsets()
+    for n in (1, 2, 2):
+        ref.ComputePass(n)
+        LS.run_lockstep(sweeps, n)
+        gd = ref.duals()
+        for p, d in zip(parts, duals):
+            lo = p.model.dual_offsets()
+            var_ghost = dict(zip(p.vars_global.tolist(), p.is_ghost.tolist()))
+            for fl, g in enumerate(p.factors_global.tolist()):
+                if var_ghost.get(g, False):
+                    continue
+                assert np.array_equal(d[lo[fl]:lo[fl + 1]], gd[g_off[g]:g_off[g + 1]]), (p.rank, fl, g)
+        lb = sum(s.local_lower_bound() for s in sweeps)
+        assert abs(lb - ref.LowerBound()) <= 1e-12 * max(1.0, abs(ref.LowerBound()))
+
+
 def test_isolated_variables_odd_label_counts_and_bad_partitions():
     """variables without any edge are updated where they live; three labels (run-time-dims classes on the device); a rank
     without variables is refused"""
@@ -217,6 +251,97 @@ def test_lockstep_on_device_equals_the_unpartitioned_engine_and_oracle(name, L):
     finally:
         for s in sweeps:
             s.engine.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("mixed_mrf", 3), ("multicut", 3), ("c5", 2), ("c5", 4)])
+def test_lockstep_of_general_models_on_device_equals_the_oracle(name, world):
+    """lockstep_model on real engines (labeling-list kernels, run-time label counts): every copy of every factor and the bound
+    are the oracle's on the unpartitioned model"""
+    from lp_mp_amd import engine as E
+    from tests.test_multi_gpu import _general_models
+    gm = _general_models()[name]
+    rng = np.random.default_rng(3 + world)
+    is_right = np.zeros(gm.n_factors, bool); is_right[gm.m_right] = True
+    part_of = rng.integers(0, world, gm.n_factors)
+    part_of[np.nonzero(~is_right)[0][:world]] = np.arange(world)
+    mode = M.REPAM_ANISOTROPIC
+    ref = Oracle(gm); ref.set_reparametrization(mode)
+    sched, parts = LS.lockstep_model(gm, part_of, world, mode)
+    dev = torch.device("cuda:0")
+    sweeps, tensors = [], []
+    for p in parts:
+        dual = torch.from_numpy(p.model.dual_data.copy()).to(dev)
+        eng = E.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual); eng.set_reparametrization(mode)
+        sweeps.append(LS.LockstepSweep(torch, p, sched, eng, dual)); tensors.append(dual)
+    g_off = gm.dual_offsets()
+    try:
+        for n in (1, 3):
+            ref.ComputePass(n); LS.run_lockstep(sweeps, n); torch.cuda.synchronize()
+            gd = ref.duals()
+            for p, t in zip(parts, tensors):
+                d, lo = t.cpu().numpy(), p.model.dual_offsets()
+                ghosts = set(p.vars_global[p.is_ghost].tolist())
+                for fl, g in enumerate(p.factors_global.tolist()):
+                    if g not in ghosts:
+                        assert np.array_equal(d[lo[fl]:lo[fl + 1]], gd[g_off[g]:g_off[g + 1]]), (p.rank, fl, g)
+            lb = sum(s.local_lower_bound() for s in sweeps)
+            assert abs(lb - ref.LowerBound()) <= 1e-9 * max(1.0, abs(ref.LowerBound()))
+    finally:
+        for s in sweeps:
+            s.engine.close()
+
+
+WORKER_MODEL = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from lp_mp_amd import model as M, multi_gpu as MG, lockstep as LS
+from tests.mgpu_helpers import OracleEngine
+from tests.test_multi_gpu import _general_models
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+gm = _general_models()["c5"]
+part_of = MG.graph_partition_model(gm, world)
+sched, parts = LS.lockstep_model(gm, part_of, world, M.REPAM_ANISOTROPIC, only=rank)
+p = parts[0]
+d = p.model.dual_data.copy()
+sw = LS.LockstepSweep(torch, p, sched, OracleEngine(p.model, d), torch.from_numpy(d))
+comm = MG.DistComm(dist, torch)
+sw.compute_pass(comm, 2); sw.compute_pass(comm, 1)
+lb = comm.all_reduce_sum(sw.local_lower_bound())
+np.save(os.path.join({out!r}, f"gm_duals_{{rank}}.npy"), d)
+np.save(os.path.join({out!r}, f"gm_factors_{{rank}}.npy"), p.factors_global)
+if rank == 0:
+    np.save(os.path.join({out!r}, "gm_lb.npy"), np.array([lb]))
+dist.destroy_process_group()
+"""
+
+
+def test_three_process_gloo_run_of_the_c5_shape_equals_the_unpartitioned_oracle(tmp_path):
+    """C5 in miniature (Potts grid + triplets + quadruples, one factor graph) in three processes over torch.distributed, the
+    variables split by graph_partition_model: every rank's copies are the oracle's duals after 3 passes, the bound its bound"""
+    from tests.test_multi_gpu import _general_models
+    script = tmp_path / "gm_worker.py"
+    script.write_text(WORKER_MODEL.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                           "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)], env=env, cwd=ROOT, timeout=600)
+    gm = _general_models()["c5"]
+    ref = Oracle(gm); ref.set_reparametrization(M.REPAM_ANISOTROPIC); ref.ComputePass(3)
+    gd, g_off = ref.duals(), gm.dual_offsets()
+    part_of = MG.graph_partition_model(gm, 3)
+    is_right = np.zeros(gm.n_factors, bool); is_right[gm.m_right] = True
+    checked = 0
+    for k in range(3):
+        d, fk = np.load(tmp_path / f"gm_duals_{k}.npy"), np.load(tmp_path / f"gm_factors_{k}.npy")
+        lo = np.concatenate([[0], np.cumsum(gm.dual_sizes()[fk])])
+        for fl, g in enumerate(fk.tolist()):
+            if is_right[g] or part_of[g] == k:               # (ghosts of remote variables are never updated)
+                assert np.array_equal(d[lo[fl]:lo[fl + 1]], gd[g_off[g]:g_off[g + 1]]), (k, g)
+                checked += 1
+    assert checked > gm.n_factors                          # higher factors are held (and checked) on several ranks
+    assert abs(np.load(tmp_path / "gm_lb.npy")[0] - ref.LowerBound()) <= 1e-12 * max(1.0, abs(ref.LowerBound()))
 
 
 WORKER_STRIPS = r"""
