@@ -50,7 +50,8 @@ def parse():
                          "the unpartitioned sweep bit for bit, gap 0 (overlap.py); 'lockstep' = the parts run the unpartitioned sweep level "
                          "by level with halo copies in between (lockstep.py; gap 0, one exchange per dependent level that reads across the "
                          "cut; any graph); 'boundary' = every part sweeps its own sub-problem, cut messages reconciled in a boundary step "
-                         "(multi_gpu.py; a small dual-bound gap, few exchanges; the default for --workload c4)")
+                         "(multi_gpu.py; a dual-bound gap of 0.1 - 2 %, few exchanges).  auto: overlap for colour-major grids, lockstep otherwise "
+                         "(the exact schedules; C4 at full size in 8 parts: lock step 2.6 ms per pass and part, boundary steps 4.0)")
     ap.add_argument("--ghost-rows", type=int, default=12, help="overlap schedule: rows of each neighbour a rank holds (even; n passes between exchanges need 2 n + 2)")
     ap.add_argument("--rows-layout", default="auto", choices=["auto", "on", "off"],
                     help="dense pairwise factors as [table | m1 | m2] rows of an engine-private buffer (lpmp_set_rows_layout): one burst per "
@@ -388,7 +389,7 @@ def main():
         sys.exit(launch_ranks(args, sys.argv[1:]))
     if args.schedule == "auto":
         # (overlap: 2-colour grids with an even number of rows per strip; anything else that must be exact runs in lock step)
-        args.schedule = "boundary" if args.workload == "c4" else ("overlap" if args.order == "colour_major" and args.grid % 2 == 0 else "lockstep")
+        args.schedule = "overlap" if args.workload == "c3" and args.order == "colour_major" and args.grid % 2 == 0 else "lockstep"
     if args.schedule == "overlap" and (args.workload != "c3" or args.order != "colour_major"):
         print("bench.py: --schedule overlap is for grids in colour-major order (random graphs: lockstep or boundary)", file=sys.stderr)
         sys.exit(2)
