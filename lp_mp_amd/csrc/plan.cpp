@@ -95,17 +95,6 @@ std::vector<int32_t> reference_topological_order(int64_t nf, const int32_t* rel,
 
 }  // namespace
 
-int64_t Plan::row_sends(int32_t f) const {
-  int64_t s = 0;
-  for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) s += fm[j].sends;
-  return s;
-}
-int64_t Plan::row_receives(int32_t f) const {
-  int64_t s = 0;
-  for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) s += fm[j].receives;
-  return s;
-}
-
 void Plan::build(const lpmp_model& m) {
   const bool timed_ = std::getenv("LPMP_PLAN_TIMES") != nullptr;
   auto t_last_ = std::chrono::steady_clock::now();
@@ -205,6 +194,7 @@ void Plan::build(const lpmp_model& m) {
     }
   }
   updated.assign(nf, 0);
+  n_row_sends.assign(nf, 0); n_row_receives.assign(nf, 0);
   lap_("msg lists");
   parallel_chunks(nf, 65536, [&](int64_t f_begin, int64_t f_end, int) {
   for (int64_t f = f_begin; f < f_end; ++f) {
@@ -220,6 +210,7 @@ void Plan::build(const lpmp_model& m) {
       p = q;
     }
     bool upd_f = ftype_primal[f_type[f]] != 0;
+    int32_t n_s = 0, n_r = 0;
     for (Tmp* p = b; p != e; ++p) {
       const SchedCaps c = caps(mtypes[m_type[p->msg]].schedule);
       MsgEntry& en = fm[fm_off[f] + (p - b)];
@@ -232,8 +223,10 @@ void Plan::build(const lpmp_model& m) {
         en.sends = c.to_left; en.receives = c.from_left; en.adj_sends = c.to_right; en.adj_receives = c.from_right;
       }
       upd_f = upd_f || en.sends || en.receives;
+      n_s += en.sends; n_r += en.receives;
     }
     updated[f] = upd_f;
+    n_row_sends[f] = n_s; n_row_receives[f] = n_r;
   }
   });
   lap_("dispatch");
@@ -252,10 +245,13 @@ void Plan::build(const lpmp_model& m) {
 }
 
 // rows for the updated members of a list (reference allocate_omega / allocate_receive_mask)
-static void shape_rows(const Plan& p, const int32_t* list, int64_t n, Csr<double>& om, Csr<uint8_t>& mk) {
+// row_of (optional): per list position its row, -1 for a member that is not updated
+static void shape_rows(const Plan& p, const int32_t* list, int64_t n, Csr<double>& om, Csr<uint8_t>& mk, std::vector<int64_t>* row_of = nullptr) {
   om.off.assign(1, 0); mk.off.assign(1, 0);
+  if (row_of) row_of->assign((size_t)n, -1);
   for (int64_t i = 0; i < n; ++i) {
     if (!p.updated[list[i]]) continue;
+    if (row_of) (*row_of)[(size_t)i] = (int64_t)om.off.size() - 1;
     om.off.push_back(om.off.back() + p.row_sends(list[i]));
     mk.off.push_back(mk.off.back() + p.row_receives(list[i]));
   }
@@ -272,7 +268,8 @@ void Plan::anisotropic_weights(const int32_t* list, int64_t n, Csr<double>& om, 
     pos[list[i]] = i;
   }
   std::vector<int64_t> n_later(n, 0), last(n, 0), first(n, INF);
-  for (int64_t i = 0; i < n; ++i) {
+  parallel_chunks(n, 65536, [&](int64_t i_begin, int64_t i_end, int) {       // every member on its own
+  for (int64_t i = i_begin; i < i_end; ++i) {
     const int32_t f = list[i];
     for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
       const MsgEntry& e = fm[j];
@@ -284,6 +281,7 @@ void Plan::anisotropic_weights(const int32_t* list, int64_t n, Csr<double>& om, 
       }
     }
   }
+  });
   // factors outside the list: only those adjacent to >= 2 members get real values, all others read the
   // value-initialised 0 of the reference's unordered_map::operator[] (LP_MP.h:1283-1303, :1322, :1342)
   std::vector<int64_t> out_min_send, out_max_recv;
@@ -305,11 +303,13 @@ void Plan::anisotropic_weights(const int32_t* list, int64_t n, Csr<double>& om, 
       out_min_send[g] = mn; out_max_recv[g] = mx;
     }
   }
-  shape_rows(*this, list, n, om, mk);
-  int64_t row = 0;
-  for (int64_t i = 0; i < n; ++i) {
+  std::vector<int64_t> row_of;
+  shape_rows(*this, list, n, om, mk, &row_of);
+  parallel_chunks(n, 65536, [&](int64_t i_begin, int64_t i_end, int) {       // every row on its own
+  for (int64_t i = i_begin; i < i_end; ++i) {
     const int32_t f = list[i];
-    if (!updated[f]) continue;
+    const int64_t row = row_of[(size_t)i];
+    if (row < 0) continue;
     double* o = om.data.data() + om.off[row];
     uint8_t* r = mk.data.data() + mk.off[row];
     int64_t ns = 0, na = 0, nr = 0;
@@ -327,14 +327,15 @@ void Plan::anisotropic_weights(const int32_t* list, int64_t n, Csr<double>& om, 
       const double w = 1.0 / double(n_later[i] + std::max(na, ns - na));   // srmp_weight, :1397
       for (int64_t k = 0; k < ns; ++k) if (o[k] > 0) o[k] *= w;
     }
-    ++row;
   }
+  });
 }
 
 void Plan::ensure_weights(int mode) {
   if (mode < 0 || mode >= LPMP_REPAM_COUNT) fail("no reparametrization mode set");
   if (have[mode]) return;
-  for (int d = 0; d < 2; ++d) {
+  parallel_chunks(2, 1, [&](int64_t d_begin, int64_t d_end, int) {              // the two directions are independent
+  for (int64_t d = d_begin; d < d_end; ++d) {
     Csr<double>& om = omega[d][mode];
     Csr<uint8_t>& mk = mask[d][mode];
     const std::vector<int32_t>& ord = order[d];
@@ -372,6 +373,7 @@ void Plan::ensure_weights(int mode) {
       std::fill(mk.data.begin(), mk.data.end(), 1);
     }
   }
+  });
   have[mode] = true;
 }
 

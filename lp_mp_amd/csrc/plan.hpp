@@ -273,8 +273,9 @@ struct Plan {
   void make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out, bool chains = true) const;
   void make_schedule(const int32_t* factors, int64_t n, const int64_t* om_off, const double* om,
                      const int64_t* mk_off, const uint8_t* mk, Schedule& out) const;
-  int64_t row_sends(int32_t f) const;
-  int64_t row_receives(int32_t f) const;
+  int64_t row_sends(int32_t f) const { return n_row_sends[(size_t)f]; }       // entries of f's message list that send / receive
+  int64_t row_receives(int32_t f) const { return n_row_receives[(size_t)f]; }
+  std::vector<int32_t> n_row_sends, n_row_receives;
   // LP::construct_factor_partition / construct_overlapping_factor_partition (reference LP_MP.h:1717-1843)
   void ensure_partition();
   // the iterator-range passes of compute_partition_pass (rtype 2, LP_MP.h:1932-1963) or

@@ -857,26 +857,35 @@ class GraphSweep:
             boundary_every = "sweep" if self.cut_fraction > 0.10 else "pass"
         self.boundary_every = boundary_every
         self.engine.set_reparametrization(mode)
+        if self.comm is None:
+            # one GPU, no process group: the engine's own pass schedules are the sweep (no boundary schedules to build beside them)
+            self.sweep = None
+            info = [self.engine.plan.schedule_info(d, mode) for d in (M.FORWARD, M.BACKWARD)]
+            self.global_updates_per_pass = sum(int(i["n_receives"] + i["n_sends"]) for i in info)
+            self.global_bytes_per_pass = sum(int(i["algorithmic_bytes"]) for i in info)
+            self.global_cut_fraction = 0.0
+            self.levels = [i["n_levels"] for i in info]
+            return
         self.sweep = PartitionedSweep(torch, part, self.engine, self.dualt, mode, omega_b, boundary_every, BOUNDARY_RESERVE)
         vals = [self.sweep.updates_per_pass(), self.sweep.bytes_per_pass(), part.out_ghost.shape[0], m]
-        if self.comm:
-            t = torch.tensor(vals[:3], dtype=torch.float64, device="cpu" if self.comm.stage_cpu else dev)
-            dist.all_reduce(t)
-            vals[:3] = [float(x) for x in t]
+        t = torch.tensor(vals[:3], dtype=torch.float64, device="cpu" if self.comm.stage_cpu else dev)
+        dist.all_reduce(t)
+        vals[:3] = [float(x) for x in t]
         self.global_updates_per_pass = int(vals[0])
         self.global_bytes_per_pass = int(vals[1])
         self.global_cut_fraction = vals[2] / m
         self.levels = [i["n_levels"] for i in self.sweep.info]
 
     def compute_pass(self, n=1):
-        if self.comm:
+        if self.sweep is not None:
             self.sweep.compute_pass(self.comm, n)
         else:                                           # one part: no boundary, plain engine passes
             self.engine.compute_pass(n)
 
     def lower_bound(self):
-        lb = self.sweep.local_lower_bound()
-        return self.comm.all_reduce_sum(lb) if self.comm else lb
+        if self.sweep is None:
+            return self.engine.lower_bound()
+        return self.comm.all_reduce_sum(self.sweep.local_lower_bound())
 
 
 class ModelSweep:

@@ -77,6 +77,23 @@ lb = sum(s.local_lower_bound() for s in sw)
 prog = sched.program(passes)
 out["lockstep"] = {"ms_per_pass_and_part": round(ms / parts, 3), "exchanges_per_pass": sum(1 for s in prog if s[0] == "halo") / passes,
                    "levels": list(sched.n_levels), "gap_percent": 100 * (lb_ref - lb) / abs(lb_ref), "lb": lb}
+# where the time goes: the runs alone (no exchange: the duals are garbage afterwards, nothing is read from them), one part alone,
+# and the exchanges alone (pack + in-process shuffle + unpack of every halo step)
+def runs_only(sweeps):
+    for step in prog:
+        if step[0] == "run":
+            for s_ in sweeps: s_.run(step[1])
+def halos_only():
+    for step in prog:
+        if step[0] == "halo":
+            packed = [s_.halo_pack(step[1], step[2]) for s_ in sw]
+            offs = [np.concatenate([[0], np.cumsum(p_[1])]) for p_ in packed]
+            for dst, s_ in enumerate(sw):
+                s_.halo_unpack(step[1], torch.cat([packed[src][0][offs[src][dst]: offs[src][dst + 1]] for src in range(parts)]), step[2])
+out["lockstep"]["ms_runs_only_per_pass_and_part"] = round(timed(lambda: runs_only(sw)) / parts, 3)
+out["lockstep"]["ms_runs_only_one_part_alone"] = round(timed(lambda: runs_only(sw[:1])), 3)
+out["lockstep"]["ms_exchanges_only_per_pass_and_part"] = round(timed(halos_only) / parts, 3)
+out["lockstep"]["halo_MB_per_pass_and_part"] = round(sum(int(s_.halo_pack(st[1], st[2])[0].numel()) for st in prog if st[0] == "halo" for s_ in sw) * 8 / 1e6 / passes / parts, 2)
 for s in sw: s.engine.close()
 del sw, keep
 
