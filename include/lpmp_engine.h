@@ -285,6 +285,21 @@ int lpmp_boundary_reply(lpmp_engine* e, lpmp_boundary* b, const double* recv_dev
 int lpmp_boundary_fold(lpmp_engine* e, lpmp_boundary* b, const double* back_dev);
 void* lpmp_engine_stream(lpmp_engine* e);                    /* the hipStream_t all engine work is issued on */
 
+/* ---- halos of the lock-step partitioned sweep, DESIGN.md 7 (lp_mp_amd/lockstep.py) ------------------------------------
+ * Several ranks execute THE unpartitioned sweep (LP::ComputePass, include/LP_MP.h:981-1005) level by level; between two runs of
+ * levels (lpmp_schedule_run) a rank ships the message vectors it wrote that the next run reads on other ranks.  No arithmetic:
+ * pack copies the listed vectors of the dual array into a contiguous DEVICE buffer in exchange order, unpack copies a received
+ * buffer into the listed vectors; the caller posts the exchange in between (ncclSend / ncclRecv, all-to-all-v) on
+ * lpmp_engine_stream.  Vectors are (offset into the packed dual array = serialize_dual order, length) pairs. */
+typedef struct lpmp_halo lpmp_halo;
+int lpmp_halo_create(lpmp_engine* e, int64_t n_out, const int64_t* out_dual_off, const int32_t* out_len, int64_t n_in,
+                     const int64_t* in_dual_off, const int32_t* in_len, lpmp_halo** out);
+void lpmp_halo_destroy(lpmp_halo* h);
+int64_t lpmp_halo_out_doubles(const lpmp_halo* h);           /* size of the buffer pack fills */
+int64_t lpmp_halo_in_doubles(const lpmp_halo* h);            /* size of the buffer unpack reads */
+int lpmp_halo_pack(lpmp_engine* e, lpmp_halo* h, double* send_dev);
+int lpmp_halo_unpack(lpmp_engine* e, lpmp_halo* h, const double* recv_dev);
+
 /* synthetic workloads: out[i] = u01(splitmix64(seed + (first+i+1)*GOLDEN)) written on the device */
 int lpmp_synth_fill(void* device_ptr, int64_t n, uint64_t seed, uint64_t first, void* hip_stream);
 /* the same for n_blocks blocks of block_len values each, block b continuing the stream at first_dev[b] (device array):

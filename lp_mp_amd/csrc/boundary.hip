@@ -12,6 +12,7 @@
 //                                                                     lpmp_boundary_fold + lpmp_schedule_run(ghost send schedule)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <memory>
 #include <new>
@@ -44,6 +45,18 @@ boundary_fold_kernel(const BVec* __restrict__ v, int64_t n, double* __restrict__
   if (i >= n) return;
   const BVec b = v[i];
   for (int x = lane; x < b.len; x += 64) dual[b.dual_off + x] = back[b.buf_off + x];
+}
+// lock-step halos (lp_mp_amd/lockstep.py): plain copies of message vectors, G lanes per vector (16 for the short vectors of a
+// 16-label model: four vectors per wave instead of one)
+template <int G>
+__global__ void __launch_bounds__(256)
+halo_copy_kernel(const BVec* __restrict__ v, int64_t n, double* __restrict__ dual, double* __restrict__ buf, int to_dual) {
+  const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+  const int64_t i = (int64_t)blockIdx.x * (256 / G) + grp;
+  if (i >= n) return;
+  const BVec b = v[i];
+  if (to_dual) { for (int x = lane; x < b.len; x += G) dual[b.dual_off + x] = buf[b.buf_off + x]; }
+  else { for (int x = lane; x < b.len; x += G) buf[b.buf_off + x] = dual[b.dual_off + x]; }
 }
 // per boundary variable and label: theta += r_1; theta += r_2; ...; snapshot; reply_k = omega_k * snapshot; theta -= reply_1; ...
 __global__ void __launch_bounds__(256)
@@ -79,6 +92,13 @@ struct lpmp_boundary {
     if (d_vars) (void)hipFree(d_vars);
     if (d_seq) (void)hipFree(d_seq);
   }
+};
+
+struct lpmp_halo {
+  BVec* d_vec[2] = {nullptr, nullptr};      // 0: what pack reads, 1: what unpack writes
+  int64_t n[2] = {0, 0}, doubles[2] = {0, 0};
+  int32_t max_len[2] = {0, 0};
+  ~lpmp_halo() { for (BVec* p : d_vec) if (p) (void)hipFree(p); }
 };
 
 extern "C" {
@@ -164,6 +184,56 @@ int lpmp_boundary_fold(lpmp_engine* e, lpmp_boundary* b, const double* back_dev)
   B_TRY(hipGetLastError());
   return lpmp_boundary_leave(e);
 }
+
+// ---- lock-step halos: the vectors one exchange ships, as (packed dual offset, length) lists in exchange order
+static int halo_create(lpmp_engine* e, const int64_t n[2], const int64_t* const off[2], const int32_t* const len[2], lpmp_halo** out) {
+  std::unique_ptr<lpmp_halo> h(new lpmp_halo());
+  hipStream_t s = (hipStream_t)lpmp_engine_stream(e);
+  for (int k = 0; k < 2; ++k) {
+    std::vector<BVec> v((size_t)n[k]);
+    int64_t at = 0;
+    for (int64_t i = 0; i < n[k]; ++i) {
+      if (len[k][i] < 0) { lpmp_set_last_error("halo: negative vector length"); return LPMP_ERR_INVALID; }
+      v[(size_t)i] = {lpmp_engine_device_dual_offset(e, off[k][i]), at, len[k][i], 0};
+      at += len[k][i]; h->max_len[k] = std::max(h->max_len[k], len[k][i]);
+    }
+    h->n[k] = n[k]; h->doubles[k] = at;
+    if (n[k] > 0) { B_TRY(hipMalloc((void**)&h->d_vec[k], v.size() * sizeof(BVec))); B_TRY(hipMemcpyAsync(h->d_vec[k], v.data(), v.size() * sizeof(BVec), hipMemcpyHostToDevice, s)); }
+    B_TRY(hipStreamSynchronize(s));      // (v leaves scope)
+  }
+  *out = h.release();
+  return LPMP_OK;
+}
+int lpmp_halo_create(lpmp_engine* e, int64_t n_out, const int64_t* out_dual_off, const int32_t* out_len, int64_t n_in,
+                     const int64_t* in_dual_off, const int32_t* in_len, lpmp_halo** out) {
+  if (!e || !out || n_out < 0 || n_in < 0 || (n_out > 0 && (!out_dual_off || !out_len)) || (n_in > 0 && (!in_dual_off || !in_len))) {
+    lpmp_set_last_error("bad argument"); return LPMP_ERR_INVALID;
+  }
+  if (const int rc = lpmp_boundary_enter(e)) return rc;
+  const int64_t n[2] = {n_out, n_in};
+  const int64_t* const off[2] = {out_dual_off, in_dual_off};
+  const int32_t* const len[2] = {out_len, in_len};
+  try { return halo_create(e, n, off, len, out); }
+  catch (const std::bad_alloc&) { lpmp_set_last_error("out of host memory"); return LPMP_ERR_INVALID; }
+  catch (const std::exception& ex) { lpmp_set_last_error(ex.what()); return LPMP_ERR_INVALID; }
+}
+void lpmp_halo_destroy(lpmp_halo* h) { delete h; }
+int64_t lpmp_halo_out_doubles(const lpmp_halo* h) { return h ? h->doubles[0] : 0; }
+int64_t lpmp_halo_in_doubles(const lpmp_halo* h) { return h ? h->doubles[1] : 0; }
+static int halo_copy(lpmp_engine* e, lpmp_halo* h, int k, double* buf) {
+  if (!e || !h || (h->n[k] > 0 && !buf)) { lpmp_set_last_error("bad argument"); return LPMP_ERR_INVALID; }
+  if (const int rc = lpmp_boundary_enter(e)) return rc;
+  if (h->n[k] > 0) {
+    hipStream_t s = (hipStream_t)lpmp_engine_stream(e);
+    double* dual = (double*)lpmp_engine_dual_base(e);
+    if (h->max_len[k] <= 16) hipLaunchKernelGGL(halo_copy_kernel<16>, dim3((unsigned)((h->n[k] + 15) / 16)), dim3(256), 0, s, h->d_vec[k], h->n[k], dual, buf, k);
+    else hipLaunchKernelGGL(halo_copy_kernel<64>, dim3((unsigned)((h->n[k] + 3) / 4)), dim3(256), 0, s, h->d_vec[k], h->n[k], dual, buf, k);
+  }
+  B_TRY(hipGetLastError());
+  return k == 1 ? lpmp_boundary_leave(e) : LPMP_OK;      // only unpack writes duals
+}
+int lpmp_halo_pack(lpmp_engine* e, lpmp_halo* h, double* send_dev) { return halo_copy(e, h, 0, send_dev); }
+int lpmp_halo_unpack(lpmp_engine* e, lpmp_halo* h, const double* recv_dev) { return halo_copy(e, h, 1, const_cast<double*>(recv_dev)); }
 
 // out[b * block_len + i] = u01(seed, first[b] + i): the cost blocks of a scattered subset of a global stream (a rank's
 // own pairwise tables of a partitioned synthetic model), generated in HBM

@@ -51,6 +51,7 @@ EXPORTS = [
     "lpmp_evaluate_primal", "lpmp_download_primal", "lpmp_upload_primal", "lpmp_streaming_access",
     "lpmp_boundary_create", "lpmp_boundary_destroy", "lpmp_boundary_out_doubles", "lpmp_boundary_in_doubles", "lpmp_boundary_pack",
     "lpmp_boundary_reply", "lpmp_boundary_fold", "lpmp_engine_stream", "lpmp_synth_fill_blocks",
+    "lpmp_halo_create", "lpmp_halo_destroy", "lpmp_halo_out_doubles", "lpmp_halo_in_doubles", "lpmp_halo_pack", "lpmp_halo_unpack",
     "lpmp_set_speculation", "lpmp_speculation_stats", "lpmp_chain_cache_bytes",
 ]
 
@@ -161,6 +162,13 @@ def lib():
         L.lpmp_boundary_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.lpmp_engine_stream.restype = C.c_void_p
         L.lpmp_engine_stream.argtypes = [C.c_void_p]
+        L.lpmp_halo_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lpmp_halo_destroy.argtypes = [C.c_void_p]
+        for n in ("lpmp_halo_out_doubles", "lpmp_halo_in_doubles"):
+            getattr(L, n).restype = C.c_int64
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.lpmp_halo_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lpmp_halo_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -529,6 +537,27 @@ class Engine:
 
     def boundary_fold(self, b: int, back_ptr: int):
         _chk(self.L.lpmp_boundary_fold(self.h, b, C.c_void_p(back_ptr)))
+
+    # ---- halos of the lock-step sweep (csrc/boundary.hip): vectors as (packed dual offset, length), exchange order ----
+    def halo_create(self, out_dual_off, out_len, in_dual_off, in_len) -> int:
+        a = [np.ascontiguousarray(out_dual_off, np.int64), np.ascontiguousarray(out_len, np.int32),
+             np.ascontiguousarray(in_dual_off, np.int64), np.ascontiguousarray(in_len, np.int32)]
+        h = C.c_void_p()
+        _chk(self.L.lpmp_halo_create(self.h, a[0].shape[0], a[0].ctypes.data, a[1].ctypes.data, a[2].shape[0], a[2].ctypes.data,
+                                     a[3].ctypes.data, C.addressof(h)))
+        return h.value
+
+    def halo_destroy(self, h: int):
+        self.L.lpmp_halo_destroy(h)
+
+    def halo_sizes(self, h: int):
+        return self.L.lpmp_halo_out_doubles(h), self.L.lpmp_halo_in_doubles(h)
+
+    def halo_pack(self, h: int, send_ptr: int):
+        _chk(self.L.lpmp_halo_pack(self.h, h, C.c_void_p(send_ptr)))
+
+    def halo_unpack(self, h: int, recv_ptr: int):
+        _chk(self.L.lpmp_halo_unpack(self.h, h, C.c_void_p(recv_ptr)))
 
     def enable_kernel_timing(self, on: bool):
         _chk(self.L.lpmp_enable_kernel_timing(self.h, 1 if on else 0))

@@ -79,13 +79,34 @@ class LockstepSchedule:
             return self._programs[n_passes]
         seq = [(d, sl) for _ in range(n_passes) for d in (0, 1) for sl in range(2 * self.n_levels[d])]
         dirty = np.zeros(self.n_vecs, bool)
-        halos, last = [], 0                             # (position in seq the exchange comes before, vectors)
+        where, last = [], 0                             # positions in seq an exchange comes before
         for i, (d, sl) in enumerate(seq):
             if dirty[self.read[d][sl]].any():
                 pos = i
                 while pos - 1 >= last and self.written[seq[pos - 1][0]][seq[pos - 1][1]].size == 0:
                     pos -= 1
-                halos.append((pos, np.nonzero(dirty)[0])); dirty[:] = False; last = pos
+                where.append(pos); dirty[:] = False; last = pos
+            dirty[self.written[d][sl]] = True
+        # what each exchange ships: not everything written since the last one, only what is READ before the next one — a vector
+        # that is rewritten before anyone reads it (anisotropic weights: the side a receive rewrites is next read after the same
+        # endpoint's send of the opposite sweep) travels once, with its later state.  (Every read still finds its vector shipped:
+        # the positions were found with everything shipped, so between a write and the next read of its vector lies an exchange,
+        # and the last one before the read takes it.)
+        dirty[:] = False
+        halos, start = [], 0
+        for k, pos in enumerate(where):
+            for (d, sl) in seq[start:pos]:
+                dirty[self.written[d][sl]] = True
+            nxt = where[k + 1] if k + 1 < len(where) else len(seq)
+            need = np.zeros(self.n_vecs, bool)
+            for (d, sl) in seq[pos:nxt]:
+                need[self.read[d][sl]] = True
+            ship = np.nonzero(dirty & need)[0]
+            dirty[ship] = False
+            if ship.size:
+                halos.append((pos, ship))
+            start = pos
+        for (d, sl) in seq[start:]:
             dirty[self.written[d][sl]] = True
         def halo(vecs):                                 # (the id is what a rank's exchange plans are kept under: a step of a pass
             hid = self._halo_ids.setdefault(vecs.tobytes(), len(self._halo_ids))   # must not hash its vector list every time)
@@ -374,6 +395,7 @@ class LockstepSweep:
         self.torch, self.part, self.sched, self.engine, self.dual = torch, part, sched, engine, dual_tensor
         self._sids: Dict[tuple, int] = {}
         self._halo: Dict[int, tuple] = {}
+        self._device_halos = hasattr(engine, "halo_create")          # the HIP engine (CPU tests run oracle-backed stand-ins without it)
         self.info = {}
 
     def _schedule(self, seg: tuple) -> int:
@@ -407,31 +429,54 @@ class LockstepSweep:
             here = p.vec_ids[at] == v if p.vec_ids.shape[0] else np.zeros(v.shape[0], bool)     # the vectors this part holds
             src = s.writer[v]
 
-            def plan(sel, peer):                                   # flat dual elements of the selected pairs, by peer, then vector id
+            def plan(sel, peer):                                   # the selected pairs by peer, then vector id: (first element, length) each
                 idx = np.nonzero(sel)[0]
                 idx = idx[np.lexsort((v[idx], peer[idx]))]
                 assert here[idx].all()
-                start, ln = p.vec_start[at[idx]], p.vec_len[at[idx]]
-                first = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
-                el = np.repeat(start, ln) + (np.arange(int(first[-1])) - np.repeat(first[:-1], ln))
-                return el, peer[idx], ln
-            dev = self.dual.device
+                return p.vec_start[at[idx]].astype(np.int64), p.vec_len[at[idx]].astype(np.int64), peer[idx]
             # (a part built from a proxy world, strips_lockstep_part: its ranks are shifted into the true world)
             shift, world = getattr(p, "rank_shift", 0), getattr(p, "true_world", p.world)
             count = lambda peer, ln: np.bincount(peer + shift, weights=ln, minlength=world).astype(np.int64)
-            out_el, out_peer, out_len = plan(src == p.rank, q)
-            in_el, in_peer, in_len = plan(q == p.rank, src)
-            self._halo[key] = (self.torch.from_numpy(out_el).to(dev), count(out_peer, out_len), self.torch.from_numpy(in_el).to(dev), count(in_peer, in_len))
+            o_start, o_len, o_peer = plan(src == p.rank, q)
+            i_start, i_len, i_peer = plan(q == p.rank, src)
+            if self._device_halos:
+                # the HIP engine: copies by its halo kernels (include/lpmp_engine.h, lpmp_halo_*), the send buffer kept with the plan
+                h = self.engine.halo_create(o_start, o_len, i_start, i_len)
+                send = self.torch.empty(int(o_len.sum()), dtype=self.torch.float64, device=self.dual.device)
+                self._halo[key] = (h, count(o_peer, o_len), send, count(i_peer, i_len))
+            else:
+                def elems(start, ln):                              # (stand-in engines on the CPU: index tensors into the dual array)
+                    first = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+                    return np.repeat(start, ln) + (np.arange(int(first[-1])) - np.repeat(first[:-1], ln))
+                dev = self.dual.device
+                self._halo[key] = (self.torch.from_numpy(elems(o_start, o_len)).to(dev), count(o_peer, o_len),
+                                   self.torch.from_numpy(elems(i_start, i_len)).to(dev), count(i_peer, i_len))
         return self._halo[key]
 
     def halo_pack(self, vecs, key=None):
-        src, out_counts, _, in_counts = self._halo_plan(vecs, key)
+        src, out_counts, buf, in_counts = self._halo_plan(vecs, key)
+        if self._device_halos:
+            self.engine.halo_pack(src, buf.data_ptr())
+            return buf, out_counts, in_counts
         return self.dual[src], out_counts, in_counts
 
     def halo_unpack(self, vecs, recv, key=None):
-        _, _, dst, _ = self._halo_plan(vecs, key)
+        h, _, dst, in_counts = self._halo_plan(vecs, key)
+        if self._device_halos:
+            if int(in_counts.sum()):
+                recv = recv.contiguous()
+                assert recv.shape[0] == int(in_counts.sum())
+                self.engine.halo_unpack(h, recv.data_ptr())
+                self._last_recv = recv                             # (alive until the copy has run: the allocator is stream-ordered)
+            return
         if dst.shape[0]:
             self.dual[dst] = recv
+
+    def close(self):
+        if self._device_halos:
+            for h in self._halo.values():
+                self.engine.halo_destroy(h[0])
+        self._halo = {}
 
     def compute_pass(self, comm, n=1):
         for step in self.sched.program(n):

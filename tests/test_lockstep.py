@@ -293,6 +293,44 @@ def test_lockstep_of_general_models_on_device_equals_the_oracle(name, world):
             s.engine.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,rows", [(16, False), (16, True), (5, False), (40, False)])
+def test_halo_kernels_copy_the_listed_vectors(L, rows):
+    """lpmp_halo_pack / _unpack through the C ABI: the listed slices of the packed dual array, in list order — also when the
+    pairwise duals live in the engine-private rows layout (offsets are translated) and for vectors longer than a quarter wave"""
+    from lp_mp_amd import engine as E
+    g = S.grid_model(6, 7, L, seed=3)
+    dev = torch.device("cuda:0")
+    eng = E.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.upload(g, rows_layout=rows); eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+    eng.compute_pass(2)
+    before = eng.download_duals()
+    off = g.dual_offsets(); nv = 42
+    rng = np.random.default_rng(L)
+    pw = nv + rng.choice(g.n_factors - nv, 20, replace=False)
+    side = rng.integers(0, 2, 20)
+    out_off = off[pw] + side * L; out_len = np.full(20, L)
+    un = rng.choice(nv, 9, replace=False)
+    in_off = np.concatenate([off[pw[:7]] + (1 - side[:7]) * L, off[un]]); in_len = np.full(16, L)
+    h = eng.halo_create(out_off, out_len, in_off, in_len)
+    try:
+        assert eng.halo_sizes(h) == (20 * L, 16 * L)
+        send = torch.zeros(20 * L, dtype=torch.float64, device=dev)
+        eng.halo_pack(h, send.data_ptr()); torch.cuda.synchronize()
+        assert np.array_equal(send.cpu().numpy(), np.concatenate([before[o:o + L] for o in out_off]))
+        assert np.array_equal(eng.download_duals(), before)                       # pack reads only
+        recv = torch.from_numpy(rng.uniform(-1, 1, 16 * L)).to(dev)
+        eng.halo_unpack(h, recv.data_ptr()); torch.cuda.synchronize()
+        want = before.copy()
+        for k, o in enumerate(in_off):
+            want[o:o + L] = recv.cpu().numpy()[k * L:(k + 1) * L]
+        assert np.array_equal(eng.download_duals(), want)
+        o = Oracle(g); o.set_duals(want)
+        assert abs(eng.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))   # tracked bounds were dropped
+    finally:
+        eng.halo_destroy(h); eng.close()
+
+
 WORKER_MODEL = r"""
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, {root!r})
