@@ -66,7 +66,7 @@ def build(force: bool = False) -> str:
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MGPU_DRIVER = os.path.join(ROOT, "build", "mgpu_rccl_driver")
 MGPU_SOURCES = [os.path.join(ROOT, "tools", "mgpu_rccl_driver.cpp"), os.path.join(ROOT, "lp_mp_amd", "include", "lpmp_multi_gpu.hxx"),
-                os.path.join(ROOT, "lp_mp_amd", "include", "lpmp_overlap.hxx"),
+                os.path.join(ROOT, "lp_mp_amd", "include", "lpmp_overlap.hxx"), os.path.join(ROOT, "lp_mp_amd", "include", "lpmp_lockstep.hxx"),
                 os.path.join(ROOT, "include", "lpmp_engine.h"), os.path.join(ROOT, "include", "lpmp_model.h")]
 
 

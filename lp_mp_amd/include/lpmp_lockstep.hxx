@@ -1,0 +1,436 @@
+// lpmp_lockstep.hxx — the lock-step partitioned sweep driven from C++ over the C ABI and RCCL (the same schedule
+// lp_mp_amd/lockstep.py runs through torch.distributed, bit for bit).
+//
+// Several parts execute THE unpartitioned sweep of an MRF (LP::ComputePass, reference include/LP_MP.h:981-1005): updates of one
+// dependency level commute, so every part runs the updates of ITS variables with the GLOBAL weights (LP::get_omega, :412-460,
+// from lpmp_plan_create on the structure of the whole model) level by level, and between two runs of levels the parts ship the
+// message vectors the next run reads across the cut.  Side s of a pairwise factor's dual is written only by the updates of
+// endpoint s; both parts of a cut edge hold the pairwise factor and a never-updated ghost of the remote variable.
+//
+//   lockstep_structure   the model as an edge list + the partition
+//   lockstep_plan        what every rank derives identically from it: levels, who writes / reads which vector when, the steps of n
+//                        passes (runs of sub-levels and exchanges; an exchange ships only what is read before the next one)
+//   lockstep_part        one part: its variables + ghosts + every edge touching a variable, costs generated in HBM from the counter
+//                        stream, its rows of the global weights per sub-level; runs as lpmp_schedule_create[_fused] / _run,
+//                        ships through lpmp_halo_pack / _unpack and ncclSend / ncclRecv (parts of one rank: device copies)
+//
+// Needs lpmp_multi_gpu.hxx (rccl_world, helpers); link with -llpmp_engine -lrccl -lamdhip64.
+#pragma once
+
+#include <map>
+
+#include "lpmp_multi_gpu.hxx"
+
+namespace lpmp_mgpu {
+
+struct lockstep_structure {
+  int64_t n_vars = 0; int32_t L = 0; bool potts = false; int n_parts = 1;
+  std::vector<int64_t> ei, ej;          // edge e joins ei[e] < ej[e]; message 2 e + s: endpoint s
+  std::vector<int32_t> part;            // part of every variable
+  uint64_t seed = 1;                    // costs: unaries u01 stream [0, n L), pairwise data of edge e at n L + e * (L^2 or 1)
+  int64_t n_edges() const { return (int64_t)ei.size(); }
+};
+
+// the (n_parts * H) x W strip grid of multi_gpu.strip_global_edges: strip-major variables, per strip its internal edges (node by
+// node: right, then down) and then the W edges to the next strip
+inline lockstep_structure strips_structure(int H, int W, int L, bool potts, bool colour_major, int n_parts, uint64_t seed) {
+  lockstep_structure s; s.L = L; s.potts = potts; s.n_parts = n_parts; s.seed = seed;
+  const int64_t n_loc = (int64_t)H * W;
+  s.n_vars = n_loc * n_parts;
+  const std::vector<int64_t> var = grid_variable_order(H, W, colour_major);
+  for (int k = 0; k < n_parts; ++k) {
+    const int64_t base = (int64_t)k * n_loc;
+    for (int r = 0; r < H; ++r) for (int c = 0; c < W; ++c) {
+      const int64_t a = base + var[(size_t)r * W + c];
+      if (c < W - 1) { const int64_t b = base + var[(size_t)r * W + c + 1]; s.ei.push_back(std::min(a, b)); s.ej.push_back(std::max(a, b)); }
+      if (r < H - 1) { const int64_t b = base + var[(size_t)(r + 1) * W + c]; s.ei.push_back(std::min(a, b)); s.ej.push_back(std::max(a, b)); }
+    }
+    if (k < n_parts - 1) for (int c = 0; c < W; ++c) { s.ei.push_back(base + var[(size_t)(H - 1) * W + c]); s.ej.push_back(base + n_loc + var[(size_t)c]); }
+  }
+  s.part.resize((size_t)s.n_vars);
+  for (int64_t v = 0; v < s.n_vars; ++v) s.part[(size_t)v] = (int32_t)(v / n_loc);
+  return s;
+}
+
+// the C4-style random graph of synthetic.counter_graph_edges: edge e joins a = h(2 e) mod n and b = a + 1 + h(2 e + 1) mod (n - 1),
+// h = the 64-bit words of the counter stream seeded with seed ^ 0x5DEECE66D; variables split into n_parts contiguous index ranges
+// (a caller with a partitioner of its own overwrites `part`)
+inline uint64_t counter_u64(uint64_t seed, uint64_t i) {
+  uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+inline lockstep_structure graph_structure(int64_t n, int64_t m, int L, int n_parts, uint64_t seed) {
+  lockstep_structure s; s.n_vars = n; s.L = L; s.potts = false; s.n_parts = n_parts; s.seed = seed;
+  s.ei.resize((size_t)m); s.ej.resize((size_t)m);
+  for (int64_t e = 0; e < m; ++e) {
+    const int64_t a = (int64_t)(counter_u64(seed ^ 0x5DEECE66DULL, (uint64_t)(2 * e)) % (uint64_t)n);
+    const int64_t b = (a + 1 + (int64_t)(counter_u64(seed ^ 0x5DEECE66DULL, (uint64_t)(2 * e + 1)) % (uint64_t)(n - 1))) % n;
+    s.ei[(size_t)e] = std::min(a, b); s.ej[(size_t)e] = std::max(a, b);
+  }
+  s.part.resize((size_t)n);
+  for (int64_t v = 0; v < n; ++v) s.part[(size_t)v] = (int32_t)(v * n_parts / n);
+  return s;
+}
+
+// an MRF as flat model arrays (the layout of the reference's MRF constructor, as part_model)
+struct mrf_arrays {
+  std::vector<int32_t> f_type, f_dim0, f_dim1, m_type, m_left, m_right, rel, rel_bwd;
+  std::vector<uint8_t> f_kind, f_flags;
+  lpmp_msg_type mtypes[2];
+  void build(int64_t n_vars, int32_t L, bool potts, const std::vector<int64_t>& li, const std::vector<int64_t>& lj) {
+    const int64_t ne = (int64_t)li.size(), nf = n_vars + ne;
+    f_type.assign((size_t)nf, 0); f_kind.assign((size_t)nf, LPMP_F_VECTOR); f_flags.assign((size_t)nf, 0);
+    f_dim0.assign((size_t)nf, L); f_dim1.assign((size_t)nf, 0);
+    m_type.resize((size_t)2 * ne); m_left.resize((size_t)2 * ne); m_right.resize((size_t)2 * ne); rel.resize((size_t)4 * ne);
+    for (int64_t e = 0; e < ne; ++e) {
+      const int64_t f = n_vars + e;
+      f_type[f] = 1; f_kind[f] = potts ? LPMP_F_PAIRWISE_POTTS : LPMP_F_PAIRWISE_DENSE; f_dim1[f] = L;
+      m_type[2 * e] = 0; m_left[2 * e] = (int32_t)li[e]; m_right[2 * e] = (int32_t)f;
+      m_type[2 * e + 1] = 1; m_left[2 * e + 1] = (int32_t)lj[e]; m_right[2 * e + 1] = (int32_t)f;
+      rel[4 * e] = (int32_t)li[e]; rel[4 * e + 1] = (int32_t)f; rel[4 * e + 2] = (int32_t)f; rel[4 * e + 3] = (int32_t)lj[e];
+    }
+    rel_bwd.resize(rel.size());
+    for (size_t i = 0; i + 1 < rel.size(); i += 2) { rel_bwd[i] = rel[i + 1]; rel_bwd[i + 1] = rel[i]; }
+    mtypes[0] = lpmp_msg_type{0, 1, LPMP_SCHED_LEFT, 0, 1, LPMP_M_UNARY_PAIRWISE, 0, 0};
+    mtypes[1] = lpmp_msg_type{0, 1, LPMP_SCHED_LEFT, 0, 1, LPMP_M_UNARY_PAIRWISE, 1, 0};
+  }
+  lpmp_model view(const double* const_dev, const double* dual_dev) const {
+    lpmp_model m{};
+    m.n_ftypes = 2; m.n_mtypes = 2; m.mtypes = mtypes;
+    m.n_factors = (int64_t)f_type.size(); m.f_type = f_type.data(); m.f_kind = f_kind.data(); m.f_flags = f_flags.data();
+    m.f_dim0 = f_dim0.data(); m.f_dim1 = f_dim1.data(); m.const_data = const_dev; m.dual_data = dual_dev;
+    m.n_messages = (int64_t)m_type.size(); m.m_type = m_type.data(); m.m_left = m_left.data(); m.m_right = m_right.data();
+    m.n_rel_fwd = (int64_t)rel.size() / 2; m.rel_fwd = rel.data(); m.n_rel_bwd = (int64_t)rel_bwd.size() / 2; m.rel_bwd = rel_bwd.data();
+    return m;
+  }
+};
+
+struct lockstep_step { bool halo = false; std::vector<std::pair<int, int>> run; std::vector<int64_t> vecs; int id = -1; };
+
+// what every rank computes identically from the global structure
+struct lockstep_plan {
+  int n_levels[2] = {0, 0};
+  int64_t n_vecs = 0;
+  std::vector<int32_t> writer, reader;                              // [2 n_edges]
+  std::vector<std::vector<int64_t>> written[2], read[2];           // [direction][sub-level]: sorted cut vectors
+  // the rows of the global sweep: update order, weights, masks, level, "touches a cut vector"
+  std::vector<int32_t> upd[2], lev[2]; std::vector<int64_t> om_off[2], mk_off[2]; std::vector<double> om[2]; std::vector<uint8_t> mk[2], touches_cut[2];
+  std::map<int, std::vector<lockstep_step>> programs;
+  std::map<std::vector<int64_t>, int> halo_ids;
+
+  void build(const lockstep_structure& s, int mode) {
+    const int64_t n = s.n_vars, ne = s.n_edges();
+    if ((int64_t)s.part.size() != n) throw std::runtime_error("lockstep: a part for every variable");
+    std::vector<int64_t> cnt((size_t)s.n_parts, 0);
+    for (int32_t p : s.part) { if (p < 0 || p >= s.n_parts) throw std::runtime_error("lockstep: part out of range"); ++cnt[(size_t)p]; }
+    for (int64_t c : cnt) if (c == 0) throw std::runtime_error("lockstep: a part without variables");
+    mrf_arrays g; g.build(n, s.L, s.potts, s.ei, s.ej);
+    const lpmp_model gm = g.view(nullptr, nullptr);
+    lpmp_plan* pl = nullptr;
+    lpmp_ok(lpmp_plan_create(&gm, &pl));
+    struct guard { lpmp_plan* p; ~guard() { lpmp_plan_destroy(p); } } gd{pl};
+    const int64_t nf = n + ne, nm = 2 * ne;
+    std::vector<int64_t> g_off((size_t)nf + 1), g_ent((size_t)2 * nm);
+    lpmp_ok(lpmp_plan_get_msg_lists(pl, g_off.data(), g_ent.data()));
+    n_vecs = nm;
+    writer.resize((size_t)nm); reader.resize((size_t)nm);
+    for (int64_t e = 0; e < ne; ++e) {
+      writer[2 * e] = s.part[(size_t)s.ei[e]]; writer[2 * e + 1] = s.part[(size_t)s.ej[e]];
+      reader[2 * e] = writer[2 * e + 1]; reader[2 * e + 1] = writer[2 * e];
+    }
+    for (int d = 0; d < 2; ++d) {
+      const int64_t nu = lpmp_plan_n_updated(pl, d);
+      upd[d].resize((size_t)nu); lev[d].resize((size_t)nu);
+      lpmp_ok(lpmp_plan_get_update_order(pl, d, upd[d].data()));
+      om_off[d].resize((size_t)nu + 1); mk_off[d].resize((size_t)nu + 1);
+      om[d].resize((size_t)std::max<int64_t>(lpmp_plan_omega_nnz(pl, d), 1)); mk[d].resize((size_t)std::max<int64_t>(lpmp_plan_mask_nnz(pl, d), 1));
+      lpmp_ok(lpmp_plan_get_omega(pl, d, mode, om_off[d].data(), om[d].data()));
+      lpmp_ok(lpmp_plan_get_mask(pl, d, mode, mk_off[d].data(), mk[d].data()));
+      lpmp_ok(lpmp_plan_get_update_levels(pl, d, mode, lev[d].data()));
+      int nl = 0;
+      for (int64_t u = 0; u < nu; ++u) {
+        if (upd[d][(size_t)u] >= n) throw std::runtime_error("lockstep: only the variables are updated (schedule `left`)");
+        lev[d][(size_t)u] = std::max(lev[d][(size_t)u], 1);       // (0: no active message; runs with the first level)
+        nl = std::max(nl, (int)lev[d][(size_t)u]);
+        const int64_t f = upd[d][(size_t)u], len = g_off[(size_t)f + 1] - g_off[(size_t)f];
+        if (len != om_off[d][(size_t)u + 1] - om_off[d][(size_t)u] || len != mk_off[d][(size_t)u + 1] - mk_off[d][(size_t)u])
+          throw std::runtime_error("lockstep: a variable's message list, weights and mask differ in length");
+      }
+      n_levels[d] = nl;
+      written[d].assign((size_t)2 * nl, {}); read[d].assign((size_t)2 * nl, {});
+      touches_cut[d].assign((size_t)nu, 0);
+      for (int64_t u = 0; u < nu; ++u) {
+        const int64_t f = upd[d][(size_t)u];
+        const int sl = 2 * (lev[d][(size_t)u] - 1);
+        for (int64_t j = g_off[(size_t)f], k = 0; j < g_off[(size_t)f + 1]; ++j, ++k) {
+          const int64_t v = g_ent[(size_t)j] / 2;                  // own-side vector = the message id (2 e + s)
+          if (writer[(size_t)v] == reader[(size_t)v]) continue;
+          const double w = om[d][(size_t)(om_off[d][(size_t)u] + k)]; const bool r = mk[d][(size_t)(mk_off[d][(size_t)u] + k)] != 0;
+          if (w != 0.0 || r) { written[d][(size_t)sl].push_back(v); touches_cut[d][(size_t)u] = 1; }
+          if (r) read[d][(size_t)sl].push_back(v ^ 1);
+        }
+      }
+      for (auto* lists : {&written[d], &read[d]}) for (auto& l : *lists) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); }
+    }
+  }
+
+  // steps of n passes (LockstepSchedule.program): sub-level 2 l = the records of level l + 1 that touch a cut edge, 2 l + 1 = the
+  // others.  An exchange comes before the first sub-level that reads a cut vector written since the last one, moved back over the
+  // sub-levels that wrote nothing; it ships what is read before the next exchange
+  const std::vector<lockstep_step>& program(int n_passes) {
+    auto it = programs.find(n_passes);
+    if (it != programs.end()) return it->second;
+    std::vector<std::pair<int, int>> seq;
+    for (int p = 0; p < n_passes; ++p) for (int d = 0; d < 2; ++d) for (int sl = 0; sl < 2 * n_levels[d]; ++sl) seq.push_back({d, sl});
+    std::vector<uint8_t> dirty((size_t)n_vecs, 0);
+    std::vector<int64_t> dirty_list;
+    auto mark = [&](const std::vector<int64_t>& w) { for (int64_t v : w) if (!dirty[(size_t)v]) { dirty[(size_t)v] = 1; dirty_list.push_back(v); } };
+    auto clear = [&] { for (int64_t v : dirty_list) dirty[(size_t)v] = 0; dirty_list.clear(); };
+    std::vector<int64_t> where; int64_t last = 0;
+    for (int64_t i = 0; i < (int64_t)seq.size(); ++i) {
+      bool hit = false;
+      for (int64_t v : read[seq[(size_t)i].first][(size_t)seq[(size_t)i].second]) if (dirty[(size_t)v]) { hit = true; break; }
+      if (hit) {
+        int64_t pos = i;
+        while (pos - 1 >= last && written[seq[(size_t)pos - 1].first][(size_t)seq[(size_t)pos - 1].second].empty()) --pos;
+        where.push_back(pos); clear(); last = pos;
+      }
+      mark(written[seq[(size_t)i].first][(size_t)seq[(size_t)i].second]);
+    }
+    clear();
+    std::vector<std::pair<int64_t, std::vector<int64_t>>> halos;
+    int64_t start = 0;
+    for (size_t k = 0; k < where.size(); ++k) {
+      const int64_t pos = where[k], nxt = k + 1 < where.size() ? where[k + 1] : (int64_t)seq.size();
+      for (int64_t i = start; i < pos; ++i) mark(written[seq[(size_t)i].first][(size_t)seq[(size_t)i].second]);
+      std::vector<int64_t> ship;
+      for (int64_t i = pos; i < nxt; ++i) for (int64_t v : read[seq[(size_t)i].first][(size_t)seq[(size_t)i].second]) if (dirty[(size_t)v] == 1) { dirty[(size_t)v] = 2; ship.push_back(v); }
+      std::sort(ship.begin(), ship.end());
+      for (int64_t v : ship) dirty[(size_t)v] = 0;
+      dirty_list.erase(std::remove_if(dirty_list.begin(), dirty_list.end(), [&](int64_t v) { return !dirty[(size_t)v]; }), dirty_list.end());
+      if (!ship.empty()) halos.push_back({pos, std::move(ship)});
+      start = pos;
+    }
+    for (int64_t i = start; i < (int64_t)seq.size(); ++i) mark(written[seq[(size_t)i].first][(size_t)seq[(size_t)i].second]);
+    auto halo_step = [&](std::vector<int64_t> vecs) {
+      lockstep_step st; st.halo = true;
+      auto ins = halo_ids.insert({vecs, (int)halo_ids.size()});
+      st.id = ins.first->second; st.vecs = std::move(vecs);
+      return st;
+    };
+    std::vector<lockstep_step> steps;
+    start = 0;
+    for (auto& h : halos) {
+      if (h.first > start) { lockstep_step st; st.run.assign(seq.begin() + start, seq.begin() + h.first); steps.push_back(std::move(st)); }
+      steps.push_back(halo_step(std::move(h.second))); start = h.first;
+    }
+    if (start < (int64_t)seq.size()) { lockstep_step st; st.run.assign(seq.begin() + start, seq.end()); steps.push_back(std::move(st)); }
+    if (!dirty_list.empty()) { std::sort(dirty_list.begin(), dirty_list.end()); steps.push_back(halo_step(dirty_list)); }   // the copies agree again when the call returns
+    return programs[n_passes] = std::move(steps);
+  }
+  double exchanges_per_pass(int n) { int64_t h = 0; for (const auto& s : program(n)) h += s.halo; return (double)h / n; }
+};
+
+// one part on its engine
+class lockstep_part {
+ public:
+  int part = 0; int32_t L = 0; bool potts = false;
+  mrf_arrays arrays;
+  std::vector<int64_t> vars_global, edges_global;     // local variable / local edge -> global (both ascending)
+  std::vector<uint8_t> is_ghost, owned;
+  struct rows { std::vector<int32_t> factors; std::vector<int64_t> om_off, mk_off; std::vector<double> om; std::vector<uint8_t> mk; };
+  std::vector<rows> sub[2];                          // this part's updates per (direction, sub-level), sequence order inside
+  lpmp_engine* e = nullptr; hipStream_t stream = nullptr;
+  double *d_const = nullptr, *d_dual = nullptr;
+  std::map<std::vector<std::pair<int, int>>, int> sids;
+  struct halo { lpmp_halo* h = nullptr; double *d_send = nullptr, *d_recv = nullptr; std::vector<int64_t> out_count, in_count; int64_t n_out = 0, n_in = 0; };
+  std::map<int, halo> halos;
+  int64_t updates_per_pass = 0;
+
+  lockstep_part() = default;
+  lockstep_part(const lockstep_part&) = delete;
+  lockstep_part& operator=(const lockstep_part&) = delete;
+  ~lockstep_part() {
+    for (auto& kv : halos) { if (kv.second.h) lpmp_halo_destroy(kv.second.h); for (double* p : {kv.second.d_send, kv.second.d_recv}) if (p) (void)hipFree(p); }
+    if (e) lpmp_destroy(e);
+    for (double* p : {d_const, d_dual}) if (p) (void)hipFree(p);
+  }
+  int64_t n_vec() const { return (int64_t)vars_global.size(); }
+
+  void build(const lockstep_structure& s, const lockstep_plan& pl, int k, int device, hipStream_t st, int mode) {
+    part = k; L = s.L; potts = s.potts; stream = st;
+    const int64_t n = s.n_vars, ne = s.n_edges();
+    std::vector<uint8_t> in_part((size_t)n, 0);
+    for (int64_t e_ = 0; e_ < ne; ++e_)                       // every edge touching a local variable, global order
+      if (s.part[(size_t)s.ei[e_]] == k || s.part[(size_t)s.ej[e_]] == k) { edges_global.push_back(e_); in_part[(size_t)s.ei[e_]] = in_part[(size_t)s.ej[e_]] = 1; }
+    for (int64_t v = 0; v < n; ++v) if (s.part[(size_t)v] == k) in_part[(size_t)v] = 1;
+    std::vector<int64_t> lmap((size_t)n, -1);
+    for (int64_t v = 0; v < n; ++v) if (in_part[(size_t)v]) { lmap[(size_t)v] = (int64_t)vars_global.size(); vars_global.push_back(v); is_ghost.push_back(s.part[(size_t)v] != k); }
+    std::vector<int64_t> li, lj;
+    for (int64_t e_ : edges_global) { li.push_back(lmap[(size_t)s.ei[e_]]); lj.push_back(lmap[(size_t)s.ej[e_]]); }
+    arrays.build(n_vec(), L, potts, li, lj);
+    owned.assign((size_t)(n_vec() + (int64_t)edges_global.size()), 0);
+    for (int64_t v = 0; v < n_vec(); ++v) owned[(size_t)v] = !is_ghost[(size_t)v];
+    for (size_t x = 0; x < edges_global.size(); ++x) owned[(size_t)n_vec() + x] = s.part[(size_t)s.ei[(size_t)edges_global[x]]] == k;   // a pairwise factor counts where its earlier endpoint lives
+    // rows per sub-level
+    for (int d = 0; d < 2; ++d) {
+      const int nsl = 2 * pl.n_levels[d];
+      sub[d].assign((size_t)nsl, {});
+      for (auto& r : sub[d]) { r.om_off.assign(1, 0); r.mk_off.assign(1, 0); }
+      for (int64_t u = 0; u < (int64_t)pl.upd[d].size(); ++u) {       // update order = sequence order inside a sub-level
+        const int64_t f = pl.upd[d][(size_t)u];
+        if (s.part[(size_t)f] != k) continue;
+        rows& r = sub[d][(size_t)(2 * (pl.lev[d][(size_t)u] - 1) + (pl.touches_cut[d][(size_t)u] ? 0 : 1))];
+        r.factors.push_back((int32_t)lmap[(size_t)f]);
+        for (int64_t j = pl.om_off[d][(size_t)u]; j < pl.om_off[d][(size_t)u + 1]; ++j) { r.om.push_back(pl.om[d][(size_t)j]); updates_per_pass += pl.om[d][(size_t)j] != 0.0; }
+        for (int64_t j = pl.mk_off[d][(size_t)u]; j < pl.mk_off[d][(size_t)u + 1]; ++j) { r.mk.push_back(pl.mk[d][(size_t)j]); updates_per_pass += pl.mk[d][(size_t)j] != 0; }
+        r.om_off.push_back((int64_t)r.om.size()); r.mk_off.push_back((int64_t)r.mk.size());
+      }
+    }
+    // costs from the counter stream, generated in HBM: unary of local vector x at vars_global[x] L, pairwise data of local edge x
+    // at n L + edges_global[x] esz (ghost unaries are generated too: they are never read)
+    hip_ok(hipSetDevice(device), "hipSetDevice");
+    const int64_t esz = potts ? 1 : (int64_t)L * L, n_e = (int64_t)edges_global.size();
+    const int64_t nc = std::max<int64_t>(n_e * esz, 2), nd = n_vec() * L + n_e * 2 * L;
+    hip_ok(hipMalloc((void**)&d_const, (size_t)nc * sizeof(double)), "hipMalloc const");
+    hip_ok(hipMalloc((void**)&d_dual, (size_t)nd * sizeof(double)), "hipMalloc dual");
+    hip_ok(hipMemsetAsync(d_dual, 0, (size_t)nd * sizeof(double), stream), "hipMemsetAsync");
+    std::vector<int64_t> first;
+    int64_t* d_first = nullptr;
+    auto fill = [&](double* dst, int64_t n_blocks, int64_t block_len) {
+      if (n_blocks == 0) return;
+      if (d_first) { (void)hipFree(d_first); d_first = nullptr; }
+      hip_ok(hipMalloc((void**)&d_first, first.size() * sizeof(int64_t)), "hipMalloc");
+      hip_ok(hipMemcpyAsync(d_first, first.data(), first.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+      lpmp_ok(lpmp_synth_fill_blocks(dst, n_blocks, block_len, s.seed, d_first, stream));
+      hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    };
+    first.resize((size_t)n_vec());
+    for (int64_t x = 0; x < n_vec(); ++x) first[(size_t)x] = vars_global[(size_t)x] * L;
+    fill(d_dual, n_vec(), L);
+    first.resize((size_t)n_e);
+    for (int64_t x = 0; x < n_e; ++x) first[(size_t)x] = n * L + edges_global[(size_t)x] * esz;
+    fill(d_const, n_e, esz);
+    hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (d_first) (void)hipFree(d_first);
+    lpmp_ok(lpmp_create(device, &e));
+    lpmp_ok(lpmp_set_stream(e, stream));
+    const lpmp_model m = arrays.view(d_const, d_dual);
+    lpmp_ok(lpmp_upload_model(e, &m, LPMP_MEM_DEVICE, LPMP_MEM_DEVICE));
+    lpmp_ok(lpmp_set_reparametrization(e, mode));
+  }
+
+  // a run of sub-levels as one schedule (rows concatenated; fused when the run spans more than one sweep)
+  int schedule(const std::vector<std::pair<int, int>>& seg) {
+    auto it = sids.find(seg);
+    if (it != sids.end()) return it->second;
+    std::vector<int32_t> f; std::vector<int64_t> oo(1, 0), mo(1, 0); std::vector<double> o; std::vector<uint8_t> m;
+    for (const auto& ds : seg) {
+      const rows& r = sub[ds.first][(size_t)ds.second];
+      f.insert(f.end(), r.factors.begin(), r.factors.end());
+      for (size_t i = 1; i < r.om_off.size(); ++i) oo.push_back((int64_t)o.size() + r.om_off[i]);
+      for (size_t i = 1; i < r.mk_off.size(); ++i) mo.push_back((int64_t)m.size() + r.mk_off[i]);
+      o.insert(o.end(), r.om.begin(), r.om.end()); m.insert(m.end(), r.mk.begin(), r.mk.end());
+    }
+    int n_sweeps = 1;
+    for (size_t i = 1; i < seg.size(); ++i) if (seg[i].first != seg[i - 1].first || seg[i].second < seg[i - 1].second) ++n_sweeps;
+    int sid = -1;
+    if (!f.empty()) {
+      if (o.empty()) o.push_back(0.0);
+      if (m.empty()) m.push_back(0);
+      if (n_sweeps > 1) lpmp_ok(lpmp_schedule_create_fused(e, (int64_t)f.size(), f.data(), oo.data(), o.data(), mo.data(), m.data(), 1, &sid));
+      else lpmp_ok(lpmp_schedule_create(e, (int64_t)f.size(), f.data(), oo.data(), o.data(), mo.data(), m.data(), &sid));
+    }
+    return sids[seg] = sid;
+  }
+  void run(const std::vector<std::pair<int, int>>& seg) { const int sid = schedule(seg); if (sid >= 0) lpmp_ok(lpmp_schedule_run(e, sid)); }
+
+  // the exchange plan of one halo step: what this part sends (its own cut vectors of the step, by destination part, then vector)
+  // and receives (by source part, then vector)
+  halo& halo_plan(const lockstep_plan& pl, const lockstep_step& st, int n_parts) {
+    auto it = halos.find(st.id);
+    if (it != halos.end()) return it->second;
+    halo h; h.out_count.assign((size_t)n_parts, 0); h.in_count.assign((size_t)n_parts, 0);
+    std::vector<std::pair<int32_t, int64_t>> out, in;
+    for (int64_t v : st.vecs) {
+      if (pl.writer[(size_t)v] == part) out.push_back({pl.reader[(size_t)v], v});
+      if (pl.reader[(size_t)v] == part) in.push_back({pl.writer[(size_t)v], v});
+    }
+    std::sort(out.begin(), out.end()); std::sort(in.begin(), in.end());
+    auto offsets = [&](const std::vector<std::pair<int32_t, int64_t>>& l, std::vector<int64_t>& off, std::vector<int32_t>& len, std::vector<int64_t>& count) {
+      for (const auto& pv : l) {
+        const int64_t ge = pv.second / 2;
+        const auto pos = std::lower_bound(edges_global.begin(), edges_global.end(), ge);
+        if (pos == edges_global.end() || *pos != ge) throw std::runtime_error("lockstep: a cut vector of an edge this part does not hold");
+        off.push_back(n_vec() * L + (int64_t)(pos - edges_global.begin()) * 2 * L + (pv.second & 1) * L);
+        len.push_back(L); count[(size_t)pv.first] += L;
+      }
+    };
+    std::vector<int64_t> o_off, i_off; std::vector<int32_t> o_len, i_len;
+    offsets(out, o_off, o_len, h.out_count); offsets(in, i_off, i_len, h.in_count);
+    h.n_out = (int64_t)out.size() * L; h.n_in = (int64_t)in.size() * L;
+    lpmp_ok(lpmp_halo_create(e, (int64_t)o_off.size(), o_off.data(), o_len.data(), (int64_t)i_off.size(), i_off.data(), i_len.data(), &h.h));
+    hip_ok(hipMalloc((void**)&h.d_send, (size_t)std::max<int64_t>(h.n_out, 1) * sizeof(double)), "hipMalloc");
+    hip_ok(hipMalloc((void**)&h.d_recv, (size_t)std::max<int64_t>(h.n_in, 1) * sizeof(double)), "hipMalloc");
+    return halos[st.id] = h;
+  }
+
+  double local_lower_bound() {
+    std::vector<double> flb(owned.size());
+    lpmp_ok(lpmp_factor_lower_bounds(e, flb.data()));
+    double lb = 0;
+    for (size_t f = 0; f < owned.size(); ++f) if (owned[f]) lb += flb[f];
+    return lb;
+  }
+  std::vector<double> download_duals() { std::vector<double> d((size_t)lpmp_dual_size(e)); lpmp_ok(lpmp_download_duals(e, d.data())); return d; }
+};
+
+// one exchange: every part packs, one ncclGroup of sends / receives between the ranks (parts of one rank: device copies), every
+// part unpacks.  parts = this rank's parts in part order
+inline void lockstep_exchange(std::vector<lockstep_part*>& parts, lockstep_plan& pl, const lockstep_step& st, rccl_world& w, int n_parts) {
+  std::vector<lockstep_part::halo*> hs;
+  for (lockstep_part* p : parts) { hs.push_back(&p->halo_plan(pl, st, n_parts)); lpmp_ok(lpmp_halo_pack(p->e, hs.back()->h, hs.back()->d_send)); }
+  const int first_part = w.rank * w.parts_per_rank;
+  nccl_ok(ncclGroupStart(), "ncclGroupStart");
+  for (size_t x = 0; x < parts.size(); ++x) {
+    lockstep_part::halo& h = *hs[x];
+    int64_t so = 0, ro = 0;
+    for (int q = 0; q < n_parts; ++q) {
+      const int64_t sc = h.out_count[(size_t)q], rc = h.in_count[(size_t)q];
+      const bool here = w.rank_of(q) == w.rank;
+      if (sc > 0) {
+        if (here) {
+          // the receiver's offset of what comes from this part: the counts of the parts before it
+          lockstep_part::halo& hq = *hs[(size_t)(q - first_part)];
+          int64_t off = 0; for (int r = 0; r < parts[x]->part; ++r) off += hq.in_count[(size_t)r];
+          if (hq.in_count[(size_t)parts[x]->part] != sc) throw std::runtime_error("lockstep: two parts disagree on an exchange");
+          hip_ok(hipMemcpyAsync(hq.d_recv + off, h.d_send + so, (size_t)sc * sizeof(double), hipMemcpyDeviceToDevice, w.stream), "hipMemcpyAsync");
+        } else nccl_ok(ncclSend(h.d_send + so, (size_t)sc, ncclDouble, w.rank_of(q), w.comm, w.stream), "ncclSend");
+      }
+      if (rc > 0 && !here) nccl_ok(ncclRecv(h.d_recv + ro, (size_t)rc, ncclDouble, w.rank_of(q), w.comm, w.stream), "ncclRecv");
+      so += sc; ro += rc;
+    }
+  }
+  nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+  for (size_t x = 0; x < parts.size(); ++x) lpmp_ok(lpmp_halo_unpack(parts[x]->e, hs[x]->h, hs[x]->d_recv));
+}
+
+inline void lockstep_compute_pass(std::vector<lockstep_part*>& parts, lockstep_plan& pl, rccl_world& w, int n_parts, int n) {
+  for (const lockstep_step& st : pl.program(n)) {
+    if (!st.halo) { for (lockstep_part* p : parts) p->run(st.run); continue; }
+    lockstep_exchange(parts, pl, st, w, n_parts);
+  }
+}
+// schedules and exchange plans of an n-pass call, outside a timed region
+inline void lockstep_prepare(std::vector<lockstep_part*>& parts, lockstep_plan& pl, int n_parts, int n) {
+  for (const lockstep_step& st : pl.program(n)) for (lockstep_part* p : parts) { if (st.halo) (void)p->halo_plan(pl, st, n_parts); else (void)p->schedule(st.run); }
+}
+inline double lockstep_lower_bound(std::vector<lockstep_part*>& parts, rccl_world& w) {
+  double lb = 0;
+  for (lockstep_part* p : parts) lb += p->local_lower_bound();
+  return w.all_reduce_sum(lb);
+}
+
+}  // namespace lpmp_mgpu

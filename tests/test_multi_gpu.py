@@ -728,3 +728,68 @@ def test_cpp_rccl_driver_overlap_schedule_equals_the_python_overlap_sweep_and_th
     finally:
         for s in sweeps:
             s.engine.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["strips dense colour-major", "strips dense row-major", "strips potts", "random graph"])
+def test_cpp_rccl_driver_lockstep_schedule_equals_the_python_lockstep_sweep_and_the_oracle(tmp_path, case):
+    """tools/mgpu_rccl_driver.cpp --schedule lockstep (lp_mp_amd/include/lpmp_lockstep.hxx: the global level structure from
+    lpmp_plan_* on the structure of the whole model, runs of sub-levels as lpmp_schedule_create[_fused], halos through lpmp_halo_*
+    and ncclSend / ncclRecv) at world 1 with several parts on the one GPU, against lp_mp_amd/lockstep.py on the same parts: every
+    part's whole dual array bit-identical, and the bound against the oracle on the unpartitioned model"""
+    import json
+    from lp_mp_amd import build as B, engine as E, lockstep as LS
+    from oracle.binding import Oracle
+    if not B.have_rccl():
+        pytest.skip("no <rccl/rccl.h> on this box")
+    passes = 3
+    exe = B.build_mgpu_driver()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    if case == "random graph":
+        n, m, L, parts, pairwise = 900, 3600, 16, 4, "dense"
+        args = ["--graph", str(n), str(m), "--L", str(L)]
+        ei, ej = S.counter_graph_edges(n, m, 1)
+        part_of = (np.arange(n) * parts) // n
+        gm = S.counter_graph_model(n, m, L, 1)
+    else:
+        H, W, parts = 8, 7, 3
+        L, pairwise, order = {"strips dense colour-major": (16, "dense", "colour_major"), "strips dense row-major": (5, "dense", "row_major"),
+                              "strips potts": (8, "potts", "colour_major")}[case]
+        args = ["--H", str(H), "--W", str(W), "--L", str(L), "--pairwise", pairwise, "--order", order]
+        ei, ej = MG.strip_global_edges(H, W, parts, order)
+        n = parts * H * W
+        part_of = np.repeat(np.arange(parts), H * W)
+        un, tables, potts = MG.strip_costs(H, W, L, parts, pairwise, 1)
+        gm = S.mrf_model(n, L, ei, ej, un, tables=tables, potts=potts)
+    out = subprocess.check_output([exe] + args + ["--passes", str(passes), "--parts-per-rank", str(parts), "--schedule", "lockstep",
+                                                  "--out", str(tmp_path / "duals")], text=True, env=env, timeout=600)
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["schedule"] == "lockstep" and line["parts"] == parts
+    sched, lparts = LS.lockstep_mrf(n, L, ei, ej, part_of, parts, M.REPAM_ANISOTROPIC, stream_seed=1, pairwise=pairwise,
+                                    unaries=None if pairwise == "dense" else np.zeros(n * L), potts=None if pairwise == "dense" else np.zeros(ei.shape[0]))
+    assert list(sched.n_levels) == line["levels"]
+    assert abs(sum(1 for s in sched.program(passes) if s[0] == "halo") / passes - line["exchanges_per_pass"]) < 1e-3
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    sweeps, tensors = [], []
+    for p in lparts:
+        mdl = p.model
+        const = torch.empty(max(int(mdl.const_sizes().sum()), 2), dtype=torch.float64, device=dev)
+        dual = torch.zeros(int(mdl.dual_sizes().sum()), dtype=torch.float64, device=dev)
+        MG.fill_device_costs(torch, E, p, const, dual, stream)
+        eng = E.Engine(0); eng.set_stream(stream)
+        eng.upload(mdl, const_dev=const.data_ptr(), dual_dev=dual.data_ptr(), keep=(const, dual)); eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+        sweeps.append(LS.LockstepSweep(torch, p, sched, eng, dual)); tensors.append(dual)
+    try:
+        lb0 = sum(s.local_lower_bound() for s in sweeps)
+        LS.run_lockstep(sweeps, passes); torch.cuda.synchronize()
+        lb1 = sum(s.local_lower_bound() for s in sweeps)
+        for k in range(parts):
+            got = np.fromfile(tmp_path / f"duals.{k}.bin", dtype=np.float64)
+            assert np.array_equal(got, tensors[k].cpu().numpy()), k
+        assert abs(line["lower_bound_before"] - lb0) <= 1e-9 * abs(lb0) and abs(line["lower_bound_after"] - lb1) <= 1e-9 * abs(lb1)
+        o = Oracle(gm); o.set_reparametrization(M.REPAM_ANISOTROPIC); o.ComputePass(passes)
+        assert abs(line["lower_bound_after"] - o.LowerBound()) <= 1e-9 * abs(o.LowerBound())
+    finally:
+        for s in sweeps:
+            s.close(); s.engine.close()

@@ -7,7 +7,7 @@
 //
 //   mgpu_rccl_driver [--H 64] [--W 64] [--L 8] [--pairwise dense|potts] [--order colour_major|row_major] [--passes 4]
 //                    [--parts-per-rank 1] [--boundary pass|sweep] [--mode 0] [--out PREFIX] [--time K]
-//                    [--schedule boundary|overlap] [--ghost-rows 12] [--chunk 0]
+//                    [--schedule boundary|overlap|lockstep] [--ghost-rows 12] [--chunk 0] [--graph n m]
 // --schedule overlap (lpmp_overlap.hxx): the EXACT schedule for colour-major grids — every part a window with ghost rows of the
 // global (n_parts * H) x W grid, plain lpmp_compute_pass calls, one exchange per (ghost-rows / 2 - 1) passes (or --chunk).
 //
@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../lp_mp_amd/include/lpmp_overlap.hxx"
+#include "../lp_mp_amd/include/lpmp_lockstep.hxx"
 
 using namespace lpmp_mgpu;
 
@@ -30,8 +31,9 @@ static int env_int(const char* name, int dflt) { const char* v = std::getenv(nam
 
 int main(int argc, char** argv) {
   int H = 64, W = 64, L = 8, passes = 4, ppr = 1, mode = LPMP_REPAM_ANISOTROPIC, timed = 0;
-  bool potts = false, colour = true, every_pass = true, overlap = false;
+  bool potts = false, colour = true, every_pass = true, overlap = false, lockstep = false;
   int ghost = 12, chunk = 0;
+  long long graph_n = 0, graph_m = 0;
   std::string out;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -42,7 +44,8 @@ int main(int argc, char** argv) {
     else if (a == "--pairwise") potts = std::string(next()) == "potts";
     else if (a == "--order") colour = std::string(next()) == "colour_major";
     else if (a == "--boundary") every_pass = std::string(next()) == "pass";
-    else if (a == "--schedule") overlap = std::string(next()) == "overlap";
+    else if (a == "--schedule") { const std::string v = next(); overlap = v == "overlap"; lockstep = v == "lockstep"; }
+    else if (a == "--graph") { graph_n = std::atoll(next()); graph_m = std::atoll(next()); }
     else if (a == "--ghost-rows") ghost = std::atoi(next()); else if (a == "--chunk") chunk = std::atoi(next());
     else if (a == "--out") out = next();
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -96,6 +99,54 @@ int main(int argc, char** argv) {
                     "\"labels\": %d, \"pairwise\": \"%s\", \"ghost_rows\": %d, \"passes_between_exchanges\": %d, \"passes\": %d, \"lower_bound_before\": %.17g, "
                     "\"lower_bound_after\": %.17g", world, n_parts, H, W, L, potts ? "potts" : "dense", ghost, chunk > 0 ? chunk : (ghost - 2) / 2, passes, lb0, lb1);
         if (timed > 0) std::printf(", \"ms_per_pass\": %.6f, \"msg_updates_per_s\": %.6g", ms_per_pass, 4.0 * E / (ms_per_pass * 1e-3));
+        std::printf("}\n");
+      }
+      own.clear();
+      w.destroy();
+      (void)hipStreamDestroy(stream);
+      return 0;
+    }
+    if (lockstep) {
+      // the exact schedule for any MRF and partition (lpmp_lockstep.hxx): strips of the grid, or --graph n m (the C4-style
+      // random graph in the generator's index order, contiguous index ranges as parts)
+      const lockstep_structure st = graph_n > 0 ? graph_structure(graph_n, graph_m, L, n_parts, 1) : strips_structure(H, W, L, potts, colour, n_parts, 1);
+      lockstep_plan pl;
+      pl.build(st, mode);
+      std::vector<std::unique_ptr<lockstep_part>> own;
+      std::vector<lockstep_part*> parts;
+      for (int k = 0; k < ppr; ++k) {
+        own.emplace_back(new lockstep_part());
+        own.back()->build(st, pl, rank * ppr + k, device, stream, mode);
+        parts.push_back(own.back().get());
+      }
+      const double lb0 = lockstep_lower_bound(parts, w);
+      lockstep_compute_pass(parts, pl, w, n_parts, passes);
+      const double lb1 = lockstep_lower_bound(parts, w);
+      if (!out.empty())
+        for (lockstep_part* p : parts) {
+          const std::vector<double> d = p->download_duals();
+          const std::string path = out + "." + std::to_string(p->part) + ".bin";
+          FILE* f = std::fopen(path.c_str(), "wb");
+          if (!f || std::fwrite(d.data(), sizeof(double), d.size(), f) != d.size()) throw std::runtime_error("cannot write " + path);
+          std::fclose(f);
+        }
+      double ms_per_pass = 0;
+      if (timed > 0) {
+        lockstep_prepare(parts, pl, n_parts, timed);
+        (void)w.all_reduce_sum(0.0);
+        const auto t0 = std::chrono::steady_clock::now();
+        lockstep_compute_pass(parts, pl, w, n_parts, timed);
+        (void)w.all_reduce_sum(0.0);
+        ms_per_pass = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
+      }
+      double upd = 0;
+      for (lockstep_part* p : parts) upd += (double)p->updates_per_pass;
+      upd = w.all_reduce_sum(upd);
+      if (rank == 0) {
+        std::printf("{\"driver\": \"mgpu_rccl_driver (C++ host, C ABI + RCCL)\", \"schedule\": \"lockstep\", \"world\": %d, \"parts\": %d, \"variables\": %lld, \"edges\": %lld, "
+                    "\"labels\": %d, \"pairwise\": \"%s\", \"levels\": [%d, %d], \"exchanges_per_pass\": %.3f, \"passes\": %d, \"lower_bound_before\": %.17g, \"lower_bound_after\": %.17g",
+                    world, n_parts, (long long)st.n_vars, (long long)st.n_edges(), L, potts ? "potts" : "dense", pl.n_levels[0], pl.n_levels[1], pl.exchanges_per_pass(std::max(passes, 1)), passes, lb0, lb1);
+        if (timed > 0) std::printf(", \"ms_per_pass\": %.6f, \"msg_updates_per_s\": %.6g", ms_per_pass, upd / (ms_per_pass * 1e-3));
         std::printf("}\n");
       }
       own.clear();
