@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--c4-edges", type=int, default=10_000_000)
     ap.add_argument("--c4-labels", type=int, default=16)
     ap.add_argument("--c4-order", default="colour_major", choices=["colour_major", "index"],
-                    help="--workload c4 --schedule lockstep: variable order of the random graph (colour_major: one dependent level per colour, "
-                         "18 exchanges per pass instead of 60; the boundary schedule and the 1-GPU line keep the generator's index order)")
+                    help="--workload c4: variable order of the random graph, the same on any number of GPUs and under every schedule "
+                         "(colour_major: ordering.colour_major_order, one dependent level per colour — 9 per directional sweep, 16 exchanges per "
+                         "lock-step pass; index: the generator's own order — 33 levels, 60 exchanges)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schedule", default="auto", choices=["auto", "overlap", "boundary", "lockstep"],
                     help="several GPUs: 'overlap' (grids in colour-major order; the default there) = every rank holds its strip plus "
@@ -133,8 +134,10 @@ def pmc_traffic(kernel_name, args):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{what}.json")))
     if not files:
         return None, None
-    for f in reversed(files):                         # the latest summary taken on this kernel
+    for f in reversed(files):                         # the latest summary taken on this kernel (C4: in this variable order)
         d = json.load(open(f))
+        if what == "c4_dense16" and d.get("variable_order", "index") != getattr(args, "c4_order", "index"):
+            continue
         if d.get("kernel") in kernel_name:
             files = [f]
             break
@@ -161,7 +164,8 @@ def dual_bound_gap_c4(torch, dist, args, mode, world, rank, schedule=None):
         sw.boundary_every, sw.global_cut_fraction = "level that reads across the cut (lock step)", sw.cut_fraction
         rank_of = sw.rank_of
     else:
-        sw = MG.GraphSweep(torch, dist, n, m, L, mode, seed=1)
+        sw = MG.GraphSweep(torch, dist, n, m, L, mode, seed=1, order=args.c4_order)
+        rank_of = sw.rank_of
     sw.compute_pass(passes)
     lb_part = sw.lower_bound()
     out = None
@@ -461,7 +465,7 @@ def main():
                            f"{100 * runner.cut_fraction:.1f} % of the edges cut")
         else:
             rows = (not dist_on) and args.rows_layout != "off"
-            runner = MG.GraphSweep(torch, dist if dist_on else None, args.c4_nodes, args.c4_edges, L, mode, seed=1, rows_layout=rows)
+            runner = MG.GraphSweep(torch, dist if dist_on else None, args.c4_nodes, args.c4_edges, L, mode, seed=1, rows_layout=rows, order=args.c4_order)
             parallelism = (f"{world} parts (reverse Cuthill-McKee + balanced KL refinement), {100 * runner.global_cut_fraction:.1f} % of the edges cut, "
                            f"boundary step every {runner.boundary_every}") if world > 1 else "1 GPU"
         updates_per_pass = runner.global_updates_per_pass
@@ -601,7 +605,7 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         other = "boundary" if args.schedule == "lockstep" else "lockstep"
-        r2 = (MG.GraphSweep(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1) if other == "boundary" else
+        r2 = (MG.GraphSweep(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1, order=args.c4_order) if other == "boundary" else
               LS.LockstepGraph(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1, order=args.c4_order))
         dt2 = time_passes(torch, dist, r2, args.steps, args.warmup, 2)
         t = torch.tensor([dt2], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
@@ -613,8 +617,7 @@ def main():
         g2 = dual_bound_gap_c4(torch, dist, args, mode, world, rank, schedule=other)
         schedules[other] = {"ms_per_step": t.item() / args.steps * 1e3, "dual_bound_gap": g2["dual_bound_gap"] if g2 else None,
                             "lower_bound_after": lb2, "timed": False,
-                            "note": "lock step runs the sweep of the colour-major variable order, the boundary-step schedule that of the index order: "
-                                    "different (equally valid) sweeps, each gap is against its own unpartitioned sweep" if args.c4_order == "colour_major" else None}
+                            "note": "both schedules run the model in the same variable order (--c4-order); each gap is against the unpartitioned sweep of that model"}
     out = None
     if rank == 0:
         value = updates_per_pass * args.steps / dt
@@ -662,9 +665,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.workload == "c3" else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"random sparse graph G({args.c4_nodes}, {args.c4_edges}), {L} labels, dense pairwise, {args.mode} weights, "
-                                    "index order" if args.workload == "c4" else
+                                    f"{args.c4_order} variable order" if args.workload == "c4" else
                                     f"{H}x{W} grid per GPU, {L} labels, {args.pairwise} pairwise, {args.mode} weights, {args.order} order"),
-                       "parallelism": parallelism,
+                       "parallelism": parallelism, "variable_order": args.c4_order if args.workload == "c4" else args.order,
                        "pairwise_layout": "rows [table | m1 | m2], engine-private" if eng_rows else "packed (tables / serialize_dual order)",
                        "levels_per_direction": levels, "msg_updates_per_pass": updates_per_pass,
                        "algorithmic_bytes_per_pass": bytes_per_pass},

@@ -116,12 +116,13 @@ def partition_mrf(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, p
     return parts
 
 
-def graph_local_part(n: int, m: int, L: int, rank: int, world: int, seed: int = 1, part: Optional[np.ndarray] = None) -> LocalPart:
+def graph_local_part(n: int, m: int, L: int, rank: int, world: int, seed: int = 1, part: Optional[np.ndarray] = None,
+                     var_rank: Optional[np.ndarray] = None) -> LocalPart:
     """this rank's part of the C4-style model synthetic.counter_graph_model(n, m, L, seed): structure from the counter
     generator (every rank derives the same edge list without communication), costs generated in this rank's HBM.
     ``part``: the variable -> rank map; a multi-process run computes it ONCE on rank 0 and broadcasts it
     (broadcast_partition); without it every caller runs the partitioner itself (same result, deterministic)."""
-    ei, ej = S.counter_graph_edges(n, m, seed)
+    ei, ej = S.counter_graph_edges(n, m, seed, var_rank)          # (var_rank: the variables renamed, counter_graph_model(..., rank=var_rank))
     if part is None:
         part = graph_partition(n, ei, ej, world) if world > 1 else np.zeros(n, np.int64)
     return partition_mrf(n, L, ei, ej, part, world, only=rank, stream_seed=seed)[0]
@@ -828,7 +829,10 @@ class GraphSweep:
     graphs cut most of their edges under any balanced partition, so the boundary step runs after every directional
     sweep (boundary_every="sweep")."""
 
-    def __init__(self, torch, dist, n, m, L, mode, seed=1, omega_b=None, boundary_every=None, rows_layout=None):
+    def __init__(self, torch, dist, n, m, L, mode, seed=1, omega_b=None, boundary_every=None, rows_layout=None, order="index"):
+        """``order``: "index" = the generator's variable order; "colour_major" = the variables renamed by
+        ordering.colour_major_order (9 dependent levels per directional sweep instead of 33 on the C4 shape): the model is then
+        synthetic.counter_graph_model(..., rank=self.rank_of) — what lockstep.LockstepGraph runs by default"""
         from . import engine as E
         self.torch, self.dist = torch, dist
         self.comm = DistComm(dist, torch) if dist is not None and dist.is_initialized() else None
@@ -839,9 +843,16 @@ class GraphSweep:
         if self.comm:
             self.comm._dev = dev
         part_of = None
+        self.order, self.rank_of = order, None
+        if order == "colour_major":
+            from . import ordering as O
+            compute = lambda: O.colour_major_order(n, *S.counter_graph_edges(n, m, seed), seed=seed)
+            self.rank_of = broadcast_partition(torch, dist, n, dev, compute) if self.comm and world > 1 else compute()
+        elif order != "index":
+            raise ValueError(order)
         if self.comm and world > 1:                      # partition once, on rank 0
-            part_of = broadcast_partition(torch, dist, n, dev, lambda: graph_partition(n, *S.counter_graph_edges(n, m, seed), world))
-        part = graph_local_part(n, m, L, rank, world, seed, part_of)
+            part_of = broadcast_partition(torch, dist, n, dev, lambda: graph_partition(n, *S.counter_graph_edges(n, m, seed, self.rank_of), world))
+        part = graph_local_part(n, m, L, rank, world, seed, part_of, self.rank_of)
         self.part = part
         mdl = part.model
         stream = torch.cuda.current_stream().cuda_stream

@@ -46,6 +46,7 @@ subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.
 pj = os.path.join(dst, f"{tag}_pmc_{wl_class}.json")
 d = json.load(open(pj))
 d["passes_per_launch"] = plain["roofline"].get("passes_per_launch")
+d["variable_order"] = plain.get("config", {}).get("variable_order")
 d["note"] = ("FETCH_SIZE / WRITE_SIZE are the L2's fabric-side request counters: reads served by the 256 MiB Infinity Cache are "
              "counted like reads served by HBM (MI355X_MICROARCH.md, HBM / rocprofv3 section)")
 json.dump(d, open(pj, "w"))
