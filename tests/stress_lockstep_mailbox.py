@@ -1,4 +1,4 @@
-"""GPU stress (not collected by pytest): the randomised lock-step check of tests/test_lockstep.py for many more seeds, and random
+"""GPU stress (not collected by pytest): the randomised lock-step check of tests/test_lockstep.py for many more seeds (MRFs and labeling-list models), and random
 deep dense / Potts chains (banded graphs with random offsets and label counts) through the mailbox against the flags-only
 executor and the oracle.   python tests/stress_lockstep_mailbox.py [minutes]"""
 import os, sys, time
@@ -9,13 +9,15 @@ import torch
 from lp_mp_amd import engine as E, model as M, synthetic as S
 from oracle.binding import Oracle
 from tests.test_lockstep import test_lockstep_random_graphs_partitions_and_modes_on_device as lockstep_case
+from tests.test_lockstep import test_lockstep_random_general_models_partitions_and_modes_on_device as general_case
 
 minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
 t_end = time.time() + 60 * minutes
-n_ls = n_mb = 0
+n_ls = n_mb = n_gen = 0
 seed = 1000
 while time.time() < t_end:
     lockstep_case(seed); n_ls += 1
+    general_case(seed); n_gen += 1
     rng = np.random.default_rng(seed)
     L = int(rng.choice([2, 3, 4, 7, 8, 16, 21, 32])); n = int(rng.integers(60, 500))
     offs = sorted(set(int(x) for x in rng.integers(1, 24, int(rng.integers(1, 5)))))
@@ -46,4 +48,4 @@ while time.time() < t_end:
         assert np.array_equal(e.download_primal(), ref.primal()), seed
         e.close()
     n_mb += 1; seed += 1
-print(f"stress_lockstep_mailbox: {n_ls} lock-step cases, {n_mb} mailbox chains against flags-only and the oracle, {minutes} minutes: 0 mismatches")
+print(f"stress_lockstep_mailbox: {n_ls} lock-step cases on random MRFs, {n_gen} on random labeling-list models, {n_mb} mailbox chains against flags-only and the oracle, {minutes} minutes: 0 mismatches")

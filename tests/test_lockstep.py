@@ -456,6 +456,54 @@ def test_lockstep_random_graphs_partitions_and_modes_on_device(seed):
             s.engine.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_lockstep_random_general_models_partitions_and_modes_on_device(seed):
+    """random multicut-style and C5-style models (labeling-list factors of three and four edge variables, optionally a Potts grid
+    beside them), random scattered partitions, random weight mode, separate calls of random length: every copy of every factor and
+    the summed bound are the oracle's on the unpartitioned model"""
+    from lp_mp_amd import engine as E
+    rng = np.random.default_rng(500 + seed)
+    if rng.uniform() < 0.5:
+        gm = S.multicut_triangle_model(int(rng.integers(8, 60)), int(rng.integers(5, 90)), seed=seed)
+    else:
+        gm = S.c5_model(int(rng.integers(2, 7)), int(rng.integers(2, 7)), int(rng.choice([2, 3, 4, 8])), int(rng.integers(12, 80)), int(rng.integers(4, 60)),
+                        int(rng.integers(2, 30)), seed=seed, window=int(rng.integers(6, 40)), colour_edge_vars=bool(rng.uniform() < 0.5))
+    world = int(rng.integers(2, 6))
+    mode = [M.REPAM_ANISOTROPIC, M.REPAM_ANISOTROPIC2, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM][int(rng.integers(0, 4))]
+    is_right = np.zeros(gm.n_factors, bool); is_right[gm.m_right] = True
+    variables = np.nonzero(~is_right)[0]
+    if variables.shape[0] < world:
+        world = 2
+    part_of = rng.integers(0, world, gm.n_factors)
+    part_of[variables[:world]] = np.arange(world)
+    ref = Oracle(gm); ref.set_reparametrization(mode)
+    sched, parts = LS.lockstep_model(gm, part_of, world, mode)
+    dev = torch.device("cuda:0")
+    sweeps, tensors = [], []
+    for p in parts:
+        dual = torch.from_numpy(p.model.dual_data.copy()).to(dev)
+        eng = E.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual); eng.set_reparametrization(mode)
+        sweeps.append(LS.LockstepSweep(torch, p, sched, eng, dual)); tensors.append(dual)
+    g_off = gm.dual_offsets()
+    try:
+        for k in rng.integers(1, 4, 3):
+            ref.ComputePass(int(k)); LS.run_lockstep(sweeps, int(k)); torch.cuda.synchronize()
+            gd = ref.duals()
+            for p, t in zip(parts, tensors):
+                d, lo = t.cpu().numpy(), p.model.dual_offsets()
+                ghosts = set(p.vars_global[p.is_ghost].tolist())
+                for fl, g in enumerate(p.factors_global.tolist()):
+                    if g not in ghosts:
+                        assert np.array_equal(d[lo[fl]:lo[fl + 1]], gd[g_off[g]:g_off[g + 1]]), (seed, p.rank, fl, g)
+            lb = sum(s.local_lower_bound() for s in sweeps)
+            assert abs(lb - ref.LowerBound()) <= 1e-9 * max(1.0, abs(ref.LowerBound())), (seed, lb, ref.LowerBound())
+    finally:
+        for s in sweeps:
+            s.close(); s.engine.close()
+
+
 def test_colour_major_order_cuts_the_exchanges_of_a_random_graph():
     """LockstepGraph's default variable order (ordering.colour_major_order): one dependent level per colour, so the sweep
     needs an exchange per colour instead of one per level of the generator's index order"""
