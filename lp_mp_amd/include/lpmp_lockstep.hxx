@@ -61,16 +61,21 @@ inline uint64_t counter_u64(uint64_t seed, uint64_t i) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
   return z ^ (z >> 31);
 }
-inline lockstep_structure graph_structure(int64_t n, int64_t m, int L, int n_parts, uint64_t seed) {
+// var_rank (optional, [n]): the variables renamed — variable v becomes var_rank[v] (synthetic.counter_graph_model(..., rank=...);
+// e.g. a colour-major order: 9 dependent levels per sweep on the C4 shape instead of 33); part_of (optional, [n], by NEW index)
+inline lockstep_structure graph_structure(int64_t n, int64_t m, int L, int n_parts, uint64_t seed, const std::vector<int64_t>* var_rank = nullptr,
+                                          const std::vector<int64_t>* part_of = nullptr) {
   lockstep_structure s; s.n_vars = n; s.L = L; s.potts = false; s.n_parts = n_parts; s.seed = seed;
+  if ((var_rank && (int64_t)var_rank->size() != n) || (part_of && (int64_t)part_of->size() != n)) throw std::runtime_error("lockstep: one entry per variable in the order / partition");
   s.ei.resize((size_t)m); s.ej.resize((size_t)m);
   for (int64_t e = 0; e < m; ++e) {
-    const int64_t a = (int64_t)(counter_u64(seed ^ 0x5DEECE66DULL, (uint64_t)(2 * e)) % (uint64_t)n);
-    const int64_t b = (a + 1 + (int64_t)(counter_u64(seed ^ 0x5DEECE66DULL, (uint64_t)(2 * e + 1)) % (uint64_t)(n - 1))) % n;
+    int64_t a = (int64_t)(counter_u64(seed ^ 0x5DEECE66DULL, (uint64_t)(2 * e)) % (uint64_t)n);
+    int64_t b = (a + 1 + (int64_t)(counter_u64(seed ^ 0x5DEECE66DULL, (uint64_t)(2 * e + 1)) % (uint64_t)(n - 1))) % n;
+    if (var_rank) { a = (*var_rank)[(size_t)a]; b = (*var_rank)[(size_t)b]; if (a < 0 || a >= n || b < 0 || b >= n) throw std::runtime_error("lockstep: variable order out of range"); }
     s.ei[(size_t)e] = std::min(a, b); s.ej[(size_t)e] = std::max(a, b);
   }
   s.part.resize((size_t)n);
-  for (int64_t v = 0; v < n; ++v) s.part[(size_t)v] = (int32_t)(v * n_parts / n);
+  for (int64_t v = 0; v < n; ++v) s.part[(size_t)v] = part_of ? (int32_t)(*part_of)[(size_t)v] : (int32_t)(v * n_parts / n);
   return s;
 }
 

@@ -731,7 +731,7 @@ def test_cpp_rccl_driver_overlap_schedule_equals_the_python_overlap_sweep_and_th
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["strips dense colour-major", "strips dense row-major", "strips potts", "random graph"])
+@pytest.mark.parametrize("case", ["strips dense colour-major", "strips dense row-major", "strips potts", "random graph", "random graph, colour-major order, partitioner"])
 def test_cpp_rccl_driver_lockstep_schedule_equals_the_python_lockstep_sweep_and_the_oracle(tmp_path, case):
     """tools/mgpu_rccl_driver.cpp --schedule lockstep (lp_mp_amd/include/lpmp_lockstep.hxx: the global level structure from
     lpmp_plan_* on the structure of the whole model, runs of sub-levels as lpmp_schedule_create[_fused], halos through lpmp_halo_*
@@ -745,12 +745,19 @@ def test_cpp_rccl_driver_lockstep_schedule_equals_the_python_lockstep_sweep_and_
     passes = 3
     exe = B.build_mgpu_driver()
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    if case == "random graph":
+    if case.startswith("random graph"):
         n, m, L, parts, pairwise = 900, 3600, 16, 4, "dense"
         args = ["--graph", str(n), str(m), "--L", str(L)]
-        ei, ej = S.counter_graph_edges(n, m, 1)
+        var_rank = None
         part_of = (np.arange(n) * parts) // n
-        gm = S.counter_graph_model(n, m, L, 1)
+        if "colour-major" in case:                     # what bench.py --workload c4 runs: order and partition from the Python side, as files
+            from lp_mp_amd import ordering as O
+            var_rank = O.colour_major_order(n, *S.counter_graph_edges(n, m, 1), seed=1)
+            part_of = MG.graph_partition(n, *S.counter_graph_edges(n, m, 1, var_rank), parts)
+            var_rank.astype(np.int64).tofile(tmp_path / "order.bin"); part_of.astype(np.int64).tofile(tmp_path / "part.bin")
+            args += ["--order-file", str(tmp_path / "order.bin"), "--part-file", str(tmp_path / "part.bin")]
+        ei, ej = S.counter_graph_edges(n, m, 1, var_rank)
+        gm = S.counter_graph_model(n, m, L, 1, rank=var_rank)
     else:
         H, W, parts = 8, 7, 3
         L, pairwise, order = {"strips dense colour-major": (16, "dense", "colour_major"), "strips dense row-major": (5, "dense", "row_major"),

@@ -7,7 +7,7 @@
 //
 //   mgpu_rccl_driver [--H 64] [--W 64] [--L 8] [--pairwise dense|potts] [--order colour_major|row_major] [--passes 4]
 //                    [--parts-per-rank 1] [--boundary pass|sweep] [--mode 0] [--out PREFIX] [--time K]
-//                    [--schedule boundary|overlap|lockstep] [--ghost-rows 12] [--chunk 0] [--graph n m]
+//                    [--schedule boundary|overlap|lockstep] [--ghost-rows 12] [--chunk 0] [--graph n m [--order-file f] [--part-file f]]
 // --schedule overlap (lpmp_overlap.hxx): the EXACT schedule for colour-major grids — every part a window with ghost rows of the
 // global (n_parts * H) x W grid, plain lpmp_compute_pass calls, one exchange per (ghost-rows / 2 - 1) passes (or --chunk).
 //
@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
   bool potts = false, colour = true, every_pass = true, overlap = false, lockstep = false;
   int ghost = 12, chunk = 0;
   long long graph_n = 0, graph_m = 0;
+  std::string order_file, part_file;
   std::string out;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -46,6 +47,7 @@ int main(int argc, char** argv) {
     else if (a == "--boundary") every_pass = std::string(next()) == "pass";
     else if (a == "--schedule") { const std::string v = next(); overlap = v == "overlap"; lockstep = v == "lockstep"; }
     else if (a == "--graph") { graph_n = std::atoll(next()); graph_m = std::atoll(next()); }
+    else if (a == "--order-file") order_file = next(); else if (a == "--part-file") part_file = next();
     else if (a == "--ghost-rows") ghost = std::atoi(next()); else if (a == "--chunk") chunk = std::atoi(next());
     else if (a == "--out") out = next();
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -109,7 +111,20 @@ int main(int argc, char** argv) {
     if (lockstep) {
       // the exact schedule for any MRF and partition (lpmp_lockstep.hxx): strips of the grid, or --graph n m (the C4-style
       // random graph in the generator's index order, contiguous index ranges as parts)
-      const lockstep_structure st = graph_n > 0 ? graph_structure(graph_n, graph_m, L, n_parts, 1) : strips_structure(H, W, L, potts, colour, n_parts, 1);
+      // (--order-file / --part-file: int64 arrays, one entry per variable — a variable order such as ordering.colour_major_order
+      // and a partition such as multi_gpu.graph_partition, computed by the caller)
+      auto load = [](const std::string& path, long long n) {
+        std::vector<int64_t> v((size_t)n);
+        FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f || std::fread(v.data(), sizeof(int64_t), v.size(), f) != v.size()) throw std::runtime_error("cannot read " + std::to_string(n) + " int64 values from " + path);
+        std::fclose(f);
+        return v;
+      };
+      std::vector<int64_t> var_rank, part_of;
+      if (graph_n > 0 && !order_file.empty()) var_rank = load(order_file, graph_n);
+      if (graph_n > 0 && !part_file.empty()) part_of = load(part_file, graph_n);
+      const lockstep_structure st = graph_n > 0 ? graph_structure(graph_n, graph_m, L, n_parts, 1, var_rank.empty() ? nullptr : &var_rank, part_of.empty() ? nullptr : &part_of)
+                                                : strips_structure(H, W, L, potts, colour, n_parts, 1);
       lockstep_plan pl;
       pl.build(st, mode);
       std::vector<std::unique_ptr<lockstep_part>> own;
