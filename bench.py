@@ -117,6 +117,14 @@ def time_passes(torch, dist, eng, steps, warmup, world, prewarm_ms=0.0):
     return time.perf_counter() - t0
 
 
+def close_runner(r):
+    """engine and, for the lock-step drivers, the exchange plans (device arrays behind lpmp_halo_*) of a finished runner"""
+    sw = getattr(r, "sweep", None)
+    if sw is not None and hasattr(sw, "close"):
+        sw.close()
+    r.engine.close()
+
+
 def pmc_traffic(kernel_name, args):
     """Bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes; summarised
@@ -178,7 +186,7 @@ def dual_bound_gap_c4(torch, dist, args, mode, world, rank, schedule=None):
         e.close()
         out = {"dual_bound_gap": (lb_ref - lb_part) / abs(lb_ref), "gap_config": f"G({n}, {m}), {L} labels in {world} parts, {passes} passes, "
                f"boundary step every {sw.boundary_every}", "cut_fraction": sw.global_cut_fraction, "lb_partitioned": lb_part, "lb_unpartitioned": lb_ref}
-    sw.engine.close()
+    close_runner(sw)
     return out
 
 
@@ -230,7 +238,7 @@ def dual_bound_gap(torch, dist, args, mode, world, rank, schedule=None):
         e.close()
         out = {"dual_bound_gap": (lb_ref - lb_part) / abs(lb_ref), "gap_config": f"{world} strips of {g}x{g}, {passes} passes, schedule {schedule}",
                "lb_partitioned": lb_part, "lb_unpartitioned": lb_ref}
-    sw.engine.close()
+    close_runner(sw)
     return out
 
 
@@ -586,7 +594,7 @@ def main():
             t = torch.tensor([dt2], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             lb2 = r2.lower_bound()
-            r2.engine.close()
+            close_runner(r2)
             del r2
             torch.cuda.empty_cache()
             g2 = dual_bound_gap(torch, dist, args, mode, world, rank, schedule=other)
@@ -611,7 +619,7 @@ def main():
         t = torch.tensor([dt2], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         lb2 = r2.lower_bound()
-        r2.engine.close()
+        close_runner(r2)
         del r2
         torch.cuda.empty_cache()
         g2 = dual_bound_gap_c4(torch, dist, args, mode, world, rank, schedule=other)
