@@ -3,8 +3,8 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-bash tools/profile_round.sh r04a --steps 20 --warmup 5
-bash tools/profile_round.sh r04_c4 --workload c4 --steps 10 --warmup 3
+bash tools/profile_round.sh r04b --steps 20 --warmup 5
+bash tools/profile_round.sh r04b_c4 --workload c4 --steps 10 --warmup 3
 # probes
 for parts in 1 2 3; do timeout 600 python tools/overlap_probe.py 1024 32 $parts 10 12; done > gpurun_out/r04_overlap_probe.txt 2>/dev/null
 timeout 600 python tools/overlap_probe.py 1024 32 2 16 18 >> gpurun_out/r04_overlap_probe.txt 2>/dev/null
