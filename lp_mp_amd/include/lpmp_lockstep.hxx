@@ -250,7 +250,7 @@ class lockstep_part {
   lpmp_engine* e = nullptr; hipStream_t stream = nullptr;
   double *d_const = nullptr, *d_dual = nullptr;
   std::map<std::vector<std::pair<int, int>>, int> sids;
-  struct halo { lpmp_halo* h = nullptr; double *d_send = nullptr, *d_recv = nullptr; std::vector<int64_t> out_count, in_count; int64_t n_out = 0, n_in = 0; };
+  struct halo { lpmp_halo* h = nullptr; double *d_send = nullptr, *d_recv = nullptr; std::vector<int64_t> out_count, in_count; int64_t n_out = 0, n_in = 0; bool ready = false; };
   std::map<int, halo> halos;
   int64_t updates_per_pass = 0;
 
@@ -356,8 +356,9 @@ class lockstep_part {
   // and receives (by source part, then vector)
   halo& halo_plan(const lockstep_plan& pl, const lockstep_step& st, int n_parts) {
     auto it = halos.find(st.id);
-    if (it != halos.end()) return it->second;
-    halo h; h.out_count.assign((size_t)n_parts, 0); h.in_count.assign((size_t)n_parts, 0);
+    if (it != halos.end()) { if (!it->second.ready) throw std::runtime_error("lockstep: an exchange plan that failed to build"); return it->second; }
+    halo& h = halos[st.id];                  // (in the map from the start: whatever is allocated below is released with the part)
+    h.out_count.assign((size_t)n_parts, 0); h.in_count.assign((size_t)n_parts, 0);
     std::vector<std::pair<int32_t, int64_t>> out, in;
     for (int64_t v : st.vecs) {
       if (pl.writer[(size_t)v] == part) out.push_back({pl.reader[(size_t)v], v});
@@ -379,7 +380,8 @@ class lockstep_part {
     lpmp_ok(lpmp_halo_create(e, (int64_t)o_off.size(), o_off.data(), o_len.data(), (int64_t)i_off.size(), i_off.data(), i_len.data(), &h.h));
     hip_ok(hipMalloc((void**)&h.d_send, (size_t)std::max<int64_t>(h.n_out, 1) * sizeof(double)), "hipMalloc");
     hip_ok(hipMalloc((void**)&h.d_recv, (size_t)std::max<int64_t>(h.n_in, 1) * sizeof(double)), "hipMalloc");
-    return halos[st.id] = h;
+    h.ready = true;
+    return h;
   }
 
   double local_lower_bound() {

@@ -396,6 +396,7 @@ class LockstepSweep:
         self._sids: Dict[tuple, int] = {}
         self._halo: Dict[int, tuple] = {}
         self._device_halos = hasattr(engine, "halo_create")          # the HIP engine (CPU tests run oracle-backed stand-ins without it)
+        self._send = None
         self.info = {}
 
     def _schedule(self, seg: tuple) -> int:
@@ -442,8 +443,7 @@ class LockstepSweep:
             if self._device_halos:
                 # the HIP engine: copies by its halo kernels (include/lpmp_engine.h, lpmp_halo_*), the send buffer kept with the plan
                 h = self.engine.halo_create(o_start, o_len, i_start, i_len)
-                send = self.torch.empty(int(o_len.sum()), dtype=self.torch.float64, device=self.dual.device)
-                self._halo[key] = (h, count(o_peer, o_len), send, count(i_peer, i_len))
+                self._halo[key] = (h, count(o_peer, o_len), int(o_len.sum()), count(i_peer, i_len))
             else:
                 def elems(start, ln):                              # (stand-in engines on the CPU: index tensors into the dual array)
                     first = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
@@ -456,8 +456,11 @@ class LockstepSweep:
     def halo_pack(self, vecs, key=None):
         src, out_counts, buf, in_counts = self._halo_plan(vecs, key)
         if self._device_halos:
-            self.engine.halo_pack(src, buf.data_ptr())
-            return buf, out_counts, in_counts
+            # one send buffer for all exchanges of this part (work on a stream is ordered: the previous exchange has read it)
+            if self._send is None or self._send.shape[0] < buf:
+                self._send = self.torch.empty(max(buf, 1), dtype=self.torch.float64, device=self.dual.device)
+            self.engine.halo_pack(src, self._send.data_ptr())
+            return self._send[:buf], out_counts, in_counts
         return self.dual[src], out_counts, in_counts
 
     def halo_unpack(self, vecs, recv, key=None):
