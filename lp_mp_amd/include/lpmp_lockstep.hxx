@@ -395,31 +395,33 @@ class lockstep_part {
 };
 
 // one exchange: every part packs, one ncclGroup of sends / receives between the ranks (parts of one rank: device copies), every
-// part unpacks.  parts = this rank's parts in part order
+// part unpacks.  parts = this rank's parts in part order.  Transfers are issued in a fixed global order — by (source part,
+// destination part) — so that the k-th send of rank a to rank b meets the k-th receive of b from a (as lpmp_multi_gpu.hxx)
 inline void lockstep_exchange(std::vector<lockstep_part*>& parts, lockstep_plan& pl, const lockstep_step& st, rccl_world& w, int n_parts) {
   std::vector<lockstep_part::halo*> hs;
   for (lockstep_part* p : parts) { hs.push_back(&p->halo_plan(pl, st, n_parts)); lpmp_ok(lpmp_halo_pack(p->e, hs.back()->h, hs.back()->d_send)); }
   const int first_part = w.rank * w.parts_per_rank;
+  auto offset = [](const std::vector<int64_t>& count, int q) { int64_t off = 0; for (int r = 0; r < q; ++r) off += count[(size_t)r]; return off; };
   nccl_ok(ncclGroupStart(), "ncclGroupStart");
-  for (size_t x = 0; x < parts.size(); ++x) {
-    lockstep_part::halo& h = *hs[x];
-    int64_t so = 0, ro = 0;
-    for (int q = 0; q < n_parts; ++q) {
-      const int64_t sc = h.out_count[(size_t)q], rc = h.in_count[(size_t)q];
-      const bool here = w.rank_of(q) == w.rank;
-      if (sc > 0) {
-        if (here) {
-          // the receiver's offset of what comes from this part: the counts of the parts before it
-          lockstep_part::halo& hq = *hs[(size_t)(q - first_part)];
-          int64_t off = 0; for (int r = 0; r < parts[x]->part; ++r) off += hq.in_count[(size_t)r];
-          if (hq.in_count[(size_t)parts[x]->part] != sc) throw std::runtime_error("lockstep: two parts disagree on an exchange");
-          hip_ok(hipMemcpyAsync(hq.d_recv + off, h.d_send + so, (size_t)sc * sizeof(double), hipMemcpyDeviceToDevice, w.stream), "hipMemcpyAsync");
-        } else nccl_ok(ncclSend(h.d_send + so, (size_t)sc, ncclDouble, w.rank_of(q), w.comm, w.stream), "ncclSend");
+  for (int src = 0; src < n_parts; ++src)
+    for (int dst = 0; dst < n_parts; ++dst) {
+      const bool src_here = w.rank_of(src) == w.rank, dst_here = w.rank_of(dst) == w.rank;
+      if (!src_here && !dst_here) continue;
+      if (src_here && dst_here) {
+        lockstep_part::halo &hs_ = *hs[(size_t)(src - first_part)], &hd = *hs[(size_t)(dst - first_part)];
+        const int64_t c = hs_.out_count[(size_t)dst];
+        if (c != hd.in_count[(size_t)src]) throw std::runtime_error("lockstep: two parts disagree on an exchange");
+        if (c > 0) hip_ok(hipMemcpyAsync(hd.d_recv + offset(hd.in_count, src), hs_.d_send + offset(hs_.out_count, dst), (size_t)c * sizeof(double), hipMemcpyDeviceToDevice, w.stream), "hipMemcpyAsync");
+      } else if (src_here) {
+        lockstep_part::halo& h = *hs[(size_t)(src - first_part)];
+        const int64_t c = h.out_count[(size_t)dst];
+        if (c > 0) nccl_ok(ncclSend(h.d_send + offset(h.out_count, dst), (size_t)c, ncclDouble, w.rank_of(dst), w.comm, w.stream), "ncclSend");
+      } else {
+        lockstep_part::halo& h = *hs[(size_t)(dst - first_part)];
+        const int64_t c = h.in_count[(size_t)src];
+        if (c > 0) nccl_ok(ncclRecv(h.d_recv + offset(h.in_count, src), (size_t)c, ncclDouble, w.rank_of(src), w.comm, w.stream), "ncclRecv");
       }
-      if (rc > 0 && !here) nccl_ok(ncclRecv(h.d_recv + ro, (size_t)rc, ncclDouble, w.rank_of(q), w.comm, w.stream), "ncclRecv");
-      so += sc; ro += rc;
     }
-  }
   nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
   for (size_t x = 0; x < parts.size(); ++x) lpmp_ok(lpmp_halo_unpack(parts[x]->e, hs[x]->h, hs[x]->d_recv));
 }
