@@ -403,10 +403,7 @@ inline void lockstep_exchange(std::vector<lockstep_part*>& parts, lockstep_plan&
   const int first_part = w.rank * w.parts_per_rank;
   auto offset = [](const std::vector<int64_t>& count, int q) { int64_t off = 0; for (int r = 0; r < q; ++r) off += count[(size_t)r]; return off; };
   nccl_ok(ncclGroupStart(), "ncclGroupStart");
-  for (int src = 0; src < n_parts; ++src)
-    for (int dst = 0; dst < n_parts; ++dst) {
-      const bool src_here = w.rank_of(src) == w.rank, dst_here = w.rank_of(dst) == w.rank;
-      if (!src_here && !dst_here) continue;
+  for_each_transfer(n_parts, w.rank, w.parts_per_rank, [&](int src, int dst, bool src_here, bool dst_here) {
       if (src_here && dst_here) {
         lockstep_part::halo &hs_ = *hs[(size_t)(src - first_part)], &hd = *hs[(size_t)(dst - first_part)];
         const int64_t c = hs_.out_count[(size_t)dst];
@@ -421,7 +418,7 @@ inline void lockstep_exchange(std::vector<lockstep_part*>& parts, lockstep_plan&
         const int64_t c = h.in_count[(size_t)src];
         if (c > 0) nccl_ok(ncclRecv(h.d_recv + offset(h.in_count, src), (size_t)c, ncclDouble, w.rank_of(src), w.comm, w.stream), "ncclRecv");
       }
-    }
+    });
   nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
   for (size_t x = 0; x < parts.size(); ++x) lpmp_ok(lpmp_halo_unpack(parts[x]->e, hs[x]->h, hs[x]->d_recv));
 }

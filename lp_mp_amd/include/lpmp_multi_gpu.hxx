@@ -359,16 +359,25 @@ class part_sweep {
   }
 };
 
+// The order in which a rank issues the point-to-point transfers of one exchange between parts: every (source part, destination
+// part) pair that touches this rank, by source, then destination — the same global order on every rank, so the k-th send of rank a
+// to rank b meets the k-th receive of b from a whatever the number of parts per rank.  f(src, dst, src_here, dst_here)
+template <class F>
+inline void for_each_transfer(int n_parts, int rank, int parts_per_rank, F&& f) {
+  for (int src = 0; src < n_parts; ++src)
+    for (int dst = 0; dst < n_parts; ++dst) {
+      const bool src_here = src / parts_per_rank == rank, dst_here = dst / parts_per_rank == rank;
+      if (src_here || dst_here) f(src, dst, src_here, dst_here);
+    }
+}
+
 // One boundary step of all parts of this rank: pack, exchange #1, reply, exchange #2, fold.
 // Transfers are issued in a fixed global order — by (source part, destination part) — so that the k-th send of rank a to
 // rank b meets the k-th receive of b from a.
 inline void exchange(std::vector<part_sweep*>& parts, rccl_world& w, bool first_leg) {
   const int n_parts = parts.empty() ? 0 : parts[0]->pm.n_parts;
   nccl_ok(ncclGroupStart(), "ncclGroupStart");
-  for (int src = 0; src < n_parts; ++src)
-    for (int dst = 0; dst < n_parts; ++dst) {
-      const bool src_here = w.rank_of(src) == w.rank, dst_here = w.rank_of(dst) == w.rank;
-      if (!src_here && !dst_here) continue;
+  for_each_transfer(n_parts, w.rank, w.parts_per_rank, [&](int src, int dst, bool src_here, bool dst_here) {
       // leg 1: what src OWNS toward dst (out lists) travels src -> dst; leg 2: dst's replies travel back dst -> src
       if (first_leg) {
         if (src_here) { part_sweep& p = *parts[src - w.rank * w.parts_per_rank]; const int64_t c = p.out_count[dst];
@@ -381,7 +390,7 @@ inline void exchange(std::vector<part_sweep*>& parts, rccl_world& w, bool first_
         if (src_here) { part_sweep& p = *parts[src - w.rank * w.parts_per_rank]; const int64_t c = p.out_count[dst];
           if (c > 0) { int64_t off = 0; for (int q = 0; q < dst; ++q) off += p.out_count[q]; nccl_ok(ncclRecv(p.d_back + off, (size_t)c, ncclDouble, w.rank_of(dst), w.comm, w.stream), "ncclRecv"); } }
       }
-    }
+    });
   nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
 }
 

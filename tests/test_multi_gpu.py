@@ -642,6 +642,24 @@ def test_nccl_unique_id_is_handed_out_over_tcp_not_through_a_file(tmp_path):
     assert "fopen" not in src and "/tmp/" not in src
 
 
+def test_cpp_hosts_issue_sends_and_receives_in_one_global_order(tmp_path):
+    """tests/cpp/test_transfer_order.cpp: the (source part, destination part) order every C++ exchange uses (for_each_transfer in
+    lpmp_multi_gpu.hxx; boundary steps and lock step) pairs the k-th send of rank a to rank b with the k-th receive of b from a,
+    for 1..8 ranks with 1..4 parts each — checked on the host, since two RCCL ranks cannot share the test box's GPU"""
+    from lp_mp_amd import build as B
+    if not B.have_rccl():
+        pytest.skip("no <rccl/rccl.h> on this box")
+    B.build()
+    exe = str(tmp_path / "test_transfer_order")
+    subprocess.check_call([B.hipcc(), "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "lp_mp_amd", "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "test_transfer_order.cpp"), "-L", B.CSRC, "-llpmp_engine", "-lrccl", "-Wl,-rpath," + B.CSRC])
+    out = subprocess.check_output([exe], text=True, timeout=120)
+    assert "pair up" in out, out
+    # both exchanges go through it
+    for f in ("lpmp_multi_gpu.hxx", "lpmp_lockstep.hxx"):
+        assert "for_each_transfer(n_parts, w.rank, w.parts_per_rank" in open(os.path.join(ROOT, "lp_mp_amd", "include", f)).read(), f
+
+
 @pytest.mark.gpu
 def test_cpp_rccl_driver_two_processes_on_one_gpu_fail_or_agree(tmp_path):
     """two rank PROCESSES of the C++ RCCL driver (the multi-process path: id hand-out over TCP, ncclCommInitRank at world 2).
