@@ -181,3 +181,17 @@ def test_bench_gpus_2_launches_its_own_ranks(schedule):
         assert abs(d["dual_bound_gap"]) <= 1e-12       # the exact schedule: the unpartitioned sweep's bound
     else:
         assert 0 <= d["dual_bound_gap"] < 0.01
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_c4_runs_in_lock_step_by_default():
+    """`python bench.py --gpus 2 --workload c4` (a 20 000-node graph here): the default schedule is the exact one (lock step, colour-major
+    variable order on every path), the line carries the boundary-step schedule of the same model beside it"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LPMP_DIST_BACKEND")}
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4", "--c4-nodes", "20000", "--c4-edges", "100000",
+                                   "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], text=True, cwd=ROOT, timeout=1200, env=env)
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["schedule"] == "lockstep" and d["config"]["variable_order"] == "colour_major"
+    assert abs(d["dual_bound_gap"]) <= 1e-12 and d["lower_bound_after"] > d["lower_bound_before"]
+    assert set(d["schedules"]) == {"lockstep", "boundary"} and 0 <= d["schedules"]["boundary"]["dual_bound_gap"] < 0.05
+    assert d["scaling"] == "strong"
