@@ -112,39 +112,130 @@ struct mrf_arrays {
   }
 };
 
+// a whole model read from a flat binary file (the arrays of lpmp_model.h in their order; written by lp_mp_amd.model.FlatModel.dump):
+//   int64 magic, n_ftypes, n_mtypes, n_tables, tab_total, n_factors, n_messages, n_rel_fwd, n_rel_bwd, n_const, n_dual; double constant;
+//   u8 ftype_computes_primal[n_ftypes]; int32 mtypes[n_mtypes][8]; int64 tab_off[n_tables + 1]; int32 tab_data[tab_total]; int32 tab_nleft[n_tables];
+//   int32 f_type[nf]; u8 f_kind[nf]; u8 f_flags[nf]; int32 f_dim0[nf]; int32 f_dim1[nf]; double const[n_const]; double dual[n_dual];
+//   int32 m_type[nm], m_left[nm], m_right[nm]; int32 rel_fwd[n_rel_fwd][2]; int32 rel_bwd[n_rel_bwd][2]
+struct model_file {
+  static constexpr int64_t MAGIC = 0x4C504D504D4F444CLL;   // "LPMPMODL"
+  std::vector<uint8_t> primal, f_kind, f_flags;
+  std::vector<lpmp_msg_type> mtypes;
+  std::vector<int64_t> tab_off;
+  std::vector<int32_t> tab_data, tab_nleft, f_type, f_dim0, f_dim1, m_type, m_left, m_right, rel_fwd, rel_bwd;
+  std::vector<double> cdata, ddata;
+  double constant = 0;
+  void load(const std::string& path) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    struct closer { FILE* f; ~closer() { std::fclose(f); } } cl{f};
+    auto rd = [&](void* p, size_t bytes) { if (bytes && std::fread(p, 1, bytes, f) != bytes) throw std::runtime_error("model file " + path + " is truncated"); };
+    int64_t h[11];
+    rd(h, sizeof(h)); rd(&constant, sizeof(double));
+    if (h[0] != MAGIC) throw std::runtime_error(path + " is not a model file");
+    for (int i = 1; i < 11; ++i) if (h[i] < 0) throw std::runtime_error("model file: negative count");
+    auto get = [&](auto& v, int64_t n) { v.resize((size_t)n); rd(v.data(), (size_t)n * sizeof(v[0])); };
+    get(primal, h[1]); get(mtypes, h[2]); get(tab_off, h[3] + 1); get(tab_data, h[4]); get(tab_nleft, h[3]);
+    get(f_type, h[5]); get(f_kind, h[5]); get(f_flags, h[5]); get(f_dim0, h[5]); get(f_dim1, h[5]); get(cdata, h[9]); get(ddata, h[10]);
+    get(m_type, h[6]); get(m_left, h[6]); get(m_right, h[6]); get(rel_fwd, 2 * h[7]); get(rel_bwd, 2 * h[8]);
+  }
+  lpmp_model view() const {
+    lpmp_model m{};
+    m.n_ftypes = (int32_t)primal.size(); m.ftype_computes_primal = primal.data(); m.n_mtypes = (int32_t)mtypes.size(); m.mtypes = mtypes.data();
+    m.n_tables = (int32_t)tab_nleft.size(); m.tab_off = tab_off.data(); m.tab_data = tab_data.data(); m.tab_nleft = tab_nleft.data();
+    m.n_factors = (int64_t)f_type.size(); m.f_type = f_type.data(); m.f_kind = f_kind.data(); m.f_flags = f_flags.data(); m.f_dim0 = f_dim0.data(); m.f_dim1 = f_dim1.data();
+    m.const_data = cdata.empty() ? nullptr : cdata.data(); m.dual_data = ddata.data();
+    m.n_messages = (int64_t)m_type.size(); m.m_type = m_type.data(); m.m_left = m_left.data(); m.m_right = m_right.data();
+    m.n_rel_fwd = (int64_t)rel_fwd.size() / 2; m.rel_fwd = rel_fwd.data(); m.n_rel_bwd = (int64_t)rel_bwd.size() / 2; m.rel_bwd = rel_bwd.data();
+    m.constant = constant;
+    return m;
+  }
+};
+
 struct lockstep_step { bool halo = false; std::vector<std::pair<int, int>> run; std::vector<int64_t> vecs; int id = -1; };
 
 // what every rank computes identically from the global structure
 struct lockstep_plan {
   int n_levels[2] = {0, 0};
-  int64_t n_vecs = 0;
-  std::vector<int32_t> writer, reader;                              // [2 n_edges]
+  int64_t n_vecs = 0;                                                // one exchange unit per message (an MRF: 2 e + s)
+  std::vector<int32_t> writer;                                       // [n_vecs] part of the message's left factor: the only writer of that slice
+  std::vector<int64_t> dest_off; std::vector<int32_t> dest;         // CSR: the other parts holding the vector's factor
+  std::vector<int64_t> v_off, v_len;                                 // the slice of its higher factor's dual a message writes
+  std::vector<int32_t> owner;                                        // [n_factors] where a factor counts in the bound
   std::vector<std::vector<int64_t>> written[2], read[2];           // [direction][sub-level]: sorted cut vectors
   // the rows of the global sweep: update order, weights, masks, level, "touches a cut vector"
   std::vector<int32_t> upd[2], lev[2]; std::vector<int64_t> om_off[2], mk_off[2]; std::vector<double> om[2]; std::vector<uint8_t> mk[2], touches_cut[2];
   std::map<int, std::vector<lockstep_step>> programs;
   std::map<std::vector<int64_t>, int> halo_ids;
+  bool is_cut(int64_t v) const { return dest_off[(size_t)v + 1] > dest_off[(size_t)v]; }
 
   void build(const lockstep_structure& s, int mode) {
-    const int64_t n = s.n_vars, ne = s.n_edges();
-    if ((int64_t)s.part.size() != n) throw std::runtime_error("lockstep: a part for every variable");
-    std::vector<int64_t> cnt((size_t)s.n_parts, 0);
-    for (int32_t p : s.part) { if (p < 0 || p >= s.n_parts) throw std::runtime_error("lockstep: part out of range"); ++cnt[(size_t)p]; }
+    mrf_arrays g; g.build(s.n_vars, s.L, s.potts, s.ei, s.ej);
+    std::vector<int32_t> part(s.part);
+    part.resize((size_t)(s.n_vars + s.n_edges()), 0);
+    build(g.view(nullptr, nullptr), part, s.n_parts, mode);
+  }
+
+  // any model whose messages all have the `left` schedule and whose factors are either variables (left factor of their messages,
+  // or no message) or higher factors (right factor), with unary-pairwise or labeling messages (lockstep.lockstep_model).
+  // part[f]: part of variable f (ignored for higher factors).  Costs are not read.
+  void build(const lpmp_model& gm, const std::vector<int32_t>& part, int n_parts, int mode) {
+    const int64_t nf = gm.n_factors, nm = gm.n_messages;
+    if ((int64_t)part.size() != nf) throw std::runtime_error("lockstep: a part for every factor (used for the variables)");
+    for (int t = 0; t < gm.n_mtypes; ++t)
+      if (gm.mtypes[t].schedule != LPMP_SCHED_LEFT || (gm.mtypes[t].kind != LPMP_M_UNARY_PAIRWISE && gm.mtypes[t].kind != LPMP_M_LABELING))
+        throw std::runtime_error("lockstep: only `left`-schedule unary-pairwise / labeling messages");
+    std::vector<uint8_t> is_right((size_t)nf, 0), is_left((size_t)nf, 0);
+    for (int64_t k = 0; k < nm; ++k) { is_right[(size_t)gm.m_right[k]] = 1; is_left[(size_t)gm.m_left[k]] = 1; }
+    std::vector<int64_t> cnt((size_t)n_parts, 0);
+    for (int64_t f = 0; f < nf; ++f) {
+      if (is_left[(size_t)f] && is_right[(size_t)f]) throw std::runtime_error("lockstep: a factor is both left and right of messages");
+      if (is_right[(size_t)f]) continue;
+      if (part[(size_t)f] < 0 || part[(size_t)f] >= n_parts) throw std::runtime_error("lockstep: part out of range");
+      ++cnt[(size_t)part[(size_t)f]];
+    }
     for (int64_t c : cnt) if (c == 0) throw std::runtime_error("lockstep: a part without variables");
-    mrf_arrays g; g.build(n, s.L, s.potts, s.ei, s.ej);
-    const lpmp_model gm = g.view(nullptr, nullptr);
     lpmp_plan* pl = nullptr;
     lpmp_ok(lpmp_plan_create(&gm, &pl));
     struct guard { lpmp_plan* p; ~guard() { lpmp_plan_destroy(p); } } gd{pl};
-    const int64_t nf = n + ne, nm = 2 * ne;
     std::vector<int64_t> g_off((size_t)nf + 1), g_ent((size_t)2 * nm);
     lpmp_ok(lpmp_plan_get_msg_lists(pl, g_off.data(), g_ent.data()));
     n_vecs = nm;
-    writer.resize((size_t)nm); reader.resize((size_t)nm);
-    for (int64_t e = 0; e < ne; ++e) {
-      writer[2 * e] = s.part[(size_t)s.ei[e]]; writer[2 * e + 1] = s.part[(size_t)s.ej[e]];
-      reader[2 * e] = writer[2 * e + 1]; reader[2 * e + 1] = writer[2 * e];
+    writer.resize((size_t)nm); v_off.resize((size_t)nm); v_len.resize((size_t)nm);
+    std::vector<uint8_t> whole((size_t)nm);
+    auto dual_size = [&](int64_t f) -> int64_t {
+      const int64_t d0 = gm.f_dim0[f], d1 = gm.f_dim1 ? gm.f_dim1[f] : 0;
+      return gm.f_kind[f] == LPMP_F_PAIRWISE_DENSE ? d0 + d1 : gm.f_kind[f] == LPMP_F_PAIRWISE_POTTS ? 2 * d0 : d0;
+    };
+    for (int64_t k = 0; k < nm; ++k) {
+      const lpmp_msg_type& mt = gm.mtypes[gm.m_type[k]];
+      const int64_t r = gm.m_right[k], d0 = gm.f_dim0[r], d1 = gm.f_kind[r] == LPMP_F_PAIRWISE_POTTS ? d0 : (gm.f_dim1 ? gm.f_dim1[r] : 0);
+      writer[(size_t)k] = part[(size_t)gm.m_left[k]];
+      if (mt.kind == LPMP_M_UNARY_PAIRWISE) { v_off[(size_t)k] = mt.param == 1 ? d0 : 0; v_len[(size_t)k] = mt.param == 1 ? d1 : d0; whole[(size_t)k] = 0; }
+      else { v_off[(size_t)k] = 0; v_len[(size_t)k] = dual_size(r); whole[(size_t)k] = 1; }   // a labeling message rewrites all of its factor's dual
     }
+    // the messages of every higher factor (siblings), the parts holding it, where it counts in the bound
+    std::vector<int64_t> sib_off((size_t)nf + 1, 0), sib((size_t)nm);
+    for (int64_t k = 0; k < nm; ++k) ++sib_off[(size_t)gm.m_right[k] + 1];
+    for (int64_t f = 0; f < nf; ++f) sib_off[(size_t)f + 1] += sib_off[(size_t)f];
+    { std::vector<int64_t> cur(sib_off.begin(), sib_off.end() - 1); for (int64_t k = 0; k < nm; ++k) sib[(size_t)cur[(size_t)gm.m_right[k]]++] = k; }
+    owner.assign(part.begin(), part.end());
+    dest_off.assign((size_t)nm + 1, 0);
+    std::vector<std::vector<int32_t>> dests((size_t)nm);
+    for (int64_t f = 0; f < nf; ++f) {
+      if (!is_right[(size_t)f]) continue;
+      std::vector<int32_t> hold; int64_t first_var = nf;
+      for (int64_t j = sib_off[(size_t)f]; j < sib_off[(size_t)f + 1]; ++j) { hold.push_back(writer[(size_t)sib[(size_t)j]]); first_var = std::min<int64_t>(first_var, gm.m_left[sib[(size_t)j]]); }
+      std::sort(hold.begin(), hold.end()); hold.erase(std::unique(hold.begin(), hold.end()), hold.end());
+      owner[(size_t)f] = part[(size_t)first_var];
+      for (int64_t j = sib_off[(size_t)f]; j < sib_off[(size_t)f + 1]; ++j) {
+        const int64_t k = sib[(size_t)j];
+        for (int32_t q : hold) if (q != writer[(size_t)k]) dests[(size_t)k].push_back(q);
+      }
+    }
+    for (int64_t k = 0; k < nm; ++k) dest_off[(size_t)k + 1] = dest_off[(size_t)k] + (int64_t)dests[(size_t)k].size();
+    dest.resize((size_t)dest_off[(size_t)nm]);
+    for (int64_t k = 0; k < nm; ++k) std::copy(dests[(size_t)k].begin(), dests[(size_t)k].end(), dest.begin() + dest_off[(size_t)k]);
     for (int d = 0; d < 2; ++d) {
       const int64_t nu = lpmp_plan_n_updated(pl, d);
       upd[d].resize((size_t)nu); lev[d].resize((size_t)nu);
@@ -156,7 +247,7 @@ struct lockstep_plan {
       lpmp_ok(lpmp_plan_get_update_levels(pl, d, mode, lev[d].data()));
       int nl = 0;
       for (int64_t u = 0; u < nu; ++u) {
-        if (upd[d][(size_t)u] >= n) throw std::runtime_error("lockstep: only the variables are updated (schedule `left`)");
+        if (is_right[(size_t)upd[d][(size_t)u]]) throw std::runtime_error("lockstep: only the variables are updated (schedule `left`)");
         lev[d][(size_t)u] = std::max(lev[d][(size_t)u], 1);       // (0: no active message; runs with the first level)
         nl = std::max(nl, (int)lev[d][(size_t)u]);
         const int64_t f = upd[d][(size_t)u], len = g_off[(size_t)f + 1] - g_off[(size_t)f];
@@ -169,12 +260,15 @@ struct lockstep_plan {
       for (int64_t u = 0; u < nu; ++u) {
         const int64_t f = upd[d][(size_t)u];
         const int sl = 2 * (lev[d][(size_t)u] - 1);
-        for (int64_t j = g_off[(size_t)f], k = 0; j < g_off[(size_t)f + 1]; ++j, ++k) {
-          const int64_t v = g_ent[(size_t)j] / 2;                  // own-side vector = the message id (2 e + s)
-          if (writer[(size_t)v] == reader[(size_t)v]) continue;
-          const double w = om[d][(size_t)(om_off[d][(size_t)u] + k)]; const bool r = mk[d][(size_t)(mk_off[d][(size_t)u] + k)] != 0;
-          if (w != 0.0 || r) { written[d][(size_t)sl].push_back(v); touches_cut[d][(size_t)u] = 1; }
-          if (r) read[d][(size_t)sl].push_back(v ^ 1);
+        for (int64_t j = g_off[(size_t)f], x = 0; j < g_off[(size_t)f + 1]; ++j, ++x) {
+          const int64_t k = g_ent[(size_t)j] / 2;                  // the entry's message = its own vector
+          const double w = om[d][(size_t)(om_off[d][(size_t)u] + x)]; const bool r = mk[d][(size_t)(mk_off[d][(size_t)u] + x)] != 0;
+          const bool writes = w != 0.0 || r;
+          if (writes && is_cut(k)) { written[d][(size_t)sl].push_back(k); touches_cut[d][(size_t)u] = 1; }
+          if (r || (writes && whole[(size_t)k])) {                 // what it reads across the cut: its factor's other messages written elsewhere
+            const int64_t rf = gm.m_right[k];
+            for (int64_t jj = sib_off[(size_t)rf]; jj < sib_off[(size_t)rf + 1]; ++jj) { const int64_t k2 = sib[(size_t)jj]; if (writer[(size_t)k2] != writer[(size_t)k]) read[d][(size_t)sl].push_back(k2); }
+          }
         }
       }
       for (auto* lists : {&written[d], &read[d]}) for (auto& l : *lists) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); }
@@ -243,8 +337,14 @@ class lockstep_part {
  public:
   int part = 0; int32_t L = 0; bool potts = false;
   mrf_arrays arrays;
-  std::vector<int64_t> vars_global, edges_global;     // local variable / local edge -> global (both ascending)
+  std::vector<int64_t> vars_global, edges_global;     // local variable / local edge -> global (both ascending); MRF parts
+  std::vector<int64_t> factors_global;                // local factor -> global factor (parts of a general model)
   std::vector<uint8_t> is_ghost, owned;
+  std::vector<int64_t> vec_ids, vec_start; std::vector<int32_t> vec_len;   // the exchange units held here: global id (ascending), first element in the local dual array, length
+  // a general part keeps the model arrays its engine was given
+  std::vector<int32_t> g_type, g_dim0, g_dim1, gm_type, gm_left, gm_right, g_rel_fwd, g_rel_bwd;
+  std::vector<uint8_t> g_kind, g_flags;
+  std::vector<double> g_const, g_dual;
   struct rows { std::vector<int32_t> factors; std::vector<int64_t> om_off, mk_off; std::vector<double> om; std::vector<uint8_t> mk; };
   std::vector<rows> sub[2];                          // this part's updates per (direction, sub-level), sequence order inside
   lpmp_engine* e = nullptr; hipStream_t stream = nullptr;
@@ -279,14 +379,83 @@ class lockstep_part {
     owned.assign((size_t)(n_vec() + (int64_t)edges_global.size()), 0);
     for (int64_t v = 0; v < n_vec(); ++v) owned[(size_t)v] = !is_ghost[(size_t)v];
     for (size_t x = 0; x < edges_global.size(); ++x) owned[(size_t)n_vec() + x] = s.part[(size_t)s.ei[(size_t)edges_global[x]]] == k;   // a pairwise factor counts where its earlier endpoint lives
-    // rows per sub-level
+    for (size_t x = 0; x < edges_global.size(); ++x) for (int sd = 0; sd < 2; ++sd) {
+      vec_ids.push_back(2 * edges_global[x] + sd); vec_start.push_back(n_vec() * L + (int64_t)x * 2 * L + sd * L); vec_len.push_back(L);
+    }
+    rows_of(pl, [&](int64_t f) { return s.part[(size_t)f] == k; }, lmap);
+    // costs from the counter stream, generated in HBM: unary of local vector x at vars_global[x] L, pairwise data of local edge x
+    // at n L + edges_global[x] esz (ghost unaries are generated too: they are never read)
+    hip_ok(hipSetDevice(device), "hipSetDevice");
+    build_device(s, n, device, mode);
+  }
+
+  // a part of ANY model the plan accepts (lockstep.lockstep_model): its variables, every higher factor touching one of them with ALL
+  // its messages, never-updated ghosts of the remote variables behind those; factors and messages keep the global relative order.
+  // Costs come from the host arrays of ``gm`` (const_data / dual_data)
+  void build(const lpmp_model& gm, const std::vector<int32_t>& part_of, const lockstep_plan& pl, int k, int device, hipStream_t st, int mode) {
+    part = k; L = 0; stream = st;
+    const int64_t nf = gm.n_factors, nm = gm.n_messages;
+    std::vector<uint8_t> is_right((size_t)nf, 0), keep((size_t)nf, 0), in_r((size_t)nf, 0);
+    for (int64_t m_ = 0; m_ < nm; ++m_) is_right[(size_t)gm.m_right[m_]] = 1;
+    auto local = [&](int64_t f) { return !is_right[(size_t)f] && part_of[(size_t)f] == k; };
+    for (int64_t m_ = 0; m_ < nm; ++m_) if (local(gm.m_left[m_])) in_r[(size_t)gm.m_right[m_]] = 1;
+    std::vector<int64_t> mk_sel;
+    for (int64_t m_ = 0; m_ < nm; ++m_) if (in_r[(size_t)gm.m_right[m_]]) { mk_sel.push_back(m_); keep[(size_t)gm.m_left[m_]] = 1; }
+    for (int64_t f = 0; f < nf; ++f) if (local(f) || in_r[(size_t)f]) keep[(size_t)f] = 1;
+    std::vector<int64_t> lmap((size_t)nf, -1), coff((size_t)nf + 1, 0), doff((size_t)nf + 1, 0);
+    for (int64_t f = 0; f < nf; ++f) {
+      const int64_t d0 = gm.f_dim0[f], d1 = gm.f_dim1 ? gm.f_dim1[f] : 0;
+      coff[(size_t)f + 1] = coff[(size_t)f] + (gm.f_kind[f] == LPMP_F_PAIRWISE_DENSE ? d0 * d1 : gm.f_kind[f] == LPMP_F_PAIRWISE_POTTS ? 1 : 0);
+      doff[(size_t)f + 1] = doff[(size_t)f] + (gm.f_kind[f] == LPMP_F_PAIRWISE_DENSE ? d0 + d1 : gm.f_kind[f] == LPMP_F_PAIRWISE_POTTS ? 2 * d0 : d0);
+    }
+    std::vector<int64_t> ldoff(1, 0);
+    for (int64_t f = 0; f < nf; ++f) {
+      if (!keep[(size_t)f]) continue;
+      lmap[(size_t)f] = (int64_t)factors_global.size(); factors_global.push_back(f);
+      g_type.push_back(gm.f_type[f]); g_kind.push_back(gm.f_kind[f]); g_flags.push_back(gm.f_flags ? gm.f_flags[f] : 0);
+      g_dim0.push_back(gm.f_dim0[f]); g_dim1.push_back(gm.f_dim1 ? gm.f_dim1[f] : 0);
+      if (gm.const_data) g_const.insert(g_const.end(), gm.const_data + coff[(size_t)f], gm.const_data + coff[(size_t)f + 1]);
+      if (gm.dual_data) g_dual.insert(g_dual.end(), gm.dual_data + doff[(size_t)f], gm.dual_data + doff[(size_t)f + 1]); else g_dual.resize(g_dual.size() + (size_t)(doff[(size_t)f + 1] - doff[(size_t)f]), 0.0);
+      ldoff.push_back(ldoff.back() + doff[(size_t)f + 1] - doff[(size_t)f]);
+      is_ghost.push_back(!is_right[(size_t)f] && part_of[(size_t)f] != k);
+      owned.push_back(pl.owner[(size_t)f] == k);
+      if (!is_right[(size_t)f]) vars_global.push_back(f);
+    }
+    for (int64_t m_ : mk_sel) {
+      gm_type.push_back(gm.m_type[m_]); gm_left.push_back((int32_t)lmap[(size_t)gm.m_left[m_]]); gm_right.push_back((int32_t)lmap[(size_t)gm.m_right[m_]]);
+      vec_ids.push_back(m_); vec_start.push_back(ldoff[(size_t)lmap[(size_t)gm.m_right[m_]]] + pl.v_off[(size_t)m_]); vec_len.push_back((int32_t)pl.v_len[(size_t)m_]);
+    }
+    auto map_rel = [&](const int32_t* rel, int64_t n_rel, std::vector<int32_t>& out) {
+      for (int64_t i = 0; i < n_rel; ++i) { const int64_t a = lmap[(size_t)rel[2 * i]], b = lmap[(size_t)rel[2 * i + 1]]; if (a >= 0 && b >= 0) { out.push_back((int32_t)a); out.push_back((int32_t)b); } }
+    };
+    map_rel(gm.rel_fwd, gm.n_rel_fwd, g_rel_fwd); map_rel(gm.rel_bwd, gm.n_rel_bwd, g_rel_bwd);
+    rows_of(pl, local, lmap);
+    hip_ok(hipSetDevice(device), "hipSetDevice");
+    lpmp_model m = gm;                          // types, tables, constant: the global model's
+    m.n_factors = (int64_t)factors_global.size(); m.f_type = g_type.data(); m.f_kind = g_kind.data(); m.f_flags = g_flags.data();
+    m.f_dim0 = g_dim0.data(); m.f_dim1 = g_dim1.data();
+    if (g_const.empty()) g_const.push_back(0.0);
+    m.const_data = g_const.data(); m.dual_data = g_dual.data();
+    m.n_messages = (int64_t)gm_type.size(); m.m_type = gm_type.data(); m.m_left = gm_left.data(); m.m_right = gm_right.data();
+    m.n_rel_fwd = (int64_t)g_rel_fwd.size() / 2; m.rel_fwd = g_rel_fwd.data(); m.n_rel_bwd = (int64_t)g_rel_bwd.size() / 2; m.rel_bwd = g_rel_bwd.data();
+    m.n_part_pairs = 0; m.part_pairs = nullptr;
+    if (k != 0) m.constant = 0.0;
+    lpmp_ok(lpmp_create(device, &e));
+    lpmp_ok(lpmp_set_stream(e, stream));
+    lpmp_ok(lpmp_upload_model(e, &m, LPMP_MEM_HOST, LPMP_MEM_HOST));
+    lpmp_ok(lpmp_set_reparametrization(e, mode));
+  }
+
+  // this part's rows of the global sweep per (direction, sub-level)
+  template <class Local>
+  void rows_of(const lockstep_plan& pl, Local&& local, const std::vector<int64_t>& lmap) {
     for (int d = 0; d < 2; ++d) {
       const int nsl = 2 * pl.n_levels[d];
       sub[d].assign((size_t)nsl, {});
       for (auto& r : sub[d]) { r.om_off.assign(1, 0); r.mk_off.assign(1, 0); }
       for (int64_t u = 0; u < (int64_t)pl.upd[d].size(); ++u) {       // update order = sequence order inside a sub-level
         const int64_t f = pl.upd[d][(size_t)u];
-        if (s.part[(size_t)f] != k) continue;
+        if (!local(f)) continue;
         rows& r = sub[d][(size_t)(2 * (pl.lev[d][(size_t)u] - 1) + (pl.touches_cut[d][(size_t)u] ? 0 : 1))];
         r.factors.push_back((int32_t)lmap[(size_t)f]);
         for (int64_t j = pl.om_off[d][(size_t)u]; j < pl.om_off[d][(size_t)u + 1]; ++j) { r.om.push_back(pl.om[d][(size_t)j]); updates_per_pass += pl.om[d][(size_t)j] != 0.0; }
@@ -294,9 +463,9 @@ class lockstep_part {
         r.om_off.push_back((int64_t)r.om.size()); r.mk_off.push_back((int64_t)r.mk.size());
       }
     }
-    // costs from the counter stream, generated in HBM: unary of local vector x at vars_global[x] L, pairwise data of local edge x
-    // at n L + edges_global[x] esz (ghost unaries are generated too: they are never read)
-    hip_ok(hipSetDevice(device), "hipSetDevice");
+  }
+
+  void build_device(const lockstep_structure& s, int64_t n, int device, int mode) {
     const int64_t esz = potts ? 1 : (int64_t)L * L, n_e = (int64_t)edges_global.size();
     const int64_t nc = std::max<int64_t>(n_e * esz, 2), nd = n_vec() * L + n_e * 2 * L;
     hip_ok(hipMalloc((void**)&d_const, (size_t)nc * sizeof(double)), "hipMalloc const");
@@ -361,22 +530,24 @@ class lockstep_part {
     h.out_count.assign((size_t)n_parts, 0); h.in_count.assign((size_t)n_parts, 0);
     std::vector<std::pair<int32_t, int64_t>> out, in;
     for (int64_t v : st.vecs) {
-      if (pl.writer[(size_t)v] == part) out.push_back({pl.reader[(size_t)v], v});
-      if (pl.reader[(size_t)v] == part) in.push_back({pl.writer[(size_t)v], v});
+      for (int64_t j = pl.dest_off[(size_t)v]; j < pl.dest_off[(size_t)v + 1]; ++j) {
+        if (pl.writer[(size_t)v] == part) out.push_back({pl.dest[(size_t)j], v});
+        if (pl.dest[(size_t)j] == part) in.push_back({pl.writer[(size_t)v], v});
+      }
     }
     std::sort(out.begin(), out.end()); std::sort(in.begin(), in.end());
     auto offsets = [&](const std::vector<std::pair<int32_t, int64_t>>& l, std::vector<int64_t>& off, std::vector<int32_t>& len, std::vector<int64_t>& count) {
+      int64_t total = 0;
       for (const auto& pv : l) {
-        const int64_t ge = pv.second / 2;
-        const auto pos = std::lower_bound(edges_global.begin(), edges_global.end(), ge);
-        if (pos == edges_global.end() || *pos != ge) throw std::runtime_error("lockstep: a cut vector of an edge this part does not hold");
-        off.push_back(n_vec() * L + (int64_t)(pos - edges_global.begin()) * 2 * L + (pv.second & 1) * L);
-        len.push_back(L); count[(size_t)pv.first] += L;
+        const auto pos = std::lower_bound(vec_ids.begin(), vec_ids.end(), pv.second);
+        if (pos == vec_ids.end() || *pos != pv.second) throw std::runtime_error("lockstep: a cut vector of a factor this part does not hold");
+        const size_t x = (size_t)(pos - vec_ids.begin());
+        off.push_back(vec_start[x]); len.push_back(vec_len[x]); count[(size_t)pv.first] += vec_len[x]; total += vec_len[x];
       }
+      return total;
     };
     std::vector<int64_t> o_off, i_off; std::vector<int32_t> o_len, i_len;
-    offsets(out, o_off, o_len, h.out_count); offsets(in, i_off, i_len, h.in_count);
-    h.n_out = (int64_t)out.size() * L; h.n_in = (int64_t)in.size() * L;
+    h.n_out = offsets(out, o_off, o_len, h.out_count); h.n_in = offsets(in, i_off, i_len, h.in_count);
     lpmp_ok(lpmp_halo_create(e, (int64_t)o_off.size(), o_off.data(), o_len.data(), (int64_t)i_off.size(), i_off.data(), i_len.data(), &h.h));
     hip_ok(hipMalloc((void**)&h.d_send, (size_t)std::max<int64_t>(h.n_out, 1) * sizeof(double)), "hipMalloc");
     hip_ok(hipMalloc((void**)&h.d_recv, (size_t)std::max<int64_t>(h.n_in, 1) * sizeof(double)), "hipMalloc");

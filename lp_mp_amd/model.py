@@ -124,6 +124,23 @@ class FlatModel:
     def const_offsets(self) -> np.ndarray:
         return np.concatenate([[0], np.cumsum(self.const_sizes())]).astype(np.int64)
 
+    def dump(self, path: str):
+        """the model as one flat binary file in the order of include/lpmp_model.h — what the C++ hosts read
+        (lp_mp_amd/include/lpmp_lockstep.hxx, model_file; tools/mgpu_rccl_driver.cpp --model-file)"""
+        if self.dual_data is None:
+            raise ValueError("dump: the model has no host duals")
+        const = np.zeros(0) if self.const_data is None else np.ascontiguousarray(self.const_data, np.float64)
+        mt = np.array([[t.left_ftype, t.right_ftype, t.schedule, t.n_left, t.n_right, t.kind, t.param, t.flags] for t in self.mtypes], np.int32).reshape(-1, 8)
+        head = np.array([0x4C504D504D4F444C, self.n_ftypes, len(self.mtypes), self.tab_nleft.shape[0], self.tab_data.shape[0], self.n_factors,
+                         self.n_messages, self.rel_fwd.shape[0], self.rel_bwd.shape[0], const.shape[0], self.dual_data.shape[0]], np.int64)
+        with open(path, "wb") as f:
+            f.write(head.tobytes()); f.write(np.float64(self.constant).tobytes())
+            for a, dt in ((self.ftype_computes_primal, np.uint8), (mt, np.int32), (self.tab_off, np.int64), (self.tab_data, np.int32), (self.tab_nleft, np.int32),
+                          (self.f_type, np.int32), (self.f_kind, np.uint8), (self.f_flags, np.uint8), (self.f_dim0, np.int32), (self.f_dim1, np.int32),
+                          (const, np.float64), (self.dual_data, np.float64), (self.m_type, np.int32), (self.m_left, np.int32), (self.m_right, np.int32),
+                          (self.rel_fwd, np.int32), (self.rel_bwd, np.int32)):
+                f.write(np.ascontiguousarray(a, dt).tobytes())
+
     def c_struct(self) -> c_model:
         """ctypes view; arrays stay owned by ``self`` (borrowed for the duration of a call)."""
         mt = (c_msg_type * max(1, len(self.mtypes)))()

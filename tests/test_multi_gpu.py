@@ -818,3 +818,52 @@ def test_cpp_rccl_driver_lockstep_schedule_equals_the_python_lockstep_sweep_and_
     finally:
         for s in sweeps:
             s.close(); s.engine.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,parts", [("mixed_mrf", 3), ("multicut", 3), ("c5", 2), ("c5", 4)])
+def test_cpp_rccl_driver_lockstep_of_general_models_equals_the_python_sweep_and_the_oracle(tmp_path, name, parts):
+    """tools/mgpu_rccl_driver.cpp --schedule lockstep --model-file: any `left`-schedule model (ragged label counts, labeling-list
+    factors whose whole dual is one exchange unit) read from FlatModel.dump with its costs, random partition of the variables —
+    every part's whole dual array equals lockstep.lockstep_model's on the same partition, the bound the oracle's"""
+    import json
+    from lp_mp_amd import build as B, engine as E, lockstep as LS
+    from oracle.binding import Oracle
+    if not B.have_rccl():
+        pytest.skip("no <rccl/rccl.h> on this box")
+    passes = 3
+    gm = _general_models()[name]
+    rng = np.random.default_rng(17 + parts)
+    is_right = np.zeros(gm.n_factors, bool); is_right[gm.m_right] = True
+    part_of = rng.integers(0, parts, gm.n_factors)
+    part_of[np.nonzero(~is_right)[0][:parts]] = np.arange(parts)
+    gm.dump(str(tmp_path / "model.bin")); part_of.astype(np.int64).tofile(tmp_path / "part.bin")
+    exe = B.build_mgpu_driver()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.check_output([exe, "--schedule", "lockstep", "--model-file", str(tmp_path / "model.bin"), "--part-file", str(tmp_path / "part.bin"),
+                                   "--passes", str(passes), "--parts-per-rank", str(parts), "--out", str(tmp_path / "duals")], text=True, env=env, timeout=600)
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["schedule"] == "lockstep" and line["parts"] == parts and line["factors"] == gm.n_factors
+    sched, lparts = LS.lockstep_model(gm, part_of, parts, M.REPAM_ANISOTROPIC)
+    assert list(sched.n_levels) == line["levels"]
+    assert abs(sum(1 for s in sched.program(passes) if s[0] == "halo") / passes - line["exchanges_per_pass"]) < 1e-3
+    dev = torch.device("cuda:0")
+    sweeps, tensors = [], []
+    for p in lparts:
+        dual = torch.from_numpy(p.model.dual_data.copy()).to(dev)
+        eng = E.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual); eng.set_reparametrization(M.REPAM_ANISOTROPIC)
+        sweeps.append(LS.LockstepSweep(torch, p, sched, eng, dual)); tensors.append(dual)
+    try:
+        lb0 = sum(s.local_lower_bound() for s in sweeps)
+        LS.run_lockstep(sweeps, passes); torch.cuda.synchronize()
+        lb1 = sum(s.local_lower_bound() for s in sweeps)
+        for k in range(parts):
+            got = np.fromfile(tmp_path / f"duals.{k}.bin", dtype=np.float64)
+            assert np.array_equal(got, tensors[k].cpu().numpy()), k
+        assert abs(line["lower_bound_before"] - lb0) <= 1e-9 * max(1.0, abs(lb0)) and abs(line["lower_bound_after"] - lb1) <= 1e-9 * max(1.0, abs(lb1))
+        o = Oracle(gm); o.set_reparametrization(M.REPAM_ANISOTROPIC); o.ComputePass(passes)
+        assert abs(line["lower_bound_after"] - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+    finally:
+        for s in sweeps:
+            s.close(); s.engine.close()

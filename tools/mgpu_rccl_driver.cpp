@@ -7,7 +7,7 @@
 //
 //   mgpu_rccl_driver [--H 64] [--W 64] [--L 8] [--pairwise dense|potts] [--order colour_major|row_major] [--passes 4]
 //                    [--parts-per-rank 1] [--boundary pass|sweep] [--mode 0] [--out PREFIX] [--time K]
-//                    [--schedule boundary|overlap|lockstep] [--ghost-rows 12] [--chunk 0] [--graph n m [--order-file f] [--part-file f]]
+//                    [--schedule boundary|overlap|lockstep] [--ghost-rows 12] [--chunk 0] [--graph n m [--order-file f] [--part-file f]] [--model-file f --part-file f]
 // --schedule overlap (lpmp_overlap.hxx): the EXACT schedule for colour-major grids — every part a window with ghost rows of the
 // global (n_parts * H) x W grid, plain lpmp_compute_pass calls, one exchange per (ghost-rows / 2 - 1) passes (or --chunk).
 //
@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
   bool potts = false, colour = true, every_pass = true, overlap = false, lockstep = false;
   int ghost = 12, chunk = 0;
   long long graph_n = 0, graph_m = 0;
-  std::string order_file, part_file;
+  std::string order_file, part_file, model_path;
   std::string out;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
     else if (a == "--schedule") { const std::string v = next(); overlap = v == "overlap"; lockstep = v == "lockstep"; }
     else if (a == "--graph") { graph_n = std::atoll(next()); graph_m = std::atoll(next()); }
     else if (a == "--order-file") order_file = next(); else if (a == "--part-file") part_file = next();
+    else if (a == "--model-file") model_path = next();
     else if (a == "--ghost-rows") ghost = std::atoi(next()); else if (a == "--chunk") chunk = std::atoi(next());
     else if (a == "--out") out = next();
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -120,6 +121,51 @@ int main(int argc, char** argv) {
         std::fclose(f);
         return v;
       };
+      if (!model_path.empty()) {
+        // any model with `left`-schedule messages (labeling-list factors: C5, multicut), read from a file with its costs;
+        // --part-file: the part of every FACTOR (used for the variables), int64
+        model_file mf; mf.load(model_path);
+        const lpmp_model gm = mf.view();
+        if (part_file.empty()) throw std::runtime_error("--model-file needs --part-file");
+        const std::vector<int64_t> p64 = load(part_file, gm.n_factors);
+        const std::vector<int32_t> part_of(p64.begin(), p64.end());
+        lockstep_plan pl;
+        pl.build(gm, part_of, n_parts, mode);
+        std::vector<std::unique_ptr<lockstep_part>> own;
+        std::vector<lockstep_part*> parts;
+        for (int k = 0; k < ppr; ++k) { own.emplace_back(new lockstep_part()); own.back()->build(gm, part_of, pl, rank * ppr + k, device, stream, mode); parts.push_back(own.back().get()); }
+        const double lb0 = lockstep_lower_bound(parts, w);
+        lockstep_compute_pass(parts, pl, w, n_parts, passes);
+        const double lb1 = lockstep_lower_bound(parts, w);
+        if (!out.empty())
+          for (lockstep_part* p : parts) {
+            const std::vector<double> d = p->download_duals();
+            const std::string path = out + "." + std::to_string(p->part) + ".bin";
+            FILE* f = std::fopen(path.c_str(), "wb");
+            if (!f || std::fwrite(d.data(), sizeof(double), d.size(), f) != d.size()) throw std::runtime_error("cannot write " + path);
+            std::fclose(f);
+          }
+        double ms_per_pass = 0;
+        if (timed > 0) {
+          lockstep_prepare(parts, pl, n_parts, timed);
+          (void)w.all_reduce_sum(0.0);
+          const auto t0 = std::chrono::steady_clock::now();
+          lockstep_compute_pass(parts, pl, w, n_parts, timed);
+          (void)w.all_reduce_sum(0.0);
+          ms_per_pass = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
+        }
+        if (rank == 0) {
+          std::printf("{\"driver\": \"mgpu_rccl_driver (C++ host, C ABI + RCCL)\", \"schedule\": \"lockstep\", \"model\": \"%s\", \"world\": %d, \"parts\": %d, \"factors\": %lld, \"messages\": %lld, "
+                      "\"levels\": [%d, %d], \"exchanges_per_pass\": %.3f, \"passes\": %d, \"lower_bound_before\": %.17g, \"lower_bound_after\": %.17g",
+                      model_path.c_str(), world, n_parts, (long long)gm.n_factors, (long long)gm.n_messages, pl.n_levels[0], pl.n_levels[1], pl.exchanges_per_pass(std::max(passes, 1)), passes, lb0, lb1);
+          if (timed > 0) std::printf(", \"ms_per_pass\": %.6f", ms_per_pass);
+          std::printf("}\n");
+        }
+        own.clear();
+        w.destroy();
+        (void)hipStreamDestroy(stream);
+        return 0;
+      }
       std::vector<int64_t> var_rank, part_of;
       if (graph_n > 0 && !order_file.empty()) var_rank = load(order_file, graph_n);
       if (graph_n > 0 && !part_file.empty()) part_of = load(part_file, graph_n);
