@@ -28,7 +28,14 @@ n, m = 2000000, 10000000
 r = O.colour_major_order(n, *S.counter_graph_edges(n, m, 1), seed=1)
 r.astype(np.int64).tofile("/tmp/c4_order.bin"); MG.graph_partition(n, *S.counter_graph_edges(n, m, 1, r), 8).astype(np.int64).tofile("/tmp/c4_part.bin")
 PY
-  ./build/mgpu_rccl_driver --graph 2000000 10000000 --L 16 --parts-per-rank 8 --schedule lockstep --passes 2 --time 6 --order-file /tmp/c4_order.bin --part-file /tmp/c4_part.bin 2>/dev/null | grep driver ) > gpurun_out/r04_cpp_host_driver.txt
+  ./build/mgpu_rccl_driver --graph 2000000 10000000 --L 16 --parts-per-rank 8 --schedule lockstep --passes 2 --time 6 --order-file /tmp/c4_order.bin --part-file /tmp/c4_part.bin 2>/dev/null | grep driver
+  python - <<'PY'
+import numpy as np
+from lp_mp_amd import multi_gpu as MG, synthetic as S
+gm = S.c5_model(512, 512, 8, 150000, 70000, 30000, seed=4, window=64)
+gm.dump("/tmp/c5_model.bin"); MG.graph_partition_model(gm, 8).astype(np.int64).tofile("/tmp/c5_part8.bin")
+PY
+  ./build/mgpu_rccl_driver --schedule lockstep --model-file /tmp/c5_model.bin --part-file /tmp/c5_part8.bin --parts-per-rank 8 --passes 2 --time 6 2>/dev/null | grep driver ) > gpurun_out/r04_cpp_host_driver.txt
 # the solver cycle
 g++ -std=c++17 -O2 -I lp_mp_amd/include -I tests/cpp tools/offload_solver_loop.cpp -L lp_mp_amd/csrc -llpmp_engine -Wl,-rpath,$PWD/lp_mp_amd/csrc -o build/offload_solver_loop
 timeout 900 ./build/offload_solver_loop --grid 1024 --labels 32 --iterations 60 --warm 25 --rounding 1 > gpurun_out/r04_solver_cycle.json 2>/dev/null
