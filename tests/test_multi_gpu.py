@@ -642,6 +642,36 @@ def test_nccl_unique_id_is_handed_out_over_tcp_not_through_a_file(tmp_path):
     assert "fopen" not in src and "/tmp/" not in src
 
 
+def test_model_dump_holds_the_arrays_of_lpmp_model_h_in_order(tmp_path):
+    """FlatModel.dump (what the C++ hosts read, model_file in lpmp_lockstep.hxx): header counts, then every array of lpmp_model.h in
+    its order and type — parsed back here field by field"""
+    gm = _general_models()["c5"]
+    path = tmp_path / "m.bin"
+    gm.dump(str(path))
+    raw = path.read_bytes()
+    h = np.frombuffer(raw, np.int64, 11)
+    assert h[0] == 0x4C504D504D4F444C and list(h[1:9]) == [gm.n_ftypes, len(gm.mtypes), gm.tab_nleft.shape[0], gm.tab_data.shape[0], gm.n_factors, gm.n_messages,
+                                                              gm.rel_fwd.shape[0], gm.rel_bwd.shape[0]]
+    at = 88
+    assert np.frombuffer(raw, np.float64, 1, at)[0] == gm.constant
+    at += 8
+    def take(dtype, n):
+        nonlocal at
+        a = np.frombuffer(raw, dtype, n, at); at += a.nbytes
+        return a
+    assert np.array_equal(take(np.uint8, gm.n_ftypes), gm.ftype_computes_primal)
+    mt = take(np.int32, 8 * len(gm.mtypes)).reshape(-1, 8)
+    assert [tuple(r) for r in mt] == [(t.left_ftype, t.right_ftype, t.schedule, t.n_left, t.n_right, t.kind, t.param, t.flags) for t in gm.mtypes]
+    assert np.array_equal(take(np.int64, h[3] + 1), gm.tab_off) and np.array_equal(take(np.int32, h[4]), gm.tab_data) and np.array_equal(take(np.int32, h[3]), gm.tab_nleft)
+    for name, dt in (("f_type", np.int32), ("f_kind", np.uint8), ("f_flags", np.uint8), ("f_dim0", np.int32), ("f_dim1", np.int32)):
+        assert np.array_equal(take(dt, gm.n_factors), getattr(gm, name)), name
+    assert np.array_equal(take(np.float64, h[9]), gm.const_data) and np.array_equal(take(np.float64, h[10]), gm.dual_data)
+    for name in ("m_type", "m_left", "m_right"):
+        assert np.array_equal(take(np.int32, gm.n_messages), getattr(gm, name)), name
+    assert np.array_equal(take(np.int32, 2 * h[7]).reshape(-1, 2), gm.rel_fwd) and np.array_equal(take(np.int32, 2 * h[8]).reshape(-1, 2), gm.rel_bwd)
+    assert at == len(raw)
+
+
 def test_cpp_hosts_issue_sends_and_receives_in_one_global_order(tmp_path):
     """tests/cpp/test_transfer_order.cpp: the (source part, destination part) order every C++ exchange uses (for_each_transfer in
     lpmp_multi_gpu.hxx; boundary steps and lock step) pairs the k-th send of rank a to rank b with the k-th receive of b from a,
