@@ -1,13 +1,15 @@
 // lpmp_lockstep.hxx — the lock-step partitioned sweep driven from C++ over the C ABI and RCCL (the same schedule
 // lp_mp_amd/lockstep.py runs through torch.distributed, bit for bit).
 //
-// Several parts execute THE unpartitioned sweep of an MRF (LP::ComputePass, reference include/LP_MP.h:981-1005): updates of one
+// Several parts execute THE unpartitioned sweep of a model (LP::ComputePass, reference include/LP_MP.h:981-1005): updates of one
 // dependency level commute, so every part runs the updates of ITS variables with the GLOBAL weights (LP::get_omega, :412-460,
 // from lpmp_plan_create on the structure of the whole model) level by level, and between two runs of levels the parts ship the
 // message vectors the next run reads across the cut.  Side s of a pairwise factor's dual is written only by the updates of
-// endpoint s; both parts of a cut edge hold the pairwise factor and a never-updated ghost of the remote variable.
+// endpoint s; both parts of a cut edge hold the pairwise factor and a never-updated ghost of the remote variable.  A labeling-list
+// factor's dual is rewritten as a whole by each of its messages: the whole vector is one exchange unit and goes to every other part
+// holding the factor (lockstep_plan::build(lpmp_model, ...), lockstep_part::build(lpmp_model, ...): any `left`-schedule model).
 //
-//   lockstep_structure   the model as an edge list + the partition
+//   lockstep_structure   an MRF as an edge list + the partition (strips_structure, graph_structure); model_file: any model with its costs
 //   lockstep_plan        what every rank derives identically from it: levels, who writes / reads which vector when, the steps of n
 //                        passes (runs of sub-levels and exchanges; an exchange ships only what is read before the next one)
 //   lockstep_part        one part: its variables + ghosts + every edge touching a variable, costs generated in HBM from the counter
