@@ -394,12 +394,21 @@ class LockstepSweep:
     def __init__(self, torch, part: LockstepPart, sched: LockstepSchedule, engine, dual_tensor):
         self.torch, self.part, self.sched, self.engine, self.dual = torch, part, sched, engine, dual_tensor
         self._sids: Dict[tuple, int] = {}
+        self._sid_of: Dict[int, tuple] = {}
         self._halo: Dict[int, tuple] = {}
         self._device_halos = hasattr(engine, "halo_create")          # the HIP engine (CPU tests run oracle-backed stand-ins without it)
         self._send = None
         self.info = {}
 
     def _schedule(self, seg: tuple) -> int:
+        hit = self._sid_of.get(id(seg))                     # (the steps of a cached program are the same tuple objects every call: no
+        if hit is not None:                                 # hashing of a run of thousands of sub-levels per step)
+            return hit[1]
+        sid = self._schedule_of(seg)
+        self._sid_of[id(seg)] = (seg, sid)                  # (the tuple is kept: its id stays its own)
+        return sid
+
+    def _schedule_of(self, seg: tuple) -> int:
         if seg not in self._sids:
             rows = [self.part.rows[d][l] for (d, l) in seg]
             n_sweeps = 1 + sum(1 for a, b in zip(seg[:-1], seg[1:]) if b[0] != a[0] or b[1] < a[1])
