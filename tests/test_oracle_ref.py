@@ -1,0 +1,82 @@
+"""The one piece of the reference's hot path that builds here from its own sources (oracle/build_ref.py -> oracle/_ref/): the CSR
+container `two_dim_variable_array` behind `weight_array` / `receive_array` (reference include/two_dimensional_variable_array.hxx,
+used at include/LP_MP.h:989-992, sized by allocate_omega :1008-1040).  The reference's own test of it must pass as built, and the
+layout the real container reports is what lpmp_plan_get_omega / _mask hand out — a check against reference CODE, not
+against a restatement.  Skipped where neither /root/reference nor a previously built oracle/_ref is present."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lp_mp_amd import engine as E, model as M, synthetic as S  # noqa: E402
+from oracle import build_ref  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ref():
+    exes = build_ref.build()
+    if "ref_two_dim" not in exes:
+        pytest.skip("no reference sources and no oracle/_ref build on this box")
+    return exes
+
+
+def _layout(exe, sizes):
+    out = subprocess.check_output([exe], input=" ".join(map(str, [len(sizes)] + list(sizes))), text=True, timeout=120)
+    rows, flat = [], []
+    for line in out.splitlines():
+        w = line.split()
+        if w[0] == "rows":
+            n = int(w[1])
+        elif w[0] == "row":
+            rows.append((int(w[3]), int(w[5])))
+        else:
+            flat.append((int(w[1]), int(w[2])))
+    assert n == len(rows)
+    return rows, flat
+
+
+def test_the_references_own_container_test_passes_as_built(ref):
+    if "ref_test_two_dimensional_variable_array" not in ref:
+        pytest.skip("the reference's test was not built")
+    assert subprocess.run([ref["ref_test_two_dimensional_variable_array"]], timeout=300).returncode == 0
+
+
+def test_reference_container_is_a_row_major_csr(ref):
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        sizes = rng.integers(0, 9, int(rng.integers(1, 40)))
+        sizes[rng.integers(0, sizes.shape[0])] = 0                      # rows without entries (factors that send nothing)
+        if sizes.sum() == 0:
+            continue
+        rows, flat = _layout(ref["ref_two_dim"], sizes)
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        first = int(off[np.nonzero(sizes)[0][0]])
+        assert [r[0] for r in rows] == list(map(int, sizes))
+        assert all(o == off[i] - first for i, (s, o) in enumerate(rows) if s > 0)
+        assert flat == [(i, j) for i, s in enumerate(sizes) for j in range(int(s))]
+
+
+@pytest.mark.parametrize("mode", [M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM])
+def test_plan_weight_and_mask_arrays_have_the_layout_of_the_reference_container(ref, mode):
+    """lpmp_plan_get_omega / _mask (what the engine's sweeps and every custom pass index): row i = the i-th updated factor, entries
+    in message-list order, rows stored back to back — the reference container given the same row sizes reports the same offsets and
+    the same storage order"""
+    models = [S.grid_model(4, 5, 3, seed=2), S.counter_graph_model(60, 150, 4, 3), S.multicut_triangle_model(12, 15, seed=4)]
+    for gm in models:
+        p = E.Plan(gm)
+        for d in (M.FORWARD, M.BACKWARD):
+            for off, data in (p.omega(d, mode), p.mask(d, mode)):
+                sizes = np.diff(off)
+                assert off[0] == 0 and data.shape[0] == off[-1]
+                if sizes.sum() == 0:
+                    continue
+                rows, flat = _layout(ref["ref_two_dim"], sizes)
+                first = int(off[np.nonzero(sizes)[0][0]])
+                assert all(o == off[i] - first for i, (s, o) in enumerate(rows) if s > 0)
+                # storage position k of the reference holds (row, column) = what data[k] holds here
+                pos = np.repeat(np.arange(sizes.shape[0]), sizes), np.concatenate([np.arange(s) for s in sizes])
+                assert flat == list(zip(map(int, pos[0]), map(int, pos[1])))
