@@ -4,7 +4,9 @@ uses it.
 
 Buildable with plain g++ (no cmake, no external library, no generated code): `include/two_dimensional_variable_array.hxx` (the CSR
 `weight_array` / `receive_array` container of the sweep) — the reference's own test of it
-(`test/test_two_dimensional_variable_array.cpp` + `test/test.h`) and a driver of ours around the header (`oracle/ref_two_dim.cpp`).
+(`test/test_two_dimensional_variable_array.cpp` + `test/test.h`) and a driver of ours around the header (`oracle/ref_two_dim.cpp`);
+`include/union_find.hxx` (numbers the partitions of the partition sweeps, a19) driven as `LP::construct_factor_partition` drives it
+(`oracle/ref_union_find.cpp`).
 Everything else on the path (`LP_MP.h`, `factors_messages.hxx`, `vector.hxx`, `topological_sort.hxx` through `config.hxx`) needs
 tclap / simdpp / meta from the empty `external/` submodules: unbuildable here, pinned by known answers instead."""
 import os
@@ -15,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref")
 REF = os.environ.get("LPMP_REFERENCE", "/root/reference")
 TARGETS = {"ref_two_dim": [os.path.join(HERE, "ref_two_dim.cpp")],
+           "ref_union_find": [os.path.join(HERE, "ref_union_find.cpp")],
            "ref_test_two_dimensional_variable_array": [os.path.join(REF, "test", "test_two_dimensional_variable_array.cpp")]}
 
 

@@ -80,3 +80,30 @@ def test_plan_weight_and_mask_arrays_have_the_layout_of_the_reference_container(
                 # storage position k of the reference holds (row, column) = what data[k] holds here
                 pos = np.repeat(np.arange(sizes.shape[0]), sizes), np.concatenate([np.arange(s) for s in sizes])
                 assert flat == list(zip(map(int, pos[0]), map(int, pos[1])))
+
+
+def test_partitions_are_numbered_as_the_references_union_find_numbers_them(ref):
+    """a19: LP::construct_factor_partition (reference LP_MP.h:1724-1745) on the reference's real union_find — merge order, root
+    choice and get_contiguous_ids decide which partition is swept first.  lpmp_plan_get_partitions and the C oracle against it, on
+    random put_in_same_partition graphs over grid and multicut models (pairs over all factors, also the never-updated ones)"""
+    from oracle.binding import Oracle
+    if "ref_union_find" not in ref:
+        pytest.skip("ref_union_find was not built")
+    rng = np.random.default_rng(9)
+    for trial in range(12):
+        gm = S.grid_model(int(rng.integers(2, 6)), int(rng.integers(2, 6)), 3, seed=trial) if trial % 2 == 0 else S.multicut_triangle_model(10, int(rng.integers(4, 14)), seed=trial)
+        nf = gm.n_factors
+        gm.part_pairs = rng.integers(0, nf, size=(int(rng.integers(0, 2 * nf)), 2)).astype(np.int32)
+        p = E.Plan(gm)
+        updated = np.zeros(nf, np.int64); updated[p.update_order(M.FORWARD)] = 1
+        text = " ".join(map(str, [nf] + list(updated) + [gm.part_pairs.shape[0]] + list(gm.part_pairs.reshape(-1))))
+        out = subprocess.check_output([ref["ref_union_find"]], input=text, text=True, timeout=60).splitlines()
+        P = int(out[0].split()[1])
+        want = [[] for _ in range(P)]
+        for line in out[1:]:
+            w = line.split()
+            want[int(w[3])].append(int(w[1]))
+        got = [list(map(int, a)) for a in p.partitions()]
+        assert got == want, trial                                       # same numbering, members in factor order
+        o = Oracle(gm)
+        assert [list(map(int, a)) for a in o.partitions()] == want, trial
