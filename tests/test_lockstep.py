@@ -504,6 +504,25 @@ def test_lockstep_random_general_models_partitions_and_modes_on_device(seed):
             s.close(); s.engine.close()
 
 
+@pytest.mark.gpu
+def test_lockstep_model_driver_on_one_gpu():
+    """LockstepModel (the one-process-per-GPU driver of lockstep_model) without a process group: one part = the whole model, its
+    passes and bound are the oracle's"""
+    from tests.test_multi_gpu import _general_models
+    gm = _general_models()["c5"]
+    d = LS.LockstepModel(torch, None, gm, np.zeros(gm.n_factors, np.int64), M.REPAM_ANISOTROPIC)
+    ref = Oracle(gm); ref.set_reparametrization(M.REPAM_ANISOTROPIC)
+    try:
+        assert abs(d.lower_bound() - ref.LowerBound()) <= 1e-9 * max(1.0, abs(ref.LowerBound()))
+        d.prepare_passes(3); d.compute_pass(3); ref.ComputePass(3)
+        torch.cuda.synchronize()
+        assert np.array_equal(d.dualt.cpu().numpy(), ref.duals())
+        assert abs(d.lower_bound() - ref.LowerBound()) <= 1e-9 * max(1.0, abs(ref.LowerBound()))
+        assert d.halo_steps_per_pass() == 0 and d.global_updates_per_pass > 0
+    finally:
+        d.sweep.close(); d.engine.close()
+
+
 def test_colour_major_order_cuts_the_exchanges_of_a_random_graph():
     """LockstepGraph's default variable order (ordering.colour_major_order): one dependent level per colour, so the sweep
     needs an exchange per colour instead of one per level of the generator's index order"""
