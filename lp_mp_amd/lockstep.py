@@ -618,6 +618,11 @@ class _Driver:
     def halo_steps_per_pass(self, n=4):
         return sum(1 for s in self.sched.program(n) if s[0] == "halo") / n
 
+    def close(self):
+        """exchange plans (device arrays behind lpmp_halo_*) and the engine"""
+        self.sweep.close()
+        self.engine.close()
+
 
 class LockstepStrips(_Driver):
     """bench.py driver: this rank's H x W strip of the (world * H) x W grid, run in lock step with the other strips —
