@@ -1079,3 +1079,31 @@ def test_bounds_stay_tracked_through_uniform_weight_passes(pairwise, L):
         assert np.array_equal(e.download_duals(), o.duals())
     finally:
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["colour_major", "index"])
+def test_c4_is_the_same_problem_on_every_path(order):
+    """bench.py --workload c4 --c4-order: the one-GPU run (GraphSweep with costs generated in HBM per part), the lock-step driver
+    (LockstepGraph) and a plain engine on the host-built counter_graph_model in that variable order run the same sweep: duals of
+    the unpartitioned model bit for bit, the oracle's bound"""
+    import torch
+    from lp_mp_amd import lockstep as LS, multi_gpu as MG
+    from oracle.binding import Oracle
+    n, m, L, passes = 3000, 12000, 16, 3
+    torch.cuda.set_device(0)
+    a = MG.GraphSweep(torch, None, n, m, L, M.REPAM_ANISOTROPIC, seed=1, order=order)
+    b = LS.LockstepGraph(torch, None, n, m, L, M.REPAM_ANISOTROPIC, seed=1, order=order)
+    try:
+        assert (a.rank_of is None) == (order == "index") and (a.rank_of is None or np.array_equal(a.rank_of, b.rank_of))
+        gm = S.counter_graph_model(n, m, L, 1, rank=a.rank_of)
+        o = Oracle(gm); o.set_reparametrization(M.REPAM_ANISOTROPIC); o.ComputePass(passes)
+        a.compute_pass(passes); b.compute_pass(passes)
+        torch.cuda.synchronize()
+        assert np.array_equal(a.dualt.cpu().numpy(), o.duals())          # one part: local order = global order
+        assert np.array_equal(b.dualt.cpu().numpy(), o.duals())
+        for lb in (a.lower_bound(), b.lower_bound()):
+            assert abs(lb - o.LowerBound()) <= 1e-9 * abs(o.LowerBound())
+        assert a.levels == list(b.levels) and (a.levels[0] <= 12 if order == "colour_major" else a.levels[0] > 12)
+    finally:
+        a.engine.close(); b.close()
