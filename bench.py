@@ -117,6 +117,12 @@ def time_passes(torch, dist, eng, steps, warmup, world, prewarm_ms=0.0):
     return time.perf_counter() - t0
 
 
+def auto_schedule(args) -> str:
+    """the default multi-GPU schedule: always an exact one.  overlap: 2-colour grids with an even number of rows per strip (plain
+    joined passes over windows with ghost rows); anything else — grids in another order, the C4 graph — runs in lock step"""
+    return "overlap" if args.workload == "c3" and args.order == "colour_major" and args.grid % 2 == 0 else "lockstep"
+
+
 def close_runner(r):
     """engine and, for the lock-step drivers, the exchange plans (device arrays behind lpmp_halo_*) of a finished runner"""
     sw = getattr(r, "sweep", None)
@@ -400,8 +406,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_run_launch):
         sys.exit(launch_ranks(args, sys.argv[1:]))
     if args.schedule == "auto":
-        # (overlap: 2-colour grids with an even number of rows per strip; anything else that must be exact runs in lock step)
-        args.schedule = "overlap" if args.workload == "c3" and args.order == "colour_major" and args.grid % 2 == 0 else "lockstep"
+        args.schedule = auto_schedule(args)
     if args.schedule == "overlap" and (args.workload != "c3" or args.order != "colour_major"):
         print("bench.py: --schedule overlap is for grids in colour-major order (random graphs: lockstep or boundary)", file=sys.stderr)
         sys.exit(2)

@@ -110,6 +110,15 @@ def test_bench_distributed_branch_on_rccl_at_world_size_one(workload, schedule):
     assert d["roofline"]["kernel"].startswith(("sweep_dense_pk_kernel", "chain_dense_pk_kernel"))
 
 
+def test_default_multi_gpu_schedule_is_always_an_exact_one():
+    """--schedule auto: overlap for colour-major grids with an even strip height, lock step for everything else (other grid orders,
+    odd heights, the C4 graph) — never the approximate boundary-step schedule"""
+    assert bench.auto_schedule(_args(workload="c3")) == "overlap"
+    assert bench.auto_schedule(_args(workload="c3", order="row_major")) == "lockstep"
+    assert bench.auto_schedule(_args(workload="c3", grid=1023)) == "lockstep"
+    assert bench.auto_schedule(_args(workload="c4")) == "lockstep"
+
+
 def test_golden_fixture_covers_whatever_pass_count_the_driver_runs():
     """bench.py's oracle_check compares the state the timed call leaves in HBM with the oracle's after warmup + steps passes
     on the same inputs (tests/golden/c3_full_lb.npz, seed 1).  The round driver chooses --warmup / --steps (round 1 and 2:
