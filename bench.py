@@ -8,6 +8,15 @@ in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 1024] [--labels 32]
                     [--order colour_major|row_major] [--no-cpu-baseline]
+                    [--workload c3|c4|c5] [--partitioner auto|metis|builtin] [--partition-file F]
+
+N > 1: one process per GPU (self-launched, or under torch.distributed.run).  Every wait of the start-up is bounded: the rendezvous
+(--rendezvous-timeout), one all_reduce and one all_to_all_single with the real split sizes before the timed region
+(--collective-timeout; on expiry the rank says what it waited for and exits with code 3 — no retry after a GPU call, no
+re-exec), the launcher (--launch-timeout).  The line of an N-rank run says where the time went: per rank and as max / mean the
+compute and exchange time per pass (events around every pack -> collective -> unpack span, in an untimed repetition of the
+timed passes), bytes and number of exchanges, the slowest rank, the partitioner, the cut, and a scaling model with its
+assumptions (`scaling_model`).
 """
 import argparse
 import json
@@ -33,10 +42,37 @@ def parse():
     ap.add_argument("--pairwise", default="dense", choices=["dense", "potts"])
     ap.add_argument("--order", default="colour_major", choices=["colour_major", "row_major"])
     ap.add_argument("--mode", default="anisotropic")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"],
                     help="c3: the headline grid (BASELINE.json configs[2], --grid/--labels/--pairwise/--order); c4: the random "
                          "sparse graph of configs[3] (--c4-nodes/--c4-edges/--c4-labels), partitioned across the ranks, every "
-                         "rank generating only its own part in HBM")
+                         "rank generating only its own part in HBM; c5: configs[4], a Potts grid + 100 k labeling-list factors of "
+                         "mixed arity in one factor graph (--c5-*), the variables partitioned across the ranks, run in lock step")
+    ap.add_argument("--c5-grid", type=int, default=512)
+    ap.add_argument("--c5-labels", type=int, default=8)
+    ap.add_argument("--c5-edge-vars", type=int, default=150_000)
+    ap.add_argument("--c5-triplets", type=int, default=70_000)
+    ap.add_argument("--c5-quads", type=int, default=30_000)
+    ap.add_argument("--c5-window", type=int, default=64, help="a labeling-list factor's members are drawn from this many consecutive edge variables")
+    ap.add_argument("--c5-order", default="index", choices=["index", "colour_major"],
+                    help="--workload c5: the edge variables as inserted (index: local triples chain them — thousands of dependent levels "
+                         "per sweep, latency-bound on any number of GPUs) or in the colour-major order the engine suggests "
+                         "(lpmp_plan_suggest_order: one level per colour)")
+    ap.add_argument("--c5-small", action="store_true",
+                    help="--workload c5 in miniature (64x64 grid, 2 000 edge variables, 900 + 400 factors): the state after warmup + steps "
+                         "passes is checked against the oracle's (tests/golden/c5_small.npz) — `oracle_check` in the line")
+    ap.add_argument("--partitioner", default="auto", choices=["auto", "metis", "builtin"],
+                    help="c4 / c5 on several GPUs: METIS (pymetis or a loadable libmetis) when present, else the built-in reverse "
+                         "Cuthill-McKee + balanced KL partitioner (multi_gpu.graph_partition); the line names what ran")
+    ap.add_argument("--partition-file", default=None,
+                    help="c4 / c5 on several GPUs: variable -> rank from a file instead (raw int64 / int32 `.bin`, `.npy`, or text as "
+                         "gpmetis writes it; multi_gpu.load_partition_file); entries in the order of the variables as the run numbers "
+                         "them (c4: after --c4-order; c5: variables in factor order, or one entry per factor)")
+    ap.add_argument("--rendezvous-timeout", type=float, default=300.0, help="several ranks: seconds to wait for all ranks at the store")
+    ap.add_argument("--collective-timeout", type=float, default=300.0,
+                    help="several ranks: bound on the self test before the timed region (one all_reduce, one all_to_all_single with the real "
+                         "split sizes) and the time-out handed to init_process_group; on expiry the rank exits with code 3")
+    ap.add_argument("--assume-exchange-latency-us", type=float, default=30.0, help="scaling_model: assumed cost of one all-to-all-v over xGMI beyond its bytes")
+    ap.add_argument("--assume-exchange-GBps", type=float, default=400.0, help="scaling_model: assumed all-to-all bandwidth per rank over xGMI (7 links x 153 GB/s peak)")
     ap.add_argument("--c4-nodes", type=int, default=2_000_000)
     ap.add_argument("--c4-edges", type=int, default=10_000_000)
     ap.add_argument("--c4-labels", type=int, default=16)
@@ -69,7 +105,7 @@ def parse():
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="--gpus N without a launcher: print the rank processes that WOULD be started (command, environment) as one "
                          "JSON object and exit; nothing touches a GPU (tests/test_bench_contract.py)")
-    ap.add_argument("--launch-timeout", type=float, default=0.0, help="self-launched ranks: give up after this many seconds (0: never)")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="self-launched ranks: give up after this many seconds (0: never)")
     ap.add_argument("--prewarm-ms", type=float, default=0.0,
                     help="untimed passes (prewarm_ms / 8 of them) before the W warmup steps so that clocks and "
                          "power state have settled; 0 disables")
@@ -131,12 +167,191 @@ def close_runner(r):
     r.engine.close()
 
 
+# ---- several ranks: bounded start-up, where the time went ------------------------------------------------------------------
+class Watchdog:
+    """`with Watchdog(seconds, what, rank):` — when the block is not left in time the process says which rank waited for what and
+    EXITS with code 3 (os._exit from a timer thread: the main thread may sit inside a collective that never returns).  Never a
+    retry, never a re-exec: the process has touched the GPU."""
+
+    def __init__(self, seconds, what, rank):
+        self.seconds, self.what, self.rank, self.timer = float(seconds), what, rank, None
+
+    def _fire(self):
+        sys.stderr.write(f"bench.py: rank {self.rank}: {self.what} did not finish within {self.seconds:.0f} s; exiting with code 3\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            import threading
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
+
+
+def rendezvous(args, torch, dist, identity, rank, world):
+    """All ranks meet at the store of MASTER_ADDR : MASTER_PORT (torch's own env:// rendezvous — under torch.distributed.run that
+    is the agent's store) within --rendezvous-timeout, tell each other which PHYSICAL device they sit on (``identity``:
+    lpmp_device_identity, the PCI address — device ordinals say nothing when every rank has a visibility mask of its own), and
+    only then choose the backend: "nccl" (= RCCL) when all ranks have a GPU of their own, gloo with CPU-staged exchanges when
+    ranks share a device (RCCL refuses two ranks per device; smoke runs on the 1-GPU box — timings of such a run mean nothing).
+    Returns (identities of all ranks, backend)."""
+    import datetime
+    timeout = datetime.timedelta(seconds=max(1.0, args.rendezvous_timeout))
+    try:
+        store, _, _ = next(dist.rendezvous("env://", rank, world, timeout=timeout))
+        store.set(f"lpmp/device/{rank}", identity)
+    except Exception as ex:
+        raise SystemExit(f"bench.py: rank {rank}: no rendezvous at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} within "
+                         f"{args.rendezvous_timeout:.0f} s ({type(ex).__name__}: {ex})")
+    idents = []
+    for r in range(world):
+        try:
+            store.wait([f"lpmp/device/{r}"], timeout)
+            idents.append(store.get(f"lpmp/device/{r}").decode())
+        except Exception as ex:
+            raise SystemExit(f"bench.py: rank {rank}: rank {r} did not show up at the rendezvous within {args.rendezvous_timeout:.0f} s ({type(ex).__name__})")
+    backend = os.environ.get("LPMP_DIST_BACKEND") or ("nccl" if len(set(idents)) == world else "gloo")
+    dist.init_process_group(backend, store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(10.0, args.collective_timeout)))
+    return idents, backend
+
+
+def collective_self_test(args, torch, dist, runner, rank, world):
+    """before the timed region, under a wall-clock bound: one all_reduce and one all_to_all_single with the REAL split sizes of this
+    runner's largest exchange (zeros: nothing is unpacked) — a communicator whose ranks cannot reach each other fails here, named"""
+    t0 = time.perf_counter()
+    with Watchdog(args.collective_timeout, "the self test of the collectives (all_reduce + all_to_all_single with the run's split sizes)", rank):
+        dev = "cpu" if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device())
+        t = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        if int(t.item()) != world:
+            raise SystemExit(f"bench.py: rank {rank}: all_reduce of 1 over {world} ranks gave {t.item()}")
+        counts = runner.exchange_counts() if hasattr(runner, "exchange_counts") else None
+        shipped = None
+        if counts is not None and getattr(runner, "comm", None) is not None:
+            out_c, in_c = counts
+            send = torch.zeros(int(sum(out_c)), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+            got = runner.comm.exchange(send, out_c, in_c)
+            torch.cuda.synchronize()
+            if got.shape[0] != int(sum(in_c)):
+                raise SystemExit(f"bench.py: rank {rank}: all_to_all_single returned {got.shape[0]} doubles, expected {int(sum(in_c))}")
+            shipped = int(sum(out_c)) * 8
+    return {"all_reduce": "ok", "all_to_all_bytes_out": shipped, "seconds": time.perf_counter() - t0, "bound_s": args.collective_timeout}
+
+
+def rank_stats_leg(torch, dist, runner, steps):
+    """untimed repetition of the timed passes with every exchange bracketed by events (multi_gpu.ExchangeProbe), gathered from all
+    ranks: {"per_rank": {key: [...]}, "max": {...}, "mean": {...}, "slowest_rank": r} with the keys compute_ms_per_pass,
+    exchange_ms_per_pass, exchanges_per_pass, exchange_bytes_out_per_pass, exchange_bytes_in_per_pass, redundant_fraction,
+    total_ms_per_pass"""
+    from lp_mp_amd import multi_gpu as MG
+    st = runner.probe_passes(steps)
+    return MG.gather_rank_stats(dist, torch, getattr(runner, "comm", None), st)
+
+
+def single_gpu_reference(args):
+    """ms per pass of the SAME workload on one GPU from the latest committed bench line (profiles/): the t_1 of the scaling model.
+    (workload, ms, file) or None"""
+    import glob
+    pats = {"c3": "r*bench_c3_default.json", "c4": "r*_c4_bench_c4_default.json", "c5": "r*_c5_bench_c5_default.json"}[args.workload]
+    want = workload_name(args)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pats)), reverse=True):
+        try:
+            d = json.loads(open(f).read().strip().splitlines()[-1])
+        except Exception:
+            continue
+        if d.get("n_gpus") == 1 and d.get("config", {}).get("workload") == want:
+            return {"ms_per_pass": d["ms_per_step"], "source": os.path.relpath(f, ROOT)}
+    return None
+
+
+def scaling_model(args, world, stats, measured_ms, shared_device):
+    """What the first run on real hardware confirms or refutes, with its assumptions in the line:
+        projected ms per pass = t_run + n_exchanges * latency + bytes / bandwidth
+    t_run = the slowest rank's compute time per pass (measured here; on a shared device it is time-sliced and means nothing),
+    n_exchanges and bytes = measured per pass, latency and bandwidth = --assume-exchange-latency-us / --assume-exchange-GBps.
+    Strong scaling (c4, c5: the graph is fixed): projected_speedup = t_1 / projected; weak scaling (c3: one grid per GPU):
+    projected_efficiency = t_1 / projected.  t_1 = this workload's single-GPU line in profiles/ (null when none is committed)."""
+    mx = stats["max"]
+    lam, bw = args.assume_exchange_latency_us * 1e-3, args.assume_exchange_GBps * 1e9
+    nbytes = max(mx["exchange_bytes_out_per_pass"], mx["exchange_bytes_in_per_pass"])
+    proj = mx["compute_ms_per_pass"] + mx["exchanges_per_pass"] * lam + nbytes / bw * 1e3
+    t1 = single_gpu_reference(args)
+    strong = args.workload != "c3"
+    out = {"formula": "t_run + n_exchanges * latency + bytes / bandwidth", "t_run_ms": mx["compute_ms_per_pass"],
+           "n_exchanges_per_pass": mx["exchanges_per_pass"], "exchange_bytes_per_pass_and_rank": nbytes,
+           "assumed_latency_us_per_exchange": args.assume_exchange_latency_us, "assumed_GBps_per_rank": args.assume_exchange_GBps,
+           "projected_ms_per_pass": proj, "measured_ms_per_pass": measured_ms, "measured_exchange_ms_per_pass": mx["exchange_ms_per_pass"],
+           "t1_ms_per_pass": t1["ms_per_pass"] if t1 else None, "t1_source": t1["source"] if t1 else None,
+           "kind": "strong" if strong else "weak",
+           "note": "ranks share a device: t_run is time-sliced, the projection means nothing" if shared_device else None}
+    if t1:
+        key = "speedup" if strong else "efficiency"
+        out["projected_" + key] = t1["ms_per_pass"] / proj
+        out["measured_" + key] = t1["ms_per_pass"] / measured_ms
+    return out
+
+
+def workload_name(args):
+    if args.workload == "c4":
+        return (f"random sparse graph G({args.c4_nodes}, {args.c4_edges}), {args.c4_labels} labels, dense pairwise, {args.mode} weights, "
+                f"{args.c4_order} variable order")
+    if args.workload == "c5":
+        g, L, ne, nt, nq, w = c5_shape(args)
+        return (f"{g}x{g} Potts grid ({L} labels) + {ne} edge variables, {nt} triplet and {nq} quadruple labeling-list factors (window {w}), "
+                f"one factor graph, {args.mode} weights, {args.c5_order} edge-variable order")
+    return f"{args.grid}x{args.grid} grid per GPU, {args.labels} labels, {args.pairwise} pairwise, {args.mode} weights, {args.order} order"
+
+
+def c5_shape(args):
+    if args.c5_small:
+        return 64, args.c5_labels, 2000, 900, 400, min(args.c5_window, 64)
+    return args.c5_grid, args.c5_labels, args.c5_edge_vars, args.c5_triplets, args.c5_quads, args.c5_window
+
+
+def c5_global_model(args, S):
+    g, L, ne, nt, nq, w = c5_shape(args)
+    return S.c5_model(g, g, L, ne, nt, nq, seed=4, window=w, colour_edge_vars=args.c5_order == "colour_major")
+
+
+def model_partition(args, torch, dist, MG, gm, world):
+    """variable -> rank for a general model (c5): --partition-file, or the partitioner on rank 0, broadcast.  Returns
+    (part per FACTOR as lockstep_model wants it, name of what made it)"""
+    import numpy as np
+    is_right = np.zeros(gm.n_factors, bool); is_right[gm.m_right] = True
+    var = np.nonzero(~is_right)[0]
+    if args.partition_file:
+        try:
+            part = MG.load_partition_file(args.partition_file, gm.n_factors, world)
+        except ValueError:
+            pv = MG.load_partition_file(args.partition_file, var.shape[0], world)
+            part = np.zeros(gm.n_factors, np.int64); part[var] = pv
+        return part, f"file {os.path.basename(args.partition_file)}"
+    if world == 1:
+        return np.zeros(gm.n_factors, np.int64), "none (1 part)"
+    used = []
+    def compute():
+        p, how = MG.graph_partition_model(gm, world, method=args.partitioner, return_method=True)
+        used.append(how)
+        return p
+    part = MG.broadcast_partition(torch, dist, gm.n_factors, None, compute)
+    return part, MG.broadcast_string(dist, used[0] if used else None)
+
+
 def pmc_traffic(kernel_name, args):
     """Bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes; summarised
     by tools/pmc_traffic.py into profiles/).  These are the L2's FABRIC-side request counters: a read served by the
     256 MiB Infinity Cache counts like one served by HBM.  None when no summary for this workload is committed."""
     import glob
+    if getattr(args, "workload", "c3") == "c5":
+        return None, None                                # (no counter passes taken for C5: latency-bound, a mix of kernel classes)
     if getattr(args, "workload", "c3") == "c4":
         if not (args.c4_nodes == 2_000_000 and args.c4_edges == 10_000_000 and args.c4_labels == 16):
             return None, None
@@ -248,11 +463,83 @@ def dual_bound_gap(torch, dist, args, mode, world, rank, schedule=None):
     return out
 
 
+def dual_bound_gap_c5(torch, dist, args, mode, world, rank, schedule=None):
+    """the same for the C5 workload: its miniature (--c5-small shape, same generator, same edge-variable order), partitioned like the
+    big one and run in lock step, against the unpartitioned sweep on rank 0"""
+    import types
+    from lp_mp_amd import engine as E, multi_gpu as MG, lockstep as LS, synthetic as S
+    small = types.SimpleNamespace(**dict(vars(args), c5_small=True, partition_file=None))
+    gm = c5_global_model(small, S)
+    part, how = model_partition(small, torch, dist, MG, gm, world)
+    sw = LS.LockstepModel(torch, dist, gm, part, mode)
+    sw.compute_pass(args.steps)
+    lb_part = sw.lower_bound()
+    out = None
+    if rank == 0:
+        e = E.Engine(torch.cuda.current_device())
+        e.upload(gm)
+        e.set_reparametrization(mode)
+        e.compute_pass(args.steps)
+        lb_ref = e.lower_bound()
+        e.close()
+        out = {"dual_bound_gap": (lb_ref - lb_part) / abs(lb_ref), "gap_config": f"{workload_name(small)} in {world} parts ({how}), {args.steps} passes, lock step",
+               "cut_fraction": sw.cut_fraction, "lb_partitioned": lb_part, "lb_unpartitioned": lb_ref}
+    close_runner(sw)
+    return out
+
+
+def golden_check_c5(torch, dist, args, runner, lb):
+    """--c5-small: the state the timed passes left on the device(s) against the oracle's after the same number of passes
+    (tests/golden/c5_small.npz, made by tests/golden/make_c5_small.py): the bound, and two exact checksums of the packed duals —
+    on several ranks every rank adds up the factors it owns at their GLOBAL positions (integer sums wrap, so they add across ranks)"""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "c5_small.npz")
+    if not (os.path.exists(path) and args.c5_labels == 8 and args.c5_window >= 64 and args.mode == "anisotropic" and args.prewarm_ms == 0):
+        return None
+    g = np.load(path)
+    passes = args.warmup + args.steps
+    hit = np.nonzero(g["passes"] == passes)[0]
+    if hit.size == 0:
+        return {"passes": passes, "note": "no oracle fixture for this pass count (fixture: 0..%d)" % int(g["passes"].max())}
+    k, o = int(hit[0]), args.c5_order
+    eng = getattr(runner, "engine", runner)
+    eng.synchronize()
+    d = eng.download_duals().view(np.uint64)
+    part = getattr(runner, "part", None)
+    with np.errstate(over="ignore"):
+        if part is None:                                 # one engine holds the whole model
+            w = np.arange(d.shape[0], dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+            c = np.array([d.sum(dtype=np.uint64), (d * w).sum(dtype=np.uint64)], np.uint64)
+        else:                                            # a lock-step part: owned factors at their global dual offsets
+            from lp_mp_amd import synthetic as S
+            import types
+            gm = c5_global_model(types.SimpleNamespace(**vars(args)), S)
+            goff, loff = gm.dual_offsets(), part.model.dual_offsets()
+            own = np.nonzero(part.owned)[0]
+            lens = (loff[own + 1] - loff[own]).astype(np.int64)
+            first = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            within = np.arange(int(first[-1])) - np.repeat(first[:-1], lens)
+            li = np.repeat(loff[own], lens) + within
+            gi = (np.repeat(goff[part.factors_global[own]], lens) + within).astype(np.uint64)
+            x = d[li]
+            c = np.array([x.sum(dtype=np.uint64), (x * (gi * np.uint64(2) + np.uint64(1))).sum(dtype=np.uint64)], np.uint64)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.from_numpy(c.view(np.int64).copy())
+        if dist.get_backend() != "gloo":
+            t = t.cuda()
+        dist.all_reduce(t)
+        c = t.cpu().numpy().view(np.uint64)
+    lbo = float(g[f"lb_{o}"][k])
+    return {"passes": passes, "lb_oracle": lbo, "lb_rel_err": abs(lb - lbo) / max(1.0, abs(lbo)),
+            "duals_bit_identical_to_oracle": (int(c[0]), int(c[1])) == (int(g[f"dual_sum_{o}"][k]), int(g[f"dual_wsum_{o}"][k])),
+            "fixture": "tests/golden/c5_small.npz (oracle/lpmp_oracle.c on the same model, tests/golden/make_c5_small.py)"}
+
+
 def hbm_min_bytes_per_pass(runner, args, world, bytes_per_pass, updates_per_pass, L):
     """Least HBM traffic of one pass: SURVEY 8(d) counts a dense table once per receive (8 L^2 per message and pass, two
     reads of every table per anisotropic pass); if every second read were served on-die, HBM would still deliver every
     table once + all vectors.  = algorithmic bytes - (table reads - tables) * 8 L^2.  Dense uniform-L workloads only."""
-    if args.workload == "c3" and args.pairwise != "dense":
+    if (args.workload == "c3" and args.pairwise != "dense") or args.workload == "c5":
         return None
     rows = args.grid * max(1, world)                 # N strips of grid x grid stacked: one (grid * N) x grid grid
     n_tables = args.c4_edges if args.workload == "c4" else rows * (args.grid - 1) + (rows - 1) * args.grid
@@ -289,6 +576,12 @@ def cpu_baseline(args, synthetic, M):
         n, e = min(args.c4_nodes, 40000), min(args.c4_edges, 200000)
         m = synthetic.counter_graph_model(n, e, args.c4_labels, 1)
         what = f"G({n}, {e}), {args.c4_labels} labels, dense pairwise"
+    elif getattr(args, "workload", "c3") == "c5":
+        import types
+        g, L, ne, nt, nq, w = c5_shape(args)
+        a5 = types.SimpleNamespace(**dict(vars(args), c5_small=False, c5_grid=min(g, 128), c5_edge_vars=min(ne, 10000), c5_triplets=min(nt, 4600), c5_quads=min(nq, 2000)))
+        m = c5_global_model(a5, synthetic)
+        what = workload_name(a5)
     else:
         g = min(args.cpu_sample_grid, args.grid)
         m = synthetic.grid_model(g, g, args.labels, pairwise=args.pairwise, order=args.order, seed=1)
@@ -426,6 +719,7 @@ def main():
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or args.force_dist
+    shared_device = False
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -433,25 +727,25 @@ def main():
         if n_dev == 0:
             raise SystemExit("bench.py: no HIP device visible to rank %d (the engine has no CPU path)" % rank)
         torch.cuda.set_device(local_rank % n_dev)
-        # "nccl" is RCCL on ROCm.  RCCL refuses two ranks on one device, so a box with fewer GPUs than ranks (the 1-GPU test
-        # box: smoke runs of the N-rank path, tests/test_bench_contract.py) falls back to gloo with CPU-staged exchanges —
-        # the line says so (`backend`), and timings of such a run mean nothing
-        backend = os.environ.get("LPMP_DIST_BACKEND") or ("nccl" if n_dev >= int(os.environ.get("LOCAL_WORLD_SIZE", world)) else "gloo")
-        dist.init_process_group(backend, rank=rank, world_size=world)
-        # which device every rank sits on (the line reports it: ranks that share a device are not a scaling measurement)
-        t = torch.zeros(world, dtype=torch.int64, device="cpu" if backend == "gloo" else torch.device("cuda", torch.cuda.current_device()))
-        t[rank] = torch.cuda.current_device()
-        dist.all_reduce(t)
+        # which PHYSICAL device this rank sits on (PCI address + uuid through the C ABI): ordinals say nothing when the launcher
+        # gives every rank a visibility mask of its own — then all of them report "device 0" and each has a GPU to itself
+        identity = E.device_identity(torch.cuda.current_device())
+        idents, backend = rendezvous(args, torch, dist, identity, rank, world)
+        distinct = sorted(set(idents))
+        shared_device = len(distinct) < world
         launch = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "ranks_seen": dist.get_world_size(),
-                  "devices": [int(x) for x in t.tolist()], "devices_visible": n_dev,
+                  "devices": [distinct.index(x) for x in idents], "device_identities": idents, "physical_devices": len(distinct),
+                  "devices_visible": n_dev, "rendezvous_timeout_s": args.rendezvous_timeout,
                   "launcher": "bench.py (self-launched ranks)" if os.environ.get("LPMP_BENCH_SELF_LAUNCHED") else "external (torch.distributed.run)"}
         if launch["ranks_seen"] != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {launch['ranks_seen']} ranks")
         launch["persistent_launches"] = True
-        if len(set(launch["devices"])) < world and not os.environ.get("LPMP_BENCH_KEEP_PERSISTENT"):   # (tools/shared_device_stall_probe.sh keeps them on)
+        if shared_device and not os.environ.get("LPMP_BENCH_KEEP_PERSISTENT"):   # (tools/shared_device_stall_probe.sh keeps them on)
             # ranks that SHARE a device (smoke runs on the 1-GPU box): the persistent chain launches assume that resident
             # workgroups keep running, which a device time-sliced between processes does not give them (kernels.hip, chain
-            # executor: about every third 8-rank run stalled until its wait bound) — one launch per step instead
+            # executor: about every third 8-rank run stalled until its wait bound) — one launch per step instead.  The drivers
+            # switch their own engine (lpmp_set_persistent_launches, DriverStats.own_the_engine finds the sharing itself); the
+            # environment covers the auxiliary engines of the gap legs below
             os.environ["LPMP_NO_CHAIN"] = "1"
             os.environ["LPMP_NO_BLOCKED_PASSES"] = "1"
             launch["persistent_launches"] = False
@@ -471,20 +765,53 @@ def main():
     if args.workload == "c4":
         from lp_mp_amd import multi_gpu as MG
         L = args.c4_labels
+        part_of = MG.load_partition_file(args.partition_file, args.c4_nodes, world) if (args.partition_file and dist_on) else None
         if dist_on and args.schedule == "lockstep":
             from lp_mp_amd import lockstep as LS
-            runner = LS.LockstepGraph(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1, order=args.c4_order)
+            runner = LS.LockstepGraph(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1, order=args.c4_order, part_of=part_of,
+                                      partitioner=args.partitioner, rows_layout=args.rows_layout == "on")
             parallelism = (f"{world} parts in lock step (the unpartitioned sweep in {args.c4_order} variable order, {runner.halo_steps_per_pass():.1f} halo exchanges per pass), "
                            f"{100 * runner.cut_fraction:.1f} % of the edges cut")
         else:
             rows = (not dist_on) and args.rows_layout != "off"
-            runner = MG.GraphSweep(torch, dist if dist_on else None, args.c4_nodes, args.c4_edges, L, mode, seed=1, rows_layout=rows, order=args.c4_order)
-            parallelism = (f"{world} parts (reverse Cuthill-McKee + balanced KL refinement), {100 * runner.global_cut_fraction:.1f} % of the edges cut, "
+            runner = MG.GraphSweep(torch, dist if dist_on else None, args.c4_nodes, args.c4_edges, L, mode, seed=1, rows_layout=rows, order=args.c4_order,
+                                   part_of=part_of, partitioner=args.partitioner)
+            parallelism = (f"{world} parts, {100 * runner.global_cut_fraction:.1f} % of the edges cut, "
                            f"boundary step every {runner.boundary_every}") if world > 1 else "1 GPU"
+        partitioner = (f"file {os.path.basename(args.partition_file)}" if part_of is not None else runner.partitioner) if dist_on else None
         updates_per_pass = runner.global_updates_per_pass
         bytes_per_pass = runner.global_bytes_per_pass
         levels = runner.levels
         eng = runner.engine
+    elif args.workload == "c5":
+        from lp_mp_amd import multi_gpu as MG, lockstep as LS
+        if dist_on and args.schedule != "lockstep":
+            raise SystemExit("bench.py: --workload c5 runs in lock step on several GPUs (--schedule lockstep)")
+        L = args.c5_labels
+        gm5 = c5_global_model(args, S)
+        setup["model_on_host_s"] = time.perf_counter() - t_setup0
+        if dist_on:
+            part5, partitioner = model_partition(args, torch, dist, MG, gm5, world)
+            runner = LS.LockstepModel(torch, dist, gm5, part5, mode)
+            parallelism = (f"{world} parts in lock step (the unpartitioned sweep, {runner.halo_steps_per_pass():.1f} halo exchanges per pass), "
+                           f"{100 * runner.cut_fraction:.1f} % of the message vectors cut")
+            updates_per_pass = runner.global_updates_per_pass
+            bytes_per_pass = runner.global_bytes_per_pass
+            levels = runner.levels
+            eng = runner.engine
+        else:                                            # one GPU: the engine's own pass schedules ARE the sweep
+            partitioner = None
+            eng = E.Engine(torch.cuda.current_device())
+            eng.set_stream(stream_ptr)
+            eng.upload(gm5)
+            eng.set_reparametrization(mode)
+            eng.synchronize()
+            runner = eng
+            info = [eng.plan.schedule_info(d, mode) for d in (0, 1)]
+            updates_per_pass = sum(i["n_receives"] + i["n_sends"] for i in info)
+            bytes_per_pass = sum(i["algorithmic_bytes"] for i in info)
+            levels = [i["n_levels"] for i in info]
+            parallelism = "1 GPU"
     elif not dist_on:
         m, const, dual = build_device_grid(torch, H, W, L, args.pairwise, args.order, 1, E, S, stream_ptr)
         setup["model_structure_and_costs_in_hbm_s"] = time.perf_counter() - t_setup0
@@ -508,6 +835,15 @@ def main():
         bytes_per_pass = runner.global_bytes_per_pass
         levels = runner.levels
         eng = runner.engine
+        partitioner = "row strips (closed form)"
+    if not dist_on and args.workload == "c3":
+        partitioner = None
+    if dist_on:
+        if hasattr(runner, "set_shared_device") and shared_device and not os.environ.get("LPMP_BENCH_KEEP_PERSISTENT"):
+            runner.set_shared_device(True)
+        launch["persistent_launches"] = bool(eng.persistent_launches)
+        launch["self_test"] = collective_self_test(args, torch, dist, runner, rank, world)
+    cut_fraction_line = float(getattr(runner, "global_cut_fraction", getattr(runner, "cut_fraction", 0.0))) if dist_on else None
 
     lb0 = runner.lower_bound()
     eng_rows = bool(getattr(eng, "rows_layout", False))
@@ -529,6 +865,8 @@ def main():
     if not dist_on and args.workload == "c3":
         eng.synchronize()                            # (rows layout: the packed dual buffer is written out here)
         oracle_check = golden_check(torch, args, dual, lb1)
+    if args.workload == "c5" and args.c5_small:
+        oracle_check = golden_check_c5(torch, dist if dist_on else None, args, runner, lb1)
 
     # roofline leg: the same passes again with every launch bracketed by HIP events on the engine's stream
     eng.reset_kernel_timing()
@@ -537,6 +875,12 @@ def main():
     torch.cuda.synchronize()
     kt = eng.kernel_timing()
     eng.enable_kernel_timing(False)
+
+    # several ranks: the same passes once more with every exchange bracketed by events — where the time of a pass goes, per rank
+    rank_stats = model_line = None
+    if dist_on:
+        rank_stats = rank_stats_leg(torch, dist, runner, args.steps)
+        model_line = scaling_model(args, world, rank_stats, dt / args.steps * 1e3, shared_device)
 
     # outside the timed region: one pass with primal rounding (what MpRoundingSolver runs every 5th iteration,
     # reference solver.hxx:387-397) and LP::EvaluatePrimal
@@ -575,8 +919,8 @@ def main():
         torch.cuda.synchronize()
         rounding["ms_pass_and_primal_" + args.mode] = (time.perf_counter() - t0) * 1e3
 
-    gap = (dual_bound_gap_c4 if args.workload == "c4" else dual_bound_gap)(torch, dist, args, mode, world, rank) if dist_on else \
-        {"dual_bound_gap": 0.0, "gap_config": "1 GPU: the unpartitioned sweep itself"}
+    gap_fn = {"c3": dual_bound_gap, "c4": dual_bound_gap_c4, "c5": dual_bound_gap_c5}[args.workload]
+    gap = gap_fn(torch, dist, args, mode, world, rank) if dist_on else {"dual_bound_gap": 0.0, "gap_config": "1 GPU: the unpartitioned sweep itself"}
     # the other multi-GPU schedules on the same strips, same pass count (outside the timed region): what the choice costs
     schedules = None
     peak_bytes = torch.cuda.max_memory_allocated()
@@ -671,16 +1015,15 @@ def main():
                 roof["hbm_min_frac_of_measured_stream_rate"] = roof["hbm_min_GBps"] / HBM_STREAM_GBS
         out = {
             "metric": "message updates/sec + dual-bound gap, 32-label grid MRF @1/2/4/8 GPUs" if L == 32 and args.pairwise == "dense" and args.workload == "c3"
-                      else "message updates/sec + dual-bound gap, " + ("random sparse graph MRF" if args.workload == "c4" else "grid MRF"),
+                      else "message updates/sec + dual-bound gap, " + {"c4": "random sparse graph MRF", "c5": "grid + labeling-list factors", "c3": "grid MRF"}[args.workload],
             "scaling_note": None if args.workload == "c3" else "strong scaling: the graph is fixed, the ranks share it",
             "value": value, "unit": "msg-updates/s", "n_gpus": world, "backend": launch["backend"], "ranks_seen": launch["ranks_seen"],
             "devices": launch["devices"], "launch": launch, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.workload == "c3" else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"random sparse graph G({args.c4_nodes}, {args.c4_edges}), {L} labels, dense pairwise, {args.mode} weights, "
-                                    f"{args.c4_order} variable order" if args.workload == "c4" else
-                                    f"{H}x{W} grid per GPU, {L} labels, {args.pairwise} pairwise, {args.mode} weights, {args.order} order"),
-                       "parallelism": parallelism, "variable_order": args.c4_order if args.workload == "c4" else args.order,
+            "config": {"workload": workload_name(args),
+                       "parallelism": parallelism, "variable_order": {"c4": args.c4_order, "c5": args.c5_order, "c3": args.order}[args.workload],
+                       "partitioner": partitioner, "cut_fraction": cut_fraction_line,
                        "pairwise_layout": "rows [table | m1 | m2], engine-private" if eng_rows else "packed (tables / serialize_dual order)",
                        "levels_per_direction": levels, "msg_updates_per_pass": updates_per_pass,
                        "algorithmic_bytes_per_pass": bytes_per_pass},
@@ -690,6 +1033,17 @@ def main():
             "oracle_check": oracle_check,
             "dual_bound_gap": gap["dual_bound_gap"], "dual_bound_gap_detail": gap, "schedule": args.schedule if dist_on else None,
             "schedules": schedules,
+            # several ranks: where a pass spends its time (untimed repetition under multi_gpu.ExchangeProbe), as max / mean over the
+            # ranks and per rank; exchange spans include waiting for the slowest peer
+            "compute_ms_per_pass": None if rank_stats is None else {"max": rank_stats["max"]["compute_ms_per_pass"], "mean": rank_stats["mean"]["compute_ms_per_pass"]},
+            "exchange_ms_per_pass": None if rank_stats is None else {"max": rank_stats["max"]["exchange_ms_per_pass"], "mean": rank_stats["mean"]["exchange_ms_per_pass"]},
+            "exchange_bytes_per_pass": None if rank_stats is None else {"max": rank_stats["max"]["exchange_bytes_out_per_pass"], "mean": rank_stats["mean"]["exchange_bytes_out_per_pass"],
+                                                                        "sum": sum(rank_stats["per_rank"]["exchange_bytes_out_per_pass"])},
+            "exchanges_per_pass": None if rank_stats is None else rank_stats["max"]["exchanges_per_pass"],
+            "redundant_fraction": None if rank_stats is None else rank_stats["max"]["redundant_fraction"],
+            "slowest_rank": None if rank_stats is None else rank_stats.get("slowest_rank"),
+            "rank_stats": rank_stats,
+            "scaling_model": model_line,
             "kernels": kt,
             "rounding": rounding,
             "roofline": roof,

@@ -199,7 +199,12 @@ int lpmp_lower_bound(lpmp_engine* e, double* out);          /* LP::LowerBound, L
 int lpmp_factor_lower_bounds(lpmp_engine* e, double* out /*[n_factors], host*/); /* FactorTypeAdapter::LowerBound */
 /* The sweep kernels keep a per-factor lower bound current as a by-product, so lpmp_lower_bound after
  * a pass is a sum over an array.  Call this after changing duals behind the engine's back (writes through
- * lpmp_device_duals or a borrowed dual buffer): the next lpmp_lower_bound recomputes every factor. */
+ * lpmp_device_duals or a borrowed dual buffer): the next lpmp_lower_bound recomputes every factor.
+ * Order of a direct access to a BORROWED dual buffer: lpmp_synchronize (or lpmp_device_duals) FIRST — it settles passes that ran
+ * ahead and, with the rows layout, writes the dense pairwise vectors out to the packed array —, then read / write, then this call.
+ * Without the first step, under the rows layout the pairwise vectors read are stale and what was written into them is replaced
+ * by the rows' contents here (vector factors live in the packed array only and are not affected).  The lpmp_boundary_* and
+ * lpmp_halo_* calls need none of this: they address the rows themselves. */
 int lpmp_invalidate_lower_bounds(lpmp_engine* e);
 /* How many per-factor bounds the last lpmp_lower_bound / lpmp_factor_lower_bounds had to recompute from the duals (the sweep
  * kernels keep the others current: DESIGN.md 5); the number of factors when it recomputed everything, -1 before the first. */
@@ -246,6 +251,18 @@ void* lpmp_device_duals(lpmp_engine* e);   /* device pointer of the packed duals
  * pass.  Costs the tables a second time in device memory; passes that run ahead of the caller (lpmp_set_speculation) stay off. */
 int lpmp_set_rows_layout(lpmp_engine* e, int on);
 int lpmp_rows_layout(const lpmp_engine* e);   /* 1 if the uploaded model uses it */
+
+/* Persistent launches (the chain executor and the joined passes in Infinity-Cache order) assume that resident
+ * workgroups keep running, i.e. that the device is this process's own.  When several processes time-share one device its scheduler
+ * switches queues, ticket holders freeze while their waiters poll, and a run may end in LPMP_ERR_DEVICE ("a dependency wait timed
+ * out") with the duals undefined.  A host that shares its device (lpmp_device_identity tells) switches them off for its engine:
+ * every schedule then runs launch by launch / as a replayed graph — same results, bit for bit.  Default on; LPMP_NO_CHAIN=1 /
+ * LPMP_NO_BLOCKED_PASSES=1 in the environment keep them off whatever is set here.  Callable at any time. */
+int lpmp_set_persistent_launches(lpmp_engine* e, int on);
+int lpmp_persistent_launches(const lpmp_engine* e);   /* 1 if on */
+/* "pci=<domain:bus:device.function> uuid=<hex>" of HIP device ordinal `device` (NUL-terminated, cap >= 64): equal strings = one
+ * physical GPU, also when every process has a visibility mask of its own and all of them call their device "0" */
+int lpmp_device_identity(int device, char* out, int64_t cap);
 
 const lpmp_plan* lpmp_engine_plan(const lpmp_engine* e);
 lpmp_plan* lpmp_engine_plan_mut(lpmp_engine* e);

@@ -108,6 +108,7 @@ int lpmp_boundary_enter(lpmp_engine* e);       // engine.cpp: the engine's devic
 void* lpmp_engine_dual_base(lpmp_engine* e);   // engine.cpp: the dual base pointer the device offsets are relative to
 int64_t lpmp_engine_device_dual_offset(lpmp_engine* e, int64_t packed_off);   // engine.cpp: a packed dual offset as a device offset (rows layout)
 int lpmp_boundary_leave(lpmp_engine* e);       // engine.cpp: duals were written through device offsets
+int lpmp_engine_dual_range_ok(lpmp_engine* e, int64_t packed_off, int64_t len);   // engine.cpp: a run of doubles inside one factor's dual
 
 #define B_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { lpmp_set_last_error((std::string(#x) + ": " + hipGetErrorString(e_)).c_str()); return LPMP_ERR_DEVICE; } } while (0)
 
@@ -118,7 +119,12 @@ static int boundary_create(lpmp_engine* e, int64_t n_out, const int64_t* out_dua
   std::unique_ptr<lpmp_boundary> b(new lpmp_boundary());
   std::vector<BVec> ov((size_t)n_out);
   int64_t at = 0;
-  for (int64_t i = 0; i < n_out; ++i) { ov[i] = {lpmp_engine_device_dual_offset(e, out_dual_off[i]), at, out_len[i], 0}; at += out_len[i]; }
+  for (int64_t i = 0; i < n_out; ++i) {
+    if (!lpmp_engine_dual_range_ok(e, out_dual_off[i], out_len[i])) { lpmp_set_last_error("boundary: an outgoing vector is not inside one factor's dual"); return LPMP_ERR_INVALID; }
+    ov[i] = {lpmp_engine_device_dual_offset(e, out_dual_off[i]), at, out_len[i], 0}; at += out_len[i];
+  }
+  for (int64_t i = 0; i < n_in; ++i)
+    if (!lpmp_engine_dual_range_ok(e, in_dual_off[i], in_len[i])) { lpmp_set_last_error("boundary: an incoming vector is not inside one factor's dual"); return LPMP_ERR_INVALID; }
   b->n_out = n_out; b->out_doubles = at;
   // incoming messages arrive in exchange order (buffer offsets by prefix sum); in_order lists them grouped by variable,
   // inside a variable in the order its message list holds them
@@ -193,7 +199,10 @@ static int halo_create(lpmp_engine* e, const int64_t n[2], const int64_t* const 
     std::vector<BVec> v((size_t)n[k]);
     int64_t at = 0;
     for (int64_t i = 0; i < n[k]; ++i) {
-      if (len[k][i] < 0) { lpmp_set_last_error("halo: negative vector length"); return LPMP_ERR_INVALID; }
+      if (!lpmp_engine_dual_range_ok(e, off[k][i], len[k][i])) {
+        lpmp_set_last_error(k == 0 ? "halo: an outgoing vector is not a run of doubles inside one factor's dual" : "halo: an incoming vector is not a run of doubles inside one factor's dual");
+        return LPMP_ERR_INVALID;
+      }
       v[(size_t)i] = {lpmp_engine_device_dual_offset(e, off[k][i]), at, len[k][i], 0};
       at += len[k][i]; h->max_len[k] = std::max(h->max_len[k], len[k][i]);
     }

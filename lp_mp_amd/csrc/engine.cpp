@@ -412,6 +412,7 @@ struct lpmp_engine {
     }
   } spec;
   bool use_blocked_passes = true;     // LPMP_NO_BLOCKED_PASSES=1: the joined passes as one launch per step
+  bool pass_chain_tried[LPMP_REPAM_COUNT] = {};   // ensure_pass_chain_plan ran for that mode
   int rot_bands = 0, rot_lag = 3, rot_depth = 4;   // skewed ticket order (0 bands: from the table bytes per step); DESIGN.md 6 has the sweep
   void release_rot_chains() {
     for (auto& m : rot_chain) {
@@ -442,7 +443,7 @@ struct lpmp_engine {
   // the built-in schedules (everything but the caller's prepared iterator-range passes)
   void release_schedules() {
     for (int d = 0; d < 2; ++d) for (int m = 0; m < LPMP_REPAM_COUNT; ++m) sched[d][m].release();
-    for (int m = 0; m < LPMP_REPAM_COUNT; ++m) { have_sched[m] = false; sched_pass[m].release(); sched_bf[m].release(); have_pass[m] = false; rotation_ok[m] = false; }
+    for (int m = 0; m < LPMP_REPAM_COUNT; ++m) { have_sched[m] = false; sched_pass[m].release(); sched_bf[m].release(); have_pass[m] = false; rotation_ok[m] = false; pass_chain_tried[m] = false; }
     for (int k = 0; k < 2; ++k) { sched_part[k].release(); have_part[k] = false; }
     release_rot_chains();
   }
@@ -719,6 +720,30 @@ void ensure_pass_schedule(lpmp_engine* e, int mode) {
   Schedule& h = e->plan->pass_cache[mode];
   h.recs.clear(); h.recs.shrink_to_fit(); h.ops.clear(); h.ops.shrink_to_fit(); h.packets.clear(); h.packets.shrink_to_fit();
   e->have_pass[mode] = true;
+}
+
+// ensure_pass_schedule plans a three-level pass whose consecutive passes join WITHOUT a chain plan of its own (the joined
+// launch never reads it).  A pass that is then run on its own after all — another send rule, one pass at a time while the joined
+// launch is unavailable — gets the plan the first time that happens: on an HBM-sized model the banded Infinity-Cache launch of
+// the single pass.  The joined-launch templates of that mode point into the schedule's device arrays and are dropped (rebuilt on demand).
+void ensure_pass_chain_plan(lpmp_engine* e, int mode) {
+  if (e->pass_chain_tried[mode] || !e->use_chain || !e->use_blocked_passes) return;
+  e->pass_chain_tried[mode] = true;
+  const DevSchedule& d = e->sched_pass[mode];
+  if (!e->have_pass[mode] || !e->rotation_ok[mode] || d.chain || d.n_levels != 3 || !e->model_big) return;
+  e->plan->have_pass[mode] = false;
+  plan_pass_schedule(e->plan.get(), mode, true);
+  check_generic_limits(e->plan->p, e->plan->pass_cache[mode]);
+  HIP_CHECK(hipStreamSynchronize(e->stream));
+  for (auto& kv : e->rot_chain[mode]) {
+    auto& c = kv.second.dc;
+    for (void* p : {(void*)c.launches, (void*)c.tk_launch, (void*)c.tk_block, (void*)c.dep_off, (void*)c.dep, (void*)c.done, (void*)c.next, (void*)c.mailbox}) if (p) (void)hipFree(p);
+    e->rot_cache_bytes -= std::min(e->rot_cache_bytes, kv.second.dev_bytes);
+  }
+  e->rot_chain[mode].clear();
+  upload_schedule(e->plan->pass_cache[mode], e->sched_pass[mode], e->stream);
+  Schedule& h = e->plan->pass_cache[mode];
+  h.recs.clear(); h.recs.shrink_to_fit(); h.ops.clear(); h.ops.shrink_to_fit(); h.packets.clear(); h.packets.shrink_to_fit();
 }
 
 void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_t stream, int only_level = 0) {
@@ -1126,6 +1151,9 @@ void require_mode(const lpmp_engine* e) {
 static void settle(lpmp_engine* e);          // speculative passes: make the device state the caller's state (below)
 // rows layout: bring the side that is about to be read up to date (stream-ordered copies of the message vectors)
 static void rows_refresh(lpmp_engine* e) {   // packed duals -> rows, before anything computes on the rows
+  // (every hand-over first writes the rows out — rows_flush — and only then lets the caller write: both copies newer than the
+  // other would mean one of the two gets lost)
+  if (e->rows && e->rows_stale && e->packed_stale) throw StateError("rows layout: packed duals and rows both hold newer vectors");
   if (e->rows && e->rows_stale) { launch_rows_copy(e->d_rowrecs, e->n_rowrecs, e->d_const, e->d_dual, e->d_rows, 1, e->stream); HIP_CHECK(hipGetLastError()); e->rows_stale = false; }
 }
 static void rows_flush(lpmp_engine* e) {     // rows -> packed duals, before the packed array is handed to anybody
@@ -1616,6 +1644,7 @@ static void compute_plain_passes(lpmp_engine* e, int n) {   // ComputeForwardPas
       issue_launches(e, fb, timed, e->stream, 3);
       if (timed && e->pending.size() > 4096) e->drain_timing();
     } else {
+      ensure_pass_chain_plan(e, e->mode);
       for (int i = 0; i < n; ++i) run_schedule(e, e->sched_pass[e->mode]);
     }
   } else {
@@ -2149,6 +2178,10 @@ int lpmp_boundary_enter(lpmp_engine* e) {
     HIP_CHECK(hipSetDevice(e->device));
     settle(e);
     check_chain(e);
+    // the boundary / halo kernels address dense pairwise vectors through device offsets, i.e. in the ROWS when that layout is on:
+    // whatever the caller put into the packed array since the last hand-over (lpmp_upload_duals, a write after lpmp_synchronize /
+    // lpmp_device_duals) must be in the rows before they are read, and before lpmp_boundary_leave marks the rows as the newer copy
+    rows_refresh(e);
   });
 }
 
@@ -2201,8 +2234,50 @@ int64_t lpmp_engine_device_dual_offset(lpmp_engine* e, int64_t packed_off) {
   if (f < 0 || f >= p.nf) return packed_off;
   return p.dev_doff[f] + (packed_off - p.f_doff[f]);
 }
+// internal (boundary.hip): is [packed_off, packed_off + len) a run of doubles inside ONE factor's dual?  (what the device
+// offset mapping above and the kernels that follow it assume)
+int lpmp_engine_dual_range_ok(lpmp_engine* e, int64_t packed_off, int64_t len) {
+  if (!e || !e->plan || len < 0 || packed_off < 0) return 0;
+  const Plan& p = e->plan->p;
+  if (packed_off + len > p.f_doff[p.nf]) return 0;
+  if (len == 0) return 1;
+  const int64_t f = (int64_t)(std::upper_bound(p.f_doff.begin(), p.f_doff.end(), packed_off) - p.f_doff.begin()) - 1;
+  return f >= 0 && f < p.nf && packed_off + len <= p.f_doff[f + 1] ? 1 : 0;
+}
 int lpmp_boundary_leave(lpmp_engine* e) {      // a boundary kernel wrote duals through device offsets: only the tracked bounds are stale
   return guarded([&] { require_model(e); e->lb_all_stale = true; if (e->rows) e->packed_stale = true; });
+}
+// Persistent launches (chain executor, joined passes in Infinity-Cache order) assume that resident workgroups keep running, i.e.
+// that the device is this process's own (kernels.hip): a host that knows it shares the device switches them off per engine.
+// The environment's LPMP_NO_CHAIN / LPMP_NO_BLOCKED_PASSES keep the last word (off stays off).
+int lpmp_set_persistent_launches(lpmp_engine* e, int on) {
+  return guarded([&] {
+    if (!e) throw std::runtime_error("null engine");
+    if (e->plan) { HIP_CHECK(hipSetDevice(e->device)); settle(e); }
+    const char* nc = std::getenv("LPMP_NO_CHAIN"); const char* nb = std::getenv("LPMP_NO_BLOCKED_PASSES");
+    e->use_chain = on != 0 && !(nc && nc[0] == '1');
+    e->use_blocked_passes = on != 0 && !(nb && nb[0] == '1');
+  });
+}
+int lpmp_persistent_launches(const lpmp_engine* e) { return e && e->use_chain && e->use_blocked_passes ? 1 : 0; }
+// "pci=<domain:bus:device.function> uuid=<32 hex digits>" of a HIP device ordinal: what tells two ranks that they sit on the same
+// physical GPU when every rank has a visibility mask of its own (then both see "device 0")
+int lpmp_device_identity(int device, char* out, int64_t cap) {
+  return guarded([&] {
+    if (!out || cap < 64) throw std::runtime_error("lpmp_device_identity: buffer of at least 64 bytes needed");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw DeviceError("no HIP device available");
+    if (device < 0 || device >= n) throw DeviceError("device ordinal out of range");
+    char pci[32] = {0};
+    HIP_CHECK(hipDeviceGetPCIBusId(pci, (int)sizeof(pci), device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    std::string s = std::string("pci=") + pci + " uuid=";
+    static const char* hex = "0123456789abcdef";
+    for (unsigned char c : prop.uuid.bytes) { s += hex[c >> 4]; s += hex[c & 15]; }
+    if ((int64_t)s.size() + 1 > cap) s.resize((size_t)cap - 1);
+    std::memcpy(out, s.c_str(), s.size() + 1);
+  });
 }
 int lpmp_set_rows_layout(lpmp_engine* e, int on) {
   return guarded([&] { if (!e) throw std::runtime_error("null engine"); e->want_rows = on != 0; });

@@ -19,21 +19,26 @@ namespace {
 // Contiguous chunks of [0, n) on up to LPMP_PLAN_THREADS (default: the hardware's, at most 16) threads; small ranges run on the
 // caller's thread.  The analysis below is a handful of linear passes over millions of updates: the two that build the
 // op records and the packets are independent per update / per record.  An exception of any chunk is rethrown.
+constexpr int PLAN_MAX_THREADS = 64;
 template <class F>
 void parallel_chunks(int64_t n, int64_t min_per_thread, F&& f) {
   static const int max_threads = [] {
     const char* e = std::getenv("LPMP_PLAN_THREADS");
     const int hw = (int)std::thread::hardware_concurrency();
-    return std::max(1, e ? std::atoi(e) : std::min(16, hw > 0 ? hw : 1));
+    // (the per-thread scratch of the callers below has PLAN_MAX_THREADS slots: the thread index never exceeds it)
+    return std::max(1, std::min(PLAN_MAX_THREADS, e ? std::atoi(e) : std::min(16, hw > 0 ? hw : 1)));
   }();
   const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(max_threads, n / std::max<int64_t>(1, min_per_thread)));
   if (nt <= 1) { f((int64_t)0, n, 0); return; }
   std::vector<std::thread> th;
   std::vector<std::exception_ptr> err((size_t)nt);
-  for (int t = 0; t < nt; ++t)
-    th.emplace_back([&, t] {
-      try { f(n * t / nt, n * (t + 1) / nt, t); } catch (...) { err[(size_t)t] = std::current_exception(); }
-    });
+  th.reserve((size_t)nt);
+  auto work = [&](int t) { try { f(n * t / nt, n * (t + 1) / nt, t); } catch (...) { err[(size_t)t] = std::current_exception(); } };
+  int started = 0;
+  try {
+    for (; started < nt - 1; ++started) th.emplace_back(work, started);
+  } catch (...) {}                                   // (no more threads to be had: the caller's thread takes the rest, chunk by chunk)
+  for (int t = started; t < nt; ++t) work(t);
   for (auto& x : th) x.join();
   for (auto& e : err) if (e) std::rethrow_exception(e);
 }
@@ -498,7 +503,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   std::vector<uint8_t> small_ok(N, 1);                       // lane-per-factor class: every size <= SMALL_MAXD
   std::vector<uint8_t> pw_right(N, 1);                       // updated dense pairwise factor, every op unary-pairwise with the factor on the right
   std::vector<int32_t> max_dim(N, 0);                        // largest peer table dim of the record
-  std::vector<int64_t> alg_bytes_of_thread(64, 0);
+  std::vector<int64_t> alg_bytes_of_thread(PLAN_MAX_THREADS, 0);
   // (several updates may share an owner record — folded sweeps — and land on different threads: the per-owner flags only
   // ever go from 1 to 0, sums and maxima are atomic)
   auto clear_flag = [](uint8_t& x) { __atomic_store_n(&x, (uint8_t)0, __ATOMIC_RELAXED); };
@@ -773,7 +778,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     }
     // flags of the records (independent of each other: chunks of the launch on several threads), then the packet stride
     const int64_t n_lr = lr.end - lr.begin;
-    std::vector<int> kmax_of(64, 0); std::vector<uint8_t> dup_of(64, 0);
+    std::vector<int> kmax_of(PLAN_MAX_THREADS, 0); std::vector<uint8_t> dup_of(PLAN_MAX_THREADS, 0);
     parallel_chunks(n_lr, 32768, [&](int64_t c0, int64_t c1, int thread) {
       int kmax_l = 0; bool dup_l = false;
       for (int64_t i = lr.begin + c0; i < lr.begin + c1; ++i) {
@@ -804,7 +809,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
       kmax_of[(size_t)thread] = kmax_l; dup_of[(size_t)thread] = dup_l;
     });
     int kmax = 0; bool dup_recv = false;
-    for (int t = 0; t < 64; ++t) { kmax = std::max(kmax, kmax_of[(size_t)t]); dup_recv = dup_recv || dup_of[(size_t)t]; }
+    for (int t = 0; t < PLAN_MAX_THREADS; ++t) { kmax = std::max(kmax, kmax_of[(size_t)t]); dup_recv = dup_recv || dup_of[(size_t)t]; }
     if (dup_recv) continue;                  // only the op-by-op kernels are safe for that: stride stays 0
     if (kmax > PK_MAX_OPS) {                 // too many ops for a packet: indirect mode if they fit the LDS slab
       if (kmax <= pk_class_cap(lr.kclass)) lr.stride = -1;

@@ -187,8 +187,13 @@ inline void parallel_blocks(int64_t n, int64_t min_per_thread, F&& f) {
   if (nt <= 1) { f((int64_t)0, n); return; }
   std::vector<std::thread> th;
   std::vector<std::exception_ptr> err((size_t)nt);
-  for (int64_t t = 0; t < nt; ++t)
-    th.emplace_back([&, t] { try { f(n * t / nt, n * (t + 1) / nt); } catch (...) { err[(size_t)t] = std::current_exception(); } });
+  th.reserve((size_t)nt);
+  auto work = [&](int64_t t) { try { f(n * t / nt, n * (t + 1) / nt); } catch (...) { err[(size_t)t] = std::current_exception(); } };
+  int64_t started = 0;
+  try {
+    for (; started < nt - 1; ++started) th.emplace_back(work, started);
+  } catch (...) {}                                   // (a thread could not be started: the caller's thread takes the remaining chunks)
+  for (int64_t t = started; t < nt; ++t) work(t);
   for (auto& x : th) x.join();
   for (auto& e : err) if (e) std::rethrow_exception(e);
 }

@@ -53,6 +53,7 @@ EXPORTS = [
     "lpmp_boundary_reply", "lpmp_boundary_fold", "lpmp_engine_stream", "lpmp_synth_fill_blocks",
     "lpmp_halo_create", "lpmp_halo_destroy", "lpmp_halo_out_doubles", "lpmp_halo_in_doubles", "lpmp_halo_pack", "lpmp_halo_unpack",
     "lpmp_set_speculation", "lpmp_speculation_stats", "lpmp_chain_cache_bytes",
+    "lpmp_set_persistent_launches", "lpmp_persistent_launches", "lpmp_device_identity",
 ]
 
 
@@ -150,6 +151,10 @@ def lib():
         if hasattr(L, "lpmp_set_rows_layout"):
             L.lpmp_set_rows_layout.argtypes = [C.c_void_p, C.c_int]
             L.lpmp_rows_layout.argtypes = [C.c_void_p]
+        if hasattr(L, "lpmp_set_persistent_launches"):
+            L.lpmp_set_persistent_launches.argtypes = [C.c_void_p, C.c_int]
+            L.lpmp_persistent_launches.argtypes = [C.c_void_p]
+            L.lpmp_device_identity.argtypes = [C.c_int, C.c_char_p, C.c_int64]
         L.lpmp_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]
         L.lpmp_synth_fill_blocks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.lpmp_boundary_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 5
@@ -408,6 +413,15 @@ class Engine:
     def chain_cache_bytes(self) -> int:
         return self.L.lpmp_chain_cache_bytes(self.h)
 
+    def set_persistent_launches(self, on: bool):
+        """chain executor / joined passes as persistent launches (include/lpmp_engine.h): off for an engine whose device is shared
+        with other processes — every schedule then runs launch by launch, same results"""
+        _chk(self.L.lpmp_set_persistent_launches(self.h, 1 if on else 0))
+
+    @property
+    def persistent_launches(self) -> bool:
+        return bool(self.L.lpmp_persistent_launches(self.h))
+
     def prepare_passes(self, n: int):
         """build ahead of time what compute_pass(n) needs that depends on n (outside of a timed region)"""
         _chk(self.L.lpmp_prepare_passes(self.h, int(n)))
@@ -591,6 +605,13 @@ class Engine:
                 out[KCLASS_NAMES[c]] = dict(kernel=name, ms=float(ms[c]), launches=int(arrs[0][c]),
                                             factors=int(arrs[1][c]), receives=int(arrs[2][c]), bytes=int(arrs[3][c]))
         return out
+
+
+def device_identity(device: int = 0) -> str:
+    """"pci=... uuid=..." of a HIP device ordinal: equal strings = one physical GPU, whatever each process calls it"""
+    buf = C.create_string_buffer(128)
+    _chk(lib().lpmp_device_identity(int(device), buf, 128))
+    return buf.value.decode()
 
 
 def synth_fill_blocks(device_ptr: int, n_blocks: int, block_len: int, seed: int, first_dev_ptr: int, stream_ptr: int = 0):

@@ -575,12 +575,16 @@ inline void lockstep_exchange(std::vector<lockstep_part*>& parts, lockstep_plan&
   for (lockstep_part* p : parts) { hs.push_back(&p->halo_plan(pl, st, n_parts)); lpmp_ok(lpmp_halo_pack(p->e, hs.back()->h, hs.back()->d_send)); }
   const int first_part = w.rank * w.parts_per_rank;
   auto offset = [](const std::vector<int64_t>& count, int q) { int64_t off = 0; for (int r = 0; r < q; ++r) off += count[(size_t)r]; return off; };
-  nccl_ok(ncclGroupStart(), "ncclGroupStart");
+  // (two parts of this rank must agree on what travels between them: checked before the group is opened)
+  for_each_transfer(n_parts, w.rank, w.parts_per_rank, [&](int src, int dst, bool src_here, bool dst_here) {
+      if (src_here && dst_here && hs[(size_t)(src - first_part)]->out_count[(size_t)dst] != hs[(size_t)(dst - first_part)]->in_count[(size_t)src])
+        throw std::runtime_error("lockstep: two parts disagree on an exchange");
+    });
+  nccl_group grp;      // (closed on every path, also when a transfer below throws)
   for_each_transfer(n_parts, w.rank, w.parts_per_rank, [&](int src, int dst, bool src_here, bool dst_here) {
       if (src_here && dst_here) {
         lockstep_part::halo &hs_ = *hs[(size_t)(src - first_part)], &hd = *hs[(size_t)(dst - first_part)];
         const int64_t c = hs_.out_count[(size_t)dst];
-        if (c != hd.in_count[(size_t)src]) throw std::runtime_error("lockstep: two parts disagree on an exchange");
         if (c > 0) hip_ok(hipMemcpyAsync(hd.d_recv + offset(hd.in_count, src), hs_.d_send + offset(hs_.out_count, dst), (size_t)c * sizeof(double), hipMemcpyDeviceToDevice, w.stream), "hipMemcpyAsync");
       } else if (src_here) {
         lockstep_part::halo& h = *hs[(size_t)(src - first_part)];
@@ -592,7 +596,7 @@ inline void lockstep_exchange(std::vector<lockstep_part*>& parts, lockstep_plan&
         if (c > 0) nccl_ok(ncclRecv(h.d_recv + offset(h.in_count, src), (size_t)c, ncclDouble, w.rank_of(src), w.comm, w.stream), "ncclRecv");
       }
     });
-  nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+  grp.end();
   for (size_t x = 0; x < parts.size(); ++x) lpmp_ok(lpmp_halo_unpack(parts[x]->e, hs[x]->h, hs[x]->d_recv));
 }
 

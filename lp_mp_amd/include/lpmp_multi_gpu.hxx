@@ -31,14 +31,17 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -49,6 +52,42 @@ namespace lpmp_mgpu {
 inline void hip_ok(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); }
 inline void nccl_ok(ncclResult_t r, const char* what) { if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r)); }
 inline void lpmp_ok(int rc) { if (rc != LPMP_OK) throw std::runtime_error(lpmp_last_error()); }   // the type the reference throws (LP_MP.h:458)
+
+// ncclGroupStart ... ncclGroupEnd that is closed on every path: an exception between the two (a failed send, a count check)
+// must not leave the group open — the next RCCL call of the process would be queued into it and never run
+struct nccl_group {
+  bool open = false;
+  nccl_group() { nccl_ok(ncclGroupStart(), "ncclGroupStart"); open = true; }
+  void end() { open = false; nccl_ok(ncclGroupEnd(), "ncclGroupEnd"); }
+  ~nccl_group() { if (open) (void)ncclGroupEnd(); }
+  nccl_group(const nccl_group&) = delete;
+  nccl_group& operator=(const nccl_group&) = delete;
+};
+
+// Bounds a call that has no time-out of its own (ncclCommInitRank waits for ever for a rank that never comes): when the
+// guarded scope is not left within timeout_s the process says which rank waited for what and EXITS non-zero (3) — never a retry
+// in a process that has touched the GPU, never a re-exec.  timeout_s <= 0: no bound.
+struct exit_watchdog {
+  std::mutex m; std::condition_variable cv; bool done = false; std::thread th;
+  exit_watchdog(double timeout_s, std::string what) {
+    if (timeout_s <= 0) return;
+    th = std::thread([this, timeout_s, what] {
+      std::unique_lock<std::mutex> l(m);
+      if (!cv.wait_for(l, std::chrono::duration<double>(timeout_s), [this] { return done; })) {
+        std::fprintf(stderr, "lpmp_mgpu: %s did not return within %.0f s; exiting with code 3\n", what.c_str(), timeout_s);
+        std::fflush(stderr);
+        ::_exit(3);
+      }
+    });
+  }
+  ~exit_watchdog() {
+    { std::lock_guard<std::mutex> l(m); done = true; }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+  exit_watchdog(const exit_watchdog&) = delete;
+  exit_watchdog& operator=(const exit_watchdog&) = delete;
+};
 
 constexpr double BOUNDARY_SHARE = 0.375;   // send weight of a boundary variable's cut messages, shared out
 
@@ -213,8 +252,21 @@ struct rccl_world {
     ncclUniqueId id;
     if (rank == 0) nccl_ok(ncclGetUniqueId(&id), "ncclGetUniqueId");
     hand_out_id(id, rank, world, master_addr, master_port, timeout_s);
-    nccl_ok(ncclCommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+    {
+      // (LPMP_RCCL_INIT_TIMEOUT_S overrides; the bound covers the rendezvous only, not later collectives)
+      const char* ev = std::getenv("LPMP_RCCL_INIT_TIMEOUT_S");
+      exit_watchdog wd(ev ? std::atof(ev) : timeout_s, "rank " + std::to_string(rank) + " of " + std::to_string(world) + ": ncclCommInitRank");
+      nccl_ok(ncclCommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+    }
     hip_ok(hipMalloc((void**)&d_scalar, 2 * sizeof(double)), "hipMalloc");
+    self_test(timeout_s);
+  }
+  // one tiny all-reduce under the same bound before any real exchange: a communicator whose ranks cannot reach each other fails
+  // HERE, named, instead of inside the first timed pass
+  void self_test(double timeout_s) {
+    exit_watchdog wd(timeout_s, "rank " + std::to_string(rank) + " of " + std::to_string(world) + ": the first ncclAllReduce");
+    const double got = all_reduce_sum(1.0);
+    if (got != (double)world) throw std::runtime_error("rccl_world: self test: all-reduce of 1 over " + std::to_string(world) + " ranks gave " + std::to_string(got));
   }
   double all_reduce_sum(double x) {
     hip_ok(hipMemcpyAsync(d_scalar, &x, sizeof(double), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
@@ -376,7 +428,7 @@ inline void for_each_transfer(int n_parts, int rank, int parts_per_rank, F&& f) 
 // rank b meets the k-th receive of b from a.
 inline void exchange(std::vector<part_sweep*>& parts, rccl_world& w, bool first_leg) {
   const int n_parts = parts.empty() ? 0 : parts[0]->pm.n_parts;
-  nccl_ok(ncclGroupStart(), "ncclGroupStart");
+  nccl_group grp;      // (closed on every path, also when a transfer below throws)
   for_each_transfer(n_parts, w.rank, w.parts_per_rank, [&](int src, int dst, bool src_here, bool dst_here) {
       // leg 1: what src OWNS toward dst (out lists) travels src -> dst; leg 2: dst's replies travel back dst -> src
       if (first_leg) {
@@ -391,7 +443,7 @@ inline void exchange(std::vector<part_sweep*>& parts, rccl_world& w, bool first_
           if (c > 0) { int64_t off = 0; for (int q = 0; q < dst; ++q) off += p.out_count[q]; nccl_ok(ncclRecv(p.d_back + off, (size_t)c, ncclDouble, w.rank_of(dst), w.comm, w.stream), "ncclRecv"); } }
       }
     });
-  nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+  grp.end();
 }
 
 inline void boundary_step(std::vector<part_sweep*>& parts, rccl_world& w) {

@@ -215,14 +215,18 @@ class window_sweep {
 inline void overlap_exchange(std::vector<window_sweep*>& parts, rccl_world& w) {
   for (window_sweep* p : parts) for (int d = 0; d < 2; ++d) if (p->n_send[d] > 0) p->pack(d);
   const int n_parts = parts.empty() ? 0 : parts[0]->wm.n_parts;
-  nccl_ok(ncclGroupStart(), "ncclGroupStart");
+  for (int q = 0; q + 1 < n_parts; ++q)              // neighbouring windows of this rank must agree: checked before the group is opened
+    if (w.rank_of(q) == w.rank && w.rank_of(q + 1) == w.rank) {
+      window_sweep &up = *parts[(size_t)(q - w.rank * w.parts_per_rank)], &down = *parts[(size_t)(q + 1 - w.rank * w.parts_per_rank)];
+      if (up.n_send[1] != down.n_recv[0] || down.n_send[0] != up.n_recv[1]) throw std::runtime_error("overlap: neighbouring windows disagree on the exchange");
+    }
+  nccl_group grp;      // (closed on every path, also when a transfer below throws)
   for (int q = 0; q + 1 < n_parts; ++q) {          // the pair (q, q + 1), both directions; fixed order: sends and receives of two ranks match
     const bool up_here = w.rank_of(q) == w.rank, down_here = w.rank_of(q + 1) == w.rank;
     if (up_here && down_here) {
       // both parts on this rank: buffer to buffer on the stream (sends of a rank to itself pair up in issue order, which is not
       // the order of this loop's receives)
       window_sweep &up = *parts[(size_t)(q - w.rank * w.parts_per_rank)], &down = *parts[(size_t)(q + 1 - w.rank * w.parts_per_rank)];
-      if (up.n_send[1] != down.n_recv[0] || down.n_send[0] != up.n_recv[1]) throw std::runtime_error("overlap: neighbouring windows disagree on the exchange");
       hip_ok(hipMemcpyAsync(down.d_recv[0], up.d_send[1], (size_t)up.n_send[1] * sizeof(double), hipMemcpyDeviceToDevice, w.stream), "hipMemcpyAsync");
       hip_ok(hipMemcpyAsync(up.d_recv[1], down.d_send[0], (size_t)down.n_send[0] * sizeof(double), hipMemcpyDeviceToDevice, w.stream), "hipMemcpyAsync");
       continue;
@@ -238,7 +242,7 @@ inline void overlap_exchange(std::vector<window_sweep*>& parts, rccl_world& w) {
       nccl_ok(ncclRecv(p.d_recv[0], (size_t)p.n_recv[0], ncclDouble, w.rank_of(q), w.comm, w.stream), "ncclRecv");
     }
   }
-  nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+  grp.end();
   for (window_sweep* p : parts) for (int d = 0; d < 2; ++d) if (p->n_recv[d] > 0) p->unpack(d);
 }
 

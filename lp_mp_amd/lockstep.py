@@ -490,13 +490,33 @@ class LockstepSweep:
                 self.engine.halo_destroy(h[0])
         self._halo = {}
 
-    def compute_pass(self, comm, n=1):
+    def compute_pass(self, comm, n=1, probe=None):
+        """``probe``: multi_gpu.ExchangeProbe — every pack -> all-to-all -> unpack span and the whole call get event pairs"""
+        if probe is not None:
+            probe.start()
         for step in self.sched.program(n):
             if step[0] == "run":
                 self.run(step[1])
             else:
+                if probe is not None:
+                    probe.begin_exchange()
                 send, out_counts, in_counts = self.halo_pack(step[1], step[2])
                 self.halo_unpack(step[1], comm.exchange(send, out_counts, in_counts), step[2])
+                if probe is not None:
+                    probe.end_exchange(out_counts.sum(), in_counts.sum())
+        if probe is not None:
+            probe.stop()
+
+    def exchange_counts(self, n=2):
+        """split sizes (doubles per peer rank) of the largest exchange of an n-pass call: for a self test of the collective"""
+        best = None
+        for step in self.sched.program(n):
+            if step[0] == "halo":
+                _, out_counts, _, in_counts = self._halo_plan(step[1], step[2])
+                if best is None or int(out_counts.sum()) > int(best[0].sum()):
+                    best = (out_counts, in_counts)
+        world = getattr(self.part, "true_world", self.part.world)
+        return best if best is not None else (np.zeros(world, np.int64), np.zeros(world, np.int64))
 
     def local_lower_bound(self) -> float:
         if hasattr(self.engine, "invalidate_lower_bounds"):
@@ -556,12 +576,28 @@ def strips_lockstep_part(H: int, W: int, L: int, pairwise: str, order: str, rank
     return sched, p
 
 
-class _Driver:
-    def _setup(self, torch, dist, part, sched, mode, fill=True):
+from .multi_gpu import DriverStats
+
+
+class _Driver(DriverStats):
+    def _setup(self, torch, dist, part, sched, mode, fill=True, rows_layout=False, engine_factory=None):
+        """``rows_layout``: dense pairwise factors as [table | m1 | m2] rows (lpmp_set_rows_layout) — the halo kernels address the
+        rows themselves, so the lock-step exchange works on either layout; never taken from the environment here.
+        ``engine_factory(part) -> (dual tensor, engine)``: tests run the driver logic (partition hand-over, program, exchange,
+        statistics) on a stand-in engine over gloo; the product path below creates the HIP engine and fails without a GPU"""
         from . import engine as E
         from . import multi_gpu as MG
         self.torch, self.dist, self.part, self.sched = torch, dist, part, sched
         self.comm = MG.DistComm(dist, torch) if dist is not None and dist.is_initialized() else None
+        if engine_factory is not None:
+            self.dualt, self.engine = engine_factory(part)
+            self.engine.set_reparametrization(mode)
+            self.sweep = LockstepSweep(torch, part, sched, self.engine, self.dualt)
+            vals = torch.tensor([float(self.sweep.updates_per_pass()), 0.0], dtype=torch.float64)
+            if self.comm:
+                dist.all_reduce(vals)
+            self.global_updates_per_pass, self.global_bytes_per_pass, self.levels = int(vals[0].item()), 0, list(sched.n_levels)
+            return
         dev = torch.device("cuda", torch.cuda.current_device())
         if self.comm:
             self.comm._dev = dev
@@ -578,7 +614,8 @@ class _Driver:
             self.dualt = torch.from_numpy(m.dual_data.copy()).to(dev)
         self.engine = E.Engine(torch.cuda.current_device())
         self.engine.set_stream(stream)
-        self.engine.upload(m, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt))
+        self.engine.upload(m, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt), rows_layout=bool(rows_layout))
+        self.own_the_engine(self.engine)
         self.engine.set_reparametrization(mode)
         self.sweep = LockstepSweep(torch, part, sched, self.engine, self.dualt)
         # the schedules of the steady state (built here, outside any timed region) and their algorithmic bytes per pass
@@ -603,13 +640,17 @@ class _Driver:
             else:
                 self.sweep._halo_plan(step[1], step[2])
 
-    def compute_pass(self, n=1):
+    def compute_pass(self, n=1, probe=None):
         if self.comm is None:
+            if probe is not None:
+                probe.start()
             for step in self.sched.program(n):
                 if step[0] == "run":
                     self.sweep.run(step[1])
+            if probe is not None:
+                probe.stop()
             return
-        self.sweep.compute_pass(self.comm, n)
+        self.sweep.compute_pass(self.comm, n, probe=probe)
 
     def lower_bound(self):
         lb = self.sweep.local_lower_bound()
@@ -632,6 +673,8 @@ class LockstepStrips(_Driver):
         rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
         sched, part = strips_lockstep_part(H, W, L, pairwise, order, rank, world, mode, seed, proxy)
         self._setup(torch, dist, part, sched, mode)
+        from . import multi_gpu as MG
+        self.cut_fraction = (world - 1) * W / max(1, world * MG.strip_sizes(H, W)[1] + (world - 1) * W)
 
 
 class LockstepGraph(_Driver):
@@ -642,13 +685,17 @@ class LockstepGraph(_Driver):
     generator's own order.  The order is part of the problem (another order is another, equally valid sweep): the
     unpartitioned sweep the result equals bit for bit is the one of counter_graph_model(..., rank=self.rank_of)."""
 
-    def __init__(self, torch, dist, n, m, L, mode, seed=1, part_of=None, order="colour_major"):
+    def __init__(self, torch, dist, n, m, L, mode, seed=1, part_of=None, order="colour_major", partitioner="auto", rows_layout=False,
+                 engine_factory=None):
+        """``part_of``: a partition handed in (variable -> rank in the ORDERED numbering, e.g. multi_gpu.load_partition_file); else
+        ``partitioner`` (multi_gpu.graph_partition's ``method``: auto / metis / builtin) computes one on rank 0"""
         from . import multi_gpu as MG
         from . import ordering as O
         on = dist is not None and dist.is_initialized()
         rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
         self.order = order
         self.rank_of = None
+        self.partitioner = "given" if part_of is not None else "none (1 part)"
         if order == "colour_major":
             compute = lambda: O.colour_major_order(n, *S.counter_graph_edges(n, m, seed), seed=seed)
             # (a colouring of 2 M variables / 10 M edges is a minute of numpy: once, on rank 0)
@@ -658,12 +705,20 @@ class LockstepGraph(_Driver):
         ei, ej = S.counter_graph_edges(n, m, seed, self.rank_of)
         if part_of is None:
             if world > 1:
-                part_of = MG.broadcast_partition(torch, dist, n, None, lambda: MG.graph_partition(n, ei, ej, world))
+                used = []
+                def compute_part():
+                    p, how = MG.graph_partition(n, ei, ej, world, method=partitioner, return_method=True)
+                    used.append(how)
+                    return p
+                part_of = MG.broadcast_partition(torch, dist, n, None, compute_part)
+                self.partitioner = MG.broadcast_string(dist, used[0] if used else None)
             else:
                 part_of = np.zeros(n, np.int64)
+        part_of = np.asarray(part_of, np.int64)
+        self.part_of = part_of
         self.cut_fraction = float((part_of[ei] != part_of[ej]).mean())
         sched, parts = lockstep_mrf(n, L, ei, ej, part_of, world, mode, only=rank, stream_seed=seed)
-        self._setup(torch, dist, parts[0], sched, mode)
+        self._setup(torch, dist, parts[0], sched, mode, rows_layout=rows_layout, engine_factory=engine_factory)
 
 
 class LockstepModel(_Driver):
@@ -671,8 +726,10 @@ class LockstepModel(_Driver):
     multicut triplets, ...  Every rank holds ``global_model`` on the host (structure and costs) and takes its own part of it;
     ``part_of[f]``: rank of variable f (e.g. multi_gpu.graph_partition_model, computed once and broadcast)."""
 
-    def __init__(self, torch, dist, global_model: M.FlatModel, part_of, mode):
+    def __init__(self, torch, dist, global_model: M.FlatModel, part_of, mode, engine_factory=None):
         rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
         sched, parts = lockstep_model(global_model, part_of, world, mode, only=rank)
-        self._setup(torch, dist, parts[0], sched, mode, fill=False)
+        self._setup(torch, dist, parts[0], sched, mode, fill=False, engine_factory=engine_factory)
+        # share of the cut: messages whose vector has a copy on another rank
+        self.cut_fraction = float((np.diff(sched.dest_off) > 0).mean()) if sched.n_vecs else 0.0
 

@@ -26,6 +26,8 @@ the oracle on the unpartitioned model (tests/test_multi_gpu.py does exactly that
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -153,6 +155,15 @@ def broadcast_partition(torch, dist, n: int, device, compute) -> np.ndarray:
     return t.numpy()
 
 
+def broadcast_string(dist, text: Optional[str]) -> Optional[str]:
+    """rank 0's string on every rank (host group): which partitioner ran there"""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return text
+    box = [text]
+    dist.broadcast_object_list(box, 0, group=host_group(dist))
+    return box[0]
+
+
 def partition_model(gm: M.FlatModel, part: np.ndarray, world: int) -> List[LocalPart]:
     """General partitioner: any factor graph whose messages all have the `left` schedule and whose factors are either
     "variables" (left factor of their messages: MRF unaries, multicut edge factors, ...) or "higher factors" (right
@@ -255,17 +266,30 @@ def partition_model(gm: M.FlatModel, part: np.ndarray, world: int) -> List[Local
 
 
 def graph_partition(n_vars: int, edge_i: np.ndarray, edge_j: np.ndarray, world: int, refine_rounds: int = 30,
-                    imbalance: float = 0.03, seed: int = 0) -> np.ndarray:
-    """k-way partition of a sparse variable graph without METIS (not in this image; SURVEY 8e allows a built-in
-    partitioner): a reverse Cuthill-McKee order (bandwidth reducing, scipy.sparse.csgraph) cut into ``world``
-    contiguous chunks, then refined by balanced Kernighan-Lin / label-propagation moves (``refine_partition``): every
-    round each variable looks at the part most of its neighbours live in and moves there if that cuts fewer edges and
-    the target stays within (1 + imbalance) of the mean size.  Graphs with locality get few cut edges; G(n, m) random
-    graphs have little to exploit (any balanced partition cuts most of the edges), the refinement recovers a few
-    percent there.  Deterministic: every rank computes the same partition from the same edge list."""
+                    imbalance: float = 0.03, seed: int = 0, method: str = "auto", return_method: bool = False):
+    """k-way partition of a sparse variable graph.  ``method``:
+      "metis"     METIS_PartGraphKway through `pymetis` or a `libmetis.so` found by the loader (metis_partition); an error when
+                  neither is there;
+      "builtin"   no METIS (not in this image; SURVEY 8e allows a built-in partitioner): a reverse Cuthill-McKee order (bandwidth
+                  reducing, scipy.sparse.csgraph) cut into ``world`` contiguous chunks, then refined by balanced Kernighan-Lin /
+                  label-propagation moves (``refine_partition``): every round each variable looks at the part most of its
+                  neighbours live in and moves there if that cuts fewer edges and the target stays within (1 + imbalance) of the
+                  mean size.  Graphs with locality get few cut edges; G(n, m) random graphs have little to exploit (any balanced
+                  partition cuts most of the edges), the refinement recovers a few percent there;
+      "auto"      METIS when present, else the built-in one (LPMP_PARTITIONER in the environment overrides "auto").
+    Deterministic for a given method: every rank computes the same partition from the same edge list (multi-process drivers
+    still compute it once, on rank 0, and broadcast it).  ``return_method``: also the name of what ran (bench.py prints it)."""
+    if method == "auto":
+        method = os.environ.get("LPMP_PARTITIONER", "auto")
+    if method not in ("auto", "metis", "builtin"):
+        raise ValueError("graph_partition: method must be auto, metis or builtin")
+    edge_i = np.asarray(edge_i, np.int64); edge_j = np.asarray(edge_j, np.int64)
+    if method in ("auto", "metis") and world > 1:
+        got = metis_partition(n_vars, edge_i, edge_j, world, imbalance, seed, required=method == "metis")
+        if got is not None:
+            return (got[0], got[1]) if return_method else got[0]
     from scipy.sparse import coo_matrix
     from scipy.sparse.csgraph import reverse_cuthill_mckee
-    edge_i = np.asarray(edge_i, np.int64); edge_j = np.asarray(edge_j, np.int64)
     a = coo_matrix((np.ones(edge_i.shape[0], np.float32), (edge_i, edge_j)), shape=(n_vars, n_vars)).tocsr()
     a = (a + a.T).tocsr()
     order = reverse_cuthill_mckee(a, symmetric_mode=True)
@@ -273,6 +297,108 @@ def graph_partition(n_vars: int, edge_i: np.ndarray, edge_j: np.ndarray, world: 
     part[order] = (np.arange(n_vars) * world) // n_vars
     if world > 1 and refine_rounds > 0:
         part = refine_partition(a, part, world, refine_rounds, imbalance, seed)
+    return (part, "builtin (reverse Cuthill-McKee + balanced KL refinement)") if return_method else part
+
+
+_METIS = {}
+
+
+def _metis_library():
+    """a libmetis the loader finds (LPMP_METIS_LIB names one explicitly), checked once in a CHILD process on a 64-ring: idx_t may be
+    32 or 64 bits wide depending on how the library was built, and a wrong guess must not take this process down.  Returns
+    (ctypes library, idx dtype, real ctype) or None."""
+    if "lib" in _METIS:
+        return _METIS["lib"]
+    import ctypes, ctypes.util, subprocess, sys
+    _METIS["lib"] = None
+    name = os.environ.get("LPMP_METIS_LIB") or ctypes.util.find_library("metis")
+    if not name:
+        return None
+    probe = (
+        "import ctypes, sys, numpy as np\n"
+        "L = ctypes.CDLL(sys.argv[1]); bits = int(sys.argv[2]); I = np.int32 if bits == 32 else np.int64\n"
+        "n = 64; xadj = (2 * np.arange(n + 1)).astype(I); adj = np.stack([(np.arange(n) - 1) % n, (np.arange(n) + 1) % n], 1).reshape(-1).astype(I)\n"
+        "nv = np.array([n], I); nc = np.array([1], I); k = np.array([2], I); obj = np.zeros(1, I); part = np.full(n, -1, I)\n"
+        "p = lambda a: a.ctypes.data_as(ctypes.c_void_p)\n"
+        "rc = L.METIS_PartGraphKway(p(nv), p(nc), p(xadj), p(adj), None, None, None, p(k), None, None, None, p(obj), p(part))\n"
+        "ok = rc == 1 and set(part.tolist()) == {0, 1} and abs(int((part == 0).sum()) - 32) <= 8 and 0 < int(obj[0]) <= 16\n"
+        "sys.exit(0 if ok else 1)\n")
+    for bits in (32, 64):
+        try:
+            rc = subprocess.run([sys.executable, "-c", probe, name, str(bits)], timeout=60, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+        except Exception:
+            rc = 1
+        if rc == 0:
+            _METIS["lib"] = (ctypes.CDLL(name), np.int32 if bits == 32 else np.int64, name)
+            break
+    return _METIS["lib"]
+
+
+def metis_partition(n_vars: int, edge_i, edge_j, world: int, imbalance: float = 0.03, seed: int = 0, required: bool = False):
+    """METIS k-way partition (edge cut objective) of the variable graph, or None when no METIS is installed (``required``: an
+    error instead).  Returns (part[int64], name of what ran).  `pymetis` first, then libmetis through ctypes."""
+    edge_i = np.asarray(edge_i, np.int64); edge_j = np.asarray(edge_j, np.int64)
+    from scipy.sparse import coo_matrix
+    def csr():
+        a = coo_matrix((np.ones(2 * edge_i.shape[0], np.int8), (np.concatenate([edge_i, edge_j]), np.concatenate([edge_j, edge_i]))), shape=(n_vars, n_vars)).tocsr()
+        a.sum_duplicates()
+        a.setdiag(0); a.eliminate_zeros()
+        return a
+    try:
+        import pymetis
+    except ImportError:
+        pymetis = None
+    if pymetis is not None:
+        a = csr()
+        _, membership = pymetis.part_graph(world, xadj=a.indptr.tolist(), adjncy=a.indices.tolist())
+        return np.asarray(membership, np.int64), "metis (pymetis %s)" % getattr(pymetis, "version", "")
+    lib = _metis_library()
+    if lib is None:
+        if required:
+            raise RuntimeError("graph_partition(method='metis'): neither pymetis nor a loadable libmetis (LPMP_METIS_LIB) is installed")
+        return None
+    import ctypes
+    L, I, name = lib
+    a = csr()
+    if I == np.int32 and (a.indices.shape[0] >= 2**31 or n_vars >= 2**31):
+        raise RuntimeError("metis_partition: this libmetis has 32-bit indices, the graph needs 64")
+    xadj, adj = np.ascontiguousarray(a.indptr, I), np.ascontiguousarray(a.indices, I)
+    nv, nc, k, obj = np.array([n_vars], I), np.array([1], I), np.array([world], I), np.zeros(1, I)
+    part = np.zeros(n_vars, I)
+    opts = np.zeros(40, I)
+    L.METIS_SetDefaultOptions(opts.ctypes.data_as(ctypes.c_void_p))
+    opts[8] = seed                                             # METIS_OPTION_SEED
+    opts[16] = max(1, int(round(1000 * imbalance)))            # METIS_OPTION_UFACTOR: allowed imbalance in 1/1000
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    rc = L.METIS_PartGraphKway(p(nv), p(nc), p(xadj), p(adj), None, None, None, p(k), None, None, p(opts), p(obj), p(part))
+    if rc != 1:
+        raise RuntimeError("METIS_PartGraphKway failed with code %d" % rc)
+    return part.astype(np.int64), "metis (%s, %d-bit idx_t)" % (os.path.basename(name), 32 if I == np.int32 else 64)
+
+
+def load_partition_file(path: str, n_vars: int, world: int) -> np.ndarray:
+    """a partition handed in as a file: n_vars entries (variable -> part) as raw little-endian int64 or int32 (`*.bin`), as text
+    (one integer per line / whitespace separated: the format METIS' own gpmetis writes), or a numpy `*.npy`.  Checked: length,
+    range, no empty part (every rank takes part in every exchange)."""
+    if path.endswith(".npy"):
+        part = np.load(path)
+    elif path.endswith(".bin"):
+        raw = np.fromfile(path, np.uint8)
+        if raw.shape[0] == 8 * n_vars:
+            part = raw.view("<i8")
+        elif raw.shape[0] == 4 * n_vars:
+            part = raw.view("<i4")
+        else:
+            raise ValueError(f"{path}: {raw.shape[0]} bytes is neither {n_vars} int64 nor {n_vars} int32 entries")
+    else:
+        part = np.loadtxt(path, dtype=np.int64, ndmin=1)
+    part = np.ascontiguousarray(part, np.int64).reshape(-1)
+    if part.shape[0] != n_vars:
+        raise ValueError(f"{path}: {part.shape[0]} entries, the model has {n_vars} variables")
+    if part.min() < 0 or part.max() >= world:
+        raise ValueError(f"{path}: parts must lie in [0, {world})")
+    if np.bincount(part, minlength=world).min() == 0:
+        raise ValueError(f"{path}: a part without variables")
     return part
 
 
@@ -319,10 +445,10 @@ def refine_partition(adj, part: np.ndarray, world: int, rounds: int = 30, imbala
     return part
 
 
-def graph_partition_model(gm: M.FlatModel, world: int) -> np.ndarray:
+def graph_partition_model(gm: M.FlatModel, world: int, method: str = "auto", return_method: bool = False):
     """``part`` for partition_model: the variables of a factor graph (left factors of its messages) split by
     graph_partition on the graph that links the variables of every higher factor in a chain; entries of higher
-    factors are unused (0)."""
+    factors are unused (0).  ``method`` / ``return_method`` as graph_partition."""
     ml, mr = gm.m_left.astype(np.int64), gm.m_right.astype(np.int64)
     order = np.lexsort((ml, mr))                              # messages grouped by higher factor
     a, b, same = ml[order][:-1], ml[order][1:], mr[order][:-1] == mr[order][1:]
@@ -331,10 +457,10 @@ def graph_partition_model(gm: M.FlatModel, world: int) -> np.ndarray:
     rank_of = np.full(gm.n_factors, -1, np.int64); rank_of[var] = np.arange(var.shape[0])
     ei, ej = rank_of[a[same]], rank_of[b[same]]
     keep = ei != ej
-    p = graph_partition(var.shape[0], np.minimum(ei, ej)[keep], np.maximum(ei, ej)[keep], world)
+    p, how = graph_partition(var.shape[0], np.minimum(ei, ej)[keep], np.maximum(ei, ej)[keep], world, method=method, return_method=True)
     part = np.zeros(gm.n_factors, np.int64)
     part[var] = p
-    return part
+    return (part, how) if return_method else part
 
 
 # ---- row-strip grids: closed-form local parts (no global model is ever materialised) ------------
@@ -454,6 +580,73 @@ class DistComm:
         return float(t.item())
 
     _dev = "cpu"
+
+
+class ExchangeProbe:
+    """Where an N-rank pass spends its time, per rank: every exchange (pack -> collective -> unpack) is bracketed by a pair of
+    events on the stream the engine works on, the whole call by another pair; compute = total - exchanges.  The span of an
+    exchange INCLUDES waiting for the slowest peer (the collective synchronises the ranks): the rank with the largest compute
+    time is the one the others wait for.  Used in an untimed repetition of the timed passes (bench.py), never inside them.
+    HIP events when the duals live on the device, the host clock for stand-in engines on the CPU (tests)."""
+
+    def __init__(self, torch, on_device: bool):
+        self.torch, self.on_device = torch, bool(on_device)
+        self.spans, self.bytes_out, self.bytes_in, self.n_exchanges = [], 0, 0, 0
+        self._t0 = self._t1 = self._b = None
+
+    def _mark(self):
+        if self.on_device:
+            ev = self.torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        import time
+        return time.perf_counter()
+
+    def start(self):
+        self._t0 = self._mark()
+
+    def stop(self):
+        self._t1 = self._mark()
+
+    def begin_exchange(self):
+        self._b = self._mark()
+
+    def end_exchange(self, doubles_out: int, doubles_in: int):
+        self.spans.append((self._b, self._mark()))
+        self.bytes_out += 8 * int(doubles_out); self.bytes_in += 8 * int(doubles_in); self.n_exchanges += 1
+
+    def _ms(self, a, b) -> float:
+        return float(a.elapsed_time(b)) if self.on_device else (b - a) * 1e3
+
+    def result(self, n_passes: int) -> dict:
+        if self.on_device:
+            self.torch.cuda.synchronize()
+        total = self._ms(self._t0, self._t1)
+        exch = sum(self._ms(a, b) for a, b in self.spans)
+        n = max(1, int(n_passes))
+        return {"total_ms_per_pass": total / n, "exchange_ms_per_pass": exch / n, "compute_ms_per_pass": (total - exch) / n,
+                "exchanges_per_pass": self.n_exchanges / n, "exchange_bytes_out_per_pass": self.bytes_out / n,
+                "exchange_bytes_in_per_pass": self.bytes_in / n}
+
+
+def gather_rank_stats(dist, torch, comm, stats: dict) -> dict:
+    """every rank's ExchangeProbe.result() (+ whatever else the driver put into ``stats``: numbers only) on every rank, as
+    {"per_rank": {key: [v_0 ... v_{N-1}]}, "max": {...}, "mean": {...}, "slowest_rank": argmax compute_ms_per_pass}"""
+    keys = sorted(stats)
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    dev = "cpu" if (comm is None or comm.stage_cpu) else comm._dev
+    t = torch.zeros(world, len(keys), dtype=torch.float64, device=dev)
+    rank = dist.get_rank() if world > 1 or (dist is not None and dist.is_initialized()) else 0
+    t[rank] = torch.tensor([float(stats[k]) for k in keys], dtype=torch.float64, device=dev)
+    if dist is not None and dist.is_initialized():
+        dist.all_reduce(t)
+    t = t.cpu()
+    per = {k: [float(x) for x in t[:, i]] for i, k in enumerate(keys)}
+    out = {"per_rank": per, "max": {k: max(v) for k, v in per.items()}, "mean": {k: sum(v) / len(v) for k, v in per.items()}}
+    if "compute_ms_per_pass" in per:
+        c = per["compute_ms_per_pass"]
+        out["slowest_rank"] = int(max(range(len(c)), key=lambda r: c[r]))
+    return out
 
 
 class LocalComm:
@@ -676,19 +869,33 @@ class PartitionedSweep:
         self.engine.schedule_run(self.ghost_send)
 
     # -- stand-alone driver over a DistComm -------------------------------------------------------------
-    def boundary_step(self, comm):
+    def boundary_step(self, comm, probe=None):
+        # (the ghost receive / ghost send schedules inside pack and fold are part of the boundary step: what a probe brackets)
+        if probe is not None:
+            probe.begin_exchange()
         send = self.boundary_pack()
         recv = comm.exchange(send, self.out_counts, self.in_counts)
         reply = self.boundary_reply(recv)
         back = comm.exchange(reply, self.in_counts, self.out_counts)
         self.boundary_fold(back)
+        if probe is not None:
+            n = int(self.out_counts.sum()) + int(self.in_counts.sum())
+            probe.end_exchange(n, n); probe.n_exchanges += 1          # two all-to-alls per boundary step
 
-    def compute_pass(self, comm, n=1):
+    def compute_pass(self, comm, n=1, probe=None):
+        if probe is not None:
+            probe.start()
         for step in self.program(n):
             if step[0] == "run":
                 self.run(step[1])
             else:
-                self.boundary_step(comm)
+                self.boundary_step(comm, probe)
+        if probe is not None:
+            probe.stop()
+
+    def exchange_counts(self):
+        """split sizes of this part's largest exchange (doubles per peer rank): what a self test of the collective uses"""
+        return self.out_counts, self.in_counts
 
     def local_lower_bound(self):
         if hasattr(self.engine, "invalidate_lower_bounds"):
@@ -770,7 +977,51 @@ def run_lockstep(sweeps: List[PartitionedSweep], n_passes: int):
                 s.boundary_fold(b)
 
 
-class StripSweep:
+class DriverStats:
+    """what the bench.py drivers of all three schedules share: an untimed repetition of the passes under an ExchangeProbe, the
+    split sizes of the largest exchange, and the switches of an engine whose device is shared with other ranks.  The drivers read
+    and write the (borrowed) dual buffer between passes — directly or through the lpmp_halo_* / lpmp_boundary_* kernels — so
+    passes that run ahead of the caller are off, and the rows layout is whatever the driver asked for explicitly (never the
+    environment's LPMP_ROWS_LAYOUT)."""
+    redundant_fraction = 0.0
+
+    def own_the_engine(self, engine):
+        if hasattr(engine, "set_speculation"):
+            engine.set_speculation(0)
+        # ranks that sit on the SAME physical device (smoke runs of an N-rank job on one GPU) must not use persistent launches:
+        # found here, by the PCI address of every rank's device, not by the caller's guess from device ordinals
+        dist = getattr(self, "dist", None)
+        if hasattr(engine, "set_persistent_launches") and dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            from . import engine as E
+            ids = [None] * dist.get_world_size()
+            dist.all_gather_object(ids, E.device_identity(self.torch.cuda.current_device()), group=host_group(dist))
+            self.shared_device = len(set(ids)) < len(ids)
+            if self.shared_device and not os.environ.get("LPMP_BENCH_KEEP_PERSISTENT"):
+                engine.set_persistent_launches(False)
+
+    shared_device = False
+
+    def set_shared_device(self, shared: bool):
+        """ranks that time-share one GPU: persistent launches off for this rank's engine (include/lpmp_engine.h)"""
+        if hasattr(self.engine, "set_persistent_launches"):
+            self.engine.set_persistent_launches(not shared)
+
+    def probe_passes(self, n: int) -> dict:
+        """n passes with every exchange bracketed by events: this rank's compute / exchange split (ExchangeProbe.result)"""
+        probe = ExchangeProbe(self.torch, bool(getattr(self.dualt, "is_cuda", False)))
+        self.compute_pass(n, probe=probe)
+        out = probe.result(n)
+        out["redundant_fraction"] = float(self.redundant_fraction)
+        return out
+
+    def exchange_counts(self):
+        sw = getattr(self, "sweep", None)
+        if sw is None or getattr(self, "comm", None) is None:
+            return None
+        return sw.exchange_counts()
+
+
+class StripSweep(DriverStats):
     """bench.py driver: this rank's H x W strip of a (world*H) x W grid on its own GPU."""
 
     def __init__(self, torch, dist, H, W, L, pairwise, order, mode, seed=1, omega_b=None, boundary_every="pass"):
@@ -789,7 +1040,8 @@ class StripSweep:
         fill_device_costs(torch, E, part, self.const, self.dualt, stream)
         self.engine = E.Engine(torch.cuda.current_device())
         self.engine.set_stream(stream)
-        self.engine.upload(m, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt))
+        self.engine.upload(m, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt), rows_layout=False)
+        self.own_the_engine(self.engine)
         self.sweep = PartitionedSweep(torch, part, self.engine, self.dualt, mode, omega_b, boundary_every)
         t = torch.tensor([self.sweep.updates_per_pass(), self.sweep.bytes_per_pass()], dtype=torch.float64,
                          device="cpu" if self.comm.stage_cpu else dev)
@@ -797,9 +1049,10 @@ class StripSweep:
         self.global_updates_per_pass = int(t[0].item())
         self.global_bytes_per_pass = int(t[1].item())
         self.levels = [i["n_levels"] for i in self.sweep.info]
+        self.cut_fraction = (world - 1) * W / max(1, world * strip_sizes(H, W)[1] + (world - 1) * W)
 
-    def compute_pass(self, n=1):
-        self.sweep.compute_pass(self.comm, n)
+    def compute_pass(self, n=1, probe=None):
+        self.sweep.compute_pass(self.comm, n, probe=probe)
 
     def lower_bound(self):
         return self.comm.all_reduce_sum(self.sweep.local_lower_bound())
@@ -823,16 +1076,19 @@ def fill_device_costs(torch, E, part: LocalPart, const_t, dual_t, stream):
     return keep
 
 
-class GraphSweep:
+class GraphSweep(DriverStats):
     """bench.py driver for C4 (BASELINE.json configs[3]): this rank's part of the random sparse graph on its own GPU.
     The global model is never materialised: structure from the counter generator, costs generated in HBM.  Random
     graphs cut most of their edges under any balanced partition, so the boundary step runs after every directional
     sweep (boundary_every="sweep")."""
 
-    def __init__(self, torch, dist, n, m, L, mode, seed=1, omega_b=None, boundary_every=None, rows_layout=None, order="index"):
+    def __init__(self, torch, dist, n, m, L, mode, seed=1, omega_b=None, boundary_every=None, rows_layout=None, order="index",
+                 part_of=None, partitioner="auto"):
         """``order``: "index" = the generator's variable order; "colour_major" = the variables renamed by
         ordering.colour_major_order (9 dependent levels per directional sweep instead of 33 on the C4 shape): the model is then
-        synthetic.counter_graph_model(..., rank=self.rank_of) — what lockstep.LockstepGraph runs by default"""
+        synthetic.counter_graph_model(..., rank=self.rank_of) — what lockstep.LockstepGraph runs by default.
+        ``part_of``: a partition handed in (variable -> rank, in the ORDERED variable numbering); else ``partitioner``
+        (graph_partition's ``method``) computes one on rank 0"""
         from . import engine as E
         self.torch, self.dist = torch, dist
         self.comm = DistComm(dist, torch) if dist is not None and dist.is_initialized() else None
@@ -842,7 +1098,6 @@ class GraphSweep:
         dev = torch.device("cuda", torch.cuda.current_device())
         if self.comm:
             self.comm._dev = dev
-        part_of = None
         self.order, self.rank_of = order, None
         if order == "colour_major":
             from . import ordering as O
@@ -850,8 +1105,15 @@ class GraphSweep:
             self.rank_of = broadcast_partition(torch, dist, n, dev, compute) if self.comm and world > 1 else compute()
         elif order != "index":
             raise ValueError(order)
-        if self.comm and world > 1:                      # partition once, on rank 0
-            part_of = broadcast_partition(torch, dist, n, dev, lambda: graph_partition(n, *S.counter_graph_edges(n, m, seed, self.rank_of), world))
+        self.partitioner = "given" if part_of is not None else ("none (1 part)" if world == 1 else None)
+        if part_of is None and self.comm and world > 1:  # partition once, on rank 0
+            used = []
+            def compute_part():
+                p, how = graph_partition(n, *S.counter_graph_edges(n, m, seed, self.rank_of), world, method=partitioner, return_method=True)
+                used.append(how)
+                return p
+            part_of = broadcast_partition(torch, dist, n, dev, compute_part)
+            self.partitioner = broadcast_string(dist, used[0] if used else None)
         part = graph_local_part(n, m, L, rank, world, seed, part_of, self.rank_of)
         self.part = part
         mdl = part.model
@@ -861,7 +1123,9 @@ class GraphSweep:
         fill_device_costs(torch, E, part, self.const, self.dualt, stream)
         self.engine = E.Engine(torch.cuda.current_device())
         self.engine.set_stream(stream)
-        self.engine.upload(mdl, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt), rows_layout=rows_layout)
+        self.engine.upload(mdl, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt), rows_layout=bool(rows_layout))
+        if self.comm is not None:
+            self.own_the_engine(self.engine)
         n_cut = int(part.out_ghost.shape[0] + part.in_unary.shape[0])
         self.cut_fraction = n_cut / max(1, int(mdl.n_messages) // 2 + int(part.in_unary.shape[0]))
         if boundary_every is None:                       # few cut edges: once per pass (fused sweeps); many: every sweep
@@ -892,11 +1156,15 @@ class GraphSweep:
         if self.sweep is None:
             self.engine.prepare_passes(n)
 
-    def compute_pass(self, n=1):
+    def compute_pass(self, n=1, probe=None):
         if self.sweep is not None:
-            self.sweep.compute_pass(self.comm, n)
+            self.sweep.compute_pass(self.comm, n, probe=probe)
         else:                                           # one part: no boundary, plain engine passes
+            if probe is not None:
+                probe.start()
             self.engine.compute_pass(n)
+            if probe is not None:
+                probe.stop()
 
     def lower_bound(self):
         if self.sweep is None:
@@ -904,7 +1172,7 @@ class GraphSweep:
         return self.comm.all_reduce_sum(self.sweep.local_lower_bound())
 
 
-class ModelSweep:
+class ModelSweep(DriverStats):
     """Driver for an arbitrary partitioned model: this rank's part of ``global_model`` (partition_model) on its own
     GPU, cut messages exchanged through torch.distributed.  Every rank derives the partition from the same inputs."""
 
@@ -921,13 +1189,14 @@ class ModelSweep:
             self.dualt = torch.from_numpy(m.dual_data.copy()).to(dev)
             self.engine = E.Engine(torch.cuda.current_device())
             self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
-            self.engine.upload(m, dual_dev=self.dualt.data_ptr(), keep=self.dualt)
+            self.engine.upload(m, dual_dev=self.dualt.data_ptr(), keep=self.dualt, rows_layout=False)
+            self.own_the_engine(self.engine)
         else:                                             # tests: an engine stand-in on a host buffer
             self.dualt, self.engine = engine_factory(m)
         self.sweep = PartitionedSweep(torch, self.part, self.engine, self.dualt, mode, omega_b, boundary_every)
 
-    def compute_pass(self, n=1):
-        self.sweep.compute_pass(self.comm, n)
+    def compute_pass(self, n=1, probe=None):
+        self.sweep.compute_pass(self.comm, n, probe=probe)
 
     def lower_bound(self):
         return self.comm.all_reduce_sum(self.sweep.local_lower_bound())

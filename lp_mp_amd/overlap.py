@@ -225,11 +225,23 @@ class OverlapSweep:
             k = min(n, self.chunk); out.append(k); n -= k
         return out
 
-    def compute_pass(self, comm, n: int = 1):
+    def compute_pass(self, comm, n: int = 1, probe=None):
+        """``probe``: multi_gpu.ExchangeProbe — every pack -> all-to-all -> unpack span and the whole call get event pairs"""
+        if probe is not None:
+            probe.start()
         for k in self.chunks(n):
             self.engine.compute_pass(k)
             if self.part.world > 1:
+                if probe is not None:
+                    probe.begin_exchange()
                 self.unpack(comm.exchange(self.pack(), self.send_counts, self.recv_counts))
+                if probe is not None:
+                    probe.end_exchange(self.send_counts.sum(), self.recv_counts.sum())
+        if probe is not None:
+            probe.stop()
+
+    def exchange_counts(self):
+        return self.send_counts, self.recv_counts
 
     def local_lower_bound(self) -> float:
         if hasattr(self.engine, "invalidate_lower_bounds"):
@@ -263,7 +275,10 @@ def grid_pass_counts(GH: int, W: int, L: int, pairwise: str = "dense") -> Tuple[
 
 
 # ---- driver (one process per GPU) -----------------------------------------------------------------------------------
-class OverlapStrips:
+from .multi_gpu import DriverStats
+
+
+class OverlapStrips(DriverStats):
     """bench.py driver: this rank's window of the (world * H) x W grid.  The result is the single-GPU sweep of the whole
     grid, bit for bit; between two exchanges a rank runs plain joined passes."""
 
@@ -288,7 +303,10 @@ class OverlapStrips:
         MG.fill_device_costs(torch, E, part, self.const, self.dualt, stream)
         self.engine = E.Engine(torch.cuda.current_device())
         self.engine.set_stream(stream)
-        self.engine.upload(m, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt))
+        # (the exchange reads and writes the borrowed packed dual buffer directly between passes: packed layout, no passes ahead)
+        self.engine.upload(m, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt), rows_layout=False)
+        if self.comm is not None:
+            self.own_the_engine(self.engine)
         self.engine.set_reparametrization(mode)
         self.sweep = OverlapSweep(torch, part, self.engine, self.dualt, chunk)
         self.global_updates_per_pass, self.global_bytes_per_pass = grid_pass_counts(world * H, W, L, pairwise)
@@ -297,16 +315,21 @@ class OverlapStrips:
         self.window_rows = (part.r0, part.r1)
         # work this rank does beyond its share (ghost rows are updated too)
         self.redundant_fraction = (part.r1 - part.r0) / H - 1.0
+        self.cut_fraction = (world - 1) * W / max(1, (world * H) * (W - 1) + (world * H - 1) * W)
 
     def prepare_passes(self, n):
         for k in sorted(set(self.sweep.chunks(n))):
             self.engine.prepare_passes(k)
 
-    def compute_pass(self, n=1):
+    def compute_pass(self, n=1, probe=None):
         if self.comm is None:
+            if probe is not None:
+                probe.start()
             self.engine.compute_pass(n)
+            if probe is not None:
+                probe.stop()
         else:
-            self.sweep.compute_pass(self.comm, n)
+            self.sweep.compute_pass(self.comm, n, probe=probe)
 
     def lower_bound(self):
         lb = self.sweep.local_lower_bound()

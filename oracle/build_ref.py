@@ -6,7 +6,8 @@ Buildable with plain g++ (no cmake, no external library, no generated code): `in
 `weight_array` / `receive_array` container of the sweep) — the reference's own test of it
 (`test/test_two_dimensional_variable_array.cpp` + `test/test.h`) and a driver of ours around the header (`oracle/ref_two_dim.cpp`);
 `include/union_find.hxx` (numbers the partitions of the partition sweeps, a19) driven as `LP::construct_factor_partition` drives it
-(`oracle/ref_union_find.cpp`).
+(`oracle/ref_union_find.cpp`); `two_smallest_elements` of `include/help_functions.hxx:106-120` (no third-party include), the scalar
+two-minimum behind the Potts O(L) message, a13 (`oracle/ref_two_smallest.cpp`).
 Everything else on the path (`LP_MP.h`, `factors_messages.hxx`, `vector.hxx`, `topological_sort.hxx` through `config.hxx`) needs
 tclap / simdpp / meta from the empty `external/` submodules: unbuildable here, pinned by known answers instead."""
 import os
@@ -18,6 +19,7 @@ OUT = os.path.join(HERE, "_ref")
 REF = os.environ.get("LPMP_REFERENCE", "/root/reference")
 TARGETS = {"ref_two_dim": [os.path.join(HERE, "ref_two_dim.cpp")],
            "ref_union_find": [os.path.join(HERE, "ref_union_find.cpp")],
+           "ref_two_smallest": [os.path.join(HERE, "ref_two_smallest.cpp")],
            "ref_test_two_dimensional_variable_array": [os.path.join(REF, "test", "test_two_dimensional_variable_array.cpp")]}
 
 

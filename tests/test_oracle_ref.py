@@ -107,3 +107,75 @@ def test_partitions_are_numbered_as_the_references_union_find_numbers_them(ref):
         assert got == want, trial                                       # same numbering, members in factor order
         o = Oracle(gm)
         assert [list(map(int, a)) for a in o.partitions()] == want, trial
+
+
+# ---- a13: the scalar two-minimum behind the O(L) Potts message, from the reference's own help_functions.hxx ------------------------
+def _ref_two_smallest(exe, vectors):
+    def tok(x):
+        return "inf" if x == np.inf else "-inf" if x == -np.inf else float(x).hex()
+    text = "\n".join(" ".join([str(len(v))] + [tok(x) for x in v]) for v in vectors)
+    out = subprocess.check_output([exe], input=text, text=True, timeout=120).split()
+    return [(float.fromhex(a) if "inf" not in a else float(a), float.fromhex(b) if "inf" not in b else float(b)) for a, b in zip(out[0::2], out[1::2])]
+
+
+def _potts_vectors(rng, n_cases, with_inf):
+    """message vectors on an exact grid (multiples of 1/8: every sum below is exact whatever the order of the additions), with ties,
+    label counts 1, 2 and non-powers of two, optionally +-inf entries"""
+    cases = []
+    for k in range(n_cases):
+        L = [1, 2, 3, 5, 8, 13, 32, 33, 64, 100][k % 10]
+        m2 = rng.integers(-40, 40, L) / 8.0
+        if k % 3 == 0 and L > 1:
+            m2[rng.integers(0, L)] = m2.min()                           # a tie for the minimum
+        if k % 4 == 1 and L > 2:
+            m2[:] = m2[0]                                               # all equal
+        if with_inf and k % 5 == 2 and L > 2:
+            m2[rng.integers(0, L)] = np.inf
+        if with_inf and k % 7 == 3 and L > 2:
+            m2[rng.integers(0, L)] = -np.inf
+        cases.append((L, rng.integers(-40, 40, L) / 8.0, m2, float(rng.integers(-16, 24)) / 8.0))
+    return cases
+
+
+def _potts_message_from_reference_two_minimum(m1, m2, d, two):
+    s, s2 = two
+    other = np.where(m2 == s, s2, s)                                    # the smallest m2[x2] over x2 != x1
+    return m1 + np.minimum(m2, d + other)
+
+
+def test_oracle_potts_message_equals_the_references_two_smallest_elements(ref):
+    """the oracle builds the Potts table literally (diff * [a != b], as the reference's test/potts_factor.cpp does) and minimises
+    over it; the O(L) form the device uses needs exactly the smallest and second smallest entry — taken here from the reference's
+    own two_smallest_elements (help_functions.hxx:106-120) compiled where it lies, incl. ties, L = 1, 2 and +-inf entries"""
+    from oracle.binding import Oracle
+    from tests.test_oracle_kat import _single_pairwise
+    if "ref_two_smallest" not in ref:
+        pytest.skip("ref_two_smallest was not built")
+    cases = _potts_vectors(np.random.default_rng(21), 60, with_inf=True)
+    twos = _ref_two_smallest(ref["ref_two_smallest"], [c[2] for c in cases])
+    for (L, m1, m2, d), two in zip(cases, twos):
+        srt = np.sort(m2)
+        assert two == (srt[0], srt[1] if L > 1 else np.inf)             # what the reference function returns
+        m, _ = _single_pairwise(None, m1, m2, potts=d, L=L)
+        got = Oracle(m).message_value(0, True)
+        assert np.array_equal(got, _potts_message_from_reference_two_minimum(m1, m2, d, two)), (L, d)
+
+
+@pytest.mark.gpu
+def test_device_two_min_equals_the_references_two_smallest_elements(ref):
+    """the device's Potts receive (kernels.hip: two-smallest butterfly over the lanes of a unary, +inf in the padding lanes)
+    against the reference's two_smallest_elements on the same vectors: ties, L = 1, 2, label counts that fill a wave only partly"""
+    from tests.test_oracle_kat import _single_pairwise
+    if "ref_two_smallest" not in ref:
+        pytest.skip("ref_two_smallest was not built")
+    cases = _potts_vectors(np.random.default_rng(22), 50, with_inf=False)
+    twos = _ref_two_smallest(ref["ref_two_smallest"], [c[2] for c in cases])
+    eng = E.Engine(0)
+    for (L, m1, m2, d), two in zip(cases, twos):
+        m, p = _single_pairwise(None, m1, m2, potts=d, L=L)
+        eng.upload(m)
+        # unary 0 receives its message from the pairwise factor (mask 1, no send): theta_0 = 0 + message
+        eng.compute_pass_custom(np.array([0], np.int32), [0, 1], [0.0], [0, 1], [1])
+        got = eng.download_duals()[:L]
+        assert np.array_equal(got, _potts_message_from_reference_two_minimum(m1, m2, d, two)), (L, d)
+    eng.close()
