@@ -845,6 +845,8 @@ def main():
         launch["self_test"] = collective_self_test(args, torch, dist, runner, rank, world)
     cut_fraction_line = float(getattr(runner, "global_cut_fraction", getattr(runner, "cut_fraction", 0.0))) if dist_on else None
 
+    if getattr(runner, "setup_laps", None) is not None:
+        setup.update(runner.setup_laps.laps)
     lb0 = runner.lower_bound()
     eng_rows = bool(getattr(eng, "rows_layout", False))
     setup["total_before_first_pass_s"] = time.perf_counter() - t_setup0

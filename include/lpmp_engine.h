@@ -111,6 +111,32 @@ int lpmp_plan_mailbox_info(lpmp_plan* p, int direction, int mode, int64_t* n_row
  * schedules; 0 when consecutive passes run one after the other; negative lpmp_status on error */
 int lpmp_plan_pass_rotates(lpmp_plan* p, int mode);
 
+/* ---- variable orders and partitions (host only; csrc/graph.cpp) ---------------------------------------------------------------
+ * The sweep is Gauss-Seidel over the factor ORDER, which is the caller's input (AddFactorRelation, include/LP_MP.h:698-702; the
+ * topological sort of include/topological_sort.hxx:100-144): the engine runs one launch per dependent level of whatever order it
+ * is given.  A grid inserted row by row has H + W - 1 levels per directional sweep; in a 2-colour order it has 2 (C3: 14.5 against
+ * 5.2 ms per pass).  Another order is another, equally valid trajectory of the dual ascent — not another algorithm.
+ *
+ * lpmp_plan_suggest_order: rank_of_factor[f] = position of factor f in an order in which the UPDATED factors come colour by colour
+ * (two of them conflict when a message joins them or both touch a common factor; 2 colours when that graph is bipartite, else a
+ * greedy Jones-Plassmann colouring with counter-hash priorities from `seed`), and every other factor keeps its place relative to
+ * the updated factors around it (an MRF's pairwise factor between its two unaries, a multicut triplet behind its edges).  The
+ * caller turns it into relations as a chain through all factors — AddFactorRelation(by_rank[i], by_rank[i + 1]) for consecutive
+ * positions: the only topological order of that chain is the suggested one, forward, and its reverse,
+ * backward — and builds its LP with those instead of its own.  n_colours (may be NULL): dependent
+ * levels per directional sweep to expect.  The engine prints one line to stderr when a schedule it builds has more than 64 levels
+ * (LPMP_QUIET=1 silences it). */
+int lpmp_plan_suggest_order(lpmp_plan* p, uint64_t seed, int32_t* rank_of_factor /*[n_factors]*/, int32_t* n_colours);
+/* the same colouring for a plain pairwise graph given as an edge list (what synthetic workloads rename their variables by):
+ * rank_out[v] = position of variable v in the colour-major order (colour classes in ascending colour, inside a class by index) */
+int lpmp_graph_colour_major_order(int64_t n, int64_t m, const int64_t* edge_i, const int64_t* edge_j, uint64_t seed, int64_t* rank_out /*[n]*/,
+                                  int32_t* n_colours_out);
+/* balanced Kernighan-Lin / label-propagation refinement of a k-way partition of that graph (lp_mp_amd/multi_gpu.py
+ * refine_partition, move for move): per round every variable looks at the part most of its neighbours live in; a pseudo-random half
+ * of those that would cut fewer edges there move, best gains first, while the target stays within (1 + imbalance) of the mean size */
+int lpmp_graph_refine_partition(int64_t n, int64_t m, const int64_t* edge_i, const int64_t* edge_j, int32_t world, int32_t rounds,
+                                double imbalance, uint64_t seed, int64_t* part_inout /*[n]*/);
+
 /* ---- device engine --------------------------------------------------------------------------- */
 /* LP<FMC>::LP(cmd) (include/LP_MP.h:589-593).  device = HIP device ordinal. */
 int lpmp_create(int device, lpmp_engine** out);

@@ -15,7 +15,7 @@ import time
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO = os.path.join(CSRC, "liblpmp_engine.so")
 STAMP = SO + ".stamp"
-SOURCES = ["kernels.hip", "engine.cpp", "plan.cpp", "boundary.hip"]
+SOURCES = ["kernels.hip", "engine.cpp", "plan.cpp", "boundary.hip", "graph.cpp"]
 HEADERS = ["plan.hpp", os.path.join("..", "..", "include", "lpmp_engine.h"), os.path.join("..", "..", "include", "lpmp_model.h")]
 # -ffp-contract=off: the sweep's duals must equal the sequential CPU semantics bit for bit
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-strict-aliasing", "-Wall",

@@ -413,6 +413,7 @@ struct lpmp_engine {
   } spec;
   bool use_blocked_passes = true;     // LPMP_NO_BLOCKED_PASSES=1: the joined passes as one launch per step
   bool pass_chain_tried[LPMP_REPAM_COUNT] = {};   // ensure_pass_chain_plan ran for that mode
+  bool deep_note_given = false;                   // the one-line note about a schedule of many levels was printed
   int rot_bands = 0, rot_lag = 3, rot_depth = 4;   // skewed ticket order (0 bands: from the table bytes per step); DESIGN.md 6 has the sweep
   void release_rot_chains() {
     for (auto& m : rot_chain) {
@@ -449,6 +450,7 @@ struct lpmp_engine {
   }
   void release_model() {
     release_schedules();
+    deep_note_given = false;
     for (auto& c : custom) if (c) c->release();
     custom.clear();
     scratch.release();
@@ -670,10 +672,21 @@ void check_generic_limits(const Plan& p, const Schedule& s) {
   }
 }
 
+// one line, once per engine: a sweep of many dependent levels is latency-bound whatever executes it, and the order is the caller's
+static void deep_schedule_note(lpmp_engine* e, int64_t n_levels, const char* what) {
+  if (n_levels <= 64 || e->deep_note_given) return;
+  e->deep_note_given = true;
+  const char* q = std::getenv("LPMP_QUIET");
+  if (q && q[0] == '1') return;
+  std::fprintf(stderr, "lpmp: %s has %lld dependent levels (one launch step each): the factor order is the caller's input — "
+               "lpmp_plan_suggest_order gives one with a level per colour (INTEGRATION.md 2a)\n", what, (long long)n_levels);
+}
+
 void ensure_device_schedules(lpmp_engine* e, int mode) {
   if (e->have_sched[mode]) return;
   for (int d = 0; d < 2; ++d) {
     plan_schedule(e->plan.get(), d, mode);
+    deep_schedule_note(e, e->plan->sched_cache[d][mode].n_levels, d == 0 ? "the forward sweep" : "the backward sweep");
     check_generic_limits(e->plan->p, e->plan->sched_cache[d][mode]);
     upload_schedule(e->plan->sched_cache[d][mode], e->sched[d][mode], e->stream);
   }
@@ -687,6 +700,7 @@ void ensure_pass_schedule(lpmp_engine* e, int mode) {
   auto lap_ = [&](const char* what) { if (!timed_) return; const auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "lpmp: pass schedule %-28s %.0f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last_).count()); t_last_ = now; };
   // (a three-level pass is the shape whose passes join: its own chain plan is only built if the joins do not check out)
   plan_pass_schedule(e->plan.get(), mode, false);
+  deep_schedule_note(e, e->plan->pass_cache[mode].n_levels / 2, "a directional sweep");
   lap_("forward+backward planned");
   plan_rotation(e->plan.get(), mode);
   lap_("backward+forward planned, joins checked");
@@ -1294,6 +1308,13 @@ int lpmp_plan_get_update_levels(lpmp_plan* p, int d, int mode, int32_t* out) {
   });
 }
 
+int lpmp_plan_suggest_order(lpmp_plan* p, uint64_t seed, int32_t* rank_of_factor, int32_t* n_colours) {
+  return guarded([&] {
+    if (!p || (!rank_of_factor && p->p.nf > 0)) throw std::runtime_error("null argument");
+    const int32_t k = suggest_order(p->p, seed, rank_of_factor);
+    if (n_colours) *n_colours = k;
+  });
+}
 int lpmp_plan_pass_schedule_info(lpmp_plan* p, int mode, int64_t* n_levels, int64_t* n_launches, int64_t* n_recv,
                                  int64_t* n_send, int64_t* alg_bytes) {
   return guarded([&] {

@@ -292,4 +292,7 @@ struct Plan {
   std::string adaptive_obstacle() const;
 };
 
+// graph.cpp: an order of all factors with the updated ones colour by colour (rank[f] = position; returns the number of colours)
+int32_t suggest_order(const Plan& p, uint64_t seed, int32_t* rank);
+
 }  // namespace lpmp

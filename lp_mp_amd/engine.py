@@ -54,6 +54,7 @@ EXPORTS = [
     "lpmp_halo_create", "lpmp_halo_destroy", "lpmp_halo_out_doubles", "lpmp_halo_in_doubles", "lpmp_halo_pack", "lpmp_halo_unpack",
     "lpmp_set_speculation", "lpmp_speculation_stats", "lpmp_chain_cache_bytes",
     "lpmp_set_persistent_launches", "lpmp_persistent_launches", "lpmp_device_identity",
+    "lpmp_plan_suggest_order", "lpmp_graph_colour_major_order", "lpmp_graph_refine_partition",
 ]
 
 
@@ -155,6 +156,9 @@ def lib():
             L.lpmp_set_persistent_launches.argtypes = [C.c_void_p, C.c_int]
             L.lpmp_persistent_launches.argtypes = [C.c_void_p]
             L.lpmp_device_identity.argtypes = [C.c_int, C.c_char_p, C.c_int64]
+        L.lpmp_plan_suggest_order.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.lpmp_graph_colour_major_order.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.lpmp_graph_refine_partition.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_uint64, C.c_void_p]
         L.lpmp_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]
         L.lpmp_synth_fill_blocks.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.lpmp_boundary_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 5
@@ -335,6 +339,38 @@ def _partitions(self):
 
 
 Plan.partitions = _partitions
+
+
+def _suggest_order(self, seed: int = 0):
+    """(rank_of_factor[n_factors], number of colours): an order of all factors with the updated ones colour by colour
+    (include/lpmp_engine.h, lpmp_plan_suggest_order); model.with_factor_order(rank) applies it"""
+    rank = np.empty(self.n_factors, np.int32)
+    k = C.c_int32()
+    _chk(self.L.lpmp_plan_suggest_order(self.h, C.c_uint64(seed), rank.ctypes.data, C.addressof(k)))
+    return rank, k.value
+
+
+Plan.suggest_order = _suggest_order
+
+
+def graph_colour_major_order(n: int, edge_i, edge_j, seed: int = 0):
+    """(rank[n] int64, number of colours): colour-major variable order of a pairwise graph on the planner's threads
+    (lpmp_graph_colour_major_order; the numpy statement of the same algorithm is ordering.colour_major_order_numpy)"""
+    ei = np.ascontiguousarray(edge_i, np.int64); ej = np.ascontiguousarray(edge_j, np.int64)
+    assert ei.shape == ej.shape
+    rank = np.empty(int(n), np.int64)
+    k = C.c_int32()
+    _chk(lib().lpmp_graph_colour_major_order(int(n), ei.shape[0], ei.ctypes.data, ej.ctypes.data, C.c_uint64(seed), rank.ctypes.data, C.addressof(k)))
+    return rank, k.value
+
+
+def graph_refine_partition(n: int, edge_i, edge_j, part, world: int, rounds: int = 30, imbalance: float = 0.03, seed: int = 0) -> np.ndarray:
+    """balanced KL refinement of a k-way partition (lpmp_graph_refine_partition; numpy statement: multi_gpu.refine_partition)"""
+    ei = np.ascontiguousarray(edge_i, np.int64); ej = np.ascontiguousarray(edge_j, np.int64)
+    out = np.array(part, np.int64, copy=True)
+    assert out.shape[0] == int(n)
+    _chk(lib().lpmp_graph_refine_partition(int(n), ei.shape[0], ei.ctypes.data, ej.ctypes.data, int(world), int(rounds), float(imbalance), C.c_uint64(seed), out.ctypes.data))
+    return out
 
 
 class Engine:

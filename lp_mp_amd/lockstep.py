@@ -695,6 +695,7 @@ class LockstepGraph(_Driver):
         rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
         self.order = order
         self.rank_of = None
+        lap = self.setup_laps = MG.SetupLaps()
         self.partitioner = "given" if part_of is not None else "none (1 part)"
         if order == "colour_major":
             compute = lambda: O.colour_major_order(n, *S.counter_graph_edges(n, m, seed), seed=seed)
@@ -703,6 +704,7 @@ class LockstepGraph(_Driver):
         elif order != "index":
             raise ValueError(order)
         ei, ej = S.counter_graph_edges(n, m, seed, self.rank_of)
+        lap("edges_and_variable_order_s")
         if part_of is None:
             if world > 1:
                 used = []
@@ -717,8 +719,11 @@ class LockstepGraph(_Driver):
         part_of = np.asarray(part_of, np.int64)
         self.part_of = part_of
         self.cut_fraction = float((part_of[ei] != part_of[ej]).mean())
+        lap("partition_s")
         sched, parts = lockstep_mrf(n, L, ei, ej, part_of, world, mode, only=rank, stream_seed=seed)
+        lap("global_plan_and_local_part_s")
         self._setup(torch, dist, parts[0], sched, mode, rows_layout=rows_layout, engine_factory=engine_factory)
+        lap("costs_plan_upload_schedules_s")
 
 
 class LockstepModel(_Driver):

@@ -124,6 +124,19 @@ class FlatModel:
     def const_offsets(self) -> np.ndarray:
         return np.concatenate([[0], np.cumsum(self.const_sizes())]).astype(np.int64)
 
+    def with_factor_order(self, rank: np.ndarray) -> "FlatModel":
+        """the same factors, messages and costs with the factor relations REPLACED by a chain through all factors in the order
+        ``rank[f]`` (position of factor f, e.g. Plan.suggest_order): AddFactorRelation(by_rank[i], by_rank[i + 1]) for consecutive
+        positions (reference LP_MP.h:698-702: forward sweep in that order, backward sweep in the reverse one; the chain is the only
+        topological order, so no tie is left to the sort) — what INTEGRATION.md 2a shows a C++ caller doing with
+        lpmp_plan_suggest_order's answer.  Arrays are shared with ``self``."""
+        import dataclasses
+        rank = np.asarray(rank, np.int64)
+        by_rank = np.empty(rank.shape[0], np.int32)
+        by_rank[rank] = np.arange(rank.shape[0], dtype=np.int32)
+        fwd = np.ascontiguousarray(np.stack([by_rank[:-1], by_rank[1:]], 1))
+        return dataclasses.replace(self, rel_fwd=fwd, rel_bwd=np.ascontiguousarray(fwd[:, ::-1]), _keep=[])
+
     def dump(self, path: str):
         """the model as one flat binary file in the order of include/lpmp_model.h — what the C++ hosts read
         (lp_mp_amd/include/lpmp_lockstep.hxx, model_file; tools/mgpu_rccl_driver.cpp --model-file)"""
@@ -258,13 +271,13 @@ class ModelBuilder:
         self._nm += n
         return ids
 
-    def add_interleaved_messages(self, mtypes, left, right) -> np.ndarray:
+    def add_interleaved_messages(self, mtypes, left, right, return_ids: bool = True):
         """Messages of several types in one insertion sequence (row i has type mtypes[i])."""
         mtypes = np.asarray(mtypes, np.int32)
         left = np.asarray(left, np.int32)
         right = np.asarray(right, np.int32)
         n = left.shape[0]
-        ids = np.arange(self._nm, self._nm + n, dtype=np.int64)
+        ids = np.arange(self._nm, self._nm + n, dtype=np.int64) if return_ids else None
         self._m.append((mtypes, left, right))
         self._nm += n
         return ids
@@ -273,8 +286,10 @@ class ModelBuilder:
         """AddFactorRelation(f1, f2): f1 before f2 forward, f2 before f1 backward."""
         f1 = np.atleast_1d(np.asarray(f1, np.int32))
         f2 = np.atleast_1d(np.asarray(f2, np.int32))
-        self._rel_fwd.append(np.stack([f1, f2], 1))
-        self._rel_bwd.append(np.stack([f2, f1], 1))
+        fwd = np.empty((f1.shape[0], 2), np.int32); fwd[:, 0] = f1; fwd[:, 1] = f2
+        bwd = np.empty((f1.shape[0], 2), np.int32); bwd[:, 0] = f2; bwd[:, 1] = f1
+        self._rel_fwd.append(fwd)
+        self._rel_bwd.append(bwd)
 
     def put_in_same_partition(self, f1, f2):
         """LP::put_in_same_partition(f1, f2) (reference LP_MP.h:465)"""
@@ -288,6 +303,8 @@ class ModelBuilder:
 
     def finish(self) -> FlatModel:
         def cat(chunks, dtype, shape=(0,)):
+            if len(chunks) == 1:                       # (models of millions of factors: no second copy of a single block)
+                return np.ascontiguousarray(chunks[0])
             return np.ascontiguousarray(np.concatenate(chunks)) if chunks else np.zeros(shape, dtype)
         tab_off = np.concatenate([[0], np.cumsum([len(t) for t in self._tables])]).astype(np.int64)
         return FlatModel(
@@ -300,7 +317,7 @@ class ModelBuilder:
             dual_data=None if self.skip_dual else cat(self._dual, np.float64),
             m_type=cat([c[0] for c in self._m], np.int32), m_left=cat([c[1] for c in self._m], np.int32),
             m_right=cat([c[2] for c in self._m], np.int32),
-            rel_fwd=cat(self._rel_fwd, np.int32, (0, 2)).astype(np.int32).reshape(-1, 2),
-            rel_bwd=cat(self._rel_bwd, np.int32, (0, 2)).astype(np.int32).reshape(-1, 2),
+            rel_fwd=cat(self._rel_fwd, np.int32, (0, 2)).astype(np.int32, copy=False).reshape(-1, 2),
+            rel_bwd=cat(self._rel_bwd, np.int32, (0, 2)).astype(np.int32, copy=False).reshape(-1, 2),
             constant=self.constant,
             part_pairs=cat(self._part, np.int32, (0, 2)).astype(np.int32).reshape(-1, 2) if self._part else None)

@@ -296,7 +296,10 @@ def graph_partition(n_vars: int, edge_i: np.ndarray, edge_j: np.ndarray, world: 
     part = np.empty(n_vars, np.int64)
     part[order] = (np.arange(n_vars) * world) // n_vars
     if world > 1 and refine_rounds > 0:
-        part = refine_partition(a, part, world, refine_rounds, imbalance, seed)
+        # on the planner's threads behind the C ABI (lpmp_graph_refine_partition); refine_partition below is the numpy statement
+        # of the same moves (20 s against 1 at 2 M variables)
+        from . import engine as E
+        part = E.graph_refine_partition(n_vars, edge_i, edge_j, part, world, refine_rounds, imbalance, seed)
     return (part, "builtin (reverse Cuthill-McKee + balanced KL refinement)") if return_method else part
 
 
@@ -977,6 +980,19 @@ def run_lockstep(sweeps: List[PartitionedSweep], n_passes: int):
                 s.boundary_fold(b)
 
 
+class SetupLaps:
+    """seconds of the steps of a driver's constructor (bench.py puts them into `setup_s`: what the time before the first pass is)"""
+
+    def __init__(self):
+        import time
+        self.t, self.laps, self._clock = time.perf_counter(), {}, time.perf_counter
+
+    def __call__(self, what: str):
+        now = self._clock()
+        self.laps[what] = self.laps.get(what, 0.0) + now - self.t
+        self.t = now
+
+
 class DriverStats:
     """what the bench.py drivers of all three schedules share: an untimed repetition of the passes under an ExchangeProbe, the
     split sizes of the largest exchange, and the switches of an engine whose device is shared with other ranks.  The drivers read
@@ -1098,6 +1114,7 @@ class GraphSweep(DriverStats):
         dev = torch.device("cuda", torch.cuda.current_device())
         if self.comm:
             self.comm._dev = dev
+        lap = self.setup_laps = SetupLaps()
         self.order, self.rank_of = order, None
         if order == "colour_major":
             from . import ordering as O
@@ -1105,6 +1122,7 @@ class GraphSweep(DriverStats):
             self.rank_of = broadcast_partition(torch, dist, n, dev, compute) if self.comm and world > 1 else compute()
         elif order != "index":
             raise ValueError(order)
+        lap("edges_and_variable_order_s")
         self.partitioner = "given" if part_of is not None else ("none (1 part)" if world == 1 else None)
         if part_of is None and self.comm and world > 1:  # partition once, on rank 0
             used = []
@@ -1114,16 +1132,20 @@ class GraphSweep(DriverStats):
                 return p
             part_of = broadcast_partition(torch, dist, n, dev, compute_part)
             self.partitioner = broadcast_string(dist, used[0] if used else None)
+        lap("partition_s")
         part = graph_local_part(n, m, L, rank, world, seed, part_of, self.rank_of)
+        lap("local_part_model_s")
         self.part = part
         mdl = part.model
         stream = torch.cuda.current_stream().cuda_stream
         self.const = torch.empty(max(int(mdl.const_sizes().sum()), 2), dtype=torch.float64, device=dev)
         self.dualt = torch.zeros(int(mdl.dual_sizes().sum()), dtype=torch.float64, device=dev)
         fill_device_costs(torch, E, part, self.const, self.dualt, stream)
+        lap("costs_in_hbm_s")
         self.engine = E.Engine(torch.cuda.current_device())
         self.engine.set_stream(stream)
         self.engine.upload(mdl, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt), rows_layout=bool(rows_layout))
+        lap("plan_and_upload_s")
         if self.comm is not None:
             self.own_the_engine(self.engine)
         n_cut = int(part.out_ghost.shape[0] + part.in_unary.shape[0])
@@ -1132,6 +1154,7 @@ class GraphSweep(DriverStats):
             boundary_every = "sweep" if self.cut_fraction > 0.10 else "pass"
         self.boundary_every = boundary_every
         self.engine.set_reparametrization(mode)
+        lap("weights_s")
         if self.comm is None:
             # one GPU, no process group: the engine's own pass schedules are the sweep (no boundary schedules to build beside them)
             self.sweep = None
@@ -1140,6 +1163,7 @@ class GraphSweep(DriverStats):
             self.global_bytes_per_pass = sum(int(i["algorithmic_bytes"]) for i in info)
             self.global_cut_fraction = 0.0
             self.levels = [i["n_levels"] for i in info]
+            lap("directional_schedules_s")
             return
         self.sweep = PartitionedSweep(torch, part, self.engine, self.dualt, mode, omega_b, boundary_every, BOUNDARY_RESERVE)
         vals = [self.sweep.updates_per_pass(), self.sweep.bytes_per_pass(), part.out_ghost.shape[0], m]

@@ -37,6 +37,9 @@ def u64(n: int, seed: int, first: int = 0) -> np.ndarray:
     return z
 
 
+_EDGE_CACHE: dict = {}
+
+
 def counter_graph_edges(n: int, m: int, seed: int, rank: Optional[np.ndarray] = None):
     """C4 (BASELINE.json configs[3]) structure from the counter generator alone, so that every rank of a partitioned
     run derives the same edge list without any communication: edge e joins a = h(2e) mod n and b = a + 1 + h(2e+1) mod
@@ -44,9 +47,13 @@ def counter_graph_edges(n: int, m: int, seed: int, rank: Optional[np.ndarray] = 
     repeated pairs at m << n^2 / 2 are kept (two pairwise factors between the same variables are a valid model).
     ``rank``: the same graph with its variables renamed (variable v becomes rank[v]) — e.g. ordering.colour_major_order,
     which turns the 30 dependent levels per sweep of the index order into one level per colour."""
-    h = u64(2 * m, seed ^ 0x5DEECE66D, 0)
-    a = (h[0::2] % np.uint64(n)).astype(np.int64)
-    b = (a + 1 + (h[1::2] % np.uint64(n - 1)).astype(np.int64)) % n
+    key = (int(n), int(m), int(seed))
+    if _EDGE_CACHE.get("key") != key:                  # (a run asks for the same graph several times: order, partition, parts)
+        h = u64(2 * m, seed ^ 0x5DEECE66D, 0)
+        a = (h[0::2] % np.uint64(n)).astype(np.int64)
+        b = (a + 1 + (h[1::2] % np.uint64(n - 1)).astype(np.int64)) % n
+        _EDGE_CACHE.clear(); _EDGE_CACHE.update(key=key, a=a, b=b)
+    a, b = _EDGE_CACHE["a"], _EDGE_CACHE["b"]
     if rank is not None:
         rank = np.asarray(rank, np.int64)
         a, b = rank[a], rank[b]
@@ -121,13 +128,15 @@ def mrf_model(n_vars: int, L: int, edge_i: np.ndarray, edge_j: np.ndarray, unari
     else:
         p = b.add_dense_pairwise(1, np.asarray(tables, np.float64).reshape(E, L, L))
     # add_message<ML>(u_i, p); add_message<MR>(u_j, p) per edge, interleaved like the reference's MRF constructor
-    mt = np.tile(np.array([0, 1], np.int32), E)
-    left = np.stack([u[edge_i], u[edge_j]], 1).reshape(-1)
-    right = np.repeat(p, 2)
-    b.add_interleaved_messages(mt, left, right)
+    # (interleaved int32 arrays filled in place: at 10 M edges every temporary is 80 MB and a pass over it)
+    ui, uj = u[edge_i], u[edge_j]
+    mt = np.empty(2 * E, np.int32); mt[0::2] = 0; mt[1::2] = 1
+    left = np.empty(2 * E, np.int32); left[0::2] = ui; left[1::2] = uj
+    right = np.empty(2 * E, np.int32); right[0::2] = p; right[1::2] = p
+    b.add_interleaved_messages(mt, left, right, return_ids=False)
     # AddFactorRelation(u_i, p); AddFactorRelation(p, u_j)
-    f1 = np.stack([u[edge_i], p], 1).reshape(-1)
-    f2 = np.stack([p, u[edge_j]], 1).reshape(-1)
+    f1 = np.empty(2 * E, np.int32); f1[0::2] = ui; f1[1::2] = p
+    f2 = np.empty(2 * E, np.int32); f2[0::2] = p; f2[1::2] = uj
     b.add_relations(f1, f2)
     return b.finish()
 

@@ -154,7 +154,7 @@ def test_halo_and_boundary_vectors_are_validated():
         eng.upload(g)
         n = eng.download_duals().shape[0]
         ok = eng.halo_create([0], [4], [4], [4]); eng.halo_destroy(ok)
-        for bad_off, bad_len in (([n - 2], [4]), ([-1], [4]), ([2], [4]), ([0], [-1]), ([25 * 4 + 2], [4])):   # past the end, negative, across two factors
+        for bad_off, bad_len in (([n - 2], [4]), ([-1], [4]), ([2], [4]), ([0], [-1]), ([25 * 4 + 6], [4])):   # past the end, negative, across two factors (unaries; pairwise duals are 8 long)
             with pytest.raises(E.EngineError) as ei:
                 eng.halo_create(bad_off, bad_len, [], [])
             assert ei.value.code == -1 and "halo" in str(ei.value)
@@ -287,3 +287,31 @@ def test_bench_gpus_2_c5_and_a_partition_file(tmp_path):
     d = _bench(["--gpus", "2", "--workload", "c4", "--c4-nodes", "20000", "--c4-edges", "100000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                 "--no-compare-schedules", "--partition-file", str(pf)])
     assert d["config"]["partitioner"] == "file c4.part" and abs(d["dual_bound_gap"]) <= 1e-12 and 0.4 < d["config"]["cut_fraction"] < 0.6
+
+
+# ---- the order the engine suggests ------------------------------------------------------------------------------------------------
+def test_suggested_order_on_the_device_two_levels_and_the_oracles_duals(capfd):
+    """a C3-shaped grid inserted row by row (79 dependent levels per direction at 40 x 40: the engine says so, once, on stderr);
+    lpmp_plan_suggest_order's answer applied as a chain of AddFactorRelation calls: 2 levels per direction, consecutive passes
+    join, and the duals are the oracle's run in that order bit for bit"""
+    m = S.grid_model(40, 40, 32, order="row_major", seed=2)
+    e = E.Engine(0)
+    try:
+        e.upload(m); e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        e.compute_pass(1)
+        err = capfd.readouterr().err
+        assert err.count("lpmp_plan_suggest_order") == 1 and "79 dependent levels" in err
+        rank, k = e.plan.suggest_order(0)
+        assert k == 2
+        m2 = m.with_factor_order(rank)
+        e.upload(m2); e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        assert [e.plan.schedule_info(d, M.REPAM_ANISOTROPIC)["n_levels"] for d in (0, 1)] == [2, 2]
+        assert e.plan.pass_rotates(M.REPAM_ANISOTROPIC)
+        o = Oracle(m2); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+        for n in (1, 4):
+            e.compute_pass(n); o.ComputePass(n)
+            assert np.array_equal(e.download_duals(), o.duals())
+        assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * abs(o.LowerBound())
+        assert "lpmp_plan_suggest_order" not in capfd.readouterr().err
+    finally:
+        e.close()
