@@ -67,6 +67,11 @@ def parse():
                     help="c4 / c5 on several GPUs: variable -> rank from a file instead (raw int64 / int32 `.bin`, `.npy`, or text as "
                          "gpmetis writes it; multi_gpu.load_partition_file); entries in the order of the variables as the run numbers "
                          "them (c4: after --c4-order; c5: variables in factor order, or one entry per factor)")
+    ap.add_argument("--overlap-exchange", action="store_true",
+                    help="lock-step schedule on several GPUs: post the collective of an exchange behind the cut-adjacent records of a level and "
+                         "await it only before the first reader of what it ships, the interior records of the level in between "
+                         "(lockstep.LockstepSchedule.program_overlapped; same results bit for bit).  Pays where the cut is thin (C5, grids); "
+                         "on C4 (60 %% of the edges cut) almost every record is cut-adjacent")
     ap.add_argument("--rendezvous-timeout", type=float, default=300.0, help="several ranks: seconds to wait for all ranks at the store")
     ap.add_argument("--collective-timeout", type=float, default=300.0,
                     help="several ranks: bound on the self test before the timed region (one all_reduce, one all_to_all_single with the real "
@@ -420,7 +425,7 @@ def make_strip_runner(torch, dist, args, schedule, H, mode):
         return OV.OverlapStrips(torch, dist, H, H, args.labels, args.pairwise, mode, seed=1, g=g)
     if schedule == "lockstep":
         from lp_mp_amd import lockstep as LS
-        return LS.LockstepStrips(torch, dist, H, H, args.labels, args.pairwise, args.order, mode, seed=1)
+        return LS.LockstepStrips(torch, dist, H, H, args.labels, args.pairwise, args.order, mode, seed=1, overlap_exchange=getattr(args, "overlap_exchange", False))
     return MG.StripSweep(torch, dist, H, H, args.labels, args.pairwise, args.order, mode, seed=1, boundary_every="pass")
 
 
@@ -769,7 +774,7 @@ def main():
         if dist_on and args.schedule == "lockstep":
             from lp_mp_amd import lockstep as LS
             runner = LS.LockstepGraph(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1, order=args.c4_order, part_of=part_of,
-                                      partitioner=args.partitioner, rows_layout=args.rows_layout == "on")
+                                      partitioner=args.partitioner, rows_layout=args.rows_layout == "on", overlap_exchange=args.overlap_exchange)
             parallelism = (f"{world} parts in lock step (the unpartitioned sweep in {args.c4_order} variable order, {runner.halo_steps_per_pass():.1f} halo exchanges per pass), "
                            f"{100 * runner.cut_fraction:.1f} % of the edges cut")
         else:
@@ -792,7 +797,7 @@ def main():
         setup["model_on_host_s"] = time.perf_counter() - t_setup0
         if dist_on:
             part5, partitioner = model_partition(args, torch, dist, MG, gm5, world)
-            runner = LS.LockstepModel(torch, dist, gm5, part5, mode)
+            runner = LS.LockstepModel(torch, dist, gm5, part5, mode, overlap_exchange=args.overlap_exchange)
             parallelism = (f"{world} parts in lock step (the unpartitioned sweep, {runner.halo_steps_per_pass():.1f} halo exchanges per pass), "
                            f"{100 * runner.cut_fraction:.1f} % of the message vectors cut")
             updates_per_pass = runner.global_updates_per_pass
@@ -1034,6 +1039,7 @@ def main():
             "lower_bound_before": lb0, "lower_bound_after": lb1,
             "oracle_check": oracle_check,
             "dual_bound_gap": gap["dual_bound_gap"], "dual_bound_gap_detail": gap, "schedule": args.schedule if dist_on else None,
+            "overlap_exchange": bool(args.overlap_exchange) if dist_on and args.schedule == "lockstep" else None,
             "schedules": schedules,
             # several ranks: where a pass spends its time (untimed repetition under multi_gpu.ExchangeProbe), as max / mean over the
             # ranks and per rank; exchange spans include waiting for the slowest peer

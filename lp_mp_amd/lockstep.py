@@ -68,6 +68,39 @@ class LockstepSchedule:
     _programs: Dict[int, list] = field(default_factory=dict)
     _halo_ids: Dict[bytes, int] = field(default_factory=dict)     # distinct exchanges (sets of vectors) of all programs -> small integer
 
+    def program_overlapped(self, n_passes: int):
+        """program(n) with every exchange taken off the critical path where the sweep allows it: the run that follows an exchange
+        begins with the sub-levels that READ nothing the exchange ships (the interior records of the level whose cut-adjacent
+        records just ran: same level, so they commute with them) — those are issued between ("halo_begin", ...) — pack, collective
+        posted — and ("halo_end", ...) — collective awaited, unpack —, so that the transfer runs while they compute.  Same records
+        in an order that differs only between commuting updates: the result is program(n)'s bit for bit.  Where a run begins with
+        a reader of the shipped vectors (a random graph with 60 % of its edges cut: C4) the exchange stays a plain ("halo", ...)."""
+        key = ("overlapped", n_passes)
+        if key in self._programs:
+            return self._programs[key]
+        steps = self.program(n_passes)
+        out, i = [], 0
+        while i < len(steps):
+            st = steps[i]
+            if st[0] == "halo" and i + 1 < len(steps) and steps[i + 1][0] == "run":
+                shipped = np.zeros(self.n_vecs, bool); shipped[st[1]] = True
+                seq = steps[i + 1][1]
+                k = 0
+                while k < len(seq) and not shipped[self.read[seq[k][0]][seq[k][1]]].any():
+                    k += 1
+                if k > 0:
+                    out.append(("halo_begin", st[1], st[2]))
+                    out.append(("run", tuple(seq[:k])))
+                    out.append(("halo_end", st[1], st[2]))
+                    if k < len(seq):
+                        out.append(("run", tuple(seq[k:])))
+                    i += 2
+                    continue
+            out.append(st)
+            i += 1
+        self._programs[key] = out
+        return out
+
     def program(self, n_passes: int):
         """steps of n passes: ("run", ((d, sub-level), ...)) and ("halo", vectors to ship: sorted global ids, id of that set).
         Sub-level 2 l = the records of level l + 1 that touch a cut edge, 2 l + 1 = the others (they write no cut vector).
@@ -391,8 +424,12 @@ class LockstepSweep:
     """one rank of the lock-step sweep.  ``engine``: lp_mp_amd.engine.Engine with the part's model uploaded (or a stand-in
     with the same methods in CPU tests); ``dual_tensor``: torch view of the engine's dual buffer."""
 
-    def __init__(self, torch, part: LockstepPart, sched: LockstepSchedule, engine, dual_tensor):
+    def __init__(self, torch, part: LockstepPart, sched: LockstepSchedule, engine, dual_tensor, overlap_exchange: bool = False):
+        """``overlap_exchange``: run LockstepSchedule.program_overlapped — the collective of an exchange is posted asynchronously and
+        awaited only before the first reader of what it ships (same results)"""
         self.torch, self.part, self.sched, self.engine, self.dual = torch, part, sched, engine, dual_tensor
+        self.overlap_exchange = bool(overlap_exchange)
+        self._open = None
         self._sids: Dict[tuple, int] = {}
         self._sid_of: Dict[int, tuple] = {}
         self._halo: Dict[int, tuple] = {}
@@ -494,9 +531,21 @@ class LockstepSweep:
         """``probe``: multi_gpu.ExchangeProbe — every pack -> all-to-all -> unpack span and the whole call get event pairs"""
         if probe is not None:
             probe.start()
-        for step in self.sched.program(n):
+        for step in self.steps(n):
             if step[0] == "run":
                 self.run(step[1])
+            elif step[0] == "halo_begin":                # pack, post the collective; the interior records that follow run meanwhile
+                send, out_counts, in_counts = self.halo_pack(step[1], step[2])
+                # (a send buffer of its own: the next pack may come before this transfer has read it)
+                self._open = (comm.exchange_begin(send.clone() if self._device_halos else send, out_counts, in_counts), out_counts, in_counts)
+            elif step[0] == "halo_end":
+                if probe is not None:
+                    probe.begin_exchange()               # (what is left of the exchange on the critical path)
+                pending, out_counts, in_counts = self._open
+                self._open = None
+                self.halo_unpack(step[1], comm.exchange_end(pending), step[2])
+                if probe is not None:
+                    probe.end_exchange(out_counts.sum(), in_counts.sum())
             else:
                 if probe is not None:
                     probe.begin_exchange()
@@ -507,10 +556,13 @@ class LockstepSweep:
         if probe is not None:
             probe.stop()
 
+    def steps(self, n):
+        return self.sched.program_overlapped(n) if self.overlap_exchange else self.sched.program(n)
+
     def exchange_counts(self, n=2):
         """split sizes (doubles per peer rank) of the largest exchange of an n-pass call: for a self test of the collective"""
         best = None
-        for step in self.sched.program(n):
+        for step in self.sched.program(n):               # (the overlapped program ships the same sets)
             if step[0] == "halo":
                 _, out_counts, _, in_counts = self._halo_plan(step[1], step[2])
                 if best is None or int(out_counts.sum()) > int(best[0].sum()):
@@ -532,12 +584,17 @@ def run_lockstep(sweeps: List[LockstepSweep], n_passes: int):
     """all parts inside one process (tests, several parts on one GPU): the all-to-all as in-process row shuffles"""
     torch = sweeps[0].torch
     world = len(sweeps)
-    for step in sweeps[0].sched.program(n_passes):
+    held = None
+    for step in sweeps[0].steps(n_passes):
         if step[0] == "run":
             for s in sweeps:
                 s.run(step[1])
             continue
-        packed = [s.halo_pack(step[1], step[2]) for s in sweeps]
+        if step[0] == "halo_begin":                      # (in one process nothing overlaps: the packed buffers wait for halo_end)
+            held = [(p[0].clone(), p[1], p[2]) for p in (s.halo_pack(step[1], step[2]) for s in sweeps)]
+            continue
+        packed = held if step[0] == "halo_end" else [s.halo_pack(step[1], step[2]) for s in sweeps]
+        held = None
         offs = [np.concatenate([[0], np.cumsum(p[1])]) for p in packed]
         for dst, s in enumerate(sweeps):
             pieces = [packed[src][0][offs[src][dst]: offs[src][dst + 1]] for src in range(world)]
@@ -617,10 +674,10 @@ class _Driver(DriverStats):
         self.engine.upload(m, const_dev=self.const.data_ptr(), dual_dev=self.dualt.data_ptr(), keep=(self.const, self.dualt), rows_layout=bool(rows_layout))
         self.own_the_engine(self.engine)
         self.engine.set_reparametrization(mode)
-        self.sweep = LockstepSweep(torch, part, sched, self.engine, self.dualt)
+        self.sweep = LockstepSweep(torch, part, sched, self.engine, self.dualt, overlap_exchange=getattr(self, "overlap_exchange", False))
         # the schedules of the steady state (built here, outside any timed region) and their algorithmic bytes per pass
         n_probe = 4
-        prog = sched.program(n_probe)
+        prog = self.sweep.steps(n_probe)
         by = 0
         for step in prog:
             if step[0] == "run" and self.sweep._schedule(step[1]) >= 0:
@@ -634,17 +691,17 @@ class _Driver(DriverStats):
 
     def prepare_passes(self, n):
         """what depends on the pass count of a call (schedules of its segments, exchange plans): outside a timed region"""
-        for step in self.sched.program(n):
+        for step in self.sweep.steps(n):
             if step[0] == "run":
                 self.sweep._schedule(step[1])
-            else:
+            elif step[0] != "halo_end":
                 self.sweep._halo_plan(step[1], step[2])
 
     def compute_pass(self, n=1, probe=None):
         if self.comm is None:
             if probe is not None:
                 probe.start()
-            for step in self.sched.program(n):
+            for step in self.sweep.steps(n):
                 if step[0] == "run":
                     self.sweep.run(step[1])
             if probe is not None:
@@ -669,7 +726,8 @@ class LockstepStrips(_Driver):
     """bench.py driver: this rank's H x W strip of the (world * H) x W grid, run in lock step with the other strips —
     the result is the single-GPU sweep of the whole grid, bit for bit."""
 
-    def __init__(self, torch, dist, H, W, L, pairwise, order, mode, seed=1, proxy=True):
+    def __init__(self, torch, dist, H, W, L, pairwise, order, mode, seed=1, proxy=True, overlap_exchange=False):
+        self.overlap_exchange = overlap_exchange
         rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
         sched, part = strips_lockstep_part(H, W, L, pairwise, order, rank, world, mode, seed, proxy)
         self._setup(torch, dist, part, sched, mode)
@@ -686,7 +744,7 @@ class LockstepGraph(_Driver):
     unpartitioned sweep the result equals bit for bit is the one of counter_graph_model(..., rank=self.rank_of)."""
 
     def __init__(self, torch, dist, n, m, L, mode, seed=1, part_of=None, order="colour_major", partitioner="auto", rows_layout=False,
-                 engine_factory=None):
+                 engine_factory=None, overlap_exchange=False):
         """``part_of``: a partition handed in (variable -> rank in the ORDERED numbering, e.g. multi_gpu.load_partition_file); else
         ``partitioner`` (multi_gpu.graph_partition's ``method``: auto / metis / builtin) computes one on rank 0"""
         from . import multi_gpu as MG
@@ -694,6 +752,7 @@ class LockstepGraph(_Driver):
         on = dist is not None and dist.is_initialized()
         rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
         self.order = order
+        self.overlap_exchange = overlap_exchange
         self.rank_of = None
         lap = self.setup_laps = MG.SetupLaps()
         self.partitioner = "given" if part_of is not None else "none (1 part)"
@@ -731,7 +790,8 @@ class LockstepModel(_Driver):
     multicut triplets, ...  Every rank holds ``global_model`` on the host (structure and costs) and takes its own part of it;
     ``part_of[f]``: rank of variable f (e.g. multi_gpu.graph_partition_model, computed once and broadcast)."""
 
-    def __init__(self, torch, dist, global_model: M.FlatModel, part_of, mode, engine_factory=None):
+    def __init__(self, torch, dist, global_model: M.FlatModel, part_of, mode, engine_factory=None, overlap_exchange=False):
+        self.overlap_exchange = overlap_exchange
         rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None and dist.is_initialized() else (0, 1)
         sched, parts = lockstep_model(global_model, part_of, world, mode, only=rank)
         self._setup(torch, dist, parts[0], sched, mode, fill=False, engine_factory=engine_factory)

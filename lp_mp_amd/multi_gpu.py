@@ -577,6 +577,27 @@ class DistComm:
                                     input_split_sizes=list(map(int, send_counts)))
         return out
 
+    def exchange_begin(self, send, send_counts, recv_counts):
+        """post the all-to-all-v and return at once (RCCL: the collective runs on the process group's own stream, ordered behind
+        what the current stream has been given so far; the caller keeps ``send`` untouched until exchange_end).  Staged through the
+        CPU (gloo) there is nothing to overlap: the exchange happens here."""
+        if self.stage_cpu or not send.is_cuda:
+            return ("done", self.exchange(send, send_counts, recv_counts))
+        n_out = int(sum(recv_counts))
+        tail = tuple(send.shape[1:])
+        out = send.new_empty((max(n_out, 1),) + tail)[:n_out]
+        src = send.contiguous() if send.shape[0] > 0 else send.new_empty((1,) + tail)[:0]
+        work = self.dist.all_to_all_single(out, src, output_split_sizes=list(map(int, recv_counts)),
+                                           input_split_sizes=list(map(int, send_counts)), async_op=True)
+        return ("posted", out, work, src)
+
+    def exchange_end(self, pending):
+        """the rows exchange_begin's transfer delivers; the current stream waits for the collective (no host synchronisation)"""
+        if pending[0] == "done":
+            return pending[1]
+        pending[2].wait()
+        return pending[1]
+
     def all_reduce_sum(self, x: float) -> float:
         t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.stage_cpu else self._dev)
         self.dist.all_reduce(t)

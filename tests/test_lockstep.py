@@ -534,3 +534,111 @@ def test_colour_major_order_cuts_the_exchanges_of_a_random_graph():
         counts[cm] = (sched.n_levels, sum(1 for s in sched.program(4) if s[0] == "halo") / 4)
     assert counts[True][0][0] < counts[False][0][0] / 2 and counts[True][1] < counts[False][1] / 2, counts
     assert counts[True][1] <= 2 * max(counts[True][0]) + 1
+
+
+# ---- the exchange off the critical path (LockstepSchedule.program_overlapped) ------------------------------------------------------
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("mode", [M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM])
+def test_overlapped_exchanges_give_the_same_sweep_bit_for_bit(name, mode):
+    """the collective of an exchange posted behind the cut-adjacent records and awaited before the first reader of what it ships,
+    the interior records of the level in between (they commute with the cut-adjacent ones): the unpartitioned oracle's duals,
+    every call; the overlapped program ships the same sets in the same order, and an exchange is split only where the run behind
+    it begins with records that read none of it"""
+    c = CASES[name]()
+    ref = Oracle(_global_of(c)); ref.set_reparametrization(mode)
+    sched, parts = _parts_of(c, mode)
+    duals = [p.model.dual_data.copy() for p in parts]
+    sweeps = [LS.LockstepSweep(torch, p, sched, OracleEngine(p.model, d), torch.from_numpy(d), overlap_exchange=True) for p, d in zip(parts, duals)]
+    for n in (1, 2, 3):
+        ref.ComputePass(n)
+        LS.run_lockstep(sweeps, n)
+        _assert_equals_global(c, parts, duals, ref)
+    plain, over = sched.program(3), sched.program_overlapped(3)
+    assert [s[2] for s in plain if s[0] == "halo"] == [s[2] for s in over if s[0] in ("halo", "halo_begin")]
+    assert [x for s in plain if s[0] == "run" for x in s[1]] == [x for s in over if s[0] == "run" for x in s[1]]     # same sub-levels, same order
+    for i, s in enumerate(over):
+        if s[0] == "halo_begin":
+            assert over[i + 1][0] == "run" and over[i + 2][0] == "halo_end" and over[i + 2][2] == s[2]
+            shipped = np.zeros(sched.n_vecs, bool); shipped[s[1]] = True
+            assert not any(shipped[sched.read[d][sl]].any() for (d, sl) in over[i + 1][1])
+    assert sum(1 for s in over if s[0] == "halo_begin") >= 1
+
+
+WORKER_OVERLAP = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from lp_mp_amd import model as M, multi_gpu as MG, lockstep as LS
+from tests.mgpu_helpers import OracleEngine
+from tests.test_multi_gpu import _general_models
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+gm = _general_models()["c5"]
+part_of = MG.graph_partition_model(gm, world)
+def factory(part):
+    d = part.model.dual_data.copy()
+    return torch.from_numpy(d), OracleEngine(part.model, d)
+lbs = []
+for overlap in (False, True):
+    sw = LS.LockstepModel(torch, dist, gm, part_of, M.REPAM_ANISOTROPIC, engine_factory=factory, overlap_exchange=overlap)
+    sw.compute_pass(2); sw.compute_pass(1)
+    lbs.append(sw.lower_bound())
+    np.save(os.path.join({out!r}, f"ov_duals_{{int(overlap)}}_{{rank}}.npy"), sw.dualt.numpy())
+    if overlap:
+        st = sw.probe_passes(2)
+if rank == 0:
+    np.save(os.path.join({out!r}, "ov_lb.npy"), np.array(lbs + [st["exchanges_per_pass"]]))
+dist.destroy_process_group()
+"""
+
+
+def test_two_process_gloo_run_with_overlapped_exchanges(tmp_path):
+    """the LockstepModel DRIVER (engine stand-in) in two gloo processes, exchanges overlapped or not: same duals on every rank, the
+    unpartitioned oracle's bound"""
+    from tests.test_multi_gpu import _general_models
+    script = tmp_path / "ov_worker.py"
+    script.write_text(WORKER_OVERLAP.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29549", str(script)], env=env, cwd=ROOT, timeout=600)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"ov_duals_0_{r}.npy"), np.load(tmp_path / f"ov_duals_1_{r}.npy"))
+    gm = _general_models()["c5"]
+    ref = Oracle(gm); ref.set_reparametrization(M.REPAM_ANISOTROPIC); ref.ComputePass(3)
+    lb = np.load(tmp_path / "ov_lb.npy")
+    assert abs(lb[0] - ref.LowerBound()) <= 1e-12 * max(1.0, abs(ref.LowerBound())) and lb[0] == lb[1] and lb[2] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["graph", "strips", "c5"])
+def test_overlapped_exchanges_on_device_equal_the_oracle(name):
+    """real engines, all parts on the one GPU: the split schedules (cut-adjacent records | exchange posted | interior records |
+    exchange awaited) leave the oracle's duals"""
+    from lp_mp_amd import engine as E
+    from tests.test_multi_gpu import _general_models
+    mode = M.REPAM_ANISOTROPIC
+    if name == "c5":
+        gm = _general_models()["c5"]
+        sched, parts = LS.lockstep_model(gm, MG.graph_partition_model(gm, 3), 3, mode)
+    else:
+        c = _graph(1500, 6000, 16, 4, 2) if name == "graph" else _strips(12, 10, 8, 3, "dense", "colour_major", 5)
+        gm = _global_of(c)
+        sched, parts = _parts_of(c, mode)
+    ref = Oracle(gm); ref.set_reparametrization(mode)
+    res = {}
+    for overlap in (False, True):
+        sweeps, tensors = [], []
+        for p in parts:
+            dual = torch.from_numpy(p.model.dual_data.copy()).to("cuda:0")
+            eng = E.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual, rows_layout=False); eng.set_reparametrization(mode)
+            sweeps.append(LS.LockstepSweep(torch, p, sched, eng, dual, overlap_exchange=overlap)); tensors.append(dual)
+        try:
+            LS.run_lockstep(sweeps, 2); LS.run_lockstep(sweeps, 1); torch.cuda.synchronize()
+            res[overlap] = ([t.cpu().numpy() for t in tensors], sum(s.local_lower_bound() for s in sweeps))
+        finally:
+            for s in sweeps:
+                s.close(); s.engine.close()
+    ref.ComputePass(3)
+    for a, b in zip(res[False][0], res[True][0]):
+        assert np.array_equal(a, b)
+    assert abs(res[True][1] - ref.LowerBound()) <= 1e-9 * max(1.0, abs(ref.LowerBound()))

@@ -13,7 +13,12 @@
 // the others the anisotropic ComputePass; LowerBound() after every iteration.  Reported: mean ms per iteration of the cycle and
 // of each kind of iteration; the bound / primal-cost history with and without passes running ahead must be identical.
 //
-//   offload_solver_loop [--grid 512] [--labels 32] [--iterations 60] [--warm 24] [--rounding 0|1]
+// --order row_major: the grid inserted row by row (u_i -> p_ij -> u_j in row-major variable order: H + W - 1 dependent levels per
+// directional sweep); --order suggested: the same insertion, then the order the engine suggests for it — lpmp_plan_suggest_order on
+// the planned row-major model — applied to a second LP as a chain of AddFactorRelation calls: a reference user
+// who inserts a grid row by row gets the colour-major time without knowing about colours.
+//
+//   offload_solver_loop [--grid 512] [--labels 32] [--iterations 60] [--warm 24] [--rounding 0|1] [--order colour_major|row_major|suggested]
 // Build: g++ -std=c++17 -O2 -I lp_mp_amd/include -I tests/cpp tools/offload_solver_loop.cpp -L lp_mp_amd/csrc -llpmp_engine -Wl,-rpath,$PWD/lp_mp_amd/csrc
 #include <algorithm>
 #include <chrono>
@@ -66,36 +71,64 @@ static double u01(uint64_t& st) { st = st * 6364136223846793005ULL + 14426950408
 
 int main(int argc, char** argv) {
   int G = 512, L = 32, iters = 60, warm = 24, rounding = 0;
+  std::string order = "colour_major";
   for (int i = 1; i + 1 < argc; i += 2) {
     const std::string a = argv[i];
     if (a == "--grid") G = std::atoi(argv[i + 1]); else if (a == "--labels") L = std::atoi(argv[i + 1]);
     else if (a == "--iterations") iters = std::atoi(argv[i + 1]); else if (a == "--warm") warm = std::atoi(argv[i + 1]);
-    else if (a == "--rounding") rounding = std::atoi(argv[i + 1]);
+    else if (a == "--rounding") rounding = std::atoi(argv[i + 1]); else if (a == "--order") order = argv[i + 1];
   }
+  if (order != "colour_major" && order != "row_major" && order != "suggested") { std::fprintf(stderr, "offload_solver_loop: --order colour_major|row_major|suggested\n"); return 2; }
   try {
     using LP_device = lpmp_offload::offloaded<LP_MP::LP<FMC_MRF>>;
     LP_MP::mock_cmd_line cmd;
-    LP_device lp(cmd);
-    // colour-major variable order (black cells first): the order whose consecutive passes join
-    std::vector<int> pos((size_t)G * G);
-    { int b = 0, w = (G * G + 1) / 2; for (int r = 0; r < G; ++r) for (int c = 0; c < G; ++c) pos[(size_t)r * G + c] = ((r + c) & 1) == 0 ? b++ : w++; }
-    std::vector<int> cell_of((size_t)G * G);
-    for (int i = 0; i < G * G; ++i) cell_of[pos[i]] = i;
-    std::vector<FMC_MRF::U*> u((size_t)G * G);
-    uint64_t st = 42;
-    std::vector<double> c((size_t)L);
-    for (int k = 0; k < G * G; ++k) { for (auto& x : c) x = u01(st); u[(size_t)cell_of[k]] = lp.add_factor<FMC_MRF::U>(c); }
-    auto edge = [&](int a, int b) {
-      if (pos[a] > pos[b]) std::swap(a, b);
-      auto* p = lp.add_factor<FMC_MRF::P>((LP_MP::INDEX)L, (LP_MP::INDEX)L);
-      for (auto& x : p->GetFactor()->pw) x = u01(st);
-      lp.add_message<FMC_MRF::ML>(u[a], p); lp.add_message<FMC_MRF::MR>(u[b], p);
-      lp.AddFactorRelation(u[a], p); lp.AddFactorRelation(p, u[b]);
+    // the grid as the caller inserts it: variable order `pos` (colour-major: black cells first — the order whose consecutive passes
+    // join; else row by row), u_i -> p_ij -> u_j per edge — or, with `rank`, the same factors and messages with the
+    // relations replaced by a chain through all factors in the suggested order
+    auto build = [&](LP_device& lp, bool colour_major, const std::vector<int32_t>* rank) {
+      std::vector<int> pos((size_t)G * G);
+      if (colour_major) { int b = 0, w = (G * G + 1) / 2; for (int r = 0; r < G; ++r) for (int c = 0; c < G; ++c) pos[(size_t)r * G + c] = ((r + c) & 1) == 0 ? b++ : w++; }
+      else for (int i = 0; i < G * G; ++i) pos[(size_t)i] = i;
+      std::vector<int> cell_of((size_t)G * G);
+      for (int i = 0; i < G * G; ++i) cell_of[pos[i]] = i;
+      std::vector<FMC_MRF::U*> u((size_t)G * G);
+      std::vector<LP_MP::FactorTypeAdapter*> all;            // every factor in insertion order = the engine's factor index
+      uint64_t st = 42;
+      std::vector<double> c((size_t)L);
+      for (int k = 0; k < G * G; ++k) { for (auto& x : c) x = u01(st); u[(size_t)cell_of[k]] = lp.add_factor<FMC_MRF::U>(c); all.push_back(u[(size_t)cell_of[k]]); }
+      auto edge = [&](int a, int b) {
+        if (pos[a] > pos[b]) std::swap(a, b);
+        auto* p = lp.add_factor<FMC_MRF::P>((LP_MP::INDEX)L, (LP_MP::INDEX)L);
+        all.push_back(p);
+        for (auto& x : p->GetFactor()->pw) x = u01(st);
+        lp.add_message<FMC_MRF::ML>(u[a], p); lp.add_message<FMC_MRF::MR>(u[b], p);
+        if (!rank) { lp.AddFactorRelation(u[a], p); lp.AddFactorRelation(p, u[b]); }
+      };
+      for (int r = 0; r < G; ++r) for (int cc = 0; cc < G; ++cc) {
+        if (cc + 1 < G) edge(r * G + cc, r * G + cc + 1);
+        if (r + 1 < G) edge(r * G + cc, (r + 1) * G + cc);
+      }
+      if (rank) {                                            // the suggestion as AddFactorRelation calls
+        std::vector<int32_t> by_rank(rank->size());
+        for (size_t f = 0; f < rank->size(); ++f) by_rank[(size_t)(*rank)[f]] = (int32_t)f;
+        for (size_t i = 0; i + 1 < by_rank.size(); ++i) lp.AddFactorRelation(all[(size_t)by_rank[i]], all[(size_t)by_rank[i + 1]]);
+      }
     };
-    for (int r = 0; r < G; ++r) for (int cc = 0; cc < G; ++cc) {
-      if (cc + 1 < G) edge(r * G + cc, r * G + cc + 1);
-      if (r + 1 < G) edge(r * G + cc, (r + 1) * G + cc);
+    std::vector<int32_t> rank;
+    int32_t n_colours = 0;
+    double suggest_ms = 0;
+    if (order == "suggested") {
+      LP_device first(cmd);
+      build(first, false, nullptr);
+      first.Begin();
+      rank.resize((size_t)lpmp_plan_n_factors(lpmp_engine_plan(first.engine())));
+      const auto t0 = std::chrono::steady_clock::now();
+      lpmp_offload::check(lpmp_plan_suggest_order(lpmp_engine_plan_mut(first.engine()), 0, rank.data(), &n_colours));
+      suggest_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      first.End();
     }
+    LP_device lp(cmd);
+    build(lp, order == "colour_major", order == "suggested" ? &rank : nullptr);
     lp.Begin();
     std::size_t iter = 0;                                    // Solver::iter: grows over the whole solve (the primal time stamps follow it)
     std::size_t iter_base = 0;                               // the second configuration continues the stamps of the first (they must not decrease)
@@ -148,7 +181,11 @@ int main(int argc, char** argv) {
       lpmp_offload::check(lpmp_speculation_stats(e, &stats[k][0], &stats[k][1], &stats[k][2], &stats[k][3]));
     }
     const bool same = hist[0] == hist[1];
-    std::printf("{\"tool\": \"offload_solver_loop\", \"grid\": %d, \"labels\": %d, \"iterations\": %d, \"lower_bound_start\": %.17g, \"lower_bound_end\": %.17g, "
+    int64_t lv[2] = {0, 0};
+    for (int d = 0; d < 2; ++d) lpmp_offload::check(lpmp_plan_schedule_info(lpmp_engine_plan_mut(e), d, 0, &lv[d], nullptr, nullptr, nullptr, nullptr));
+    std::printf("{\"tool\": \"offload_solver_loop\", \"order\": \"%s\", \"levels_per_direction\": [%lld, %lld], \"suggest_order_ms\": %.1f, \"colours\": %d, ",
+                order.c_str(), (long long)lv[0], (long long)lv[1], suggest_ms, (int)n_colours);
+    std::printf("\"grid\": %d, \"labels\": %d, \"iterations\": %d, \"lower_bound_start\": %.17g, \"lower_bound_end\": %.17g, "
                 "\"ms_per_iteration_every_call_as_it_comes\": %.4f, \"ms_per_iteration_passes_running_ahead\": %.4f, "
                 "\"rounding_cycle\": %s, \"ms_plain_iteration\": [%.4f, %.4f], \"ms_rounding_iteration\": [%.4f, %.4f], \"best_primal_cost\": %.17g, "
                 "\"bound_history_identical\": %s, \"batches\": %lld, \"passes_launched\": %lld, \"passes_used\": %lld, \"rollbacks\": %lld}\n",
