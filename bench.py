@@ -349,40 +349,58 @@ def model_partition(args, torch, dist, MG, gm, world):
     return part, MG.broadcast_string(dist, used[0] if used else None)
 
 
+def library_source_hash():
+    """hash of the sources, headers and flags the RUNNING liblpmp_engine.so was compiled from (lp_mp_amd/build.py writes it next
+    to the library; build() rebuilds whenever it differs from the sources, so after build() it is also the hash of the sources)"""
+    from lp_mp_amd import build as B
+    try:
+        return open(B.STAMP).read().strip()
+    except OSError:
+        return None
+
+
 def pmc_traffic(kernel_name, args):
     """Bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected in separate runs of this same command, corrected as MI355X_MICROARCH.md prescribes; summarised
     by tools/pmc_traffic.py into profiles/).  These are the L2's FABRIC-side request counters: a read served by the
-    256 MiB Infinity Cache counts like one served by HBM.  None when no summary for this workload is committed."""
+    256 MiB Infinity Cache counts like one served by HBM.
+    Returns (bytes or None, source or the reason there is none).  A summary counts only if it was taken with THIS library: it
+    carries the source hash of the library that ran under the profiler (tools/profile_collect.py), compared here with the running
+    library's stamp — a kernel change without a re-profile gives `traffic: null`, not a stale ratio."""
     import glob
     if getattr(args, "workload", "c3") == "c5":
-        return None, None                                # (no counter passes taken for C5: latency-bound, a mix of kernel classes)
+        return None, "no counter passes for C5 (latency-bound, a mix of kernel classes)"
     if getattr(args, "workload", "c3") == "c4":
         if not (args.c4_nodes == 2_000_000 and args.c4_edges == 10_000_000 and args.c4_labels == 16):
-            return None, None
+            return None, "counter passes exist for the full-size workload only"
         what = "c4_dense16"
     elif args.grid == 1024 and args.labels == 32 and args.pairwise == "dense" and args.order == "colour_major":
         what = "c3_dense32"
     else:
-        return None, None
+        return None, "counter passes exist for the full-size workload only"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{what}.json")))
     if not files:
-        return None, None
+        return None, "no counter summary committed"
+    mine = library_source_hash()
+    stale = None
     for f in reversed(files):                         # the latest summary taken on this kernel (C4: in this variable order)
         d = json.load(open(f))
         if what == "c4_dense16" and d.get("variable_order", "index") != getattr(args, "c4_order", "index"):
             continue
-        if d.get("kernel") in kernel_name:
-            files = [f]
-            break
-    else:
-        return None, None
-    b = d.get("fabric_bytes_per_launch_avg", d.get("hbm_bytes_per_launch_avg"))   # r01/r02 summaries used the second name
-    if d.get("passes_per_launch"):                   # one chain launch = all passes of the call
-        b = b / d["passes_per_launch"] * args.steps
-    elif d.get("launches_per_chain_launch"):         # a deep sweep as ONE persistent launch: the summary is per step inside it
-        b = b * d["launches_per_chain_launch"]
-    return b, os.path.relpath(files[-1], ROOT)
+        if d.get("kernel") not in kernel_name:
+            continue
+        if d.get("library_source_hash") != mine:
+            if stale is None:
+                stale = (f"stale: {os.path.relpath(f, ROOT)} was taken with library {str(d.get('library_source_hash'))[:12]}, "
+                         f"the running one is {str(mine)[:12]} — re-profile (tools/profile_round.sh)")
+            continue
+        b = d.get("fabric_bytes_per_launch_avg", d.get("hbm_bytes_per_launch_avg"))   # r01/r02 summaries used the second name
+        if d.get("passes_per_launch"):                   # one chain launch = all passes of the call
+            b = b / d["passes_per_launch"] * args.steps
+        elif d.get("launches_per_chain_launch"):         # a deep sweep as ONE persistent launch: the summary is per step inside it
+            b = b * d["launches_per_chain_launch"]
+        return b, os.path.relpath(f, ROOT)
+    return None, stale or "no counter summary for this kernel"
 
 
 def dual_bound_gap_c4(torch, dist, args, mode, world, rank, schedule=None):
@@ -860,6 +878,11 @@ def main():
         runner.prepare_passes(args.warmup); runner.prepare_passes(args.steps)
         setup["prepare_passes_s"] = time.perf_counter() - t1
     dt = time_passes(torch, dist, runner, args.steps, args.warmup, 2 if dist_on else 1, args.prewarm_ms)
+    if updates_per_pass is None:                     # C4 on one GPU: what the line reports about the directional sweeps (multi_gpu.GraphSweep.query_info)
+        t1 = time.perf_counter()
+        runner.query_info()
+        setup["directional_schedule_info_after_the_timed_region_s"] = time.perf_counter() - t1
+        updates_per_pass, bytes_per_pass, levels = runner.global_updates_per_pass, runner.global_bytes_per_pass, runner.levels
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -991,7 +1014,7 @@ def main():
             k = dom[1]
             avg_ms = k["ms"] / k["launches"]
             achieved = (k["bytes"] / k["launches"]) / (avg_ms * 1e-3) / 1e9
-            traffic, src = pmc_traffic(k["kernel"], args) if not dist_on else (None, None)
+            traffic, src = pmc_traffic(k["kernel"], args) if not dist_on else (None, "one-GPU profiles only")
             hbm_min = hbm_min_bytes_per_pass(runner, args, world, bytes_per_pass, updates_per_pass, L)
             launch_s = avg_ms * 1e-3
             chain = bool(k.get("chain_launches"))
@@ -1027,7 +1050,7 @@ def main():
             "value": value, "unit": "msg-updates/s", "n_gpus": world, "backend": launch["backend"], "ranks_seen": launch["ranks_seen"],
             "devices": launch["devices"], "launch": launch, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.workload == "c3" else "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "library": {"source_hash": library_source_hash(), "version": E.lib().lpmp_version().decode()},
             "config": {"workload": workload_name(args),
                        "parallelism": parallelism, "variable_order": {"c4": args.c4_order, "c5": args.c5_order, "c3": args.order}[args.workload],
                        "partitioner": partitioner, "cut_fraction": cut_fraction_line,

@@ -682,6 +682,7 @@ static void deep_schedule_note(lpmp_engine* e, int64_t n_levels, const char* wha
                "lpmp_plan_suggest_order gives one with a level per colour (INTEGRATION.md 2a)\n", what, (long long)n_levels);
 }
 
+constexpr int64_t LAZY_SCHEDULES_MIN_FACTORS = (int64_t)1 << 20;
 void ensure_device_schedules(lpmp_engine* e, int mode) {
   if (e->have_sched[mode]) return;
   for (int d = 0; d < 2; ++d) {
@@ -1561,7 +1562,12 @@ int lpmp_set_reparametrization(lpmp_engine* e, int mode) {
     if (mode < 0 || mode >= LPMP_REPAM_COUNT) throw std::runtime_error("unknown reparametrization mode");
     HIP_CHECK(hipSetDevice(e->device));
     if (mode != e->mode) settle(e);          // (Solver::PreIterate sets the same mode before every pass, solver.hxx:268-271)
-    ensure_device_schedules(e, mode);
+    // The directional schedules (ComputeForwardPass / ComputeBackwardPass, the ...AndPrimal sweeps) are built here for models of
+    // ordinary size — a model the device kernels cannot run is refused at this call — and on first use for models of millions of
+    // factors: LP::ComputePass runs the fused pass schedule and the partitioned drivers their own iterator-range schedules, and
+    // two directional schedules nobody runs were 2.6 s of the 10 s before the first pass of the 2 M / 10 M graph
+    if (e->plan->p.nf <= LAZY_SCHEDULES_MIN_FACTORS) ensure_device_schedules(e, mode);
+    else e->plan->p.ensure_weights(mode);
     e->mode = mode;
   });
 }
@@ -1636,10 +1642,10 @@ static void ensure_partition_schedule(lpmp_engine* e, int rtype) {
 }
 
 int lpmp_compute_forward_pass(lpmp_engine* e) {
-  return guarded([&] { require_mode(e); HIP_CHECK(hipSetDevice(e->device)); settle(e); begin_compute(e); run_schedule(e, e->sched[0][e->mode]); });
+  return guarded([&] { require_mode(e); HIP_CHECK(hipSetDevice(e->device)); settle(e); ensure_device_schedules(e, e->mode); begin_compute(e); run_schedule(e, e->sched[0][e->mode]); });
 }
 int lpmp_compute_backward_pass(lpmp_engine* e) {
-  return guarded([&] { require_mode(e); HIP_CHECK(hipSetDevice(e->device)); settle(e); begin_compute(e); run_schedule(e, e->sched[1][e->mode]); });
+  return guarded([&] { require_mode(e); HIP_CHECK(hipSetDevice(e->device)); settle(e); ensure_device_schedules(e, e->mode); begin_compute(e); run_schedule(e, e->sched[1][e->mode]); });
 }
 static void compute_plain_passes(lpmp_engine* e, int n) {   // ComputeForwardPass(); ComputeBackwardPass(); n times
   if (e->use_fused) {
@@ -1669,6 +1675,7 @@ static void compute_plain_passes(lpmp_engine* e, int n) {   // ComputeForwardPas
       for (int i = 0; i < n; ++i) run_schedule(e, e->sched_pass[e->mode]);
     }
   } else {
+    ensure_device_schedules(e, e->mode);
     for (int i = 0; i < n; ++i) { run_schedule(e, e->sched[0][e->mode]); run_schedule(e, e->sched[1][e->mode]); }
   }
 }
@@ -1937,6 +1944,7 @@ static void run_primal_sweep(lpmp_engine* e, int d, uint64_t t) {
     launch_primal_init(e->d_pinit, e->n_pinit, e->d_primal, e->stream);
     e->primal_t = t;
   }
+  ensure_device_schedules(e, e->mode);
   e->primal_pass = true;
   try { run_schedule(e, e->sched[d][e->mode]); } catch (...) { e->primal_pass = false; throw; }
   e->primal_pass = false;

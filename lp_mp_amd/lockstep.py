@@ -561,14 +561,16 @@ class LockstepSweep:
 
     def exchange_counts(self, n=2):
         """split sizes (doubles per peer rank) of the largest exchange of an n-pass call: for a self test of the collective"""
+        # (every rank must name the SAME exchange: the one that ships the most vectors over all ranks — the program is global)
         best = None
         for step in self.sched.program(n):               # (the overlapped program ships the same sets)
-            if step[0] == "halo":
-                _, out_counts, _, in_counts = self._halo_plan(step[1], step[2])
-                if best is None or int(out_counts.sum()) > int(best[0].sum()):
-                    best = (out_counts, in_counts)
+            if step[0] == "halo" and (best is None or step[1].shape[0] > best[1].shape[0]):
+                best = step
         world = getattr(self.part, "true_world", self.part.world)
-        return best if best is not None else (np.zeros(world, np.int64), np.zeros(world, np.int64))
+        if best is None:
+            return np.zeros(world, np.int64), np.zeros(world, np.int64)
+        _, out_counts, _, in_counts = self._halo_plan(best[1], best[2])
+        return out_counts, in_counts
 
     def local_lower_bound(self) -> float:
         if hasattr(self.engine, "invalidate_lower_bounds"):

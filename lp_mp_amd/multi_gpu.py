@@ -1178,13 +1178,12 @@ class GraphSweep(DriverStats):
         lap("weights_s")
         if self.comm is None:
             # one GPU, no process group: the engine's own pass schedules are the sweep (no boundary schedules to build beside them)
+            # (message updates, algorithmic bytes and levels per directional sweep come from the directional schedules, which a run of
+            # plain passes never builds for a model of this size: query_info() plans them — bench.py asks after its timed region)
             self.sweep = None
-            info = [self.engine.plan.schedule_info(d, mode) for d in (M.FORWARD, M.BACKWARD)]
-            self.global_updates_per_pass = sum(int(i["n_receives"] + i["n_sends"]) for i in info)
-            self.global_bytes_per_pass = sum(int(i["algorithmic_bytes"]) for i in info)
+            self._mode = mode
             self.global_cut_fraction = 0.0
-            self.levels = [i["n_levels"] for i in info]
-            lap("directional_schedules_s")
+            self.global_updates_per_pass = self.global_bytes_per_pass = self.levels = None
             return
         self.sweep = PartitionedSweep(torch, part, self.engine, self.dualt, mode, omega_b, boundary_every, BOUNDARY_RESERVE)
         vals = [self.sweep.updates_per_pass(), self.sweep.bytes_per_pass(), part.out_ghost.shape[0], m]
@@ -1195,6 +1194,16 @@ class GraphSweep(DriverStats):
         self.global_bytes_per_pass = int(vals[1])
         self.global_cut_fraction = vals[2] / m
         self.levels = [i["n_levels"] for i in self.sweep.info]
+
+    def query_info(self):
+        """one GPU: message updates / algorithmic bytes per pass (summed over the two directional sweeps) and dependent
+        levels per direction, from the directional schedules (host planning only; seconds at the full C4 size)"""
+        if self.sweep is None and self.levels is None:
+            info = [self.engine.plan.schedule_info(d, self._mode) for d in (M.FORWARD, M.BACKWARD)]
+            self.global_updates_per_pass = sum(int(i["n_receives"] + i["n_sends"]) for i in info)
+            self.global_bytes_per_pass = sum(int(i["algorithmic_bytes"]) for i in info)
+            self.levels = [i["n_levels"] for i in info]
+        return self
 
     def prepare_passes(self, n):
         """what the first call of compute_pass(n) would build (one GPU: the engine's pass schedule): outside a timed region"""

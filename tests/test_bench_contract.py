@@ -27,20 +27,45 @@ def test_cpu_baseline_leg_runs_the_oracle_on_a_bounded_sample():
     assert "16x16" in out["sample"]
 
 
-def test_pmc_traffic_lookup_matches_committed_profile():
-    traffic, src = bench.pmc_traffic("sweep_dense_pk_kernel<32, 2>", _args())
-    assert src is not None and os.path.exists(os.path.join(ROOT, src))
-    assert 1e9 < traffic < 3e10
-    assert bench.pmc_traffic("sweep_dense_pk_kernel<32, 2>", _args(grid=512)) == (None, None)
-    # the joined-pass chain launch covers all passes of a call: the summary's bytes are scaled to the call's pass count
-    t20, src20 = bench.pmc_traffic("void lpmp::chain_dense_pk_kernel<32, 2, false, false>", _args(steps=20))
-    t10, _ = bench.pmc_traffic("void lpmp::chain_dense_pk_kernel<32, 2, false, false>", _args(steps=10))
-    assert src20 is not None and "pmc_c3_dense32" in src20 and 3e10 < t20 / 20 < 4.5e10 and abs(t10 * 2 - t20) < 1e-6 * t20
-    # C4 (round 3: the random-graph workload has counters too): bytes per launch of the 16-label packed kernel
-    c4 = _args(workload="c4", c4_nodes=2_000_000, c4_edges=10_000_000, c4_labels=16)
-    t4, src4 = bench.pmc_traffic("sweep_dense_pk_kernel<16, 2, false, true>", c4)
-    assert src4 is not None and "pmc_c4_dense16" in src4 and 5e8 < t4 < 1.5e9
-    assert bench.pmc_traffic("sweep_dense_pk_kernel<16, 2, false, true>", _args(workload="c4", c4_nodes=20000, c4_edges=100000, c4_labels=16)) == (None, None)
+def _latest_pmc(what):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{what}.json")))
+    return files[-1], json.load(open(files[-1]))
+
+
+def test_pmc_traffic_lookup_is_tied_to_the_library_that_was_profiled(monkeypatch):
+    """roofline.traffic comes from a committed counter summary ONLY when that summary was taken with the library that is running:
+    the summary carries the source hash of the library under the profiler, bench.py compares it with the running library's stamp
+    and reports `traffic: null` + the reason otherwise (a kernel change without a re-profile must not leave a stale ratio)"""
+    f3, d3 = _latest_pmc("c3_dense32")
+    kern3 = "void lpmp::" + d3["kernel"] + ", 2, false, false, false>" if d3["kernel"].startswith("chain_") else d3["kernel"]
+    # (1) another library than the profiled one: no traffic, and the line says why
+    monkeypatch.setattr(bench, "library_source_hash", lambda: "0" * 64)
+    t, why = bench.pmc_traffic(kern3, _args(steps=20))
+    assert t is None and why.startswith("stale: profiles/") and "re-profile" in why
+    # (2) the profiled library itself (a summary of a round that recorded the hash): bytes, scaled to the call's pass count
+    if d3.get("library_source_hash"):
+        monkeypatch.setattr(bench, "library_source_hash", lambda: d3["library_source_hash"])
+        t20, src20 = bench.pmc_traffic(kern3, _args(steps=20))
+        t10, _ = bench.pmc_traffic(kern3, _args(steps=10))
+        assert src20 == os.path.relpath(f3, ROOT) and 3e10 < t20 / 20 < 4.5e10 and abs(t10 * 2 - t20) < 1e-6 * t20
+        assert d3["kernel_full_names"] and all(d3["kernel"] in n for n in d3["kernel_full_names"])
+        f4, d4 = _latest_pmc("c4_dense16")
+        if d4.get("library_source_hash"):
+            monkeypatch.setattr(bench, "library_source_hash", lambda: d4["library_source_hash"])
+            c4 = _args(workload="c4", c4_nodes=2_000_000, c4_edges=10_000_000, c4_labels=16, c4_order=d4.get("variable_order", "index"))
+            t4, src4 = bench.pmc_traffic(d4["kernel"], c4)
+            assert src4 == os.path.relpath(f4, ROOT) and 5e8 < t4 < 1.5e9
+    # other sizes, other workloads: never a number
+    assert bench.pmc_traffic(kern3, _args(grid=512))[0] is None
+    assert bench.pmc_traffic("sweep_dense_pk_kernel<16, 2, false, true>", _args(workload="c4", c4_nodes=20000, c4_edges=100000, c4_labels=16))[0] is None
+    assert bench.pmc_traffic("sweep_generic_kernel<1>", _args(workload="c5"))[0] is None
+
+
+def test_running_library_reports_the_hash_of_its_sources():
+    from lp_mp_amd import build as B
+    B.build()
+    assert bench.library_source_hash() == B.source_hash() and len(B.source_hash()) == 64
 
 
 @pytest.mark.gpu

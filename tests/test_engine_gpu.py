@@ -1104,6 +1104,9 @@ def test_c4_is_the_same_problem_on_every_path(order):
         assert np.array_equal(b.dualt.cpu().numpy(), o.duals())
         for lb in (a.lower_bound(), b.lower_bound()):
             assert abs(lb - o.LowerBound()) <= 1e-9 * abs(o.LowerBound())
+        assert a.levels is None                                            # (one GPU: planned when asked for)
+        a.query_info()
         assert a.levels == list(b.levels) and (a.levels[0] <= 12 if order == "colour_major" else a.levels[0] > 12)
+        assert a.global_updates_per_pass == 4 * m
     finally:
         a.engine.close(); b.close()

@@ -46,6 +46,23 @@ subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.
 pj = os.path.join(dst, f"{tag}_pmc_{wl_class}.json")
 d = json.load(open(pj))
 d["passes_per_launch"] = plain["roofline"].get("passes_per_launch")
+# provenance: the library that ran under the profiler (bench.py compares it with the running library's stamp and reports
+# `traffic: null` on a mismatch) and the kernel's full name as the profiler printed it
+def _hash_of(log):
+    try:
+        for line in open(os.path.join(src, log)):
+            if line.startswith('{"metric"'):
+                return json.loads(line).get("library", {}).get("source_hash")
+    except OSError:
+        pass
+    return None
+hashes = {h for h in (_hash_of("bench_fetch.log"), _hash_of("bench_write.log"), prof.get("library", {}).get("source_hash"), plain.get("library", {}).get("source_hash")) if h}
+if len(hashes) != 1:
+    raise SystemExit(f"the runs of this profile were not made with ONE library: {hashes}")
+d["library_source_hash"] = hashes.pop()
+import csv
+names = sorted({r["Kernel_Name"] for r in csv.DictReader(open(os.path.join(dst, f"{tag}_pmc_fetch_counter_collection.csv"))) if kernel in r["Kernel_Name"]})
+d["kernel_full_names"] = names
 d["variable_order"] = plain.get("config", {}).get("variable_order")
 d["note"] = ("FETCH_SIZE / WRITE_SIZE are the L2's fabric-side request counters: reads served by the 256 MiB Infinity Cache are "
              "counted like reads served by HBM (MI355X_MICROARCH.md, HBM / rocprofv3 section)")
