@@ -437,25 +437,51 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   std::vector<int32_t> last_level(nf, 0), last_toucher(nf, -1), last_update_of(nf, -1);
   std::vector<int32_t> nr_of_u(N, 0), ns_of_u(N, 0);            // active receives / sends of every single update (its own, not the owner's sum)
   int32_t max_level = 0;
-  std::vector<int32_t> touched;
-  for (int64_t u = 0; u < N; ++u) {
-    const int32_t f = uf[u];
-    touched.clear();
-    touched.push_back(f);
-    int32_t nr = 0, ns = 0;
-    {
+  // what every update touches (its own factor first, then the peers of its active messages) — independent per update, so the
+  // walk over the message lists and the weight / mask rows runs on the planner's threads; the recurrence over the levels below
+  // is sequential by nature and only chases these lists
+  std::vector<int64_t> t_off((size_t)N + 1, 0);
+  parallel_chunks(N, 65536, [&](int64_t u_begin, int64_t u_end, int) {
+    for (int64_t u = u_begin; u < u_end; ++u) {
+      const int32_t f = uf[u];
+      int32_t nr = 0, ns = 0; int64_t nt = 1;
       int64_t ks = 0, kr = 0;
+      const bool all = ftype_primal[f_type[f]] && f_kind[f] != LPMP_F_VECTOR;
       for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
         const MsgEntry& e = fm[j];
         bool active = false;
         if (e.receives && umk[u][kr++]) { active = true; ++nr; }
         if (e.sends) { const double w = uom[u][ks++]; if (w < 0) fail("negative send weight"); if (w != 0.0) { active = true; ++ns; } }
-        // a pairwise factor that rounds itself reads and writes the labels of ALL its unaries in a primal pass
-        // (engine.cpp, ensure_primal), whether or not the message is active in this sweep
-        if (active || (ftype_primal[f_type[f]] && f_kind[f] != LPMP_F_VECTOR)) touched.push_back(e.adjacent);
+        if (active || all) ++nt;
+      }
+      nr_of_u[u] = nr; ns_of_u[u] = ns; t_off[(size_t)u + 1] = nt;
+    }
+  });
+  for (int64_t u = 0; u < N; ++u) t_off[(size_t)u + 1] += t_off[(size_t)u];
+  std::vector<int32_t, default_init_allocator<int32_t>> t_data((size_t)t_off[(size_t)N]);
+  parallel_chunks(N, 65536, [&](int64_t u_begin, int64_t u_end, int) {
+    for (int64_t u = u_begin; u < u_end; ++u) {
+      const int32_t f = uf[u];
+      int32_t* out_t = t_data.data() + t_off[(size_t)u];
+      *out_t++ = f;
+      int64_t ks = 0, kr = 0;
+      // a pairwise factor that rounds itself reads and writes the labels of ALL its unaries in a primal pass
+      // (engine.cpp, ensure_primal), whether or not the message is active in this sweep
+      const bool all = ftype_primal[f_type[f]] && f_kind[f] != LPMP_F_VECTOR;
+      for (int64_t j = fm_off[f]; j < fm_off[f + 1]; ++j) {
+        const MsgEntry& e = fm[j];
+        bool active = false;
+        if (e.receives && umk[u][kr++]) active = true;
+        if (e.sends && uom[u][ks++] != 0.0) active = true;
+        if (active || all) *out_t++ = e.adjacent;
       }
     }
-    nr_of_u[u] = nr; ns_of_u[u] = ns;
+  });
+  struct Touched { const int32_t* b; const int32_t* e; const int32_t* begin() const { return b; } const int32_t* end() const { return e; } };
+  for (int64_t u = 0; u < N; ++u) {
+    const int32_t f = uf[u];
+    const Touched touched{t_data.data() + t_off[(size_t)u], t_data.data() + t_off[(size_t)u + 1]};
+    const int32_t nr = nr_of_u[u], ns = ns_of_u[u];
     int32_t lv = 0;
     for (int32_t g : touched) lv = std::max(lv, last_level[g]);
     const int32_t prev = last_update_of[f];

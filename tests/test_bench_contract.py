@@ -55,7 +55,7 @@ def test_pmc_traffic_lookup_is_tied_to_the_library_that_was_profiled(monkeypatch
             monkeypatch.setattr(bench, "library_source_hash", lambda: d4["library_source_hash"])
             c4 = _args(workload="c4", c4_nodes=2_000_000, c4_edges=10_000_000, c4_labels=16, c4_order=d4.get("variable_order", "index"))
             t4, src4 = bench.pmc_traffic(d4["kernel"], c4)
-            assert src4 == os.path.relpath(f4, ROOT) and 5e8 < t4 < 1.5e9
+            assert src4 == os.path.relpath(f4, ROOT) and 5e8 < t4 < 5e9            # (index order: 66 launches of ~0.8 GB per pass; colour-major: 18 of ~3.4 GB)
     # other sizes, other workloads: never a number
     assert bench.pmc_traffic(kern3, _args(grid=512))[0] is None
     assert bench.pmc_traffic("sweep_dense_pk_kernel<16, 2, false, true>", _args(workload="c4", c4_nodes=20000, c4_edges=100000, c4_labels=16))[0] is None
