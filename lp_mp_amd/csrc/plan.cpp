@@ -718,6 +718,35 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     lr.n_recv = key_recv[k]; lr.n_send = key_send[k]; lr.bytes = key_bytes[k];
     out.launches.push_back(lr);
   }
+  // Inside a launch the order of the records is free (they are independent).  They were placed in SEQUENCE order; what the
+  // kernels and the Infinity-Cache ticket orders want is MEMORY order — duals and tables lie in factor insertion order — so that
+  // blocks that are near in the list touch tables that are near in HBM, in every step alike.  The two agree for a sweep in
+  // insertion order; a backward sweep whose order is the exact reverse of the forward one (a chain of relations through all
+  // factors: lpmp_plan_suggest_order's answer) lists every level backwards, and a band order across its steps would need block 0
+  // of one step to wait for the last block of the step before (measured: 6.75 instead of 5.25 ms per pass on the headline grid).
+  // Records of a launch that are not ascending in the factor index are put in that order (reversed when exactly descending).
+  for (const auto& lr : out.launches) {
+    const int64_t nrec = lr.end - lr.begin;
+    if (nrec < 2) continue;
+    bool asc = true, desc = true;
+    for (int64_t i = lr.begin + 1; i < lr.end && (asc || desc); ++i) {
+      asc = asc && out.recs[i - 1].factor <= out.recs[i].factor;
+      desc = desc && out.recs[i - 1].factor >= out.recs[i].factor;
+    }
+    if (asc) continue;
+    if (desc) {
+      std::reverse(out.recs.begin() + lr.begin, out.recs.begin() + lr.end);
+      std::reverse(rec_upd.begin() + lr.begin, rec_upd.begin() + lr.end);
+      continue;
+    }
+    std::vector<int64_t> perm((size_t)nrec);
+    std::iota(perm.begin(), perm.end(), lr.begin);
+    std::stable_sort(perm.begin(), perm.end(), [&](int64_t x, int64_t y) { return out.recs[x].factor < out.recs[y].factor; });
+    std::vector<UpdRec> tr(perm.size()); std::vector<int32_t> tu(perm.size());
+    for (size_t i = 0; i < perm.size(); ++i) { tr[i] = out.recs[perm[i]]; tu[i] = rec_upd[perm[i]]; }
+    std::copy(tr.begin(), tr.end(), out.recs.begin() + lr.begin);
+    std::copy(tu.begin(), tu.end(), rec_upd.begin() + lr.begin);
+  }
   lap_("records");
   out.ops = std::move(ops);
   // inside a launch the order of the records is free (they are independent): sub-wave kernels run several
