@@ -1300,7 +1300,18 @@ int lpmp_plan_custom_schedule_info(lpmp_plan* p, int64_t n, const int32_t* facto
 int lpmp_plan_get_update_levels(lpmp_plan* p, int d, int mode, int32_t* out) {
   return guarded([&] {
     if (!p || !out || d < 0 || d > 1 || mode < 0 || mode >= LPMP_REPAM_COUNT) throw std::runtime_error("bad argument");
-    plan_schedule(p, d, mode);
+    if (!p->have_sched[d][mode]) {
+      // the sweep has not been planned (a multi-GPU host asking for the GLOBAL level structure never runs it): the levels alone
+      p->p.ensure_weights(mode);
+      const auto& om = p->p.omega[d][mode];
+      const auto& mk = p->p.mask[d][mode];
+      std::vector<int32_t> lv;
+      Schedule scratch;
+      p->p.make_schedule(std::vector<Plan::Segment>{{p->p.upd[d].data(), (int64_t)p->p.upd[d].size(), om.off.data(), om.data.data(), mk.off.data(), mk.data.data()}},
+                         false, scratch, false, &lv);
+      std::copy(lv.begin(), lv.end(), out);
+      return;
+    }
     const Schedule& s = p->sched_cache[d][mode];
     std::vector<int32_t> level_of(p->p.nf, 0);
     for (const auto& lr : s.launches) for (int64_t i = lr.begin; i < lr.end; ++i) level_of[s.recs[i].factor] = lr.level;

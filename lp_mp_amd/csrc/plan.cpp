@@ -394,7 +394,7 @@ void Plan::ensure_weights(int mode) {
 // from the state after the receives" is exactly what running u1 then u2 computes, and the factor's dual
 // makes one round trip instead of two (2-colour grids: the receive level of the forward sweep and the
 // send level of the backward sweep are the same factors).
-void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out, bool chains) const {
+void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out, bool chains, std::vector<int32_t>* levels_only) const {
   out = Schedule();
   const bool timed_ = std::getenv("LPMP_PLAN_TIMES") != nullptr;
   auto t_last_ = std::chrono::steady_clock::now();
@@ -510,6 +510,14 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
   }
   lap_("levels");
   out.n_levels = max_level;
+  if (levels_only) {
+    levels_only->resize((size_t)N);
+    for (int64_t u = 0; u < N; ++u) {
+      const int32_t o = owner[u];
+      (*levels_only)[(size_t)u] = (n_recv_of[o] + n_send_of[o] > 0 || ftype_primal[f_type[uf[o]]]) ? level[o] : 0;
+    }
+    return;
+  }
 
   // records of the owners, ops = all receives of the members (sequence order), then all sends
   std::vector<int64_t> op_start(N + 1, 0);

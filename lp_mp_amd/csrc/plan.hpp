@@ -275,7 +275,9 @@ struct Plan {
   // chains = false: a schedule of exactly three levels (the shape whose consecutive passes the engine joins into its own
   // persistent launch, engine.cpp rotation_chain) gets no chain plan of its own — a third of the planning time at the
   // headline size for lists the joined launch never reads
-  void make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out, bool chains = true) const;
+  // levels_only (optional): only the dependent level of every update is wanted — filled ([sum of the segments' n]; 0 for an update
+  // that becomes no record: no active message and no primal to round) and nothing else is built (a third of the work)
+  void make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& out, bool chains = true, std::vector<int32_t>* levels_only = nullptr) const;
   void make_schedule(const int32_t* factors, int64_t n, const int64_t* om_off, const double* om,
                      const int64_t* mk_off, const uint8_t* mk, Schedule& out) const;
   int64_t row_sends(int32_t f) const { return n_row_sends[(size_t)f]; }       // entries of f's message list that send / receive

@@ -482,3 +482,19 @@ def test_oracle_partition_and_adaptive_rules_are_dual_ascent():
             lb = o.LowerBound()
             assert abs(energy(o.duals()) - e0) <= 1e-9
         assert lb <= e0 + 1e-9 and lb > 0
+
+
+def test_update_levels_without_planning_the_sweep_equal_those_of_the_planned_sweep():
+    """lpmp_plan_get_update_levels on a sweep nobody has planned (the global structure of a lock-step run: its sweeps are never
+    executed as such) computes the levels alone; the same numbers as read off the full schedule, every mode, both directions"""
+    from lp_mp_amd import synthetic as S
+    models = [S.grid_model(9, 8, 4, order="row_major", seed=1), S.counter_graph_model(500, 2000, 4, 2),
+              S.c5_model(8, 8, 4, 200, 120, 40, seed=3, window=16), S.multicut_triangle_model(12, 15, seed=4)]
+    for m in models:
+        for mode in (M.REPAM_ANISOTROPIC, M.REPAM_ANISOTROPIC2, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM):
+            p1, p2 = E.Plan(m), E.Plan(m)
+            for d in (M.FORWARD, M.BACKWARD):
+                alone = p1.update_levels(d, mode)
+                p2.schedule_info(d, mode)
+                assert np.array_equal(alone, p2.update_levels(d, mode)), (mode, d)
+                assert alone.max() <= p2.schedule_info(d, mode)["n_levels"]          # (updates without an active message count no level)

@@ -16,7 +16,9 @@ echo "# Sanitizer runs of the HOST side of the engine (round 5; CPU container, n
 echo "## AddressSanitizer + UndefinedBehaviorSanitizer"
 ( cd lp_mp_amd/csrc && hipcc $FLAGS -fsanitize=address,undefined -o ../../build/exp/liblpmp_engine_asan.so $SRC ) 2>&1 | tail -3
 LD_PRELOAD=$RT/libclang_rt.asan-x86_64.so ASAN_OPTIONS=detect_leaks=0 LPMP_ENGINE_SO=$PWD/build/exp/liblpmp_engine_asan.so \
-  timeout 3000 python -m pytest $FILES -q -m "not gpu" -p no:cacheprovider 2>&1 | grep -v "Gloo\|^$" | tail -6
+  timeout 3000 python -m pytest $FILES -q -m "not gpu" -p no:cacheprovider > build/exp/asan_pytest.log 2>&1
+grep -v "Gloo\|^$" build/exp/asan_pytest.log | tail -4
+echo "AddressSanitizer reports: $(grep -c 'ERROR: AddressSanitizer' build/exp/asan_pytest.log)   UBSan reports: $(grep -c 'runtime error:' build/exp/asan_pytest.log)"
 LD_PRELOAD=$RT/libclang_rt.asan-x86_64.so ASAN_OPTIONS=detect_leaks=0 LPMP_ENGINE_SO=$PWD/build/exp/liblpmp_engine_asan.so python - <<'PY' 2>&1 | tail -5
 import numpy as np
 from lp_mp_amd import engine as E, synthetic as S, multi_gpu as MG, model as M
@@ -33,7 +35,9 @@ echo "## ThreadSanitizer (planning threads: LPMP_PLAN_THREADS=8)"
 ( cd lp_mp_amd/csrc && hipcc $FLAGS -fsanitize=thread -o ../../build/exp/liblpmp_engine_tsan.so $SRC ) 2>&1 | tail -3
 LD_PRELOAD=$RT/libclang_rt.tsan-x86_64.so LPMP_PLAN_THREADS=8 LPMP_ENGINE_SO=$PWD/build/exp/liblpmp_engine_tsan.so \
   timeout 3000 python -m pytest tests/test_plan_host.py tests/test_graph_host.py tests/test_lockstep.py tests/test_overlap.py tests/test_lp_mirror.py tests/test_oracle_ref.py -q -m "not gpu" -p no:cacheprovider \
-  -k "not gloo and not two_process and not four_process and not three_process" 2>&1 | grep -v "Gloo\|^$" | tail -6
+  -k "not gloo and not two_process and not four_process and not three_process" > build/exp/tsan_pytest.log 2>&1
+grep -v "Gloo\|^$" build/exp/tsan_pytest.log | tail -4
+echo "ThreadSanitizer warnings: $(grep -c 'WARNING: ThreadSanitizer' build/exp/tsan_pytest.log)"
 LD_PRELOAD=$RT/libclang_rt.tsan-x86_64.so LPMP_PLAN_THREADS=8 LPMP_ENGINE_SO=$PWD/build/exp/liblpmp_engine_tsan.so python - <<'PY' 2>&1 | tail -8
 import numpy as np
 from lp_mp_amd import engine as E, synthetic as S, multi_gpu as MG
