@@ -89,7 +89,8 @@ int lpmp_plan_custom_schedule_info(lpmp_plan* p, int64_t n, const int32_t* facto
                                    int64_t* n_levels, int64_t* n_launches, int64_t* n_receives, int64_t* n_sends,
                                    int64_t* algorithmic_bytes);
 
-/* dependent step (1-based level; 0 = no active message) of every entry of the update order in that sweep */
+/* dependent step (1-based level; 0 = no active message) of every entry of the update order in that sweep (computed alone when the
+ * sweep has not been planned: a multi-GPU host asks for the level structure of a global model it never runs as such) */
 int lpmp_plan_get_update_levels(lpmp_plan* p, int direction, int mode, int32_t* out /*[n_updated]*/);
 /* the same for a whole pass (forward then backward sweep scheduled as one sequence; back-to-back updates
  * of one factor across the two sweeps are folded into one record) */
@@ -156,7 +157,11 @@ int lpmp_set_stream(lpmp_engine* e, void* hip_stream);
  * receives and 32767 active sends per updated factor. */
 int lpmp_upload_model(lpmp_engine* e, const lpmp_model* m, int const_mem, int dual_mem);
 
-int lpmp_set_reparametrization(lpmp_engine* e, int mode);   /* LP::set_reparametrization, LP_MP.h:330 */
+/* LP::set_reparametrization, LP_MP.h:330 (+ the lazy get_omega, :412-460).  Builds the weights of that mode and, for models of up
+ * to 2^20 factors, the two directional schedules — a model the device kernels cannot run is refused here (LPMP_ERR_UNSUPPORTED).
+ * Larger models get every schedule on first use (lpmp_compute_pass: the fused pass schedule; lpmp_compute_forward_pass / ...: the
+ * directional ones; the partitioned drivers: their own iterator-range schedules), and the same refusal then. */
+int lpmp_set_reparametrization(lpmp_engine* e, int mode);
 /* --reparametrizationType parsed by LP::Begin (LP_MP.h:589-593, :710-722) and switched on in the hot loop (:869-887,
  * :988-1004).  All five run on the device:
  *   shared                 UpdateFactor (factors_messages.hxx:2256-2261)
