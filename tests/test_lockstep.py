@@ -443,11 +443,15 @@ def test_lockstep_random_graphs_partitions_and_modes_on_device(seed):
     for p in parts:
         dual = torch.from_numpy(p.model.dual_data.copy()).to(dev)
         eng = E.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual); eng.set_reparametrization(mode)
-        sweeps.append(LS.LockstepSweep(torch, p, sched, eng, dual)); tensors.append(dual)
+        # (tests/stress_lockstep_mailbox.py runs these cases for many more seeds, also with LPMP_STRESS_OVERLAP=1: the overlapped
+        # program, and LPMP_STRESS_ROWS=1: parts on the rows layout)
+        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual, rows_layout=bool(os.environ.get("LPMP_STRESS_ROWS"))); eng.set_reparametrization(mode)
+        sweeps.append(LS.LockstepSweep(torch, p, sched, eng, dual, overlap_exchange=bool(os.environ.get("LPMP_STRESS_OVERLAP")))); tensors.append(dual)
     try:
         for k in rng.integers(1, 4, 3):
-            ref.ComputePass(int(k)); LS.run_lockstep(sweeps, int(k)); torch.cuda.synchronize()
+            ref.ComputePass(int(k)); LS.run_lockstep(sweeps, int(k))
+            for s in sweeps:
+                s.engine.synchronize()                     # (rows layout: the packed buffer is written out here)
             _assert_equals_global(c, parts, [t.cpu().numpy() for t in tensors], ref)
             lb = sum(s.local_lower_bound() for s in sweeps)
             assert abs(lb - ref.LowerBound()) <= 1e-9 * max(1.0, abs(ref.LowerBound())), (seed, lb, ref.LowerBound())
@@ -484,8 +488,8 @@ def test_lockstep_random_general_models_partitions_and_modes_on_device(seed):
     for p in parts:
         dual = torch.from_numpy(p.model.dual_data.copy()).to(dev)
         eng = E.Engine(0); eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual); eng.set_reparametrization(mode)
-        sweeps.append(LS.LockstepSweep(torch, p, sched, eng, dual)); tensors.append(dual)
+        eng.upload(p.model, dual_dev=dual.data_ptr(), keep=dual, rows_layout=bool(os.environ.get("LPMP_STRESS_ROWS"))); eng.set_reparametrization(mode)
+        sweeps.append(LS.LockstepSweep(torch, p, sched, eng, dual, overlap_exchange=bool(os.environ.get("LPMP_STRESS_OVERLAP")))); tensors.append(dual)
     g_off = gm.dual_offsets()
     try:
         for k in rng.integers(1, 4, 3):
