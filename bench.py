@@ -264,7 +264,7 @@ def single_gpu_reference(args):
     """ms per pass of the SAME workload on one GPU from the latest committed bench line (profiles/): the t_1 of the scaling model.
     (workload, ms, file) or None"""
     import glob
-    pats = {"c3": "r*bench_c3_default.json", "c4": "r*_c4_bench_c4_default.json", "c5": "r*_c5_bench_c5_default.json"}[args.workload]
+    pats = {"c3": "r*bench_c3_default.json", "c4": "r*_c4_bench_c4_default.json", "c5": "r*_c5_bench_c5_*.json"}[args.workload]   # (c5: one line per edge-variable order)
     want = workload_name(args)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pats)), reverse=True):
         try:

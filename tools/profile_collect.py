@@ -34,7 +34,10 @@ def bench_line(log, out):
 
 plain = bench_line("bench_plain.log", f"{tag}_bench_{wl}_default.json")
 prof = bench_line("bench_stats.log", f"{tag}_bench_{wl}_under_rocprof.json")
-db = lambda d: glob.glob(os.path.join(src, d, "*", "*.db"))[0]
+def db(d):
+    """the database of that run — the NEWEST one: gpurun merges a call's output into gpurun_out/, so an earlier run of the same tag
+    leaves its database beside the new one"""
+    return max(glob.glob(os.path.join(src, d, "*", "*.db")), key=os.path.getmtime)
 tool = os.path.join(ROOT, "tools", "rocpd_summary.py")
 subprocess.check_call([sys.executable, tool, "stats", db("stats"), os.path.join(dst, f"{tag}_bench_{wl}_kernel_stats.csv")])
 for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):

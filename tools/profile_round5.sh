@@ -31,7 +31,7 @@ probes)
 solver)
   g++ -std=c++17 -O2 -I lp_mp_amd/include -I tests/cpp tools/offload_solver_loop.cpp -L lp_mp_amd/csrc -llpmp_engine -Wl,-rpath,$PWD/lp_mp_amd/csrc -o build/offload_solver_loop
   for o in colour_major row_major suggested; do
-    timeout 1500 ./build/offload_solver_loop --grid 1024 --labels 32 --iterations 40 --warm 20 --order $o 2>> gpurun_out/r05_solver_orders.err
+    timeout 1500 ./build/offload_solver_loop --grid 1024 --labels 32 --iterations 64 --warm 24 --order $o 2>> gpurun_out/r05_solver_orders.err
   done > gpurun_out/r05_solver_orders.json
   timeout 900 ./build/offload_solver_loop --grid 1024 --labels 32 --iterations 60 --warm 25 --rounding 1 > gpurun_out/r05_solver_cycle.json 2>/dev/null
   ;;
