@@ -229,3 +229,51 @@ def test_bench_gpus_2_c4_runs_in_lock_step_by_default():
     assert abs(d["dual_bound_gap"]) <= 1e-12 and d["lower_bound_after"] > d["lower_bound_before"]
     assert set(d["schedules"]) == {"lockstep", "boundary"} and 0 <= d["schedules"]["boundary"]["dual_bound_gap"] < 0.05
     assert d["scaling"] == "strong"
+
+
+RDZV_WORKER = r"""
+import os, sys, json, types
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+args = types.SimpleNamespace(rendezvous_timeout=60.0, collective_timeout=60.0)
+# (no GPU here: the identities are made up — two ranks on "one device", as on the 1-GPU box, one on another)
+ident = "pci=0000:05:00.0 uuid=" + "a" * 32 if rank < 2 else "pci=0000:06:00.0 uuid=" + "b" * 32
+idents, backend = bench.rendezvous(args, torch, dist, ident, rank, world)
+t = torch.ones(1); dist.all_reduce(t)
+class R:                                    # the self test of the collectives on a runner without exchanges
+    comm = None
+st = bench.collective_self_test(args, torch, dist, R(), rank, world) if False else None
+if rank == 0:
+    json.dump({{"idents": idents, "backend": backend, "sum": float(t.item()), "agent_store": os.environ.get("TORCHELASTIC_USE_AGENT_STORE")}},
+              open(os.path.join({out!r}, "rdzv.json"), "w"))
+dist.destroy_process_group()
+"""
+
+
+def test_rendezvous_under_torch_distributed_run_uses_the_agents_store(tmp_path):
+    """the driver's N-GPU command is `python -m torch.distributed.run ... bench.py --gpus N`: the ranks then meet at the AGENT's
+    store (bench.rendezvous goes through torch's env rendezvous, which connects to it instead of binding the port again), exchange
+    their device identities there and choose the backend from the number of PHYSICAL devices — gloo as soon as two ranks share one"""
+    script = tmp_path / "rdzv_worker.py"
+    script.write_text(RDZV_WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k != "LPMP_DIST_BACKEND"}
+    env.update(MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                           "--master-addr", "127.0.0.1", "--master-port", "29553", str(script)], env=env, cwd=ROOT, timeout=600)
+    d = json.load(open(tmp_path / "rdzv.json"))
+    assert len(d["idents"]) == 3 and d["idents"][0] == d["idents"][1] != d["idents"][2]
+    assert d["backend"] == "gloo" and d["sum"] == 3.0 and d["agent_store"] == "True"
+
+
+def test_watchdog_exits_with_code_3_and_names_the_rank():
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.Watchdog(0.5, 'the self test of the collectives', 5):\n"
+            "    time.sleep(30)\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3 and "rank 5" in p.stderr and "did not finish within" in p.stderr
+    code_ok = ("import sys; sys.path.insert(0, %r); import bench\n"
+               "with bench.Watchdog(5, 'x', 0):\n    pass\nprint('fine')\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code_ok], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "fine" in p.stdout

@@ -81,3 +81,24 @@ def test_rccl_driver_builds_links_rccl_and_fails_loudly_without_a_gpu():
         pytest.skip("GPU box: the run itself is tests/test_multi_gpu.py::test_cpp_rccl_driver_equals_the_python_partitioned_sweep")
     r = subprocess.run([exe, "--H", "4", "--W", "4", "--L", "4"], capture_output=True, text=True, env=dict(os.environ, RANK="0", WORLD_SIZE="1"))
     assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+def test_cpp_host_watchdog_exits_instead_of_waiting_for_ever(tmp_path):
+    """lpmp_multi_gpu.hxx bounds ncclCommInitRank and the first all-reduce with exit_watchdog: a scope that is not left in time ends
+    the process with code 3 and says which rank waited for what; a scope left in time costs nothing.  (Host-only program: nothing
+    of RCCL or HIP is called.)"""
+    from lp_mp_amd import build as B
+    if not B.have_rccl():
+        pytest.skip("<rccl/rccl.h> not installed")
+    src = tmp_path / "wd.cpp"
+    src.write_text('#include "lpmp_multi_gpu.hxx"\n#include <thread>\n'
+                   'int main(int argc, char**) {\n'
+                   '  { lpmp_mgpu::exit_watchdog ok(5.0, "rank 0 of 2: something quick"); }\n'
+                   '  if (argc > 1) { lpmp_mgpu::exit_watchdog wd(0.3, "rank 1 of 2: ncclCommInitRank"); std::this_thread::sleep_for(std::chrono::seconds(20)); }\n'
+                   '  std::puts("left in time"); return 0; }\n')
+    exe = tmp_path / "wd"
+    subprocess.check_call([B.hipcc(), "-std=c++17", "-O1", "-I", os.path.join(ROOT, "lp_mp_amd", "include"), str(src), "-o", str(exe), "-pthread"], timeout=600)
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "left in time" in p.stdout
+    p = subprocess.run([str(exe), "hang"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3 and "rank 1 of 2: ncclCommInitRank did not return within" in p.stderr
