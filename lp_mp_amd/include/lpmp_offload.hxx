@@ -356,6 +356,19 @@ class offloaded : public LP_BASE {
   // how many passes the engine may run ahead of the Solve loop (0: every call as it comes; default 16)
   void set_speculation(int max_passes_ahead) { speculation_ = max_passes_ahead; if (engine_) check(lpmp_set_speculation(engine_, speculation_)); }
   lpmp_engine* engine() { sync_to_device(); return engine_; }
+  // The order the engine suggests for this LP as it stands (lpmp_plan_suggest_order): by_rank[i] = the factor
+  // (by insertion index: the i-th add_factor) at position i.  A caller whose insertion order is deep (a grid row by row, chains of
+  // local higher-order factors: one launch step per dependent level) builds its LP with
+  //   for (i = 0; i + 1 < by_rank.size(); ++i) lp.AddFactorRelation(factor[by_rank[i]], factor[by_rank[i + 1]]);
+  // INSTEAD of its own relations: same factors, messages and costs, the updated factors colour by colour.
+  std::vector<int32_t> suggested_order(uint64_t seed = 0, int32_t* n_colours = nullptr) {
+    sync_to_device();
+    lpmp_plan* plan = lpmp_engine_plan_mut(engine_);
+    std::vector<int32_t> rank((std::size_t)lpmp_plan_n_factors(plan)), by_rank(rank.size());
+    check(lpmp_plan_suggest_order(plan, seed, rank.data(), n_colours));
+    for (std::size_t f = 0; f < rank.size(); ++f) by_rank[(std::size_t)rank[f]] = (int32_t)f;
+    return by_rank;
+  }
 
   void ComputePass(const std::size_t /*iteration*/) { ready_mode(); check(lpmp_compute_pass(engine_, 1)); device_ahead_ = true; }
   // n consecutive passes in one call (the engine joins them); results equal n calls of ComputePass
