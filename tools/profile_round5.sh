@@ -33,7 +33,7 @@ solver)
   for o in colour_major row_major suggested; do
     timeout 1500 ./build/offload_solver_loop --grid 1024 --labels 32 --iterations 64 --warm 24 --order $o 2>> gpurun_out/r05_solver_orders.err
   done > gpurun_out/r05_solver_orders.json
-  timeout 900 ./build/offload_solver_loop --grid 1024 --labels 32 --iterations 60 --warm 25 --rounding 1 > gpurun_out/r05_solver_cycle.json 2>/dev/null
+  timeout 900 ./build/offload_solver_loop --grid 1024 --labels 32 --iterations 60 --warm 26 --rounding 1 > gpurun_out/r05_solver_cycle.json 2>/dev/null
   ;;
 ranks)
   for n in 2 8; do
