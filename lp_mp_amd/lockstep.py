@@ -157,11 +157,35 @@ class LockstepSchedule:
         return steps
 
 
+def _small_ints(a):
+    """the same values in the narrowest unsigned type that holds them: numpy's stable argsort is a radix sort for 8- and 16-bit
+    keys (levels of a sweep: a handful to a few thousand), a merge sort otherwise"""
+    if a.size and a.min() >= 0:
+        m = int(a.max())
+        if m < 256:
+            return a.astype(np.uint8)
+        if m < 65536:
+            return a.astype(np.uint16)
+    return a
+
+
 def _csr_take(off, data, idx):
+    """rows ``idx`` of the CSR array (off, data), back to back: (offsets of the taken rows, their entries)"""
     lens = off[idx + 1] - off[idx]
     first = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    pos = np.repeat(off[idx], lens) + (np.arange(int(first[-1])) - np.repeat(first[:-1], lens))
-    return first, data[pos]
+    total = int(first[-1])
+    if total == 0:
+        return first, data[:0]
+    # positions as a running sum: +1 inside a row, a jump to the next row's start at every row boundary (one pass over the
+    # output instead of two repeats and an arange: these arrays hold 20 M entries at the C4 size)
+    step = np.ones(total, np.int64)
+    nz = lens > 0
+    starts = off[idx][nz].astype(np.int64)
+    at = first[:-1][nz]
+    step[at[0]] = starts[0]
+    if at.shape[0] > 1:
+        step[at[1:]] = starts[1:] - (starts[:-1] + lens[nz][:-1] - 1)
+    return first, data[np.cumsum(step)]
 
 
 def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: int, unaries=None, tables=None, potts=None,
@@ -206,7 +230,7 @@ def lockstep_mrf(n_vars: int, L: int, edge_i, edge_j, part, world: int, mode: in
 
         def by_level(sel, flip):                             # cut vectors of the selected row entries, grouped by level
             v, lv = vec_own[sel] ^ flip, lev[row_of[sel]]
-            order = np.argsort(lv, kind="stable")
+            order = np.argsort(_small_ints(lv), kind="stable")
             bounds = np.searchsorted(lv[order], np.arange(1, nl + 2))
             out = []
             for l in range(nl):                              # sub-levels: the records that touch a cut edge, then the others
@@ -334,7 +358,7 @@ def lockstep_model(gm: M.FlatModel, part, world: int, mode: int, only: Optional[
         nl = int(lev.max()) if lev.size else 0
 
         def by_level(v, lv):
-            order = np.argsort(lv, kind="stable")
+            order = np.argsort(_small_ints(lv), kind="stable")
             bounds = np.searchsorted(lv[order], np.arange(1, nl + 2))
             out = []
             for l in range(nl):                              # sub-levels: the records that touch a cut vector, then the others
