@@ -53,10 +53,11 @@ def parse():
     ap.add_argument("--c5-triplets", type=int, default=70_000)
     ap.add_argument("--c5-quads", type=int, default=30_000)
     ap.add_argument("--c5-window", type=int, default=64, help="a labeling-list factor's members are drawn from this many consecutive edge variables")
-    ap.add_argument("--c5-order", default="index", choices=["index", "colour_major"],
+    ap.add_argument("--c5-order", default="index", choices=["index", "colour_major", "suggested"],
                     help="--workload c5: the edge variables as inserted (index: local triples chain them — thousands of dependent levels "
-                         "per sweep, latency-bound on any number of GPUs) or in the colour-major order the engine suggests "
-                         "(lpmp_plan_suggest_order: one level per colour)")
+                         "per sweep, latency-bound on any number of GPUs); colour_major: the generator inserts them colour by colour "
+                         "(ordering.colour_major_order_hyper); suggested: the model as inserted, run in the order the engine suggests for "
+                         "it (lpmp_plan_suggest_order applied as a chain of relations: one level per colour)")
     ap.add_argument("--c5-small", action="store_true",
                     help="--workload c5 in miniature (64x64 grid, 2 000 edge variables, 900 + 400 factors): the state after warmup + steps "
                          "passes is checked against the oracle's (tests/golden/c5_small.npz) — `oracle_check` in the line")
@@ -322,7 +323,13 @@ def c5_shape(args):
 
 def c5_global_model(args, S):
     g, L, ne, nt, nq, w = c5_shape(args)
-    return S.c5_model(g, g, L, ne, nt, nq, seed=4, window=w, colour_edge_vars=args.c5_order == "colour_major")
+    m = S.c5_model(g, g, L, ne, nt, nq, seed=4, window=w, colour_edge_vars=args.c5_order == "colour_major")
+    if args.c5_order == "suggested":
+        # the model as inserted, in the order the ENGINE suggests for it through the C ABI (lpmp_plan_suggest_order on the host-only
+        # plan), applied as a chain of relations through all factors — what a C++ caller does
+        from lp_mp_amd.engine import Plan
+        m = m.with_factor_order(Plan(m).suggest_order(4)[0])
+    return m
 
 
 def model_partition(args, torch, dist, MG, gm, world):

@@ -62,41 +62,50 @@ Adj build_adj(int64_t n, int64_t m, const int64_t* ei, const int64_t* ej, bool k
   return g;
 }
 
-// colours in {0, 1} = BFS depth parity from the lowest-numbered vertex of every component, or false when an odd cycle exists
-// (ordering.two_colouring: the component labelling of the bipartite double cover gives exactly this colouring)
-bool two_colouring(int64_t n, const Adj& g, std::vector<int8_t>& colour) {
+// Component by component: colours in {0, 1} = BFS depth parity from the lowest-numbered vertex of a component that has no odd cycle
+// (ordering.two_colouring: the component labelling of the bipartite double cover gives exactly this colouring); the vertices of
+// every other component stay uncoloured (-1) for the greedy colouring.  A model of several parts (a 2-colourable grid beside
+// higher-order factors: C5) keeps the 2 levels of its grid — and with them the joined passes — whatever the rest needs.
+// Returns the number of vertices left uncoloured.
+int64_t two_colouring_by_component(int64_t n, const Adj& g, const int64_t* ei, const int64_t* ej, int64_t m, std::vector<int8_t>& colour) {
   colour.assign((size_t)n, -1);
-  if (g.self_loop) return false;                          // (in the double cover a loop joins the two copies of its vertex)
+  std::vector<uint8_t> loop((size_t)n, 0);                 // (in the double cover a loop joins the two copies of its vertex)
+  if (g.self_loop) for (int64_t e = 0; e < m; ++e) if (ei[e] == ej[e]) loop[(size_t)ei[e]] = 1;
   std::vector<int32_t> queue;
   queue.reserve(1024);
+  int64_t left = 0;
   for (int64_t s = 0; s < n; ++s) {
-    if (colour[(size_t)s] >= 0) continue;
+    if (colour[(size_t)s] != -1) continue;
     colour[(size_t)s] = 0;
     queue.clear(); queue.push_back((int32_t)s);
+    bool odd = false;
     for (size_t h = 0; h < queue.size(); ++h) {
       const int32_t v = queue[h];
       const int8_t c = colour[(size_t)v];
+      odd = odd || loop[(size_t)v];
       for (int64_t k = g.off[(size_t)v]; k < g.off[(size_t)v + 1]; ++k) {
         const int32_t u = g.adj[(size_t)k];
-        if (colour[(size_t)u] < 0) { colour[(size_t)u] = (int8_t)(1 - c); queue.push_back(u); }
-        else if (colour[(size_t)u] == c) return false;
+        if (colour[(size_t)u] == -1) { colour[(size_t)u] = (int8_t)(1 - c); queue.push_back(u); }
+        else if (colour[(size_t)u] == c) odd = true;
       }
     }
+    if (odd) { for (int32_t v : queue) colour[(size_t)v] = -2; left += (int64_t)queue.size(); }   // (-2: seen, not 2-colourable)
   }
-  return true;
+  if (left) for (int64_t v = 0; v < n; ++v) if (colour[(size_t)v] == -2) colour[(size_t)v] = -1;
+  return left;
 }
 
 // Jones-Plassmann greedy colouring (ordering.greedy_colouring): in every round the uncoloured vertices whose priority beats all
 // their uncoloured neighbours' take the smallest colour none of their coloured neighbours has.  Priorities: the counter hash of
 // the vertex (ties by index), so that the numpy statement and this one agree without sharing a random generator.  Winners of a
 // round are never adjacent, and a round reads only the colours of earlier rounds: the result does not depend on the threads.
+// Vertices that already hold a colour (the 2-colourable components) keep it; they are adjacent to none of the others.
 void greedy_colouring(int64_t n, const Adj& g, uint64_t seed, std::vector<int8_t>& colour) {
-  colour.assign((size_t)n, -1);
   std::vector<uint64_t> h((size_t)n);
   parallel_blocks(n, 1 << 16, [&](int64_t b, int64_t e) { for (int64_t v = b; v < e; ++v) h[(size_t)v] = splitmix(seed + (uint64_t)(v + 1) * GOLD); });
   auto beats = [&](int32_t a, int32_t b) { return h[(size_t)a] > h[(size_t)b] || (h[(size_t)a] == h[(size_t)b] && a > b); };
-  std::vector<int32_t> live((size_t)n), next;
-  for (int64_t v = 0; v < n; ++v) live[(size_t)v] = (int32_t)v;
+  std::vector<int32_t> live, next;
+  for (int64_t v = 0; v < n; ++v) if (colour[(size_t)v] < 0) live.push_back((int32_t)v);
   std::vector<int8_t> chosen((size_t)n, -1);
   while (!live.empty()) {
     const int64_t nl = (int64_t)live.size();
@@ -143,7 +152,7 @@ int32_t colour_major_order(int64_t n, int64_t m, const int64_t* ei, const int64_
   if (n >= ((int64_t)1 << 31)) throw std::runtime_error("graph: more than 2^31 variables");
   const Adj g = build_adj(n, m, ei, ej);
   std::vector<int8_t> colour;
-  if (!two_colouring(n, g, colour)) greedy_colouring(n, g, seed, colour);
+  if (two_colouring_by_component(n, g, ei, ej, m, colour) > 0) greedy_colouring(n, g, seed, colour);
   return colour_major_rank(n, colour, rank);
 }
 

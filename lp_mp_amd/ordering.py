@@ -28,7 +28,24 @@ def two_colouring(n: int, ei: np.ndarray, ej: np.ndarray):
     return (comp[:n] > comp[n:]).astype(np.int64)
 
 
-def greedy_colouring(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0) -> np.ndarray:
+def two_colouring_by_component(n: int, ei: np.ndarray, ej: np.ndarray) -> np.ndarray:
+    """colours in {0, 1} for the vertices of every connected component without an odd cycle (BFS depth parity from the component's
+    first vertex, as two_colouring gives it), -1 for the vertices of all other components.  A model of several parts — a
+    2-colourable grid beside higher-order factors — keeps the 2 levels of its grid whatever the rest needs."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    ei = np.asarray(ei, np.int64); ej = np.asarray(ej, np.int64)
+    rows = np.concatenate([ei, ei + n]); cols = np.concatenate([ej + n, ej])
+    cover = coo_matrix((np.ones(rows.shape[0], np.int8), (rows, cols)), shape=(2 * n, 2 * n)).tocsr()
+    _, comp = connected_components(cover, directed=False)
+    graph = coo_matrix((np.ones(ei.shape[0], np.int8), (ei, ej)), shape=(n, n)).tocsr()
+    _, part = connected_components(graph, directed=False)
+    odd = np.zeros(int(part.max()) + 1 if n else 0, bool)
+    odd[part[comp[:n] == comp[n:]]] = True                              # both copies of a vertex in one cover component: an odd cycle
+    return np.where(odd[part], -1, (comp[:n] > comp[n:]).astype(np.int64))
+
+
+def greedy_colouring(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0, colour=None) -> np.ndarray:
     """Luby / Jones-Plassmann style parallel greedy colouring with numpy: in every round the uncoloured vertices that
     beat all their uncoloured neighbours (random priorities) take the smallest colour their neighbours do not use.
     At most 63 colours (max degree < 63 is plenty for sparse MRFs).  A round looks only at the directed edges whose
@@ -38,7 +55,8 @@ def greedy_colouring(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0) -> n
     from .synthetic import u64
     prio = np.empty(n, np.int64)
     prio[np.argsort(u64(n, seed), kind="stable")] = np.arange(n)
-    colour = np.full(n, -1, np.int64)
+    # (``colour``: vertices that already hold one — the 2-colourable components — keep it; they are adjacent to none of the others)
+    colour = np.full(n, -1, np.int64) if colour is None else np.array(colour, np.int64)
     a = np.concatenate([ei, ej]); b = np.concatenate([ej, ei])          # directed both ways
     while True:
         un = colour < 0
@@ -64,7 +82,8 @@ def greedy_colouring(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0) -> n
 
 
 def colour_major_order(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0) -> np.ndarray:
-    """rank[v] = position of variable v in a colour-major order (2 colours if the graph is bipartite): computed on the planner's
+    """rank[v] = position of variable v in a colour-major order (2 colours for every component without an odd cycle, a greedy
+    colouring for the others): computed on the planner's
     threads behind the C ABI (lpmp_graph_colour_major_order) — a colouring of 2 M variables / 10 M edges is 6 s of numpy on the
     GPU box and a fraction of a second there; colour_major_order_numpy is the same algorithm as readable numpy, same result"""
     from . import engine as E
@@ -73,9 +92,9 @@ def colour_major_order(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0) ->
 
 def colour_major_order_numpy(n: int, ei: np.ndarray, ej: np.ndarray, seed: int = 0) -> np.ndarray:
     ei = np.asarray(ei, np.int64); ej = np.asarray(ej, np.int64)
-    col = two_colouring(n, ei, ej)
-    if col is None:
-        col = greedy_colouring(n, ei, ej, seed)
+    col = two_colouring_by_component(n, ei, ej)
+    if (col < 0).any():
+        col = greedy_colouring(n, ei, ej, seed, colour=col)
     order = np.argsort(col, kind="stable")
     rank = np.empty(n, np.int64)
     rank[order] = np.arange(n)

@@ -1,6 +1,7 @@
 """Generates tests/golden/c5_small.npz: the CPU oracle on the model of `bench.py --workload c5 --c5-small` (BASELINE.json configs[4]
 in miniature: 64 x 64 Potts grid with 8 labels + 2 000 binary edge variables, 900 triplet and 400 quadruple labeling-list
-factors, one factor graph; anisotropic weights) in both edge-variable orders bench.py offers (--c5-order index / colour_major).
+factors, one factor graph; anisotropic weights) in the edge-variable orders bench.py offers (--c5-order index / colour_major /
+suggested: the index model in the order lpmp_plan_suggest_order gives for it).
 
     python tests/golden/make_c5_small.py
 
@@ -27,7 +28,7 @@ PASSES = list(range(0, 33))
 
 def main():
     out = {"passes": np.array(PASSES)}
-    for order in ("index", "colour_major"):
+    for order in ("index", "colour_major", "suggested"):
         args = types.SimpleNamespace(c5_small=True, c5_labels=8, c5_window=64, c5_order=order, c5_grid=512, c5_edge_vars=150000,
                                      c5_triplets=70000, c5_quads=30000)
         o = Oracle(bench.c5_global_model(args, S))

@@ -26,8 +26,29 @@ def test_colour_major_order_equals_the_numpy_statement_on_random_graphs(n, m, se
 
 
 def _colours(rank, n, ei, ej, seed):
-    col = O.two_colouring(n, ei, ej)
-    return col if col is not None else O.greedy_colouring(n, ei, ej, seed)
+    col = O.two_colouring_by_component(n, ei, ej)
+    return col if (col >= 0).all() else O.greedy_colouring(n, ei, ej, seed, colour=col)
+
+
+def test_components_without_an_odd_cycle_keep_two_colours_beside_components_that_need_more():
+    """a 2-colourable grid beside a clique and a triangle with a tail (one graph, several components): the grid's vertices get the
+    BFS parity colours 0 / 1 as if the grid were alone, the others a greedy colouring — C++ and numpy alike"""
+    gi, gj = S.grid_edges(6, 7)                                      # vertices 0..41
+    k5 = [(42 + a, 42 + b) for a in range(5) for b in range(a + 1, 5)]
+    tri = [(47, 48), (48, 49), (47, 49), (49, 50), (50, 51)]
+    ei = np.concatenate([gi, [a for a, _ in k5 + tri]]); ej = np.concatenate([gj, [b for _, b in k5 + tri]])
+    n = 54                                                           # 52, 53 isolated
+    perm = np.random.default_rng(3).permutation(n)                   # scatter the components over the index range
+    ei, ej = perm[ei], perm[ej]
+    col = O.two_colouring_by_component(n, ei, ej)
+    grid_v = perm[:42]
+    alone = O.two_colouring(n, perm[gi], perm[gj])                   # the grid (+ isolated vertices) on its own
+    assert np.array_equal(col[grid_v], alone[grid_v]) and set(col[perm[42:52]]) == {-1} and list(col[perm[52:]]) == [0, 0]
+    want = O.colour_major_order_numpy(n, ei, ej, 5)
+    got, k = E.graph_colour_major_order(n, ei, ej, 5)
+    assert np.array_equal(got, want) and k == 5                      # the clique needs 5 colours; the grid's vertices sit in the first two classes
+    full = _colours(got, n, ei, ej, 5)
+    assert set(full[grid_v]) == {0, 1} and np.all(full[ei] != full[ej])
 
 
 def test_bipartite_graphs_get_two_colours_and_self_loops_are_handled_like_numpy():

@@ -238,7 +238,7 @@ N_RANK_KEYS = ("compute_ms_per_pass", "exchange_ms_per_pass", "exchange_bytes_pe
                "slowest_rank", "rank_stats", "scaling_model")
 
 
-@pytest.mark.parametrize("order", ["index", "colour_major"])
+@pytest.mark.parametrize("order", ["index", "colour_major", "suggested"])
 def test_bench_c5_small_on_one_gpu_is_checked_against_the_oracle_fixture(order):
     d = _bench(["--workload", "c5", "--c5-small", "--c5-order", order, "--steps", "4", "--warmup", "2", "--cpu-sample-grid", "16"])
     assert d["n_gpus"] == 1 and "labeling-list" in d["config"]["workload"] and d["scaling"] == "strong"
@@ -282,6 +282,9 @@ def test_bench_gpus_2_c5_and_a_partition_file(tmp_path):
     assert d["config"]["partitioner"].startswith(("builtin", "metis")) and 0 < d["config"]["cut_fraction"] < 1
     assert len(d["rank_stats"]["per_rank"]["exchange_ms_per_pass"]) == 2 and d["exchanges_per_pass"] > 0 and d["exchange_bytes_per_pass"]["max"] > 0
     assert d["scaling_model"]["note"] is not None                       # shared device: the projection says it means nothing
+    # the same model in the order the engine suggests for it (a chain of relations through all factors), again on two ranks
+    d = _bench(["--gpus", "2", "--workload", "c5", "--c5-small", "--c5-order", "suggested", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["oracle_check"]["duals_bit_identical_to_oracle"] is True and abs(d["dual_bound_gap"]) <= 1e-12 and max(d["config"]["levels_per_direction"]) <= 12
     pf = tmp_path / "c4.part"
     np.savetxt(pf, (np.arange(20000) * 7 % 2).astype(np.int64), fmt="%d")
     d = _bench(["--gpus", "2", "--workload", "c4", "--c4-nodes", "20000", "--c4-edges", "100000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
