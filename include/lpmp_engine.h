@@ -119,8 +119,9 @@ int lpmp_plan_pass_rotates(lpmp_plan* p, int mode);
  * 5.2 ms per pass).  Another order is another, equally valid trajectory of the dual ascent — not another algorithm.
  *
  * lpmp_plan_suggest_order: rank_of_factor[f] = position of factor f in an order in which the UPDATED factors come colour by colour
- * (two of them conflict when a message joins them or both touch a common factor; 2 colours when that graph is bipartite, else a
- * greedy Jones-Plassmann colouring with counter-hash priorities from `seed`), and every other factor keeps its place relative to
+ * (two of them conflict when a message joins them or both touch a common factor; component by component: 2 colours where the
+ * component has no odd cycle — a grid keeps its 2 levels beside whatever else the model holds —, else a greedy Jones-Plassmann
+ * colouring with counter-hash priorities from `seed`), and every other factor keeps its place relative to
  * the updated factors around it (an MRF's pairwise factor between its two unaries, a multicut triplet behind its edges).  The
  * caller turns it into relations as a chain through all factors — AddFactorRelation(by_rank[i], by_rank[i + 1]) for consecutive
  * positions: the only topological order of that chain is the suggested one, forward, and its reverse,
