@@ -318,3 +318,22 @@ def test_suggested_order_on_the_device_two_levels_and_the_oracles_duals(capfd):
         assert "lpmp_plan_suggest_order" not in capfd.readouterr().err
     finally:
         e.close()
+
+
+def test_bench_under_torch_distributed_run_the_drivers_own_command():
+    """the driver's N-GPU command verbatim, at N = 2 on the one GPU of the test box: `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` — the ranks meet at the AGENT's store, find
+    that they share a physical device (gloo, persistent launches off), pass the self test, run the overlap schedule exactly"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LPMP_DIST_BACKEND")}
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                   "--master-port", "29591", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "4", "--warmup", "2",
+                                   "--no-cpu-baseline", "--no-compare-schedules"], text=True, cwd=ROOT, timeout=1500, env=env, stderr=subprocess.DEVNULL)
+    lines = [l for l in out.strip().splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1                                               # rank 0 prints the one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["launch"]["launcher"].startswith("external") and d["schedule"] == "overlap"
+    assert d["launch"]["physical_devices"] == 1 and d["backend"] == "gloo" and d["launch"]["persistent_launches"] is False
+    assert d["launch"]["self_test"]["all_reduce"] == "ok" and abs(d["dual_bound_gap"]) <= 1e-12
+    for k in N_RANK_KEYS:
+        assert d[k] is not None, k
+    assert len(d["rank_stats"]["per_rank"]["compute_ms_per_pass"]) == 2 and d["redundant_fraction"] > 0
