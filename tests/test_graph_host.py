@@ -158,3 +158,51 @@ def test_deep_schedule_note_names_the_remedy(capfd):
     m = S.grid_model(40, 40, 4, pairwise="potts", order="row_major", seed=1)
     E.Plan(m).schedule_info(0, M.REPAM_ANISOTROPIC)
     assert "lpmp_plan_suggest_order" not in capfd.readouterr().err
+
+
+def _random_models(seed):
+    rng = np.random.default_rng(seed)
+    kind = seed % 4
+    if kind == 0:
+        return S.grid_model(int(rng.integers(3, 12)), int(rng.integers(3, 12)), int(rng.choice([2, 3, 5])), pairwise=str(rng.choice(["dense", "potts"])), order="row_major", seed=seed)
+    if kind == 1:
+        return S.counter_graph_model(int(rng.integers(30, 200)), int(rng.integers(60, 500)), int(rng.choice([2, 4])), seed)
+    if kind == 2:
+        return S.c5_model(int(rng.integers(2, 6)), int(rng.integers(2, 6)), 3, int(rng.integers(20, 90)), int(rng.integers(8, 50)), int(rng.integers(2, 20)), seed=seed, window=int(rng.integers(6, 30)))
+    return S.multicut_triangle_model(int(rng.integers(8, 40)), int(rng.integers(6, 60)), seed=seed)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_suggested_order_on_random_models(seed):
+    """random grids, graphs, C5-style and multicut models: the suggestion is a permutation; in that order no sweep has more dependent
+    levels than colours; every message keeps its direction relative to the higher factor it ends in (a factor that came after k
+    of its updated neighbours comes after k of them again); and the oracle's bound ascends from the same start as in the
+    caller's order"""
+    m = _random_models(seed)
+    p = E.Plan(m)
+    rank, k = p.suggest_order(seed)
+    assert sorted(rank.tolist()) == list(range(m.n_factors))
+    m2 = m.with_factor_order(rank)
+    p2 = E.Plan(m2)
+    for mode in (M.REPAM_ANISOTROPIC, M.REPAM_UNIFORM):
+        lv = [p2.schedule_info(d, mode)["n_levels"] for d in (0, 1)]
+        assert max(lv) <= max(k, 1), (seed, lv, k)
+    # how many of its updated neighbours precede every non-updated factor: unchanged
+    upd0 = np.zeros(m.n_factors, bool); upd0[p.update_order(M.FORWARD)] = True
+    pos0 = np.empty(m.n_factors, np.int64); pos0[p.order(M.FORWARD)] = np.arange(m.n_factors)
+    pos1 = np.empty(m.n_factors, np.int64); pos1[p2.order(M.FORWARD)] = np.arange(m.n_factors)
+    assert np.array_equal(pos1, rank)                                   # the chain's only topological order is the suggestion
+    l, r = m.m_left.astype(np.int64), m.m_right.astype(np.int64)
+    for a, b in ((l, r), (r, l)):                                       # a: updated end, b: other end not updated
+        sel = upd0[a] & ~upd0[b]
+        before0 = np.bincount(b[sel], weights=(pos0[a[sel]] < pos0[b[sel]]), minlength=m.n_factors)
+        before1 = np.bincount(b[sel], weights=(pos1[a[sel]] < pos1[b[sel]]), minlength=m.n_factors)
+        assert np.array_equal(before0, before1), seed
+    o1, o2 = Oracle(m), Oracle(m2)
+    assert abs(o1.LowerBound() - o2.LowerBound()) <= 1e-9 * max(1.0, abs(o1.LowerBound()))
+    o2.set_reparametrization(M.REPAM_ANISOTROPIC)
+    last = o2.LowerBound()
+    for _ in range(3):
+        o2.ComputePass(1)
+        assert o2.LowerBound() >= last - 1e-9 * max(1.0, abs(last))
+        last = o2.LowerBound()

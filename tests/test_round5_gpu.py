@@ -337,3 +337,27 @@ def test_bench_under_torch_distributed_run_the_drivers_own_command():
     for k in N_RANK_KEYS:
         assert d[k] is not None, k
     assert len(d["rank_stats"]["per_rank"]["compute_ms_per_pass"]) == 2 and d["redundant_fraction"] > 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_models_in_the_suggested_order_equal_the_oracle(seed):
+    """random grids, graphs, C5-style and multicut models (tests/test_graph_host.py) run in the order the engine suggests for them:
+    the oracle's duals and bound in that order, bit for bit, plain and residual sends"""
+    from tests.test_graph_host import _random_models
+    m = _random_models(100 + seed)
+    rank, _ = E.Plan(m).suggest_order(seed)
+    m2 = m.with_factor_order(rank)
+    o = Oracle(m2)
+    e = E.Engine(0)
+    try:
+        e.upload(m2)
+        for rtype in (0, 1):
+            o.set_reparametrization_type(rtype); e.set_reparametrization_type(rtype)
+            for mode in (M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM):
+                o.set_reparametrization(mode); e.set_reparametrization(mode)
+                for n in (1, 2):
+                    o.ComputePass(n); e.compute_pass(n)
+                    assert np.array_equal(e.download_duals(), o.duals()), (seed, rtype, mode, n)
+                assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+    finally:
+        e.close()
