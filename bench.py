@@ -1086,7 +1086,7 @@ def main():
             "rounding": rounding,
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (the contract: the CPU baseline is timed on rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(args, S, M)
     if not dist_on and args.workload == "c3" and args.also_row_major and args.order != "row_major":
         del eng, runner
