@@ -228,18 +228,17 @@ int32_t suggest_order(const Plan& p, uint64_t seed, int32_t* rank) {
   std::vector<int32_t> nb((size_t)noff[(size_t)nf]);
   { std::vector<int64_t> at(noff.begin(), noff.end() - 1);
     for (int64_t k = 0; k < p.nm; ++k) { const int32_t l = p.m_left[(size_t)k], r = p.m_right[(size_t)k]; nb[(size_t)at[(size_t)l]++] = r; nb[(size_t)at[(size_t)r]++] = l; } }
-  // conflict edges between updated factors
+  // conflict edges between updated factors: two updates conflict when what they touch — their own factor and the peers of their
+  // messages — overlaps (plan.cpp, level recurrence), i.e. all updated factors around ANY factor f (f itself included when it
+  // is updated: `right` / `full` schedules update the higher factors too) are pairwise in conflict
   std::vector<int64_t> ei, ej;
   std::vector<int32_t> un;
   for (int64_t f = 0; f < nf; ++f) {
-    if (p.updated[(size_t)f]) {
-      for (int64_t k = noff[(size_t)f]; k < noff[(size_t)f + 1]; ++k) { const int32_t g = nb[(size_t)k]; if (p.updated[(size_t)g] && g > f) { ei.push_back(uid[(size_t)f]); ej.push_back(uid[(size_t)g]); } }
-      continue;
-    }
     un.clear();
+    if (p.updated[(size_t)f]) un.push_back(uid[(size_t)f]);
     for (int64_t k = noff[(size_t)f]; k < noff[(size_t)f + 1]; ++k) if (p.updated[(size_t)nb[(size_t)k]]) un.push_back(uid[(size_t)nb[(size_t)k]]);
     std::sort(un.begin(), un.end()); un.erase(std::unique(un.begin(), un.end()), un.end());
-    if (un.size() > 63) throw std::runtime_error("suggest_order: a factor with more than 63 updated neighbours (they would need as many colours)");
+    if (un.size() > 63) throw std::runtime_error("suggest_order: a factor with more than 62 updated neighbours (they would need as many colours)");
     for (size_t a = 0; a < un.size(); ++a) for (size_t b = a + 1; b < un.size(); ++b) { ei.push_back(un[a]); ej.push_back(un[b]); }
   }
   std::vector<int64_t> urank((size_t)std::max<int64_t>(nu, 1));

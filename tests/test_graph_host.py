@@ -206,3 +206,17 @@ def test_suggested_order_on_random_models(seed):
         o2.ComputePass(1)
         assert o2.LowerBound() >= last - 1e-9 * max(1.0, abs(last))
         last = o2.LowerBound()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_suggested_order_on_models_of_every_schedule(seed):
+    """models with `right` / `full` / `only send` messages (higher factors updated too, messages between vector factors, labeling
+    lists: tests/test_fuzz_gpu.random_model): two updates conflict whenever what they touch overlaps — also around an UPDATED
+    factor — so in the suggested order no sweep of any weight mode has more dependent levels than colours"""
+    from tests.test_fuzz_gpu import random_model
+    m = random_model(np.random.default_rng(7000 + seed))
+    rank, k = E.Plan(m).suggest_order(seed)
+    assert sorted(rank.tolist()) == list(range(m.n_factors))
+    p2 = E.Plan(m.with_factor_order(rank))
+    for mode in (M.REPAM_ANISOTROPIC, M.REPAM_ANISOTROPIC2, M.REPAM_UNIFORM, M.REPAM_DAMPED_UNIFORM):
+        assert max(p2.schedule_info(d, mode)["n_levels"] for d in (0, 1)) <= max(k, 1), (seed, mode, k)
