@@ -125,8 +125,15 @@ def graph_local_part(n: int, m: int, L: int, rank: int, world: int, seed: int = 
     ``part``: the variable -> rank map; a multi-process run computes it ONCE on rank 0 and broadcasts it
     (broadcast_partition); without it every caller runs the partitioner itself (same result, deterministic)."""
     ei, ej = S.counter_graph_edges(n, m, seed, var_rank)          # (var_rank: the variables renamed, counter_graph_model(..., rank=var_rank))
+    if world == 1:
+        # one part = the whole model: what partition_mrf builds for it, without its index arithmetic over 10 M edges
+        mdl = S.mrf_model(n, L, ei, ej, None, device_const=True, device_dual=True)
+        e = np.arange(m, dtype=np.int64)
+        none_i, none_32 = np.zeros(0, np.int64), np.zeros(0, np.int32)
+        return LocalPart(0, 1, L, mdl, n, 0, np.arange(n + m, dtype=np.int64), np.arange(2 * m, dtype=np.int64), none_i, none_32, none_i,
+                         none_i, none_32, none_i, [("blocks", L * L, seed, n * L + e * (L * L))], [("blocks", L, seed, np.arange(n, dtype=np.int64) * L)])
     if part is None:
-        part = graph_partition(n, ei, ej, world) if world > 1 else np.zeros(n, np.int64)
+        part = graph_partition(n, ei, ej, world)
     return partition_mrf(n, L, ei, ej, part, world, only=rank, stream_seed=seed)[0]
 
 

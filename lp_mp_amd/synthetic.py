@@ -27,14 +27,30 @@ def u01(n: int, seed: int, first: int = 0) -> np.ndarray:
     return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
-def u64(n: int, seed: int, first: int = 0) -> np.ndarray:
-    """the 64-bit words behind u01 (same counter-based stream)"""
+def _u64_block(out: np.ndarray, seed: int, first: int):
+    n = out.shape[0]
     with np.errstate(over="ignore"):
         z = np.uint64(seed) + (np.arange(first + 1, first + n + 1, dtype=np.uint64)) * _GOLD
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    return z
+        np.bitwise_xor(z, z >> np.uint64(31), out=out)
+
+
+def u64(n: int, seed: int, first: int = 0) -> np.ndarray:
+    """the 64-bit words behind u01 (same counter-based stream).  Long streams (the 20 M words behind the C4 edge list) are
+    filled block by block on a few threads: numpy releases the GIL inside its loops, and the stream is a pure function of
+    the counter"""
+    out = np.empty(n, np.uint64)
+    if n < (1 << 21):
+        _u64_block(out, seed, first)
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    nt = max(1, min(8, os.cpu_count() or 1))
+    cuts = [n * k // nt for k in range(nt + 1)]
+    with ThreadPoolExecutor(nt) as ex:
+        list(ex.map(lambda k: _u64_block(out[cuts[k]: cuts[k + 1]], seed, first + cuts[k]), range(nt)))
+    return out
 
 
 _EDGE_CACHE: dict = {}
