@@ -572,7 +572,9 @@ class lockstep_part {
 // destination part) — so that the k-th send of rank a to rank b meets the k-th receive of b from a (as lpmp_multi_gpu.hxx)
 inline void lockstep_exchange(std::vector<lockstep_part*>& parts, lockstep_plan& pl, const lockstep_step& st, rccl_world& w, int n_parts) {
   std::vector<lockstep_part::halo*> hs;
-  for (lockstep_part* p : parts) { hs.push_back(&p->halo_plan(pl, st, n_parts)); lpmp_ok(lpmp_halo_pack(p->e, hs.back()->h, hs.back()->d_send)); }
+  for (lockstep_part* p : parts) hs.push_back(&p->halo_plan(pl, st, n_parts));      // (plans are built outside the probed span)
+  w.probe_begin();
+  for (size_t x = 0; x < parts.size(); ++x) lpmp_ok(lpmp_halo_pack(parts[x]->e, hs[x]->h, hs[x]->d_send));
   const int first_part = w.rank * w.parts_per_rank;
   auto offset = [](const std::vector<int64_t>& count, int q) { int64_t off = 0; for (int r = 0; r < q; ++r) off += count[(size_t)r]; return off; };
   // (two parts of this rank must agree on what travels between them: checked before the group is opened)
@@ -598,6 +600,7 @@ inline void lockstep_exchange(std::vector<lockstep_part*>& parts, lockstep_plan&
     });
   grp.end();
   for (size_t x = 0; x < parts.size(); ++x) lpmp_ok(lpmp_halo_unpack(parts[x]->e, hs[x]->h, hs[x]->d_recv));
+  if (w.probe.on) { int64_t by = 0; for (auto* h : hs) for (int64_t c : h->out_count) by += 8 * c; w.probe_end(by); }
 }
 
 inline void lockstep_compute_pass(std::vector<lockstep_part*>& parts, lockstep_plan& pl, rccl_world& w, int n_parts, int n) {

@@ -268,6 +268,57 @@ struct rccl_world {
     const double got = all_reduce_sum(1.0);
     if (got != (double)world) throw std::runtime_error("rccl_world: self test: all-reduce of 1 over " + std::to_string(world) + " ranks gave " + std::to_string(got));
   }
+  // Where a pass spends its time (tools/mgpu_rccl_driver.cpp --time: an untimed repetition of the timed passes): with the probe on,
+  // every exchange — pack -> ncclGroup of sends / receives -> unpack — is bracketed by a pair of events on the stream all parts of
+  // this rank work on.  The span includes waiting for the slowest peer.
+  struct exchange_probe {
+    bool on = false; hipEvent_t open = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans; int64_t bytes_out = 0, exchanges = 0;
+  } probe;
+  void probe_begin() { if (!probe.on) return; hip_ok(hipEventCreate(&probe.open), "hipEventCreate"); hip_ok(hipEventRecord(probe.open, stream), "hipEventRecord"); }
+  void probe_end(int64_t bytes_out) {
+    if (!probe.on) return;
+    hipEvent_t e = nullptr;
+    hip_ok(hipEventCreate(&e), "hipEventCreate"); hip_ok(hipEventRecord(e, stream), "hipEventRecord");
+    probe.spans.emplace_back(probe.open, e); probe.open = nullptr; probe.bytes_out += bytes_out; ++probe.exchanges;
+  }
+  // milliseconds inside exchanges since the probe was switched on (synchronises the stream; the events are released)
+  double probe_exchange_ms() {
+    hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    double ms = 0;
+    for (auto& s : probe.spans) { float t = 0; hip_ok(hipEventElapsedTime(&t, s.first, s.second), "hipEventElapsedTime"); ms += t; (void)hipEventDestroy(s.first); (void)hipEventDestroy(s.second); }
+    probe.spans.clear();
+    return ms;
+  }
+  double all_reduce_max(double x) {
+    hip_ok(hipMemcpyAsync(d_scalar, &x, sizeof(double), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+    nccl_ok(ncclAllReduce(d_scalar, d_scalar + 1, 1, ncclDouble, ncclMax, comm, stream), "ncclAllReduce");
+    double out = 0;
+    hip_ok(hipMemcpyAsync(&out, d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+    hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    return out;
+  }
+  // the probe's numbers of `run()` (n_passes passes), maximum over the ranks: {compute, exchange} ms per pass, exchanges and bytes
+  // sent per pass on the busiest rank
+  struct probe_result { double compute_ms = 0, exchange_ms = 0, exchanges = 0, bytes_out = 0; };
+  template <class RUN> probe_result probe_run(RUN&& run, int n_passes) {
+    (void)all_reduce_sum(0.0);
+    probe = exchange_probe(); probe.on = true;
+    hipEvent_t a = nullptr, b = nullptr;
+    hip_ok(hipEventCreate(&a), "hipEventCreate"); hip_ok(hipEventCreate(&b), "hipEventCreate");
+    hip_ok(hipEventRecord(a, stream), "hipEventRecord");
+    run();
+    hip_ok(hipEventRecord(b, stream), "hipEventRecord");
+    const double ex = probe_exchange_ms();
+    float total = 0;
+    hip_ok(hipEventElapsedTime(&total, a, b), "hipEventElapsedTime");
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    probe.on = false;
+    probe_result r;
+    r.exchange_ms = all_reduce_max(ex / n_passes); r.compute_ms = all_reduce_max(((double)total - ex) / n_passes);
+    r.exchanges = all_reduce_max((double)probe.exchanges / n_passes); r.bytes_out = all_reduce_max((double)probe.bytes_out / n_passes);
+    return r;
+  }
   double all_reduce_sum(double x) {
     hip_ok(hipMemcpyAsync(d_scalar, &x, sizeof(double), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
     nccl_ok(ncclAllReduce(d_scalar, d_scalar + 1, 1, ncclDouble, ncclSum, comm, stream), "ncclAllReduce");
@@ -447,11 +498,13 @@ inline void exchange(std::vector<part_sweep*>& parts, rccl_world& w, bool first_
 }
 
 inline void boundary_step(std::vector<part_sweep*>& parts, rccl_world& w) {
+  w.probe_begin();
   for (part_sweep* p : parts) if (p->pm.n_ghost > 0) { lpmp_ok(lpmp_schedule_run(p->e, p->sid_ghost_recv)); lpmp_ok(lpmp_boundary_pack(p->e, p->bd, p->d_send)); }
   exchange(parts, w, true);
   for (part_sweep* p : parts) if (!p->pm.in_unary.empty()) lpmp_ok(lpmp_boundary_reply(p->e, p->bd, p->d_recv, p->d_reply));
   exchange(parts, w, false);
   for (part_sweep* p : parts) if (p->pm.n_ghost > 0) { lpmp_ok(lpmp_boundary_fold(p->e, p->bd, p->d_back)); lpmp_ok(lpmp_schedule_run(p->e, p->sid_ghost_send)); }
+  if (w.probe.on) { int64_t by = 0; for (part_sweep* p : parts) by += 8 * (p->n_out + p->n_in); w.probe_end(by); }
 }
 
 // n passes.  boundary_every_pass: [forward + backward main sweeps as one fused schedule, boundary step] x n (what bench.py

@@ -213,6 +213,7 @@ class window_sweep {
 
 // owners' values into every part's ghost rows: one ncclSend / ncclRecv per pair of neighbouring parts, all in one group
 inline void overlap_exchange(std::vector<window_sweep*>& parts, rccl_world& w) {
+  w.probe_begin();
   for (window_sweep* p : parts) for (int d = 0; d < 2; ++d) if (p->n_send[d] > 0) p->pack(d);
   const int n_parts = parts.empty() ? 0 : parts[0]->wm.n_parts;
   for (int q = 0; q + 1 < n_parts; ++q)              // neighbouring windows of this rank must agree: checked before the group is opened
@@ -244,6 +245,7 @@ inline void overlap_exchange(std::vector<window_sweep*>& parts, rccl_world& w) {
   }
   grp.end();
   for (window_sweep* p : parts) for (int d = 0; d < 2; ++d) if (p->n_recv[d] > 0) p->unpack(d);
+  if (w.probe.on) { int64_t by = 0; for (window_sweep* p : parts) by += 8 * (p->n_send[0] + p->n_send[1]); w.probe_end(by); }
 }
 
 // n passes in chunks of at most g / 2 - 1 (chunk <= 0: that maximum), an exchange behind every chunk

@@ -363,3 +363,24 @@ def test_random_models_in_the_suggested_order_equal_the_oracle(seed):
                 assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("schedule", ["overlap", "lockstep", "boundary"])
+def test_cpp_host_line_says_where_the_time_went(schedule):
+    """tools/mgpu_rccl_driver.cpp --time K: after the timed passes the same passes run once more with every exchange (pack -> group
+    of ncclSend / ncclRecv -> unpack) bracketed by events (rccl_world::probe_run): compute / exchange ms per pass, exchanges and
+    bytes per pass in the line, maximum over the ranks — the C++ host's counterpart of bench.py's per-rank split.  Parts of one rank
+    on the one GPU here (the transfers are device copies)."""
+    from lp_mp_amd import build as B
+    if not B.have_rccl():
+        pytest.skip("no <rccl/rccl.h> on this box")
+    exe = B.build_mgpu_driver()
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    args = [exe, "--H", "32", "--W", "32", "--L", "8", "--parts-per-rank", "2", "--passes", "4", "--time", "6"]
+    args += [] if schedule == "boundary" else ["--schedule", schedule]
+    out = subprocess.check_output(args, text=True, env=env, timeout=600, stderr=subprocess.DEVNULL)
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["ms_per_pass"] > 0 and d["compute_ms_per_pass"] > 0 and d["exchange_ms_per_pass"] > 0
+    assert d["exchanges_per_pass"] > 0 and d["exchange_bytes_out_per_pass"] > 0 and d["lower_bound_after"] > d["lower_bound_before"]
+    if schedule == "overlap":
+        assert abs(d["exchanges_per_pass"] - 2 / 6) < 1e-9            # 6 passes in chunks of 5 + 1: two exchanges

@@ -11,7 +11,9 @@
 // --schedule overlap (lpmp_overlap.hxx): the EXACT schedule for colour-major grids — every part a window with ghost rows of the
 // global (n_parts * H) x W grid, plain lpmp_compute_pass calls, one exchange per (ghost-rows / 2 - 1) passes (or --chunk).
 //
-// Prints one JSON line on rank 0 (lower bound before / after, msg-updates/s when --time is given); with --out every part's
+// Prints one JSON line on rank 0 (lower bound before / after; with --time K: ms per pass, msg-updates/s, and — from an untimed
+// repetition with every exchange bracketed by events, maximum over the ranks — compute_ms_per_pass, exchange_ms_per_pass,
+// exchanges_per_pass, exchange_bytes_out_per_pass: where the time of a pass went); with --out every part's
 // packed duals go to PREFIX.<part>.bin (tests/test_multi_gpu.py compares them with lp_mp_amd/multi_gpu.py's run).
 // Build: hipcc -std=c++17 -O2 tools/mgpu_rccl_driver.cpp -o build/mgpu_rccl_driver -L lp_mp_amd/csrc -llpmp_engine -lrccl
 #include <chrono>
@@ -28,6 +30,10 @@
 using namespace lpmp_mgpu;
 
 static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
+static void print_probe(const rccl_world::probe_result& r) {
+  std::printf(", \"compute_ms_per_pass\": %.6f, \"exchange_ms_per_pass\": %.6f, \"exchanges_per_pass\": %.3f, \"exchange_bytes_out_per_pass\": %.0f",
+              r.compute_ms, r.exchange_ms, r.exchanges, r.bytes_out);
+}
 
 int main(int argc, char** argv) {
   int H = 64, W = 64, L = 8, passes = 4, ppr = 1, mode = LPMP_REPAM_ANISOTROPIC, timed = 0;
@@ -89,12 +95,14 @@ int main(int argc, char** argv) {
           std::fclose(f);
         }
       double ms_per_pass = 0;
+      rccl_world::probe_result pr;
       if (timed > 0) {
         (void)w.all_reduce_sum(0.0);
         const auto t0 = std::chrono::steady_clock::now();
         overlap_compute_pass(parts, w, timed, chunk);
         (void)w.all_reduce_sum(0.0);
         ms_per_pass = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
+        pr = w.probe_run([&] { overlap_compute_pass(parts, w, timed, chunk); }, timed);
       }
       if (rank == 0) {
         const double E = (double)n_parts * H * (W - 1) + ((double)n_parts * H - 1) * W;       // edges of the whole grid: 4 E message updates per anisotropic pass
@@ -102,6 +110,7 @@ int main(int argc, char** argv) {
                     "\"labels\": %d, \"pairwise\": \"%s\", \"ghost_rows\": %d, \"passes_between_exchanges\": %d, \"passes\": %d, \"lower_bound_before\": %.17g, "
                     "\"lower_bound_after\": %.17g", world, n_parts, H, W, L, potts ? "potts" : "dense", ghost, chunk > 0 ? chunk : (ghost - 2) / 2, passes, lb0, lb1);
         if (timed > 0) std::printf(", \"ms_per_pass\": %.6f, \"msg_updates_per_s\": %.6g", ms_per_pass, 4.0 * E / (ms_per_pass * 1e-3));
+        if (timed > 0) print_probe(pr);
         std::printf("}\n");
       }
       own.clear();
@@ -146,6 +155,7 @@ int main(int argc, char** argv) {
             std::fclose(f);
           }
         double ms_per_pass = 0;
+        rccl_world::probe_result pr;
         if (timed > 0) {
           lockstep_prepare(parts, pl, n_parts, timed);
           (void)w.all_reduce_sum(0.0);
@@ -153,12 +163,13 @@ int main(int argc, char** argv) {
           lockstep_compute_pass(parts, pl, w, n_parts, timed);
           (void)w.all_reduce_sum(0.0);
           ms_per_pass = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
+          pr = w.probe_run([&] { lockstep_compute_pass(parts, pl, w, n_parts, timed); }, timed);
         }
         if (rank == 0) {
           std::printf("{\"driver\": \"mgpu_rccl_driver (C++ host, C ABI + RCCL)\", \"schedule\": \"lockstep\", \"model\": \"%s\", \"world\": %d, \"parts\": %d, \"factors\": %lld, \"messages\": %lld, "
                       "\"levels\": [%d, %d], \"exchanges_per_pass\": %.3f, \"passes\": %d, \"lower_bound_before\": %.17g, \"lower_bound_after\": %.17g",
                       model_path.c_str(), world, n_parts, (long long)gm.n_factors, (long long)gm.n_messages, pl.n_levels[0], pl.n_levels[1], pl.exchanges_per_pass(std::max(passes, 1)), passes, lb0, lb1);
-          if (timed > 0) std::printf(", \"ms_per_pass\": %.6f", ms_per_pass);
+          if (timed > 0) { std::printf(", \"ms_per_pass\": %.6f", ms_per_pass); print_probe(pr); }
           std::printf("}\n");
         }
         own.clear();
@@ -192,6 +203,7 @@ int main(int argc, char** argv) {
           std::fclose(f);
         }
       double ms_per_pass = 0;
+      rccl_world::probe_result pr;
       if (timed > 0) {
         lockstep_prepare(parts, pl, n_parts, timed);
         (void)w.all_reduce_sum(0.0);
@@ -199,6 +211,7 @@ int main(int argc, char** argv) {
         lockstep_compute_pass(parts, pl, w, n_parts, timed);
         (void)w.all_reduce_sum(0.0);
         ms_per_pass = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
+        pr = w.probe_run([&] { lockstep_compute_pass(parts, pl, w, n_parts, timed); }, timed);
       }
       double upd = 0;
       for (lockstep_part* p : parts) upd += (double)p->updates_per_pass;
@@ -207,7 +220,7 @@ int main(int argc, char** argv) {
         std::printf("{\"driver\": \"mgpu_rccl_driver (C++ host, C ABI + RCCL)\", \"schedule\": \"lockstep\", \"world\": %d, \"parts\": %d, \"variables\": %lld, \"edges\": %lld, "
                     "\"labels\": %d, \"pairwise\": \"%s\", \"levels\": [%d, %d], \"exchanges_per_pass\": %.3f, \"passes\": %d, \"lower_bound_before\": %.17g, \"lower_bound_after\": %.17g",
                     world, n_parts, (long long)st.n_vars, (long long)st.n_edges(), L, potts ? "potts" : "dense", pl.n_levels[0], pl.n_levels[1], pl.exchanges_per_pass(std::max(passes, 1)), passes, lb0, lb1);
-        if (timed > 0) std::printf(", \"ms_per_pass\": %.6f, \"msg_updates_per_s\": %.6g", ms_per_pass, upd / (ms_per_pass * 1e-3));
+        if (timed > 0) { std::printf(", \"ms_per_pass\": %.6f, \"msg_updates_per_s\": %.6g", ms_per_pass, upd / (ms_per_pass * 1e-3)); print_probe(pr); }
         std::printf("}\n");
       }
       own.clear();
@@ -234,6 +247,7 @@ int main(int argc, char** argv) {
         std::fclose(f);
       }
     double ms_per_pass = 0, updates = 0;
+    rccl_world::probe_result pr;
     if (timed > 0) {
       double upd = 0;
       for (part_sweep* p : parts) upd += (double)p->updates_per_pass;
@@ -243,12 +257,13 @@ int main(int argc, char** argv) {
       compute_pass(parts, w, timed, every_pass);
       (void)w.all_reduce_sum(0.0);                                     // every rank's stream drained + barrier
       ms_per_pass = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / timed;
+      pr = w.probe_run([&] { compute_pass(parts, w, timed, every_pass); }, timed);
     }
     if (rank == 0) {
       std::printf("{\"driver\": \"mgpu_rccl_driver (C++ host, C ABI + RCCL)\", \"world\": %d, \"parts\": %d, \"grid_per_part\": [%d, %d], \"labels\": %d, "
                   "\"pairwise\": \"%s\", \"boundary_every\": \"%s\", \"passes\": %d, \"lower_bound_before\": %.17g, \"lower_bound_after\": %.17g",
                   world, n_parts, H, W, L, potts ? "potts" : "dense", every_pass ? "pass" : "sweep", passes, lb0, lb1);
-      if (timed > 0) std::printf(", \"ms_per_pass\": %.6f, \"msg_updates_per_s\": %.6g", ms_per_pass, updates / (ms_per_pass * 1e-3));
+      if (timed > 0) { std::printf(", \"ms_per_pass\": %.6f, \"msg_updates_per_s\": %.6g", ms_per_pass, updates / (ms_per_pass * 1e-3)); print_probe(pr); }
       std::printf("}\n");
     }
     own.clear();
