@@ -383,4 +383,4 @@ def test_cpp_host_line_says_where_the_time_went(schedule):
     assert d["ms_per_pass"] > 0 and d["compute_ms_per_pass"] > 0 and d["exchange_ms_per_pass"] > 0
     assert d["exchanges_per_pass"] > 0 and d["exchange_bytes_out_per_pass"] > 0 and d["lower_bound_after"] > d["lower_bound_before"]
     if schedule == "overlap":
-        assert abs(d["exchanges_per_pass"] - 2 / 6) < 1e-9            # 6 passes in chunks of 5 + 1: two exchanges
+        assert abs(d["exchanges_per_pass"] - 2 / 6) < 1e-3            # 6 passes in chunks of 5 + 1: two exchanges (printed with three digits)
