@@ -217,6 +217,26 @@ class LP:
     def BackwardPassFactorRelation(self, f1: int, f2: int):
         self._rel_bwd.append((f1, f2)); self._dirty = True
 
+    def suggested_order(self, seed: int = 0):
+        """the order the engine suggests for this LP as it stands (lpmp_plan_suggest_order on the host-only plan: no GPU needed):
+        (by_rank, n_colours) with by_rank[i] = the factor (add_factor's return value) at position i — the updated factors colour by
+        colour, one dependent level per colour.  apply_suggested_order() replaces the relations with it."""
+        from .engine import Plan
+        rank, k = Plan(self.flat_model()).suggest_order(seed)
+        by_rank = np.empty(rank.shape[0], np.int64)
+        by_rank[rank] = np.arange(rank.shape[0])
+        return by_rank.tolist(), k
+
+    def apply_suggested_order(self, seed: int = 0) -> int:
+        """drop this LP's factor relations and chain all factors in the suggested order instead — AddFactorRelation(by_rank[i],
+        by_rank[i + 1]), what INTEGRATION.md 2a shows a C++ caller doing: same factors, messages and costs, another (equally valid)
+        sweep order with far fewer dependent levels for LPs inserted row by row / chain by chain.  Returns the number of colours."""
+        by_rank, k = self.suggested_order(seed)
+        self._rel_fwd, self._rel_bwd = [], []
+        for a, b in zip(by_rank[:-1], by_rank[1:]):
+            self.AddFactorRelation(a, b)
+        return k
+
     def put_in_same_partition(self, f1: int, f2: int):
         """reference LP_MP.h:465"""
         self._partition_graph.append((f1, f2)); self._dirty = True

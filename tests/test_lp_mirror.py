@@ -267,3 +267,21 @@ def test_constant_factor_offsets_the_bound():
     for it in range(5):
         lp.ComputePass(it)
     assert lp.LowerBound() == pytest.approx(2.5)
+
+
+def test_lp_mirror_applies_the_engines_suggested_order():
+    """an LP built call by call in row-major order (as `_grid_through_lp` inserts it: 10 dependent levels per direction on a 5 x 6
+    grid) asks the engine for an order and applies it with AddFactorRelation calls: 2 levels per direction, same factors, messages
+    and costs (host only: the plan needs no GPU)"""
+    from lp_mp_amd.engine import Plan
+    lp, ref = _grid_through_lp(5, 6, 3, 4)
+    m0 = lp.flat_model()
+    before = Plan(m0)
+    assert [before.schedule_info(d, M.REPAM_ANISOTROPIC)["n_levels"] for d in (0, 1)] == [10, 10]
+    by_rank, k = lp.suggested_order()
+    assert sorted(by_rank) == list(range(lp.GetNumberOfFactors())) and k == 2
+    assert lp.apply_suggested_order() == 2
+    m = lp.flat_model()
+    assert [Plan(m).schedule_info(d, M.REPAM_ANISOTROPIC)["n_levels"] for d in (0, 1)] == [2, 2]
+    assert m.rel_fwd.shape[0] == m.n_factors - 1
+    assert np.array_equal(m.const_data, m0.const_data) and np.array_equal(m.dual_data, m0.dual_data) and np.array_equal(m.m_left, m0.m_left)
