@@ -370,6 +370,26 @@ class LP_gpu {
   void ForwardPassFactorRelation(FactorTypeAdapter* f1, FactorTypeAdapter* f2) { rel_fwd_.push_back((int32_t)f1->index_); rel_fwd_.push_back((int32_t)f2->index_); set_flags_dirty(); }
   void BackwardPassFactorRelation(FactorTypeAdapter* f1, FactorTypeAdapter* f2) { rel_bwd_.push_back((int32_t)f1->index_); rel_bwd_.push_back((int32_t)f2->index_); set_flags_dirty(); }
 
+  // Not in the reference: replace this LP's factor relations by the order the engine suggests for it (lpmp_plan_suggest_order: the
+  // updated factors colour by colour, one dependent level — one launch step — per colour) as a chain of relations through all
+  // factors, exactly what INTEGRATION.md 2a shows a caller of the reference's LP doing with AddFactorRelation.  Same factors,
+  // messages and costs; another, equally valid sweep order.  Returns the number of colours.
+  int apply_suggested_order(uint64_t seed = 0) {
+    ready();
+    pull_duals();                                          // (duals the device holds go back into the factor ops before the re-upload)
+    std::vector<int32_t> rank(f_.size()), by_rank(f_.size());
+    int32_t colours = 0;
+    check(lpmp_plan_suggest_order(lpmp_engine_plan_mut(engine_), seed, rank.data(), &colours));
+    for (std::size_t f = 0; f < rank.size(); ++f) by_rank[(std::size_t)rank[f]] = (int32_t)f;
+    rel_fwd_.clear(); rel_bwd_.clear();
+    for (std::size_t i = 0; i + 1 < by_rank.size(); ++i) {
+      rel_fwd_.push_back(by_rank[i]); rel_fwd_.push_back(by_rank[i + 1]);
+      rel_bwd_.push_back(by_rank[i + 1]); rel_bwd_.push_back(by_rank[i]);
+    }
+    set_flags_dirty();
+    return (int)colours;
+  }
+
   void put_in_same_partition(FactorTypeAdapter* f1, FactorTypeAdapter* f2) { part_.push_back((int32_t)f1->index_); part_.push_back((int32_t)f2->index_); set_flags_dirty(); }   // LP_MP.h:465
   void set_inner_iterations(const INDEX n) { inner_ = (int)n; }   // --innerIteration, LP_MP.h:590
   void Begin() { repamMode_ = LPReparametrizationMode::Undefined; }   // reference LP_MP.h:705-708

@@ -322,6 +322,41 @@ int main(int argc, char** argv) {
     test(lp.LowerBound() >= lb0 - eps && lp.LowerBound() <= 0.0 + eps);
     test(std::abs(lp.LowerBound() - 0.0) <= 1e-6);
   }
+  if (!host_only) {   // ---- a grid inserted row by row, then run in the order the engine suggests (LP::apply_suggested_order) ----
+    using FMC = FMC_SRMP_ROUNDING;
+    const int H = 9, W = 8, L = 3;
+    auto build = [&](LP<FMC>& lp) {
+      std::vector<typename FMC::UnaryFactor*> u;
+      for (int i = 0; i < H * W; ++i) { std::vector<REAL> c(L); for (int a = 0; a < L; ++a) c[a] = ((i * 7 + a * 3) % 11) / 11.0; u.push_back(lp.template add_factor<typename FMC::UnaryFactor>(c)); }
+      auto edge = [&](int a, int b) {
+        auto* p = lp.template add_factor<typename FMC::PairwiseFactor>(L, L);
+        for (int x = 0; x < L; ++x) for (int y = 0; y < L; ++y) p->GetFactor()->cost(x, y) = ((a + 2 * b + 5 * x + 3 * y) % 7) / 7.0;
+        lp.template add_message<typename FMC::UnaryPairwiseMessageLeftContainer>(u[a], p);
+        lp.template add_message<typename FMC::UnaryPairwiseMessageRightContainer>(u[b], p);
+        lp.AddFactorRelation(u[a], p);
+        lp.AddFactorRelation(p, u[b]);
+      };
+      for (int r = 0; r < H; ++r) for (int c = 0; c < W; ++c) { if (c + 1 < W) edge(r * W + c, r * W + c + 1); if (r + 1 < H) edge(r * W + c, (r + 1) * W + c); }
+    };
+    LP<FMC> row_major, suggested;
+    build(row_major); build(suggested);
+    for (LP<FMC>* lp : {&row_major, &suggested}) { lp->Begin(); lp->set_reparametrization(LPReparametrizationMode::Anisotropic); }
+    const double lb0 = row_major.LowerBound();
+    test(std::abs(suggested.LowerBound() - lb0) <= eps);                 // same problem
+    test(row_major.forward_update_ordering().size() == (std::size_t)(H * W));
+    test(suggested.apply_suggested_order() == 2);                        // a grid is 2-colourable: 2 dependent levels per sweep instead of H + W - 1
+    suggested.set_reparametrization(LPReparametrizationMode::Anisotropic);
+    // black cells first, then white ones: the updated factors colour by colour
+    const auto order = suggested.forward_update_ordering();
+    test(order.size() == (std::size_t)(H * W));
+    bool colour_major = true;
+    for (std::size_t i = 0; i < order.size(); ++i) { const int cell = (int)order[i]->index_; const bool black = ((cell / W + cell % W) & 1) == 0; if (black != (i < (std::size_t)((H * W + 1) / 2))) colour_major = false; }
+    test(colour_major);
+    for (int it = 0; it < 30; ++it) { row_major.ComputePass(it); suggested.ComputePass(it); }
+    // two trajectories of the same dual ascent: both bounds ascend from lb0 and end close to each other
+    test(row_major.LowerBound() > lb0 && suggested.LowerBound() > lb0);
+    test(std::abs(row_major.LowerBound() - suggested.LowerBound()) <= 0.05 * std::abs(row_major.LowerBound()));
+  }
   std::cout << "all tests passed\n";
   return 0;
 }
