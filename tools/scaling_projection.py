@@ -41,7 +41,7 @@ def table(lat_us=30.0, gbps=400.0):
     for n in (2, 4, 8):
         d = c3[2] if n == 2 else inner
         ex_per_pass = d["exchanges_per_pass"]
-        byts = max(d["doubles_sent_per_exchange_by_part"]) * 8 * (1 if n == 2 else 2)      # an inner rank ships to two neighbours
+        byts = max(d["doubles_sent_per_exchange_by_part"]) * 8             # (3 windows: the inner one ships to both neighbours, like every inner rank of 8)
         t = d["ms_per_pass_and_part"] + ex_per_pass * lam + ex_per_pass * byts / bw * 1e3
         rows[str(n)] = {"ms_per_pass": round(t, 4), "efficiency": round(t1 / t, 4), "aggregate_speedup_weak": round(n * t1 / t, 3)}
     out["c3 (weak scaling: one 1024 x 1024 grid per GPU, overlap schedule)"] = rows
