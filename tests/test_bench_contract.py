@@ -277,3 +277,19 @@ def test_watchdog_exits_with_code_3_and_names_the_rank():
                "with bench.Watchdog(5, 'x', 0):\n    pass\nprint('fine')\n" % ROOT)
     p = subprocess.run([sys.executable, "-c", code_ok], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "fine" in p.stdout
+
+
+def test_rendezvous_gives_up_with_a_message_when_a_rank_never_comes():
+    """WORLD_SIZE 2, one process: the rendezvous waits --rendezvous-timeout and ends the process with a message naming what was
+    missing — no hang, no retry"""
+    code = ("import os, sys, types; sys.path.insert(0, %r)\n"
+            "import torch, torch.distributed as dist, bench\n"
+            "args = types.SimpleNamespace(rendezvous_timeout=3.0, collective_timeout=5.0)\n"
+            "bench.rendezvous(args, torch, dist, 'pci=0 uuid=0', 0, 2)\n" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29557", RANK="0", WORLD_SIZE="2")
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and time.time() - t0 < 120
+    assert "bench.py: rank 0:" in p.stderr and ("no rendezvous" in p.stderr or "did not show up" in p.stderr)
