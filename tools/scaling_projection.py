@@ -51,7 +51,11 @@ def table(lat_us=30.0, gbps=400.0):
     for n in sorted(c4):
         ls = c4[n]["lockstep"]
         t = ls["ms_runs_only_per_pass_and_part"] + ls["exchanges_per_pass"] * lam + ls["halo_MB_per_pass_and_part"] * 1e6 / bw * 1e3
+        # t_run: the runs of a part while the other parts' runs interleave with it on the one GPU (1.80 ms at 8 parts) — a part running
+        # ALONE takes 1.44, but then the pack / unpack copies of its 16 exchanges (0.2 - 0.46 ms, inside `ms_exchanges_only` here) come
+        # on top: the interleaved figure stands for both
         rows[str(n)] = {"ms_per_pass": round(t, 4), "speedup": round(t1 / t, 3), "t_run_ms": ls["ms_runs_only_per_pass_and_part"],
+                        "t_run_one_part_alone_ms": ls["ms_runs_only_one_part_alone"], "in_process_exchange_copies_ms": ls["ms_exchanges_only_per_pass_and_part"],
                         "exchanges_per_pass": round(ls["exchanges_per_pass"], 2), "MB_per_pass_and_rank": ls["halo_MB_per_pass_and_part"], "cut_fraction": c4[n]["cut_fraction"]}
     out["c4 (strong scaling: G(2 M, 10 M), 16 labels, lock step)"] = rows
     for name in ("local triples", "local triples, colour-major edge variables"):
