@@ -99,9 +99,11 @@ def parse():
     ap.add_argument("--rows-layout", default="auto", choices=["auto", "on", "off"],
                     help="dense pairwise factors as [table | m1 | m2] rows of an engine-private buffer (lpmp_set_rows_layout): one burst per "
                          "receive instead of a table and two single lines elsewhere.  auto: on for --workload c4 on one GPU")
-    ap.add_argument("--no-compare-schedules", action="store_true",
-                    help="several GPUs, grid workload: do NOT also run the other schedules (same pass count, after the timed region) for "
-                         "the `schedules` entry of the line")
+    ap.add_argument("--compare-schedules", action="store_true",
+                    help="several GPUs, c3 / c4: ALSO run the other multi-GPU schedules on the same model (same pass count, after the timed "
+                         "region and every other leg) for the `schedules` entry of the line.  Off by default: it builds two more full-size "
+                         "runners, and on a real N-GPU node nothing that is not the measurement should be able to cost the line")
+    ap.add_argument("--no-compare-schedules", action="store_true", help="(accepted for older command lines: the comparison is off unless --compare-schedules)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path even at WORLD_SIZE 1: init_process_group(nccl = RCCL), the partitioned "
                          "sweep with its (empty) all_to_all_single exchanges, device all_reduce — what an N-GPU launch executes "
@@ -961,7 +963,7 @@ def main():
     # the other multi-GPU schedules on the same strips, same pass count (outside the timed region): what the choice costs
     schedules = None
     peak_bytes = torch.cuda.max_memory_allocated()
-    if dist_on and args.workload == "c3" and not args.no_compare_schedules:
+    if dist_on and args.workload == "c3" and args.compare_schedules and not args.no_compare_schedules:
         schedules = {args.schedule: {"ms_per_step": dt / args.steps * 1e3, "dual_bound_gap": gap["dual_bound_gap"] if gap else None, "timed": True}}
         # (the timed runner's 18.5 GB go first: N ranks may share one device in a smoke run)
         eng.close()
@@ -986,7 +988,7 @@ def main():
             g2 = dual_bound_gap(torch, dist, args, mode, world, rank, schedule=other)
             schedules[other] = {"ms_per_step": t.item() / args.steps * 1e3, "dual_bound_gap": g2["dual_bound_gap"] if g2 else None,
                                 "lower_bound_after": lb2, "timed": False}
-    if dist_on and args.workload == "c4" and not args.no_compare_schedules:
+    if dist_on and args.workload == "c4" and args.compare_schedules and not args.no_compare_schedules:
         # C4: the exact schedule (lock step, colour-major variable order) beside the boundary-step one, same graph size
         from lp_mp_amd import multi_gpu as MG, lockstep as LS
         schedules = {args.schedule: {"ms_per_step": dt / args.steps * 1e3, "dual_bound_gap": gap["dual_bound_gap"] if gap else None, "timed": True}}

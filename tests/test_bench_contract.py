@@ -205,9 +205,12 @@ def test_bench_gpus_2_launches_its_own_ranks(schedule):
     (backend falls back to gloo: RCCL refuses two ranks on one GPU), the line says how many ranks ran and where"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LPMP_DIST_BACKEND")}
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "4", "--warmup", "2",
-                                   "--no-cpu-baseline", "--schedule", schedule], text=True, cwd=ROOT, timeout=1200, env=env)
+                                   "--no-cpu-baseline", "--schedule", schedule] + (["--compare-schedules"] if schedule == "overlap" else []),
+                                  text=True, cwd=ROOT, timeout=1200, env=env)
     assert out.strip().splitlines()[-1].startswith('{"metric"'), out[-600:]
     d = json.loads(out.strip().splitlines()[-1])
+    # (the other schedules on the same strips only when asked for: nothing that is not the measurement runs by default)
+    assert (set(d["schedules"]) == {"overlap", "lockstep", "boundary"}) if schedule == "overlap" else d["schedules"] is None
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["devices"]) == 2 and d["launch"]["launcher"].startswith("bench.py")
     assert d["backend"] in ("gloo", "rccl (torch.distributed nccl)")
     assert d["value"] > 0 and d["lower_bound_after"] > d["lower_bound_before"]
@@ -223,7 +226,7 @@ def test_bench_gpus_2_c4_runs_in_lock_step_by_default():
     variable order on every path), the line carries the boundary-step schedule of the same model beside it"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LPMP_DIST_BACKEND")}
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4", "--c4-nodes", "20000", "--c4-edges", "100000",
-                                   "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], text=True, cwd=ROOT, timeout=1200, env=env)
+                                   "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--compare-schedules"], text=True, cwd=ROOT, timeout=1200, env=env)
     d = json.loads(out.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["schedule"] == "lockstep" and d["config"]["variable_order"] == "colour_major"
     assert abs(d["dual_bound_gap"]) <= 1e-12 and d["lower_bound_after"] > d["lower_bound_before"]
