@@ -12,8 +12,8 @@ in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
 N > 1: one process per GPU (self-launched, or under torch.distributed.run).  Every wait of the start-up is bounded: the rendezvous
 (--rendezvous-timeout), one all_reduce and one all_to_all_single with the real split sizes before the timed region
-(--collective-timeout; on expiry the rank says what it waited for and exits with code 3 — no retry after a GPU call, no
-re-exec), the launcher (--launch-timeout).  The line of an N-rank run says where the time went: per rank and as max / mean the
+(--collective-timeout; on expiry or on a wrong answer the rank says what it waited for and exits with code 3 — no retry after a
+GPU call, no re-exec), the launcher (--launch-timeout).  The line of an N-rank run says where the time went: per rank and as max / mean the
 compute and exchange time per pass (events around every pack -> collective -> unpack span, in an untimed repetition of the
 timed passes), bytes and number of exchanges, the slowest rank, the partitioner, the cut, and a scaling model with its
 assumptions (`scaling_model`).
@@ -203,6 +203,14 @@ class Watchdog:
         return False
 
 
+def exit_startup(message):
+    """a start-up step of an N-rank run failed or timed out (rendezvous, self test of the collectives): the message on stderr and
+    exit code 3 — the same code the watchdogs use, so that a driver can tell "the ranks never got together" (3) from a crash (1)"""
+    sys.stderr.write(message + "\n")
+    sys.stderr.flush()
+    sys.exit(3)
+
+
 def rendezvous(args, torch, dist, identity, rank, world):
     """All ranks meet at the store of MASTER_ADDR : MASTER_PORT (torch's own env:// rendezvous — under torch.distributed.run that
     is the agent's store) within --rendezvous-timeout, tell each other which PHYSICAL device they sit on (``identity``:
@@ -216,15 +224,15 @@ def rendezvous(args, torch, dist, identity, rank, world):
         store, _, _ = next(dist.rendezvous("env://", rank, world, timeout=timeout))
         store.set(f"lpmp/device/{rank}", identity)
     except Exception as ex:
-        raise SystemExit(f"bench.py: rank {rank}: no rendezvous at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} within "
-                         f"{args.rendezvous_timeout:.0f} s ({type(ex).__name__}: {ex})")
+        exit_startup(f"bench.py: rank {rank}: no rendezvous at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')} within "
+                     f"{args.rendezvous_timeout:.0f} s ({type(ex).__name__}: {ex})")
     idents = []
     for r in range(world):
         try:
             store.wait([f"lpmp/device/{r}"], timeout)
             idents.append(store.get(f"lpmp/device/{r}").decode())
         except Exception as ex:
-            raise SystemExit(f"bench.py: rank {rank}: rank {r} did not show up at the rendezvous within {args.rendezvous_timeout:.0f} s ({type(ex).__name__})")
+            exit_startup(f"bench.py: rank {rank}: rank {r} did not show up at the rendezvous within {args.rendezvous_timeout:.0f} s ({type(ex).__name__})")
     backend = os.environ.get("LPMP_DIST_BACKEND") or ("nccl" if len(set(idents)) == world else "gloo")
     dist.init_process_group(backend, store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(10.0, args.collective_timeout)))
     return idents, backend
@@ -239,7 +247,7 @@ def collective_self_test(args, torch, dist, runner, rank, world):
         t = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(t)
         if int(t.item()) != world:
-            raise SystemExit(f"bench.py: rank {rank}: all_reduce of 1 over {world} ranks gave {t.item()}")
+            exit_startup(f"bench.py: rank {rank}: all_reduce of 1 over {world} ranks gave {t.item()}")
         counts = runner.exchange_counts() if hasattr(runner, "exchange_counts") else None
         shipped = None
         if counts is not None and getattr(runner, "comm", None) is not None:
@@ -248,7 +256,7 @@ def collective_self_test(args, torch, dist, runner, rank, world):
             got = runner.comm.exchange(send, out_c, in_c)
             torch.cuda.synchronize()
             if got.shape[0] != int(sum(in_c)):
-                raise SystemExit(f"bench.py: rank {rank}: all_to_all_single returned {got.shape[0]} doubles, expected {int(sum(in_c))}")
+                exit_startup(f"bench.py: rank {rank}: all_to_all_single returned {got.shape[0]} doubles, expected {int(sum(in_c))}")
             shipped = int(sum(out_c)) * 8
     return {"all_reduce": "ok", "all_to_all_bytes_out": shipped, "seconds": time.perf_counter() - t0, "bound_s": args.collective_timeout}
 
@@ -275,7 +283,8 @@ def single_gpu_reference(args):
         except Exception:
             continue
         if d.get("n_gpus") == 1 and d.get("config", {}).get("workload") == want:
-            return {"ms_per_pass": d["ms_per_step"], "source": os.path.relpath(f, ROOT)}
+            return {"ms_per_pass": d["ms_per_step"], "source": os.path.relpath(f, ROOT),
+                    "library_source_hash": (d.get("library") or {}).get("source_hash")}
     return None
 
 
@@ -297,12 +306,18 @@ def scaling_model(args, world, stats, measured_ms, shared_device):
            "assumed_latency_us_per_exchange": args.assume_exchange_latency_us, "assumed_GBps_per_rank": args.assume_exchange_GBps,
            "projected_ms_per_pass": proj, "measured_ms_per_pass": measured_ms, "measured_exchange_ms_per_pass": mx["exchange_ms_per_pass"],
            "t1_ms_per_pass": t1["ms_per_pass"] if t1 else None, "t1_source": t1["source"] if t1 else None,
+           # t_1 comes from a committed line, i.e. from another box and possibly another build: the line says which
+           "t1_library_source_hash": t1["library_source_hash"] if t1 else None,
+           "t1_stale": None if not t1 else t1["library_source_hash"] != library_source_hash(),
            "kind": "strong" if strong else "weak",
            "note": "ranks share a device: t_run is time-sliced, the projection means nothing" if shared_device else None}
     if t1:
         key = "speedup" if strong else "efficiency"
         out["projected_" + key] = t1["ms_per_pass"] / proj
         out["measured_" + key] = t1["ms_per_pass"] / measured_ms
+        if out["t1_stale"]:
+            out["t1_note"] = (f"t_1 was measured with library {str(t1['library_source_hash'])[:12]}, the running one is {str(library_source_hash())[:12]}: "
+                              f"{key} compares two builds — re-run `bench.py --workload {args.workload}` on one GPU and commit its line")
     return out
 
 
@@ -413,19 +428,21 @@ def pmc_traffic(kernel_name, args):
 
 
 def dual_bound_gap_c4(torch, dist, args, mode, world, rank, schedule=None):
-    """the same for the C4 workload: a 20 000-node / 100 000-edge graph of the same generator, partitioned like the big
-    one (same partitioner, same boundary schedule) against its unpartitioned sweep on rank 0"""
+    """the same for the C4 workload: a 20 000-node / 100 000-edge graph of the same generator, partitioned by the same partitioner
+    (--partitioner; a --partition-file lists the big graph's variables and cannot be applied to the miniature: gap_config says what
+    partitioned it), same schedule, against its unpartitioned sweep on rank 0"""
     from lp_mp_amd import engine as E, multi_gpu as MG, synthetic as S
     n, m, L, passes = 20000, 100000, args.c4_labels, args.steps
     rank_of = None
     schedule = schedule or args.schedule
     if schedule == "lockstep":
         from lp_mp_amd import lockstep as LS
-        sw = LS.LockstepGraph(torch, dist, n, m, L, mode, seed=1, order=args.c4_order)
+        sw = LS.LockstepGraph(torch, dist, n, m, L, mode, seed=1, order=args.c4_order, partitioner=args.partitioner,
+                              overlap_exchange=getattr(args, "overlap_exchange", False))
         sw.boundary_every, sw.global_cut_fraction = "level that reads across the cut (lock step)", sw.cut_fraction
         rank_of = sw.rank_of
     else:
-        sw = MG.GraphSweep(torch, dist, n, m, L, mode, seed=1, order=args.c4_order)
+        sw = MG.GraphSweep(torch, dist, n, m, L, mode, seed=1, order=args.c4_order, partitioner=args.partitioner)
         rank_of = sw.rank_of
     sw.compute_pass(passes)
     lb_part = sw.lower_bound()
@@ -437,7 +454,9 @@ def dual_bound_gap_c4(torch, dist, args, mode, world, rank, schedule=None):
         e.compute_pass(passes)
         lb_ref = e.lower_bound()
         e.close()
-        out = {"dual_bound_gap": (lb_ref - lb_part) / abs(lb_ref), "gap_config": f"G({n}, {m}), {L} labels in {world} parts, {passes} passes, "
+        how = f"partitioner {sw.partitioner}" + (f" (the timed run took its partition from {os.path.basename(args.partition_file)}, which lists the big "
+                                                 f"graph's variables)" if getattr(args, "partition_file", None) else "")
+        out = {"dual_bound_gap": (lb_ref - lb_part) / abs(lb_ref), "gap_config": f"G({n}, {m}), {L} labels in {world} parts ({how}), {passes} passes, "
                f"boundary step every {sw.boundary_every}", "cut_fraction": sw.global_cut_fraction, "lb_partitioned": lb_part, "lb_unpartitioned": lb_ref}
     close_runner(sw)
     return out
@@ -1001,8 +1020,10 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         other = "boundary" if args.schedule == "lockstep" else "lockstep"
-        r2 = (MG.GraphSweep(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1, order=args.c4_order) if other == "boundary" else
-              LS.LockstepGraph(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1, order=args.c4_order))
+        # (the same partition as the timed run: same partitioner, same file)
+        r2 = (MG.GraphSweep(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1, order=args.c4_order, part_of=part_of, partitioner=args.partitioner)
+              if other == "boundary" else
+              LS.LockstepGraph(torch, dist, args.c4_nodes, args.c4_edges, L, mode, seed=1, order=args.c4_order, part_of=part_of, partitioner=args.partitioner))
         dt2 = time_passes(torch, dist, r2, args.steps, args.warmup, 2)
         t = torch.tensor([dt2], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1077,6 +1098,8 @@ def main():
             # ranks and per rank; exchange spans include waiting for the slowest peer
             "compute_ms_per_pass": None if rank_stats is None else {"max": rank_stats["max"]["compute_ms_per_pass"], "mean": rank_stats["mean"]["compute_ms_per_pass"]},
             "exchange_ms_per_pass": None if rank_stats is None else {"max": rank_stats["max"]["exchange_ms_per_pass"], "mean": rank_stats["mean"]["exchange_ms_per_pass"]},
+            # --overlap-exchange: the part of exchange_ms that is pack + copy + posting the collective (nothing hides it); 0 otherwise
+            "exchange_post_ms_per_pass": None if rank_stats is None else {"max": rank_stats["max"].get("exchange_post_ms_per_pass"), "mean": rank_stats["mean"].get("exchange_post_ms_per_pass")},
             "exchange_bytes_per_pass": None if rank_stats is None else {"max": rank_stats["max"]["exchange_bytes_out_per_pass"], "mean": rank_stats["mean"]["exchange_bytes_out_per_pass"],
                                                                         "sum": sum(rank_stats["per_rank"]["exchange_bytes_out_per_pass"])},
             "exchanges_per_pass": None if rank_stats is None else rank_stats["max"]["exchanges_per_pass"],

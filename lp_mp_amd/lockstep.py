@@ -559,9 +559,13 @@ class LockstepSweep:
             if step[0] == "run":
                 self.run(step[1])
             elif step[0] == "halo_begin":                # pack, post the collective; the interior records that follow run meanwhile
+                if probe is not None:
+                    probe.begin_post()                   # (exchange work on this stream that nothing hides: booked as such)
                 send, out_counts, in_counts = self.halo_pack(step[1], step[2])
                 # (a send buffer of its own: the next pack may come before this transfer has read it)
                 self._open = (comm.exchange_begin(send.clone() if self._device_halos else send, out_counts, in_counts), out_counts, in_counts)
+                if probe is not None:
+                    probe.end_post()
             elif step[0] == "halo_end":
                 if probe is not None:
                     probe.begin_exchange()               # (what is left of the exchange on the critical path)

@@ -291,8 +291,14 @@ def graph_partition(n_vars: int, edge_i: np.ndarray, edge_j: np.ndarray, world: 
     if method not in ("auto", "metis", "builtin"):
         raise ValueError("graph_partition: method must be auto, metis or builtin")
     edge_i = np.asarray(edge_i, np.int64); edge_j = np.asarray(edge_j, np.int64)
+    metis_failed = None
     if method in ("auto", "metis") and world > 1:
-        got = metis_partition(n_vars, edge_i, edge_j, world, imbalance, seed, required=method == "metis")
+        try:
+            got = metis_partition(n_vars, edge_i, edge_j, world, imbalance, seed, required=method == "metis")
+        except Exception as ex:                       # "auto": an installed METIS that fails must not cost the run its partition
+            if method == "metis":
+                raise
+            got, metis_failed = None, f"{type(ex).__name__}: {ex}"
         if got is not None:
             return (got[0], got[1]) if return_method else got[0]
     from scipy.sparse import coo_matrix
@@ -307,16 +313,41 @@ def graph_partition(n_vars: int, edge_i: np.ndarray, edge_j: np.ndarray, world: 
         # of the same moves (20 s against 1 at 2 M variables)
         from . import engine as E
         part = E.graph_refine_partition(n_vars, edge_i, edge_j, part, world, refine_rounds, imbalance, seed)
-    return (part, "builtin (reverse Cuthill-McKee + balanced KL refinement)") if return_method else part
+    how = "builtin (reverse Cuthill-McKee + balanced KL refinement)"
+    if metis_failed:
+        how += f"; a METIS was found but failed: {metis_failed[:200]}"
+    return (part, how) if return_method else part
 
 
 _METIS = {}
+# where metis.h's moptions_et puts the two options set here: 5.1.x has SEED = 8, UFACTOR = 16; 5.2.x inserted NIPARTS and ONDISK
+# before them (SEED = 9, UFACTOR = 17).  Slot numbers are never assumed: the layout is PROBED (below), and when neither answers the
+# call is made with METIS' own defaults (options = NULL: 3 % imbalance for k-way, its fixed seed).
+_METIS_OPTION_LAYOUTS = (("5.1", 8, 16), ("5.2", 9, 17))
+
+_METIS_PROBE = (
+    "import ctypes, sys, numpy as np\n"
+    "L = ctypes.CDLL(sys.argv[1]); bits = int(sys.argv[2]); I = np.int32 if bits == 32 else np.int64\n"
+    "seed_slot, ufactor_slot = int(sys.argv[3]), int(sys.argv[4])\n"
+    "n = 64; xadj = (2 * np.arange(n + 1)).astype(I); adj = np.stack([(np.arange(n) - 1) % n, (np.arange(n) + 1) % n], 1).reshape(-1).astype(I)\n"
+    "nv = np.array([n], I); nc = np.array([1], I); k = np.array([2], I); obj = np.zeros(1, I); part = np.full(n, -1, I)\n"
+    "p = lambda a: a.ctypes.data_as(ctypes.c_void_p)\n"
+    "opts = None\n"
+    "if seed_slot >= 0:\n"
+    "    o = np.zeros(64, I); L.METIS_SetDefaultOptions(p(o)); o[seed_slot] = 0; o[ufactor_slot] = 30; opts = p(o)\n"
+    "rc = L.METIS_PartGraphKway(p(nv), p(nc), p(xadj), p(adj), None, None, None, p(k), None, None, opts, p(obj), p(part))\n"
+    "ok = rc == 1 and set(part.tolist()) == {0, 1} and abs(int((part == 0).sum()) - 32) <= 8 and 0 < int(obj[0]) <= 16\n"
+    "sys.exit(0 if ok else 1)\n")
 
 
 def _metis_library():
-    """a libmetis the loader finds (LPMP_METIS_LIB names one explicitly), checked once in a CHILD process on a 64-ring: idx_t may be
-    32 or 64 bits wide depending on how the library was built, and a wrong guess must not take this process down.  Returns
-    (ctypes library, idx dtype, real ctype) or None."""
+    """a libmetis the loader finds (LPMP_METIS_LIB names one explicitly), checked once in CHILD processes on a 64-ring: idx_t may be
+    32 or 64 bits wide depending on how the library was built, and the slots of the option array differ between METIS 5.1 and 5.2 —
+    a wrong guess must neither take this process down nor hand METIS a zero where it wants a count.  The probe makes the real
+    call's kind of call: first without options (index width), then with the seed / imbalance options in each known layout, the
+    values the default call sets (seed 0, UFACTOR 30: a 5.2 library reads a 5.1 layout's seed slot as NCUTS = 0 and refuses; a 5.1
+    library reads a 5.2 layout's imbalance slot as NUMBERING = 30 and refuses).  Returns (ctypes library, idx dtype, name,
+    (layout name, seed slot, ufactor slot) or None when options cannot be set safely) or None."""
     if "lib" in _METIS:
         return _METIS["lib"]
     import ctypes, ctypes.util, subprocess, sys
@@ -324,29 +355,27 @@ def _metis_library():
     name = os.environ.get("LPMP_METIS_LIB") or ctypes.util.find_library("metis")
     if not name:
         return None
-    probe = (
-        "import ctypes, sys, numpy as np\n"
-        "L = ctypes.CDLL(sys.argv[1]); bits = int(sys.argv[2]); I = np.int32 if bits == 32 else np.int64\n"
-        "n = 64; xadj = (2 * np.arange(n + 1)).astype(I); adj = np.stack([(np.arange(n) - 1) % n, (np.arange(n) + 1) % n], 1).reshape(-1).astype(I)\n"
-        "nv = np.array([n], I); nc = np.array([1], I); k = np.array([2], I); obj = np.zeros(1, I); part = np.full(n, -1, I)\n"
-        "p = lambda a: a.ctypes.data_as(ctypes.c_void_p)\n"
-        "rc = L.METIS_PartGraphKway(p(nv), p(nc), p(xadj), p(adj), None, None, None, p(k), None, None, None, p(obj), p(part))\n"
-        "ok = rc == 1 and set(part.tolist()) == {0, 1} and abs(int((part == 0).sum()) - 32) <= 8 and 0 < int(obj[0]) <= 16\n"
-        "sys.exit(0 if ok else 1)\n")
-    for bits in (32, 64):
+
+    def probe(bits, seed_slot, ufactor_slot):
         try:
-            rc = subprocess.run([sys.executable, "-c", probe, name, str(bits)], timeout=60, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+            return subprocess.run([sys.executable, "-c", _METIS_PROBE, name, str(bits), str(seed_slot), str(ufactor_slot)], timeout=60,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
         except Exception:
-            rc = 1
-        if rc == 0:
-            _METIS["lib"] = (ctypes.CDLL(name), np.int32 if bits == 32 else np.int64, name)
+            return False
+    for bits in (32, 64):
+        if probe(bits, -1, -1):
+            ok = [lay for lay in _METIS_OPTION_LAYOUTS if probe(bits, lay[1], lay[2])]
+            # exactly one layout may answer; a library that accepts both (it ignores options, or checks nothing) gets none set
+            _METIS["lib"] = (ctypes.CDLL(name), np.int32 if bits == 32 else np.int64, name, ok[0] if len(ok) == 1 else None)
             break
     return _METIS["lib"]
 
 
 def metis_partition(n_vars: int, edge_i, edge_j, world: int, imbalance: float = 0.03, seed: int = 0, required: bool = False):
     """METIS k-way partition (edge cut objective) of the variable graph, or None when no METIS is installed (``required``: an
-    error instead).  Returns (part[int64], name of what ran).  `pymetis` first, then libmetis through ctypes."""
+    error instead).  Returns (part[int64], name of what ran).  `pymetis` first, then libmetis through ctypes.  Seed and imbalance
+    are handed over only in an option layout the probe has seen this library accept (_metis_library); otherwise the call runs with
+    METIS' defaults and the name says so."""
     edge_i = np.asarray(edge_i, np.int64); edge_j = np.asarray(edge_j, np.int64)
     from scipy.sparse import coo_matrix
     def csr():
@@ -368,22 +397,28 @@ def metis_partition(n_vars: int, edge_i, edge_j, world: int, imbalance: float = 
             raise RuntimeError("graph_partition(method='metis'): neither pymetis nor a loadable libmetis (LPMP_METIS_LIB) is installed")
         return None
     import ctypes
-    L, I, name = lib
+    L, I, name, layout = lib
     a = csr()
     if I == np.int32 and (a.indices.shape[0] >= 2**31 or n_vars >= 2**31):
         raise RuntimeError("metis_partition: this libmetis has 32-bit indices, the graph needs 64")
     xadj, adj = np.ascontiguousarray(a.indptr, I), np.ascontiguousarray(a.indices, I)
     nv, nc, k, obj = np.array([n_vars], I), np.array([1], I), np.array([world], I), np.zeros(1, I)
     part = np.zeros(n_vars, I)
-    opts = np.zeros(40, I)
-    L.METIS_SetDefaultOptions(opts.ctypes.data_as(ctypes.c_void_p))
-    opts[8] = seed                                             # METIS_OPTION_SEED
-    opts[16] = max(1, int(round(1000 * imbalance)))            # METIS_OPTION_UFACTOR: allowed imbalance in 1/1000
     p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
-    rc = L.METIS_PartGraphKway(p(nv), p(nc), p(xadj), p(adj), None, None, None, p(k), None, None, p(opts), p(obj), p(part))
+    opts = None
+    if layout is not None:
+        opts = np.zeros(64, I)
+        L.METIS_SetDefaultOptions(p(opts))
+        opts[layout[1]] = seed                                       # METIS_OPTION_SEED
+        opts[layout[2]] = max(1, int(round(1000 * imbalance)))       # METIS_OPTION_UFACTOR: allowed imbalance in 1/1000
+    rc = L.METIS_PartGraphKway(p(nv), p(nc), p(xadj), p(adj), None, None, None, p(k), None, None, None if opts is None else p(opts), p(obj), p(part))
     if rc != 1:
         raise RuntimeError("METIS_PartGraphKway failed with code %d" % rc)
-    return part.astype(np.int64), "metis (%s, %d-bit idx_t)" % (os.path.basename(name), 32 if I == np.int32 else 64)
+    part = part.astype(np.int64)
+    if part.min() < 0 or part.max() >= world or np.bincount(part, minlength=world).min() == 0:
+        raise RuntimeError("METIS_PartGraphKway returned a partition with an empty or out-of-range part")
+    how = "options in the %s layout" % layout[0] if layout is not None else "METIS' default options"
+    return part, "metis (%s, %d-bit idx_t, %s)" % (os.path.basename(name), 32 if I == np.int32 else 64, how)
 
 
 def load_partition_file(path: str, n_vars: int, world: int) -> np.ndarray:
@@ -566,7 +601,11 @@ class DistComm:
     def __init__(self, dist, torch):
         self.dist, self.torch = dist, torch
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.stage_cpu = dist.get_backend() == "gloo"     # CPU tests, and GPU smoke runs without RCCL
+        # gloo: CPU tests, and GPU smoke runs without RCCL (ranks sharing one device) — device rows are staged through the host.
+        # LPMP_DIST_DEVICE_COLLECTIVES=1 hands DEVICE tensors to the backend whatever it is (gloo's own CUDA collectives): the code
+        # path of an RCCL run — device all-to-all-v, the asynchronous exchange_begin / exchange_end — with real data between two
+        # processes on a box where RCCL cannot run two ranks (tests/test_round6_gpu.py)
+        self.stage_cpu = dist.get_backend() == "gloo" and not os.environ.get("LPMP_DIST_DEVICE_COLLECTIVES")
 
     def exchange(self, send, send_counts, recv_counts):
         """rows of ``send`` are grouped by destination rank (send_counts[r] rows each); returns the rows
@@ -623,7 +662,8 @@ class ExchangeProbe:
     def __init__(self, torch, on_device: bool):
         self.torch, self.on_device = torch, bool(on_device)
         self.spans, self.bytes_out, self.bytes_in, self.n_exchanges = [], 0, 0, 0
-        self._t0 = self._t1 = self._b = None
+        self.post_spans = []
+        self._t0 = self._t1 = self._b = self._p = None
 
     def _mark(self):
         if self.on_device:
@@ -646,6 +686,14 @@ class ExchangeProbe:
         self.spans.append((self._b, self._mark()))
         self.bytes_out += 8 * int(doubles_out); self.bytes_in += 8 * int(doubles_in); self.n_exchanges += 1
 
+    def begin_post(self):
+        """overlapped program: pack + copy + posting the collective (halo_begin) — exchange work on the engine's stream that is not
+        hidden behind anything, booked apart from both the compute time and the awaited rest of the exchange (halo_end)"""
+        self._p = self._mark()
+
+    def end_post(self):
+        self.post_spans.append((self._p, self._mark()))
+
     def _ms(self, a, b) -> float:
         return float(a.elapsed_time(b)) if self.on_device else (b - a) * 1e3
 
@@ -654,8 +702,13 @@ class ExchangeProbe:
             self.torch.cuda.synchronize()
         total = self._ms(self._t0, self._t1)
         exch = sum(self._ms(a, b) for a, b in self.spans)
+        post = sum(self._ms(a, b) for a, b in self.post_spans)
         n = max(1, int(n_passes))
-        return {"total_ms_per_pass": total / n, "exchange_ms_per_pass": exch / n, "compute_ms_per_pass": (total - exch) / n,
+        # exchange_ms = everything of the exchanges that sits on the engine's stream: the posts of an overlapped program (pack,
+        # copy, posting) + the awaited spans — so compute_ms (and scaling_model's t_run) means the same with and without
+        # --overlap-exchange; exchange_post_ms says how much of it was the posts (0 for the plain program)
+        return {"total_ms_per_pass": total / n, "exchange_ms_per_pass": (exch + post) / n, "exchange_post_ms_per_pass": post / n,
+                "compute_ms_per_pass": (total - exch - post) / n,
                 "exchanges_per_pass": self.n_exchanges / n, "exchange_bytes_out_per_pass": self.bytes_out / n,
                 "exchange_bytes_in_per_pass": self.bytes_in / n}
 

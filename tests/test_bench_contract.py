@@ -294,5 +294,25 @@ def test_rendezvous_gives_up_with_a_message_when_a_rank_never_comes():
     import time
     t0 = time.time()
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
-    assert p.returncode != 0 and time.time() - t0 < 120
+    assert p.returncode == 3 and time.time() - t0 < 120         # the start-up code (watchdogs, rendezvous, self test), not a crash's 1
     assert "bench.py: rank 0:" in p.stderr and ("no rendezvous" in p.stderr or "did not show up" in p.stderr)
+
+
+def test_scaling_model_says_when_t1_comes_from_another_library(monkeypatch):
+    """scaling_model's t_1 (single-GPU ms per pass of the same workload) is read from the latest committed bench line; the line
+    carries the source hash of the library that produced it, and the model flags a t_1 taken with another build than the running
+    one (`t1_stale`, `t1_note`) instead of silently dividing two builds' times"""
+    a = types.SimpleNamespace(workload="c3", grid=1024, labels=32, pairwise="dense", order="colour_major", mode="anisotropic",
+                              assume_exchange_latency_us=30.0, assume_exchange_GBps=400.0)
+    t1 = bench.single_gpu_reference(a)
+    assert t1 is not None and t1["source"].startswith("profiles/") and 4.0 < t1["ms_per_pass"] < 7.0
+    stats = {"max": {"compute_ms_per_pass": 5.3, "exchange_ms_per_pass": 0.1, "exchanges_per_pass": 0.2, "exchange_bytes_out_per_pass": 3e6,
+                     "exchange_bytes_in_per_pass": 3e6}}
+    monkeypatch.setattr(bench, "library_source_hash", lambda: "f" * 64)
+    m = bench.scaling_model(a, 8, stats, 5.4, False)
+    assert m["t1_stale"] is True and "compares two builds" in m["t1_note"] and m["t1_library_source_hash"] == t1["library_source_hash"]
+    assert m["kind"] == "weak" and abs(m["projected_efficiency"] - t1["ms_per_pass"] / m["projected_ms_per_pass"]) < 1e-12
+    if t1["library_source_hash"]:
+        monkeypatch.setattr(bench, "library_source_hash", lambda: t1["library_source_hash"])
+        m = bench.scaling_model(a, 8, stats, 5.4, False)
+        assert m["t1_stale"] is False and "t1_note" not in m

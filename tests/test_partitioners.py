@@ -14,23 +14,46 @@ from lp_mp_amd import model as M, multi_gpu as MG, synthetic as S  # noqa: E402
 from oracle.binding import Oracle  # noqa: E402
 
 
-@pytest.mark.parametrize("bits", [32, 64])
-def test_libmetis_binding_finds_the_index_width_and_partitions(tmp_path, bits):
-    so = tmp_path / f"libfakemetis{bits}.so"
-    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", f"-DIDX_BITS={bits}", os.path.join(ROOT, "tests", "cpp", "fake_metis.c"), "-o", str(so)])
+@pytest.mark.parametrize("bits,layout", [(32, 51), (64, 51), (32, 52), (64, 52), (32, 0)])
+def test_libmetis_binding_finds_the_index_width_and_the_option_layout(tmp_path, bits, layout):
+    so = tmp_path / f"libfakemetis{bits}_{layout}.so"
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", f"-DIDX_BITS={bits}", f"-DMETIS_LAYOUT={layout}",
+                           os.path.join(ROOT, "tests", "cpp", "fake_metis.c"), "-o", str(so)])
     # (the library is looked up once per process: a child per width)
     code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
             "from lp_mp_amd import multi_gpu as MG, synthetic as S\n"
             "ei, ej = S.counter_graph_edges(3000, 9000, 1)\n"
             "p, how = MG.graph_partition(3000, ei, ej, 4, method='metis', return_method=True)\n"
             "q, how2 = MG.graph_partition(3000, ei, ej, 4, return_method=True)\n"
-            "print(json.dumps({'how': how, 'how_auto': how2, 'sizes': np.bincount(p, minlength=4).tolist(), 'same': bool((p == q).all()),\n"
+            "r, how3 = MG.graph_partition(3000, ei, ej, 4, seed=7, imbalance=0.1, return_method=True)\n"
+            "print(json.dumps({'how': how, 'how_auto': how2, 'how_seeded': how3, 'sizes': np.bincount(p, minlength=4).tolist(), 'same': bool((p == q).all()),\n"
             "                  'contiguous': bool((np.diff(p) >= 0).all())}))\n" % ROOT)
     env = dict(os.environ, LPMP_METIS_LIB=str(so))
     env.pop("LPMP_PARTITIONER", None)
     d = json.loads(subprocess.check_output([sys.executable, "-c", code], env=env, text=True, timeout=300).strip().splitlines()[-1])
-    assert d["how"].startswith("metis (") and f"{bits}-bit idx_t" in d["how"] and d["how_auto"] == d["how"]
+    assert d["how"].startswith("metis (") and f"{bits}-bit idx_t" in d["how"] and d["how_auto"] == d["how"] == d["how_seeded"]
+    # the option slots are the library's own (metis.h 5.1 and 5.2 number them differently); a library that tells nothing gets none
+    assert {51: "options in the 5.1 layout", 52: "options in the 5.2 layout", 0: "METIS' default options"}[layout] in d["how"]
     assert d["sizes"] == [750] * 4 and d["same"] and d["contiguous"]
+
+
+def test_a_metis_that_fails_costs_auto_nothing_and_metis_an_error(tmp_path):
+    so = tmp_path / "libbrokenmetis.so"
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-DFAIL_ABOVE=64", os.path.join(ROOT, "tests", "cpp", "fake_metis.c"), "-o", str(so)])
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+            "from lp_mp_amd import multi_gpu as MG, synthetic as S\n"
+            "ei, ej = S.counter_graph_edges(3000, 9000, 1)\n"
+            "p, how = MG.graph_partition(3000, ei, ej, 4, return_method=True)\n"
+            "try:\n"
+            "    MG.graph_partition(3000, ei, ej, 4, method='metis'); err = None\n"
+            "except RuntimeError as ex:\n"
+            "    err = str(ex)\n"
+            "print(json.dumps({'how': how, 'sizes': np.bincount(p, minlength=4).tolist(), 'err': err}))\n" % ROOT)
+    env = dict(os.environ, LPMP_METIS_LIB=str(so))
+    env.pop("LPMP_PARTITIONER", None)
+    d = json.loads(subprocess.check_output([sys.executable, "-c", code], env=env, text=True, timeout=300).strip().splitlines()[-1])
+    assert d["how"].startswith("builtin") and "a METIS was found but failed" in d["how"] and "code -4" in d["how"]
+    assert min(d["sizes"]) > 600 and "code -4" in d["err"]
 
 
 def test_without_metis_auto_is_the_builtin_partitioner_and_metis_is_an_error():
@@ -115,7 +138,7 @@ def test_hand_made_partition_file_through_the_lock_step_driver_in_two_gloo_proce
     assert d["partitioner"] == "given" and 0.3 < d["cut"] < 0.7
     st = d["stats"]
     keys = {"compute_ms_per_pass", "exchange_ms_per_pass", "exchanges_per_pass", "exchange_bytes_out_per_pass", "exchange_bytes_in_per_pass",
-            "redundant_fraction", "total_ms_per_pass"}
+            "redundant_fraction", "total_ms_per_pass", "exchange_post_ms_per_pass"}
     assert set(st["per_rank"]) == keys and all(len(v) == 2 for v in st["per_rank"].values())
     assert set(st["max"]) == keys and set(st["mean"]) == keys and st["slowest_rank"] in (0, 1)
     assert st["max"]["exchanges_per_pass"] >= 2 and st["max"]["exchange_bytes_out_per_pass"] > 0
