@@ -205,17 +205,20 @@ dist.destroy_process_group()
 """
 
 
-def test_two_process_gloo_run_equals_the_unpartitioned_oracle(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_processes_equal_the_unpartitioned_oracle(tmp_path, world):
+    """one process per part over torch.distributed (gloo), 2 and 8 ranks (the node size north_star names): every rank's duals are
+    the unpartitioned oracle's"""
     script = tmp_path / "ls_worker.py"
     script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29536", str(script)], env=env, cwd=ROOT, timeout=300)
-    c = _graph(300, 800, 3, 2, seed=2)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                           "--master-addr", "127.0.0.1", "--master-port", str(29534 + world), str(script)], env=env, cwd=ROOT, timeout=600)
+    c = _graph(300, 800, 3, world, seed=2)
     ref = Oracle(_global_of(c)); ref.set_reparametrization(M.REPAM_ANISOTROPIC)
     ref.ComputePass(3)
     _, parts = _parts_of(c, M.REPAM_ANISOTROPIC)
-    _assert_equals_global(c, parts, [np.load(tmp_path / f"ls_duals_{k}.npy") for k in range(2)], ref)
+    _assert_equals_global(c, parts, [np.load(tmp_path / f"ls_duals_{k}.npy") for k in range(world)], ref)
     assert abs(np.load(tmp_path / "ls_lb.npy")[0] - ref.LowerBound()) <= 1e-12 * abs(ref.LowerBound())
 
 

@@ -142,7 +142,7 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_gloo_run_equals_the_unpartitioned_oracle(tmp_path, world):
     """what bench.py --gpus N does per rank, over torch.distributed (gloo): 7 passes in chunks of 2 = 4 exchanges"""
     script = tmp_path / "ov_worker.py"
