@@ -151,6 +151,9 @@ struct RotationInfo {
   // every factor's bound at a pass seam is known to a W record (its own, at the end) or a K record (its own after the
   // receives, or as the pairwise peer of one of its receives): then a joined launch can emit one bound row per pass
   bool hist_ok = false;
+  // how far AHEAD in a step's block list a steady-state block's predecessors of the step before lie, as a fraction of the
+  // list (a W x H grid in a 2-colour order: one grid row, 1 / H): what the lag of the skewed ticket order has to cover before any slack
+  double reach = 0;
 };
 
 struct lpmp_plan {
@@ -314,6 +317,12 @@ static void plan_rotation_chain(lpmp_plan* pl, int mode) {
       for (const auto& d : v) { ri.delta[kind].push_back(d.first); ri.block[kind].push_back(d.second); }
       ri.off[kind].push_back((int64_t)ri.block[kind].size());
     }
+    if (kind == 2 || kind == 3) {
+      const double nbs = (double)std::max<int64_t>(1, nbk), nbp = (double)std::max<int32_t>(1, ri.t[Y1[kind]].nb);
+      for (int64_t b = 0; b < nbk; ++b)
+        for (const auto& d : per[(size_t)b])
+          if (d.first == 1) ri.reach = std::max(ri.reach, (d.second + 0.5) / nbp - (b + 0.5) / nbs);
+    }
   }
   {   // coverage of the per-pass bound rows (kernels.hip HIST_END / HIST_MID)
     std::vector<uint8_t> cov((size_t)pl->p.nf, 0);
@@ -415,6 +424,7 @@ struct lpmp_engine {
   bool pass_chain_tried[LPMP_REPAM_COUNT] = {};   // ensure_pass_chain_plan ran for that mode
   bool deep_note_given = false;                   // the one-line note about a schedule of many levels was printed
   int rot_bands = 0, rot_lag = 3, rot_depth = 4;   // skewed ticket order (0 bands: from the table bytes per step); DESIGN.md 6 has the sweep
+  bool rot_lag_set = false, rot_depth_set = false; // LPMP_ROT_LAG / LPMP_ROT_DEPTH given: used as they are; else from the model (rot_geometry)
   void release_rot_chains() {
     for (auto& m : rot_chain) {
       for (auto& kv : m) {
@@ -930,8 +940,41 @@ void check_rows(int64_t n, const int64_t* om_off, const double* om, const int64_
 // parity: the kernel maps ticket t to (template ticket, copy of the period) (kernels.hip, chain_ticket_ref), and the
 // completion flags are a ring of a few groups.  Host work, upload and device memory of an n-pass launch no longer depend on n.
 constexpr int ROT_EXPLICIT_MAX = 7;
+// The window of the skewed order — (bands, lag, depth) — from the model (round 6).  A table is read by two consecutive steps; with
+// bands of a step issued at time b + lag * d (d = the step's place in its group of `depth` steps) the second read comes
+// lag * depth bands after the first, and it finds the table in the 256 MiB Infinity Cache while that window stays below it.
+// The lag has to cover the REACH of the dependencies — how far ahead in the block list a block's predecessors lie: one grid row —
+// plus slack: a ticket whose predecessors were issued fewer tickets ago than there are resident workgroups (256 CUs x 3) is drawn
+// while they are still running, and its workgroup waits.  In ticket order the steps of a group are interleaved, so a slack of
+// S tickets is S / depth blocks of one step.  Measured (profiles/r06_blocked_pass_probe_*.txt, 32 labels, bands of 16 MiB, a
+// block = 156 KB): 1024^2 (row 20 MB) lag 3, depth 4: 5.12 ms per pass (lag 2: 5.24, lag 4: 5.18); 1536^2 (row 30 MB) lag 3 / 4 / 5:
+// 12.17 / 11.94 / 12.85 (11.5 = 2.25 times the 1024^2 time; 14.5 launch by launch); 2048^2 (row 40 MB) 25.3 with lag 3 (slack
+// 260 tickets: no better than one launch per step, 26.0), 21.3 with lag 4 (700 tickets; 20.4 = four times), 22.6 with lag 5
+// (window 336 MB: the reuse goes); 3072^2 (row 60 MB) 65.4 with lag 3 / depth 4 (57.2 launch by launch), 50.3 with lag 6 / depth 2
+// (46 = nine times; depth 3 and 4 with lags 5-6: 50.2-52.1).  So: a slack of 700 tickets behind the reach; depth 4 while
+// (reach + slack) * 4 stays under 275 MiB, else 2 (half of the second reads instead of three quarters, but they hit); the lag
+// stretched to a window of 200 MiB where the reach leaves room; no chain at all when even depth 2 cannot hold the window.
+struct RotGeometry { int bands = 1, lag = 3, depth = 4; bool fits = true; double reach_bytes = 0; };
+static RotGeometry rot_geometry(const lpmp_engine* e, const RotationInfo& ri) {
+  RotGeometry g;
+  g.lag = std::max(1, e->rot_lag); g.depth = std::max(1, e->rot_depth);
+  if (!ri.valid) return g;
+  g.bands = e->rot_bands > 0 ? e->rot_bands : (int)std::max<int64_t>(1, std::min<int64_t>(ri.t[1].nb, ri.t[1].bytes / ((int64_t)16 << 20)));
+  if (e->rot_bands > 0) return g;                   // bands forced (tests, probes): lag and depth as given or their defaults
+  constexpr double MiB = 1048576.0, SLACK_TICKETS = 700, WINDOW_TARGET = 200 * MiB, WINDOW_MAX = 275 * MiB;
+  const double step_bytes = (double)ri.t[1].bytes, band_bytes = step_bytes / g.bands;
+  const double slack1 = SLACK_TICKETS * step_bytes / (double)std::max<int32_t>(1, ri.t[1].nb);   // the slack as bytes of ONE step's block list, depth 1
+  g.reach_bytes = ri.reach * step_bytes;
+  if (!e->rot_depth_set) g.depth = (g.reach_bytes + slack1 / 4) * 4 <= WINDOW_MAX ? 4 : 2;
+  const double need = g.reach_bytes + slack1 / g.depth;
+  // (rounded up from .3: a band short on slack costs more than a band of window — 1536^2: 3.4 bands -> 4)
+  if (!e->rot_lag_set) g.lag = std::max(2, (int)std::floor(std::max(need, WINDOW_TARGET / g.depth) / band_bytes + 0.7));
+  g.fits = e->rot_depth_set || e->rot_lag_set || need * g.depth <= 1.25 * WINDOW_MAX;
+  return g;
+}
 lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n_call) {
-  const int depth = std::max(1, e->rot_depth);
+  const RotGeometry geo = rot_geometry(e, e->plan->rot[mode]);
+  const int depth = geo.depth;
   // template: groups 0, 1 (prologue), 2 (the period) and a tail as long as the call's: r = (2 n + 1) mod depth steps
   const int tail = depth % 2 == 0 ? (2 * n_call + 1) % depth : 0;
   const int n_template = (3 * depth + tail - 1) / 2;
@@ -988,12 +1031,13 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n_call) {
   // lag * depth bands (3 * 4 * 16 MiB = 192 MiB of the 256 MiB Infinity Cache); measured on C3: windows of 200-230 MB are
   // the fastest whatever the split (1024:3:4 5.09, 2048:4:6 5.03, 1536:3:6 5.09 ms per pass), 290 MB and more lose the
   // reuse (1024:3:5 5.67, 1024:3:6 6.37), lag 2 leaves the waiting workgroups less slack (1024:2:4 5.24)
-  int bands = e->rot_bands;
-  if (bands <= 0) bands = (int)std::max<int64_t>(1, std::min<int64_t>(ri.t[1].nb, ri.t[1].bytes / ((int64_t)16 << 20)));
+  // (round 6: lag and depth follow the reach of the dependencies — rot_geometry above; C3 keeps 3 and 4)
+  if (!geo.fits) return no("a step's dependencies reach further than the Infinity Cache window can cover");
+  const int bands = geo.bands;
   std::vector<int32_t> new_of((size_t)N), tk_launch((size_t)N), tk_block((size_t)N);
   std::vector<int64_t> group_begin;                                 // first ticket of every group of `depth` steps
   auto band_begin = [](int64_t b, int64_t nb, int64_t bands_) { return (b * nb + bands_ - 1) / bands_; };   // first block of band b
-  for (int lag = std::max(1, e->rot_lag); lag <= 16; ++lag) {
+  for (int lag = geo.lag; lag <= std::max(16, 2 * geo.lag); ++lag) {
     int64_t at = 0;
     group_begin.clear();
     for (int s0 = 0; s0 < n_steps; s0 += depth) {
@@ -1113,8 +1157,8 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n_call) {
     e->rot_cache_bytes += rc.dev_bytes;
     rc.n_steps = n_steps; rc.periodic = periodic; rc.n_tmpl = n; rc.depth = depth; rc.ring = ring;
     if (verbose)
-      std::fprintf(stderr, "lpmp: %d passes as one launch%s: %lld tickets, %d bands, lag %d, depth %d; built and uploaded in %.0f ms\n", n,
-                   periodic ? " (periodic template)" : "", (long long)N, bands, lag, depth, since());
+      std::fprintf(stderr, "lpmp: %d passes as one launch%s: %lld tickets, %d bands, lag %d, depth %d (reach %.1f MB of %.1f MB per band); built and uploaded in %.0f ms\n", n,
+                   periodic ? " (periodic template)" : "", (long long)N, bands, lag, depth, geo.reach_bytes / 1e6, (double)ri.t[1].bytes / bands / 1e6, since());
     return &rc;
   }
   return no("no band order keeps the dependencies backwards");
@@ -1417,8 +1461,8 @@ int lpmp_create(int device, lpmp_engine** out) {
     const char* nb = std::getenv("LPMP_NO_BLOCKED_PASSES");
     e->use_blocked_passes = !(nb && nb[0] == '1');
     if (const char* v = std::getenv("LPMP_ROT_BANDS")) e->rot_bands = std::atoi(v);
-    if (const char* v = std::getenv("LPMP_ROT_LAG")) e->rot_lag = std::max(1, std::atoi(v));
-    if (const char* v = std::getenv("LPMP_ROT_DEPTH")) e->rot_depth = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("LPMP_ROT_LAG")) { e->rot_lag = std::max(1, std::atoi(v)); e->rot_lag_set = true; }
+    if (const char* v = std::getenv("LPMP_ROT_DEPTH")) { e->rot_depth = std::max(1, std::atoi(v)); e->rot_depth_set = true; }
     if (const char* v = std::getenv("LPMP_CHAIN_CACHE_MB")) e->rot_cache_limit = (size_t)std::max(1, std::atoi(v)) << 20;
     if (const char* v = std::getenv("LPMP_ROWS_LAYOUT")) e->want_rows = std::atoi(v) != 0;                             // as lpmp_set_rows_layout
     if (const char* v = std::getenv("LPMP_SPECULATION")) e->spec.max_depth = std::min(32, std::max(0, std::atoi(v)));   // as lpmp_set_speculation

@@ -19,6 +19,20 @@ _GOLD = np.uint64(0x9E3779B97F4A7C15)
 def u01(n: int, seed: int, first: int = 0) -> np.ndarray:
     """Counter-based uniforms in [0,1): splitmix64 finaliser of seed + (first+i+1)*GOLDEN.
     Bit-identical to the engine's device generator (lpmp_synth_fill) and the oracle's orc_synth_u01."""
+    if n >= (1 << 22):                       # long streams (the tables of an HBM-sized test model): block by block on a few threads
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+        out = np.empty(n, np.float64)
+        nb = (n + (1 << 20) - 1) >> 20
+
+        def fill(k):
+            lo, hi = k << 20, min(n, (k + 1) << 20)
+            w = np.empty(hi - lo, np.uint64)
+            _u64_block(w, seed, first + lo)
+            np.multiply(w >> np.uint64(11), 1.0 / 9007199254740992.0, out=out[lo:hi])
+        with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
+            list(ex.map(fill, range(nb)))
+        return out
     with np.errstate(over="ignore"):
         z = np.uint64(seed) + (np.arange(first + 1, first + n + 1, dtype=np.uint64)) * _GOLD
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)

@@ -79,3 +79,120 @@ def test_two_processes_exchange_device_tensors_plain_and_overlapped(tmp_path):
     # the headline grid's overlap schedule (ghost rows refreshed by a device all-to-all every n passes)
     d = _bench(["--gpus", "2", "--grid", "128", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"], env)
     assert d["schedule"] == "overlap" and abs(d["dual_bound_gap"]) <= 1e-12 and d["exchange_bytes_per_pass"]["max"] > 0
+
+
+# ---- hard constraints: +inf entries in pairwise tables -------------------------------------------------------------------------
+def _hard_grid(H, W, L, seed, order, frac=0.35, potts=False):
+    """a grid MRF whose pairwise tables forbid label pairs (+inf, as the reference's users write hard constraints; its own `matrix`
+    pads rows with +inf, include/vector.hxx:708-735); every row and column keeps a finite entry (the diagonal), so all min-marginals
+    stay finite — an all-inf row makes the reference itself produce inf - inf"""
+    import numpy as np
+    from lp_mp_amd import synthetic as S
+    rng = np.random.default_rng(seed)
+    m = S.grid_model(H, W, L, pairwise="potts" if potts else "dense", order=order, seed=seed)
+    c = np.asarray(m.const_data)
+    if potts:
+        c[rng.random(c.shape[0]) < frac] = np.inf                    # hard equality constraints
+    else:
+        T = c.reshape(-1, L, L)
+        mask = rng.random(T.shape) < frac
+        mask[:, np.arange(L), np.arange(L)] = False
+        T[mask] = np.inf
+    return m
+
+
+@pytest.mark.parametrize("L", [3, 4, 8, 16, 32, 40])
+@pytest.mark.parametrize("order", ["row_major", "colour_major"])
+def test_forbidden_label_pairs_dense(L, order):
+    import numpy as np
+    from lp_mp_amd import engine as E, model as M
+    from oracle.binding import Oracle
+    m = _hard_grid(9, 7, L, 60 + L, order)
+    e = E.Engine(0)
+    try:
+        for mode in (M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM, M.REPAM_UNIFORM, M.REPAM_ANISOTROPIC2):
+            o = Oracle(m); o.set_reparametrization(mode)
+            e.upload(m); e.set_reparametrization(mode)
+            for n in (1, 3):
+                o.ComputePass(n); e.compute_pass(n)
+                d = e.download_duals()
+                assert np.isfinite(d).all() and np.array_equal(d, o.duals()), (L, order, mode, n)
+                assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("L", [2, 5, 8, 32])
+def test_hard_equality_constraints_potts(L):
+    import numpy as np
+    from lp_mp_amd import engine as E, model as M
+    from oracle.binding import Oracle
+    m = _hard_grid(8, 9, L, 80 + L, "colour_major", potts=True)
+    e = E.Engine(0)
+    try:
+        for mode in (M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM):
+            o = Oracle(m); o.set_reparametrization(mode)
+            e.upload(m); e.set_reparametrization(mode)
+            for n in (1, 4):
+                o.ComputePass(n); e.compute_pass(n)
+                d = e.download_duals()
+                assert np.isfinite(d).all() and np.array_equal(d, o.duals()), (L, mode, n)
+                assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+    finally:
+        e.close()
+
+
+def test_forbidden_label_pairs_through_the_joined_pass_launch():
+    """the headline path's launch (colour-major grid: n joined passes as one persistent launch) on a model with forbidden label pairs"""
+    import numpy as np
+    from lp_mp_amd import engine as E, model as M
+    from oracle.binding import Oracle
+    m = _hard_grid(96, 96, 32, 7, "colour_major", frac=0.2)
+    o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    e = E.Engine(0)
+    try:
+        e.upload(m); e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        e.compute_pass(6); o.ComputePass(6)
+        assert np.array_equal(e.download_duals(), o.duals())
+        e.compute_pass(1); o.ComputePass(1)
+        assert np.array_equal(e.download_duals(), o.duals())
+        assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * abs(o.LowerBound())
+    finally:
+        e.close()
+
+
+# ---- joined passes on WIDE grids: lag and depth of the Infinity-Cache ticket order follow the reach of the dependencies ----------
+@pytest.mark.parametrize("H,W,want", [(16, 4096, "chain"), (5, 16384, "sweep")])
+def test_wide_grids_joined_launch_geometry_against_the_oracle(H, W, want, capfd, monkeypatch):
+    """HBM-sized colour-major grids whose ROWS are long (80 MB and 320 MB of a step's algorithmic bytes per grid row of one colour; the
+    headline grid: 20 MB): the engine chooses lag and depth of the skewed ticket order from that reach (engine.cpp rot_geometry) —
+    depth 2 and a lag that covers one row plus slack for the 4096-wide grid, no persistent launch at all when even that window cannot
+    sit in the Infinity Cache (16384 wide) — and the duals equal the oracle's bit for bit either way"""
+    import numpy as np
+    from lp_mp_amd import engine as E, model as M, synthetic as S
+    from oracle.binding import Oracle
+    monkeypatch.setenv("LPMP_ROT_VERBOSE", "1")
+    m = S.grid_model(H, W, 32, order="colour_major", seed=11)
+    o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    e = E.Engine(0)
+    try:
+        e.upload(m)
+        assert e.L.lpmp_streaming_access(e.h) == 1                   # tables + duals > 1 GiB
+        e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        e.enable_kernel_timing(True)
+        e.compute_pass(3); o.ComputePass(3)
+        kt = e.kernel_timing()
+        e.enable_kernel_timing(False)
+        names = [v["kernel"] for v in kt.values()]
+        assert len(names) == 1 and names[0].startswith(want + "_dense_pk_kernel<32"), names
+        assert np.array_equal(e.download_duals(), o.duals())
+        e.compute_pass(9); o.ComputePass(9)                          # (more than ROT_EXPLICIT_MAX passes: the periodic template)
+        assert np.array_equal(e.download_duals(), o.duals())
+        assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * abs(o.LowerBound())
+        err = capfd.readouterr().err
+        if want == "chain":
+            assert "depth 2" in err and "periodic template" in err, err[-600:]
+        else:
+            assert "reach further than the Infinity Cache window" in err, err[-600:]
+    finally:
+        e.close()
