@@ -786,7 +786,8 @@ void issue_launches(lpmp_engine* e, const DevSchedule& s, bool timed, hipStream_
     else if (!(e->use_packed && lr.stride != 0 &&
           launch_sweep_packed(lr.kclass, lr.stride > 0 ? s.packets + lr.pk_begin : nullptr, s.recs + lr.begin, s.ops, lr.stride, e->d_dual,
                               e->d_const, e->d_lb, e->d_primal, lr.end - lr.begin, flags, stream)))
-      launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->d_primal, e->d_pw_unary, lr.begin, lr.end - lr.begin, flags, stream);
+      launch_sweep(lr.kclass, s.recs, s.ops, e->d_dual, e->d_const, e->d_tabs, e->d_lb, e->d_primal, e->d_pw_unary, lr.begin, lr.end - lr.begin,
+                   flags | (lr.kclass == KC_DENSE_BIG ? sweep_bigdim_flags(lr.max_dim) : 0), stream);   // (LDS of the streaming class: by the launch's label counts)
     if (timed) {
       HIP_CHECK(hipEventRecord(b, stream));
       e->pending.push_back({a, b, lr.kclass, lr.end - lr.begin, lr.n_recv, lr.bytes});

@@ -2196,7 +2196,15 @@ chain_potts_pk_kernel(ChainArgs ca, const ChainLaunch* __restrict__ launches, do
 //   side 1 (own label = column): lane-local minimum over the rows, m1[row] broadcast from LDS
 // -------------------------------------------------------------------------------------------------
 constexpr int BIG_WAVES = 4;
-struct BigLds { double theta[BIG_MAX_LABELS]; double mo[BIG_MAX_LABELS]; double q[BIG_MAX_LABELS]; };
+static_assert(BIG_WAVES == BIG_BLOCK_RECORDS, "plan.hpp: records per workgroup of the streaming dense kernel");
+// LDS of one wave: theta, m_o, q — `ldim` doubles each, ldim = the launch's largest label count rounded up to 64 (round 6: was
+// BIG_MAX_LABELS for every launch, 48 KiB per workgroup, which alone held the kernel at 3 waves per SIMD whatever its registers)
+struct BigLds { double* theta; double* mo; double* q; };
+__device__ __forceinline__ int big_ldim(int flags) { const int k = (flags & SWEEP_BIGDIM_MASK) >> SWEEP_BIGDIM_SHIFT; return k ? 64 * k : BIG_MAX_LABELS; }
+static size_t big_lds_bytes(int flags) { const int k = (flags & SWEEP_BIGDIM_MASK) >> SWEEP_BIGDIM_SHIFT; return (size_t)BIG_WAVES * 3 * (k ? 64 * k : BIG_MAX_LABELS) * sizeof(double); }
+// record and op fields are the same in all lanes of the wave: as scalars, so that row addresses are scalar-base + lane offset
+// (one VGPR of offsets for the 16 loads of a block instead of 16 64-bit addresses) and the loop bounds are uniform
+__device__ __forceinline__ double uni_f64(double v) { return __longlong_as_double(uni64<64>(__double_as_longlong(v))); }
 
 // v[r] = this lane's partial minimum of row r (16 rows).  Returns the minimum over all 64 lanes of ONE row:
 // row 8*bit0 + 4*bit1 + 2*bit2 + bit3 of the lane index.
@@ -2236,25 +2244,38 @@ __device__ __forceinline__ double transpose_min16(double (&v)[16], int lane) {
   return r;
 }
 
-template <bool NT>
-__global__ void __launch_bounds__(64 * BIG_WAVES)
-sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
-                       const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal,
-                       int64_t first, int64_t count, int flags) {
-  __shared__ BigLds lds[BIG_WAVES];
+// NT: the tables with non-temporal loads (one launch per step of an HBM-sized model); A: access policy of the duals (ACC_PLAIN in
+// the launches of the product.  Round 6 also ran this body inside the chain executor with ACC_COH — joined passes of a 2-colour
+// grid with 33 ... 48 labels as one persistent launch in Infinity-Cache order: bit-identical and SLOWER than one launch per step,
+// 12.6 against 9.9 ms per pass at 33 labels, 15.4 against 12.1 at 40, 16.8 against 16.6 at 48, and from about 56 labels on the
+// window cannot sit in the cache at all — EXPERIMENTS.md K; the kernel went, the policy parameter stayed)
+template <bool NT, int A>
+__device__ __forceinline__ void dense_big_body(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+                                               const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal,
+                                               int64_t first, int64_t count, int flags, int64_t block) {
+  extern __shared__ double big_lds_pool[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t idx = (int64_t)blockIdx.x * BIG_WAVES + wave;
+  const int64_t idx = block * BIG_WAVES + wave;
   if (idx >= count) return;
-  BigLds& S = lds[wave];
-  const UpdRec rec = recs[first + idx];
+  const int ldim = big_ldim(flags);
+  BigLds S{big_lds_pool + (size_t)wave * 3 * ldim, big_lds_pool + (size_t)wave * 3 * ldim + ldim, big_lds_pool + (size_t)wave * 3 * ldim + 2 * ldim};
+  UpdRec rec = recs[first + idx];
+  rec.dual_off = uni64<64>(rec.dual_off); rec.d0 = uni<64>(rec.d0); rec.op_begin = uni<64>(rec.op_begin);
+  rec.n_recv = (int16_t)uni<64>((int)rec.n_recv); rec.n_send = (int16_t)uni<64>((int)rec.n_send);
+  rec.factor = uni<64>(rec.factor); rec.kind_flags = uni<64>(rec.kind_flags);
+  auto uni_op = [](Op o) {
+    o.peer_dual = uni64<64>(o.peer_dual); o.peer_const = uni64<64>(o.peer_const); o.omega = uni_f64(o.omega);
+    o.info = uni<64>(o.info); o.pd0 = uni<64>(o.pd0); o.pd1 = uni<64>(o.pd1); o.peer = uni<64>(o.peer);
+    return o;
+  };
   const int Lr = rec.d0;
   double* own_g = dual + rec.dual_off;
-  for (int i = lane; i < Lr; i += 64) S.theta[i] = own_g[i];
+  for (int i = lane; i < Lr; i += 64) S.theta[i] = ld_dual<A>(own_g + i);
   const int my_row = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
   Op nxt{};
   if (rec.n_recv > 0) nxt = ops[rec.op_begin];
   for (int k = 0; k < rec.n_recv; ++k) {
-    const Op op = nxt;
+    const Op op = uni_op(nxt);
     if (k + 1 < rec.n_recv) nxt = ops[rec.op_begin + k + 1];   // requested before this receive's table stream starts
     const int side = (op.info >> 5) & 1;
     const int R = op.pd0, C = op.pd1;
@@ -2262,7 +2283,7 @@ sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ o
     double* ms = dual + op.peer_dual + (side == 0 ? 0 : R);
     const double* mo = dual + op.peer_dual + (side == 0 ? R : 0);
     const int Lo = side == 0 ? C : R;
-    for (int i = lane; i < Lo; i += 64) S.mo[i] = mo[i];
+    for (int i = lane; i < Lo; i += 64) S.mo[i] = ld_dual<A>(mo + i);
     wave_sync();
     if (((op.info >> 8) & 15) == LPMP_F_PAIRWISE_POTTS) {
       // q[x] = min(m_o[x], diff + min_{y != x} m_o[y]) from the two smallest entries of m_o (multiset) and the
@@ -2318,15 +2339,15 @@ sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ o
     wave_sync();
     double pb = LPMP_INF;                              // peer's bound after this receive
     for (int i = lane; i < Lr; i += 64) {
-      const double msv = ms[i], qv = S.q[i];
+      const double msv = ld_dual<A>(ms + i), qv = S.q[i];
       const double delta = msv + qv;                   // omega = 1: delta = min-marginal
       S.theta[i] += delta;
       const double mn = msv - delta;
-      ms[i] = mn;
+      st_dual<A>(ms + i, mn);
       pb = fmin(pb, mn + qv);
     }
     pb = wave_min(pb);
-    if (lane == 0) lb[op.peer] = pb;
+    if (lane == 0) st_lb<A>(lb + op.peer, pb);
     wave_sync();
   }
   if ((flags & SWEEP_PRIMAL) && (rec.kind_flags & UPD_PRIMAL)) {   // first minimiser of theta after the receives
@@ -2341,34 +2362,40 @@ sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ o
   // sends from the state after the receives (kept in q); a lane always owns the same elements: no barrier needed
   for (int i = lane; i < Lr; i += 64) S.q[i] = S.theta[i];
   for (int k = 0; k < rec.n_send; ++k) {
-    const Op op = ops[rec.op_begin + rec.n_recv + k];
+    const Op op = uni_op(ops[rec.op_begin + rec.n_recv + k]);
     double* ms = dual + op.peer_dual + (((op.info >> 5) & 1) ? op.pd0 : 0);
     for (int i = lane; i < Lr; i += 64) {
       const double delta = op.omega * S.q[i];
-      ms[i] += delta;
+      st_dual<A>(ms + i, ld_dual<A>(ms + i) + delta);
       S.theta[i] -= delta;
     }
-    if (lane == 0) lb[op.peer] = LPMP_NAN;
+    if (lane == 0) st_lb<A>(lb + op.peer, LPMP_NAN);
   }
   if (flags & SWEEP_RESIDUAL) {
     double residual = 0.0;
     for (int k = 0; k < rec.n_send; ++k) {
-      const Op op = ops[rec.op_begin + rec.n_recv + k];
+      const Op op = uni_op(ops[rec.op_begin + rec.n_recv + k]);
       double* ms = dual + op.peer_dual + (((op.info >> 5) & 1) ? op.pd0 : 0);
       residual += op.omega;
       for (int i = lane; i < Lr; i += 64) {
         const double delta = residual * S.theta[i];
-        ms[i] += delta;
+        st_dual<A>(ms + i, ld_dual<A>(ms + i) + delta);
         S.theta[i] -= delta;
       }
     }
   }
   double ob = LPMP_INF;
-  for (int i = lane; i < Lr; i += 64) { const double x = S.theta[i]; own_g[i] = x; ob = fmin(ob, x); }
+  for (int i = lane; i < Lr; i += 64) { const double x = S.theta[i]; st_dual<A>(own_g + i, x); ob = fmin(ob, x); }
   ob = wave_min(ob);
-  if (lane == 0) lb[rec.factor] = ob;
+  if (lane == 0) st_lb<A>(lb + rec.factor, ob);
 }
-
+template <bool NT>
+__global__ void __launch_bounds__(64 * BIG_WAVES)
+sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
+                       const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal,
+                       int64_t first, int64_t count, int flags) {
+  dense_big_body<NT, ACC_PLAIN>(recs, ops, dual, cdata, lb, primal, first, count, flags, (int64_t)blockIdx.x);
+}
 // -------------------------------------------------------------------------------------------------
 // Updated pairwise factors (dense or Potts), packed form (classes KC_PW_4..32; `right` / `full` schedules, e.g. MPLP-style
 // FMCs): the factor is on the right of all its (unary-pairwise) messages.  A receive pulls the whole unary in
@@ -2688,8 +2715,8 @@ void launch_sweep(int kclass, const UpdRec* recs, const Op* ops, double* dual, c
     case KC_POTTS_8: hipLaunchKernelGGL(sweep_potts_kernel<8>, blocks(256 / 8), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
     case KC_POTTS_4: hipLaunchKernelGGL(sweep_potts_kernel<4>, blocks(256 / 4), dim3(256), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags); break;
     case KC_DENSE_BIG:
-      if (flags & SWEEP_NT) hipLaunchKernelGGL(sweep_dense_big_kernel<true>, blocks(BIG_WAVES), dim3(64 * BIG_WAVES), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags);
-      else hipLaunchKernelGGL(sweep_dense_big_kernel<false>, blocks(BIG_WAVES), dim3(64 * BIG_WAVES), 0, s, recs, ops, dual, cdata, lb, primal, first, count, flags);
+      if (flags & SWEEP_NT) hipLaunchKernelGGL(sweep_dense_big_kernel<true>, blocks(BIG_WAVES), dim3(64 * BIG_WAVES), big_lds_bytes(flags), s, recs, ops, dual, cdata, lb, primal, first, count, flags);
+      else hipLaunchKernelGGL(sweep_dense_big_kernel<false>, blocks(BIG_WAVES), dim3(64 * BIG_WAVES), big_lds_bytes(flags), s, recs, ops, dual, cdata, lb, primal, first, count, flags);
       break;
     case KC_SMALL: hipLaunchKernelGGL(sweep_generic_kernel<1>, blocks(GenCtx<1>::FPB), dim3(GenCtx<1>::THREADS), 0, s, recs, ops, dual, cdata, tabs, lb, primal, pw_unary, first, count, flags); break;
     default: hipLaunchKernelGGL(sweep_generic_kernel<64>, blocks(GEN_WAVES), dim3(64 * GEN_WAVES), 0, s, recs, ops, dual, cdata, tabs, lb, primal, pw_unary, first, count, flags); break;

@@ -690,13 +690,14 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     return level_base[l] + __builtin_popcount(level_mask[l] & ((1u << kclass[u]) - 1u));
   };
   std::vector<int64_t> key_count(n_keys + 1, 0), key_recv(n_keys, 0), key_send(n_keys, 0), key_bytes(n_keys, 0);
-  std::vector<int32_t> key_level(n_keys, 0), key_class(n_keys, 0);
+  std::vector<int32_t> key_level(n_keys, 0), key_class(n_keys, 0), key_maxdim(n_keys, 0);
   for (int64_t u = 0; u < N; ++u) {
     if (!is_rec(u)) continue;
     const int64_t k = key(u);
     ++key_count[k + 1];
     key_level[k] = level[u]; key_class[k] = kclass[u];
     key_recv[k] += n_recv_of[u]; key_send[k] += n_send_of[u]; key_bytes[k] += rec_bytes[u];
+    key_maxdim[k] = std::max(key_maxdim[k], std::max(std::max(f_dim0[uf[u]], f_dim1[uf[u]]), max_dim[u]));
     out.n_recv += n_recv_of[u]; out.n_send += n_send_of[u];
   }
   std::partial_sum(key_count.begin(), key_count.end(), key_count.begin());
@@ -724,6 +725,7 @@ void Plan::make_schedule(const std::vector<Segment>& segs, bool fuse, Schedule& 
     lr.kclass = key_class[k]; lr.begin = key_count[k]; lr.end = key_count[k + 1];
     lr.level = key_level[k];
     lr.n_recv = key_recv[k]; lr.n_send = key_send[k]; lr.bytes = key_bytes[k];
+    lr.max_dim = key_maxdim[k];
     out.launches.push_back(lr);
   }
   // Inside a launch the order of the records is free (they are independent).  They were placed in SEQUENCE order; what the

@@ -106,6 +106,7 @@ struct LevelRange {            // one kernel launch: a range of UpdRec indices o
   // pk_begin + i*stride of Schedule::packets and its ops in the following slots -> one coalesced load, no
   // dependent rec -> ops hop.  stride 0: not packed.
   int32_t stride = 0; int64_t pk_begin = 0;
+  int32_t max_dim = 0;                          // largest label count of any vector or table side the launch's records touch
 };
 constexpr int PK_MAX_OPS = 8;                 // packets hold at most this many ops per factor
 // launches whose factors have more ops than that (but at most this many: the LDS slab of a lane group) run the
@@ -128,6 +129,9 @@ constexpr int32_t UPD_PRIMAL = 1 << 17;       // UpdRec::kind_flags: the factor 
 constexpr int SWEEP_RESIDUAL = 1;   // --reparametrizationType residual
 constexpr int SWEEP_NT = 4;         // host-side selector: the model is far larger than the caches -> non-temporal variants
 constexpr int SWEEP_ADAPTIVE = 8;   // --reparametrizationType adaptive (generic kernels only)
+// bits 8-11: streaming dense class — LDS per wave sized for ceil(max label count of the launch / 64) * 64 labels (0: BIG_MAX_LABELS)
+constexpr int SWEEP_BIGDIM_SHIFT = 8, SWEEP_BIGDIM_MASK = 15 << SWEEP_BIGDIM_SHIFT;
+constexpr int sweep_bigdim_flags(int max_dim) { return max_dim <= 0 ? 0 : (((max_dim + 63) / 64) << SWEEP_BIGDIM_SHIFT) & SWEEP_BIGDIM_MASK; }
 constexpr int SWEEP_PRIMAL = 2;     // UpdateFactorPrimal (reference factors_messages.hxx:2332-2373): factors of a
                                     // COMPUTE_PRIMAL type round their label from the state after the receives
 
@@ -165,6 +169,7 @@ struct ChainPlan {
 };
 // records one workgroup of the packed kernels takes (256 threads / lanes per record)
 constexpr int GENERIC_BLOCK_RECORDS = 4, SMALL_BLOCK_RECORDS = 64;   // sweep_generic_kernel<64> / <1> (kernels.hip asserts them)
+constexpr int BIG_BLOCK_RECORDS = 4;          // sweep_dense_big_kernel: one wave per record (kernels.hip asserts it)
 constexpr int kc_block_records(int kclass) {
   if (kclass == KC_GENERIC) return GENERIC_BLOCK_RECORDS;
   if (kclass == KC_SMALL) return SMALL_BLOCK_RECORDS;

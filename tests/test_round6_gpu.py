@@ -196,3 +196,63 @@ def test_wide_grids_joined_launch_geometry_against_the_oracle(H, W, want, capfd,
             assert "reach further than the Infinity Cache window" in err, err[-600:]
     finally:
         e.close()
+
+
+# ---- more than 32 labels: the streaming dense class with LDS sized by the launch's label counts --------------------------------------
+@pytest.mark.parametrize("L,H,W", [(33, 12, 14), (40, 9, 11), (64, 10, 9), (65, 5, 6), (130, 6, 7), (300, 3, 4)])
+def test_streaming_class_every_lds_size_against_the_oracle(L, H, W):
+    """33 ... 512 labels (class dense_big: one wave per unary, record and op fields as scalars, tables streamed in 16-row blocks): the
+    LDS of a wave holds three vectors of the launch's largest label count rounded up to 64 — every size class, both orders, two
+    weight modes and the residual send rule against the oracle bit for bit"""
+    import numpy as np
+    from lp_mp_amd import engine as E, model as M, synthetic as S
+    from oracle.binding import Oracle
+    e = E.Engine(0)
+    try:
+        for order in ("colour_major", "row_major"):
+            m = S.grid_model(H, W, L, order=order, seed=L)
+            o = Oracle(m)
+            e.upload(m)
+            for rtype in (0, 1):
+                o.set_reparametrization_type(rtype); e.set_reparametrization_type(rtype)
+                for mode in (M.REPAM_ANISOTROPIC, M.REPAM_DAMPED_UNIFORM):
+                    o.set_reparametrization(mode); e.set_reparametrization(mode)
+                    assert list(e.plan.schedule_classes(M.FORWARD, mode)) == ["dense_big"]
+                    for n in (1, 3):
+                        o.ComputePass(n); e.compute_pass(n)
+                        assert np.array_equal(e.download_duals(), o.duals()), (L, order, rtype, mode, n)
+                    assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+    finally:
+        e.close()
+
+
+def test_ragged_label_counts_in_one_launch_of_the_streaming_class():
+    """variables with 34 ... 90 labels in one model (rectangular tables): the launch's LDS is sized by its largest label count"""
+    import numpy as np
+    from lp_mp_amd import engine as E, model as M
+    from oracle.binding import Oracle
+    rng = np.random.default_rng(5)
+    n = 40
+    labels = rng.integers(34, 91, n)
+    from lp_mp_amd import synthetic as S
+    b = M.ModelBuilder(2, S.mrf_mtypes())
+    u = [int(b.add_vector_factors(0, rng.random((1, int(l))))[0]) for l in labels]
+    for i in range(n - 1):
+        for j in (i + 1, i + 7):
+            if j >= n:
+                continue
+            p = int(b.add_dense_pairwise(1, rng.random((1, int(labels[i]), int(labels[j]))))[0])
+            b.add_messages(0, u[i], p); b.add_messages(1, u[j], p)
+            b.add_relations(u[i], p); b.add_relations(p, u[j])
+    m = b.finish()
+    o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    e = E.Engine(0)
+    try:
+        e.upload(m); e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        assert "dense_big" in list(e.plan.schedule_classes(M.FORWARD, M.REPAM_ANISOTROPIC))
+        for k in (1, 2, 4):
+            o.ComputePass(k); e.compute_pass(k)
+            assert np.array_equal(e.download_duals(), o.duals())
+        assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+    finally:
+        e.close()
