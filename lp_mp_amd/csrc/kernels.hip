@@ -2283,6 +2283,11 @@ __device__ __forceinline__ void dense_big_body(const UpdRec* __restrict__ recs, 
     double* ms = dual + op.peer_dual + (side == 0 ? 0 : R);
     const double* mo = dual + op.peer_dual + (side == 0 ? R : 0);
     const int Lo = side == 0 ? C : R;
+    // the own side m_s is requested together with m_o (round 6: it used to be loaded after the table had been reduced — one more
+    // exposed round trip per receive; one or two values per lane up to 128 labels, later ones are loaded where they are needed)
+    double ms_pre[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ms_pre[j] = lane + 64 * j < Lr ? ld_dual<A>(ms + lane + 64 * j) : 0.0;
     for (int i = lane; i < Lo; i += 64) S.mo[i] = ld_dual<A>(mo + i);
     wave_sync();
     if (((op.info >> 8) & 15) == LPMP_F_PAIRWISE_POTTS) {
@@ -2338,8 +2343,8 @@ __device__ __forceinline__ void dense_big_body(const UpdRec* __restrict__ recs, 
     }
     wave_sync();
     double pb = LPMP_INF;                              // peer's bound after this receive
-    for (int i = lane; i < Lr; i += 64) {
-      const double msv = ld_dual<A>(ms + i), qv = S.q[i];
+    for (int i = lane, j = 0; i < Lr; i += 64, ++j) {
+      const double msv = j == 0 ? ms_pre[0] : j == 1 ? ms_pre[1] : ld_dual<A>(ms + i), qv = S.q[i];
       const double delta = msv + qv;                   // omega = 1: delta = min-marginal
       S.theta[i] += delta;
       const double mn = msv - delta;
@@ -2389,8 +2394,9 @@ __device__ __forceinline__ void dense_big_body(const UpdRec* __restrict__ recs, 
   ob = wave_min(ob);
   if (lane == 0) st_lb<A>(lb + rec.factor, ob);
 }
+// (five waves per SIMD: the body needs 96-101 VGPRs depending on small things, and the kernel is bound by round trips per wave)
 template <bool NT>
-__global__ void __launch_bounds__(64 * BIG_WAVES)
+__global__ void __launch_bounds__(64 * BIG_WAVES, 5)
 sweep_dense_big_kernel(const UpdRec* __restrict__ recs, const Op* __restrict__ ops, double* __restrict__ dual,
                        const double* __restrict__ cdata, double* __restrict__ lb, int32_t* __restrict__ primal,
                        int64_t first, int64_t count, int flags) {

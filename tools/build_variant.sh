@@ -8,5 +8,5 @@ NAME=$1; shift
 cd "$(dirname "$0")/../lp_mp_amd/csrc"
 mkdir -p ../../build/exp
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-strict-aliasing -Wno-unused-function -DLPMP_EXPERIMENT_BUILD "$@" \
-  -o ../../build/exp/liblpmp_engine_$NAME.so kernels.hip engine.cpp plan.cpp boundary.hip
+  -o ../../build/exp/liblpmp_engine_$NAME.so kernels.hip engine.cpp plan.cpp boundary.hip graph.cpp
 echo build/exp/liblpmp_engine_$NAME.so
