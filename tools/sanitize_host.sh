@@ -12,7 +12,7 @@ FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -
 RT=$(dirname "$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)")
 FILES="tests/test_plan_host.py tests/test_graph_host.py tests/test_partitioners.py tests/test_lockstep.py tests/test_overlap.py tests/test_multi_gpu.py tests/test_lp_mirror.py tests/test_bench_contract.py tests/test_oracle_ref.py"
 {
-echo "# Sanitizer runs of the HOST side of the engine (round 5; CPU container, no GPU call), sources of $(git rev-parse --short HEAD) + working tree"
+echo "# Sanitizer runs of the HOST side of the engine (round 6; CPU container, no GPU call), sources of $(git rev-parse --short HEAD) + working tree"
 echo "## AddressSanitizer + UndefinedBehaviorSanitizer"
 ( cd lp_mp_amd/csrc && hipcc $FLAGS -fsanitize=address,undefined -o ../../build/exp/liblpmp_engine_asan.so $SRC ) 2>&1 | tail -3
 LD_PRELOAD=$RT/libclang_rt.asan-x86_64.so ASAN_OPTIONS=detect_leaks=0 LPMP_ENGINE_SO=$PWD/build/exp/liblpmp_engine_asan.so \
