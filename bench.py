@@ -784,7 +784,9 @@ def main():
         idents, backend = rendezvous(args, torch, dist, identity, rank, world)
         distinct = sorted(set(idents))
         shared_device = len(distinct) < world
-        launch = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "ranks_seen": dist.get_world_size(),
+        dev_coll = backend != "nccl" and bool(os.environ.get("LPMP_DIST_DEVICE_COLLECTIVES"))   # (multi_gpu.DistComm: no staging through the host)
+        launch = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend + (" (device tensors handed to the backend)" if dev_coll else ""),
+                  "exchange_buffers": "device" if backend == "nccl" or dev_coll else "staged through the host", "ranks_seen": dist.get_world_size(),
                   "devices": [distinct.index(x) for x in idents], "device_identities": idents, "physical_devices": len(distinct),
                   "devices_visible": n_dev, "rendezvous_timeout_s": args.rendezvous_timeout,
                   "launcher": "bench.py (self-launched ranks)" if os.environ.get("LPMP_BENCH_SELF_LAUNCHED") else "external (torch.distributed.run)"}

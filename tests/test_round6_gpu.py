@@ -58,7 +58,8 @@ def test_two_processes_exchange_device_tensors_plain_and_overlapped(tmp_path):
     # C5 miniature in lock step, 2 ranks: the state of BOTH ranks bit-identical to the oracle fixture, plain program ...
     c5 = ["--gpus", "2", "--workload", "c5", "--c5-small", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
     d = _bench(c5, env)
-    assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["schedule"] == "lockstep" and d["overlap_exchange"] is False
+    assert d["n_gpus"] == 2 and d["backend"].startswith("gloo (device tensors") and d["launch"]["exchange_buffers"] == "device"
+    assert d["schedule"] == "lockstep" and d["overlap_exchange"] is False
     assert d["oracle_check"]["duals_bit_identical_to_oracle"] is True and abs(d["dual_bound_gap"]) <= 1e-12
     assert d["exchange_bytes_per_pass"]["max"] > 0 and d["exchange_post_ms_per_pass"]["max"] == 0
     plain_lb = d["lower_bound_after"]
