@@ -187,12 +187,13 @@ def test_random_mrfs_fast_kernels_multi_pass_calls_and_fused_custom_schedules(se
 
 
 def random_mrf_any_labels(rng, primal=False):
-    """unary / pairwise MRF where every variable has its own label count (1..40): rectangular dense tables between
+    """unary / pairwise MRF where every variable has its own label count (1..130): rectangular dense tables between
     any two variables, Potts between variables of equal count -> the run-time-dims kernel classes of every padded
     width, next to exact classes and (above 32 labels, or for variables with both kinds of edges) the generic one"""
     from lp_mp_amd import synthetic as S
     n = int(rng.integers(6, 30))
-    pool = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 11, 16, 21, 27, 32, 40], size=int(rng.integers(1, 5)))
+    # (round 6: label counts above 32 of every LDS size class of the streaming kernel — 33 ... 64, 65 ... 128, 129 ... 192)
+    pool = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 11, 16, 21, 27, 32, 40, 33, 48, 64, 65, 100, 130], size=int(rng.integers(1, 5)))
     kind = rng.choice(["dense", "potts", "mixed"])
     labels = rng.choice(pool if kind != "potts" else pool[:1], size=n)
     b = M.ModelBuilder(2, S.mrf_mtypes(), [1, 0] if primal else None)
