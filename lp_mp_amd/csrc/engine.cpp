@@ -425,6 +425,12 @@ struct lpmp_engine {
   bool deep_note_given = false;                   // the one-line note about a schedule of many levels was printed
   int rot_bands = 0, rot_lag = 3, rot_depth = 4;   // skewed ticket order (0 bands: from the table bytes per step); DESIGN.md 6 has the sweep
   bool rot_lag_set = false, rot_depth_set = false; // LPMP_ROT_LAG / LPMP_ROT_DEPTH given: used as they are; else from the model (rot_geometry)
+  // tiled ticket order of the joined passes (rotation_chain): LPMP_ROT_TILES=T forces tiles of T blocks per step, =0 forbids them;
+  // unset: the engine's own choice (tiles of 1024 blocks where the band order is down to depth 2 or does not fit at all)
+  int rot_tiles = 0; bool rot_tiles_set = false;
+  // delayed[sd]: share of a steady-state step's blocks that run later than their own tile's phase, sd steps into a group
+  struct TileSet { bool built = false; int T = 0; std::vector<int32_t> w, k; int32_t n = 0; double radius = 0; double delayed[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+  TileSet rot_tile_set[LPMP_REPAM_COUNT];
   void release_rot_chains() {
     for (auto& m : rot_chain) {
       for (auto& kv : m) {
@@ -434,6 +440,7 @@ struct lpmp_engine {
       m.clear();
     }
     rot_cache_bytes = 0;
+    for (auto& t : rot_tile_set) t = TileSet();
   }
   bool timing = false;
   ClassTiming ct[KC_COUNT];
@@ -766,6 +773,7 @@ void ensure_pass_chain_plan(lpmp_engine* e, int mode) {
     e->rot_cache_bytes -= std::min(e->rot_cache_bytes, kv.second.dev_bytes);
   }
   e->rot_chain[mode].clear();
+  e->rot_tile_set[mode] = lpmp_engine::TileSet();
   upload_schedule(e->plan->pass_cache[mode], e->sched_pass[mode], e->stream);
   Schedule& h = e->plan->pass_cache[mode];
   h.recs.clear(); h.recs.shrink_to_fit(); h.ops.clear(); h.ops.shrink_to_fit(); h.packets.clear(); h.packets.shrink_to_fit();
@@ -973,8 +981,102 @@ static RotGeometry rot_geometry(const lpmp_engine* e, const RotationInfo& ri) {
   g.fits = e->rot_depth_set || e->rot_lag_set || need * g.depth <= 1.25 * WINDOW_MAX;
   return g;
 }
+// Tiled ticket order (round 6, experiment: LPMP_ROT_TILES).  The band order walks a step's block list in memory order, so its lag has
+// to cover how far ahead a block's predecessors lie IN THAT LIST — a grid row, a z-slice of a 3-D grid — whatever the distance in
+// the graph is.  Tiles are compact in the GRAPH instead: sets of about T blocks of either alternating step template (W and K; H and
+// T update K's factors), grown breadth-first over the block dependencies.  Inside a group of `depth` steps a block runs in the phase
+// of its own tile or of the latest tile one of its predecessors ran in, whichever is later — the skew of a time-tiled stencil
+// without any geometry: valid by construction, a table is read again by the next step T blocks later, and nothing grows with the
+// width of the grid.
+static int32_t grow_tiles(const RotationInfo& ri, int64_t T, std::vector<int32_t>& tile_w, std::vector<int32_t>& tile_k, double& radius) {
+  const int64_t nw = ri.t[1].nb, nk = ri.t[2].nb, nn = nw + nk;
+  std::vector<int64_t> deg((size_t)nn + 1, 0);
+  auto each_edge = [&](auto f) {      // W block j <-> K block p (kind 2: W after K), K block j <-> W block p (kind 3: K after W)
+    for (int kind = 2; kind <= 3; ++kind) {
+      const int64_t nb = kind == 2 ? nw : nk;
+      for (int64_t j = 0; j < nb; ++j)
+        for (int64_t q = ri.off[kind][j]; q < ri.off[kind][j + 1]; ++q)
+          if (ri.delta[kind][q] == 1) { const int64_t a = kind == 2 ? j : nw + j, b = kind == 2 ? nw + ri.block[kind][q] : ri.block[kind][q]; f(a, b); }
+    }
+  };
+  each_edge([&](int64_t a, int64_t b) { ++deg[a + 1]; ++deg[b + 1]; });
+  for (int64_t i = 0; i < nn; ++i) deg[i + 1] += deg[i];
+  std::vector<int32_t> adj((size_t)deg[nn]);
+  { std::vector<int64_t> cur(deg.begin(), deg.end() - 1); each_edge([&](int64_t a, int64_t b) { adj[cur[a]++] = (int32_t)b; adj[cur[b]++] = (int32_t)a; }); }
+  std::vector<int32_t> tile((size_t)nn, -1), queue, hops;
+  int32_t n_tiles = 0;
+  double radius_sum = 0; int64_t full_tiles = 0;    // hops from the seed to the last block of a tile that reached its size
+  for (int64_t seed0 = 0; seed0 < std::max(nw, nk); ++seed0)
+    for (int64_t seed : {seed0 < nw ? seed0 : (int64_t)-1, seed0 < nk ? nw + seed0 : (int64_t)-1}) {
+      if (seed < 0 || tile[seed] >= 0) continue;
+      queue.assign(1, (int32_t)seed); hops.assign(1, 0);
+      int64_t taken = 0; int32_t last_hops = 0;
+      for (size_t head = 0; head < queue.size() && taken < 2 * T; ++head) {
+        const int32_t v = queue[head];
+        if (tile[v] >= 0) continue;
+        tile[v] = n_tiles; ++taken; last_hops = hops[head];
+        for (int64_t q = deg[v]; q < deg[v + 1]; ++q) if (tile[adj[q]] < 0) { queue.push_back(adj[q]); hops.push_back(hops[head] + 1); }
+      }
+      if (taken >= 2 * T) { radius_sum += last_hops; ++full_tiles; }
+      ++n_tiles;
+    }
+  radius = full_tiles ? radius_sum / (double)full_tiles : 0.0;
+  tile_w.assign(tile.begin(), tile.begin() + nw);
+  tile_k.assign(tile.begin() + nw, tile.end());
+  return n_tiles;
+}
+
+// how much of a tile is left after sd steps: phases of a steady-state group (K, W, K, W, ...) of 8 steps, share of delayed blocks per step
+static void tile_delays(const RotationInfo& ri, const std::vector<int32_t>& tile_w, const std::vector<int32_t>& tile_k, double (&delayed)[8]) {
+  std::vector<int32_t> ph[3];
+  for (int sd = 0; sd < 8; ++sd) {
+    const int kd = sd % 2 == 0 ? 3 : 2;
+    const std::vector<int32_t>& tl = sd % 2 == 0 ? tile_k : tile_w;
+    const int64_t nb = (int64_t)tl.size();
+    std::vector<int32_t>& cur = ph[sd % 3];
+    cur.resize((size_t)nb);
+    int64_t late = 0;
+    for (int64_t j = 0; j < nb; ++j) {
+      int32_t p = tl[j];
+      if (sd > 0)
+        for (int64_t q = ri.off[kd][j]; q < ri.off[kd][j + 1]; ++q) {
+          const int dl = ri.delta[kd][q];
+          if (dl <= sd) p = std::max(p, ph[(sd - dl) % 3][ri.block[kd][q]]);
+        }
+      cur[j] = p;
+      late += p != tl[j];
+    }
+    delayed[sd] = nb ? (double)late / (double)nb : 0.0;
+  }
+}
+
 lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n_call) {
-  const RotGeometry geo = rot_geometry(e, e->plan->rot[mode]);
+  RotGeometry geo = rot_geometry(e, e->plan->rot[mode]);
+  // Band order or tiled order?  Measured (profiles/r06_tile_sweep.txt, r06_blocked_pass_probe_tiles_*.txt; tiles of 1024 blocks): where
+  // the band order runs at depth 4 it is as good or better (1024^2: 5.09 against 5.31 ms per pass, 2048^2: 21.35 / 21.26); where
+  // the reach of the dependencies has pushed it to depth 2 or out of the cache, tiles win — 3072^2: 49.5 -> 47.7 ms, 256 x 4096: 5.89
+  // -> 5.44, 128 x 8192 (no band order fits: 6.95 launch by launch) -> 5.37, 3-D grids 96^3 x 32 labels: 8.88 -> 7.27, 128^3 x 16
+  // labels: 6.23 -> 5.72.  Calls of fewer than 4 passes keep the band order (single passes: 9.0 against 6.8 ms at 1024^2).
+  // Depth: a block whose predecessor ran in a later tile is delayed to that tile's phase — one more shell of every tile per step: the
+  // deepest even depth (up to 8) whose LAST step still runs at least half of its blocks in their own tile's phase (tile_delays: the
+  // flat tiles of a 2-D grid lose about 4 % per step: depth 8; the balls of a 3-D grid 16 %: depth 4 — measured there: depth 2 / 4 /
+  // 6 / 8 = 7.9 / 7.27 / 7.28 / 7.6 ms per pass at 96^3 x 32 labels, 5.92 / 5.72 / - / 7.24 at 128^3 x 16).
+  bool tiled = false;
+  lpmp_engine::TileSet* ts = nullptr;
+  {
+    const RotationInfo& ri0 = e->plan->rot[mode];
+    const bool worthwhile = ri0.valid && kc_is_dense(ri0.kclass) && !kc_is_var(ri0.kclass) &&
+                            (e->rot_bands > 0 || (e->model_big && ri0.t[1].bytes >= ((int64_t)64 << 20)));
+    const int want = !worthwhile || ri0.t[0].nb != ri0.t[2].nb || ri0.t[3].nb != ri0.t[2].nb ? 0
+                   : e->rot_tiles_set ? e->rot_tiles
+                   : (e->rot_bands <= 0 && (geo.depth != 4 || !geo.fits) && n_call >= 4 ? 1024 : 0);
+    if (want > 0) {
+      ts = &e->rot_tile_set[mode];
+      if (!ts->built || ts->T != want) { ts->n = grow_tiles(ri0, want, ts->w, ts->k, ts->radius); tile_delays(ri0, ts->w, ts->k, ts->delayed); ts->T = want; ts->built = true; }
+      tiled = true;
+      if (!e->rot_depth_set) { geo.depth = 2; for (int d = 4; d <= 8; d += 2) if (ts->delayed[d - 1] <= 0.5) geo.depth = d; }
+    }
+  }
   const int depth = geo.depth;
   // template: groups 0, 1 (prologue), 2 (the period) and a tail as long as the call's: r = (2 n + 1) mod depth steps
   const int tail = depth % 2 == 0 ? (2 * n_call + 1) % depth : 0;
@@ -1033,14 +1135,61 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n_call) {
   // the fastest whatever the split (1024:3:4 5.09, 2048:4:6 5.03, 1536:3:6 5.09 ms per pass), 290 MB and more lose the
   // reuse (1024:3:5 5.67, 1024:3:6 6.37), lag 2 leaves the waiting workgroups less slack (1024:2:4 5.24)
   // (round 6: lag and depth follow the reach of the dependencies — rot_geometry above; C3 keeps 3 and 4)
-  if (!geo.fits) return no("a step's dependencies reach further than the Infinity Cache window can cover");
+  if (!geo.fits && !tiled) return no("a step's dependencies reach further than the Infinity Cache window can cover");
   const int bands = geo.bands;
+  static const std::vector<int32_t> no_tiles;
+  const std::vector<int32_t>& tile_w = tiled ? ts->w : no_tiles;
+  const std::vector<int32_t>& tile_k = tiled ? ts->k : no_tiles;
+  const int32_t n_tiles = tiled ? ts->n : 0;
+  if (tiled && verbose) std::fprintf(stderr, "lpmp:   %d tiles of about %d blocks per step, radius %.1f hops, delayed after 1 / 3 / 5 / 7 steps: %.2f / %.2f / %.2f / %.2f\n", n_tiles, ts->T, ts->radius,
+                                     ts->delayed[1], ts->delayed[3], ts->delayed[5], ts->delayed[7]);
   std::vector<int32_t> new_of((size_t)N), tk_launch((size_t)N), tk_block((size_t)N);
   std::vector<int64_t> group_begin;                                 // first ticket of every group of `depth` steps
   auto band_begin = [](int64_t b, int64_t nb, int64_t bands_) { return (b * nb + bands_ - 1) / bands_; };   // first block of band b
   for (int lag = geo.lag; lag <= std::max(16, 2 * geo.lag); ++lag) {
     int64_t at = 0;
     group_begin.clear();
+    if (tiled) {
+      // phase of (step of the group, block) = max(own tile, phases of its predecessors inside the group); tickets by (phase, step, block)
+      std::vector<int32_t> ph[3];
+      std::vector<int64_t> bucket;
+      std::vector<std::vector<int32_t>> key_of((size_t)depth);
+      for (int s0 = 0; s0 < n_steps; s0 += depth) {
+        group_begin.push_back(at);
+        const int d = std::min(depth, n_steps - s0);
+        bucket.assign((size_t)n_tiles * d + 1, 0);
+        for (int sd = 0; sd < d; ++sd) {
+          const int s = s0 + sd;
+          const int64_t nb = ri.t[tmpl[s]].nb;
+          const std::vector<int32_t>& tl = tmpl[s] == 1 ? tile_w : tile_k;
+          std::vector<int32_t>& cur = ph[sd % 3];
+          cur.resize((size_t)nb);
+          key_of[sd].resize((size_t)nb);
+          const int kd = kind[s];
+          for (int64_t j = 0; j < nb; ++j) {
+            int32_t p = tl[j];
+            if (kd >= 0)
+              for (int64_t q = ri.off[kd][j]; q < ri.off[kd][j + 1]; ++q) {
+                const int dl = ri.delta[kd][q];
+                if (dl <= sd) p = std::max(p, ph[(sd - dl) % 3][ri.block[kd][q]]);
+              }
+            cur[j] = p;
+            key_of[sd][j] = p * d + sd;
+            ++bucket[(size_t)key_of[sd][j] + 1];
+          }
+        }
+        for (size_t k = 0; k + 1 < bucket.size(); ++k) bucket[k + 1] += bucket[k];
+        for (int sd = 0; sd < d; ++sd) {
+          const int s = s0 + sd;
+          const int64_t nb = ri.t[tmpl[s]].nb;
+          for (int64_t j = 0; j < nb; ++j) {
+            const int64_t t = at + bucket[key_of[sd][j]]++;
+            new_of[base[s] + j] = (int32_t)t; tk_launch[t] = s; tk_block[t] = (int32_t)j;
+          }
+        }
+        for (int sd = 0; sd < d; ++sd) at += ri.t[tmpl[s0 + sd]].nb;
+      }
+    } else
     for (int s0 = 0; s0 < n_steps; s0 += depth) {
       group_begin.push_back(at);
       const int d = std::min(depth, n_steps - s0);
@@ -1072,6 +1221,7 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n_call) {
           }
     }
     if (verbose) std::fprintf(stderr, "lpmp:   checked after %.0f ms (%s)\n", since(), ok ? "valid" : "a dependency points forward");
+    if (!ok && tiled) { tiled = false; if (!geo.fits) return no("the tiled order broke a dependency and the band order does not fit"); --lag; continue; }
     if (!ok) continue;
     // dependencies in ticket order
     std::vector<int32_t> dep_off((size_t)N + 1, 0);
@@ -1159,7 +1309,7 @@ lpmp_engine::RotChain* rotation_chain(lpmp_engine* e, int mode, int n_call) {
     rc.n_steps = n_steps; rc.periodic = periodic; rc.n_tmpl = n; rc.depth = depth; rc.ring = ring;
     if (verbose)
       std::fprintf(stderr, "lpmp: %d passes as one launch%s: %lld tickets, %d bands, lag %d, depth %d (reach %.1f MB of %.1f MB per band); built and uploaded in %.0f ms\n", n,
-                   periodic ? " (periodic template)" : "", (long long)N, bands, lag, depth, geo.reach_bytes / 1e6, (double)ri.t[1].bytes / bands / 1e6, since());
+                   periodic ? (tiled ? " (periodic template, tiled order)" : " (periodic template)") : tiled ? " (tiled order)" : "", (long long)N, bands, lag, depth, geo.reach_bytes / 1e6, (double)ri.t[1].bytes / bands / 1e6, since());
     return &rc;
   }
   return no("no band order keeps the dependencies backwards");
@@ -1464,6 +1614,7 @@ int lpmp_create(int device, lpmp_engine** out) {
     if (const char* v = std::getenv("LPMP_ROT_BANDS")) e->rot_bands = std::atoi(v);
     if (const char* v = std::getenv("LPMP_ROT_LAG")) { e->rot_lag = std::max(1, std::atoi(v)); e->rot_lag_set = true; }
     if (const char* v = std::getenv("LPMP_ROT_DEPTH")) { e->rot_depth = std::max(1, std::atoi(v)); e->rot_depth_set = true; }
+    if (const char* v = std::getenv("LPMP_ROT_TILES")) { e->rot_tiles = std::max(0, std::atoi(v)); e->rot_tiles_set = true; }
     if (const char* v = std::getenv("LPMP_CHAIN_CACHE_MB")) e->rot_cache_limit = (size_t)std::max(1, std::atoi(v)) << 20;
     if (const char* v = std::getenv("LPMP_ROWS_LAYOUT")) e->want_rows = std::atoi(v) != 0;                             // as lpmp_set_rows_layout
     if (const char* v = std::getenv("LPMP_SPECULATION")) e->spec.max_depth = std::min(32, std::max(0, std::atoi(v)));   // as lpmp_set_speculation

@@ -167,8 +167,9 @@ def test_forbidden_label_pairs_through_the_joined_pass_launch():
 def test_wide_grids_joined_launch_geometry_against_the_oracle(H, W, want, capfd, monkeypatch):
     """HBM-sized colour-major grids whose ROWS are long (80 MB and 320 MB of a step's algorithmic bytes per grid row of one colour; the
     headline grid: 20 MB): the engine chooses lag and depth of the skewed ticket order from that reach (engine.cpp rot_geometry) —
-    depth 2 and a lag that covers one row plus slack for the 4096-wide grid, no persistent launch at all when even that window cannot
-    sit in the Infinity Cache (16384 wide) — and the duals equal the oracle's bit for bit either way"""
+    depth 2 and a lag that covers one row plus slack for the 4096-wide grid, no band order at all when even that window cannot sit in
+    the Infinity Cache (16384 wide); calls of 4 and more passes take the tiled order there — and the duals equal the oracle's bit for
+    bit every way"""
     import numpy as np
     from lp_mp_amd import engine as E, model as M, synthetic as S
     from oracle.binding import Oracle
@@ -191,10 +192,13 @@ def test_wide_grids_joined_launch_geometry_against_the_oracle(H, W, want, capfd,
         assert np.array_equal(e.download_duals(), o.duals())
         assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * abs(o.LowerBound())
         err = capfd.readouterr().err
+        # the 9-pass call: rows this long take the TILED ticket order (tiles grown over the block dependencies: nothing in it depends on
+        # the width of the grid), whether or not a band order would still fit
+        assert "tiled order" in err, err[-800:]
         if want == "chain":
-            assert "depth 2" in err and "periodic template" in err, err[-600:]
+            assert "depth 2" in err, err[-800:]                      # the 3-pass call: band order, depth 2
         else:
-            assert "reach further than the Infinity Cache window" in err, err[-600:]
+            assert "reach further than the Infinity Cache window" in err, err[-800:]   # the 3-pass call: one launch per step
     finally:
         e.close()
 
@@ -254,6 +258,34 @@ def test_ragged_label_counts_in_one_launch_of_the_streaming_class():
         for k in (1, 2, 4):
             o.ComputePass(k); e.compute_pass(k)
             assert np.array_equal(e.download_duals(), o.duals())
+        assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
+    finally:
+        e.close()
+
+
+# ---- tiled ticket order of the joined-pass launch (experiment, LPMP_ROT_TILES) -------------------------------------------------------
+@pytest.mark.parametrize("pairwise,L,H,W", [("dense", 32, 40, 36), ("dense", 8, 60, 70), ("dense", 16, 33, 31)])
+@pytest.mark.parametrize("tiles,depth", [(8, 4), (3, 2), (20, 6), (1, 4)])
+def test_joined_passes_in_the_tiled_order(pairwise, L, H, W, tiles, depth, monkeypatch):
+    """the joined-pass launch with its tickets in the TILED order (blocks grouped by tiles grown over the block dependencies; inside a
+    group of `depth` steps a block runs in the phase of its tile or of its latest predecessor's): forced on small models, every
+    pass count, against the oracle bit for bit"""
+    import numpy as np
+    from lp_mp_amd import engine as E, model as M, synthetic as S
+    from oracle.binding import Oracle
+    monkeypatch.setenv("LPMP_ROT_BANDS", "4"); monkeypatch.setenv("LPMP_ROT_TILES", str(tiles)); monkeypatch.setenv("LPMP_ROT_DEPTH", str(depth))
+    monkeypatch.setenv("LPMP_ROT_VERBOSE", "1")
+    m = S.grid_model(H, W, L, pairwise=pairwise, order="colour_major", seed=L + tiles)
+    o = Oracle(m); o.set_reparametrization(M.REPAM_ANISOTROPIC)
+    e = E.Engine(0)
+    try:
+        e.upload(m); e.set_reparametrization(M.REPAM_ANISOTROPIC)
+        for n in (1, 5, 2, 9, 70, 12, 31, 13):
+            e.enable_kernel_timing(True)
+            e.compute_pass(n); o.ComputePass(n)
+            kt = e.kernel_timing(); e.reset_kernel_timing(); e.enable_kernel_timing(False)
+            assert all(v["kernel"].startswith("chain_") for v in kt.values()), kt
+            assert np.array_equal(e.download_duals(), o.duals()), (n,)
         assert abs(e.lower_bound() - o.LowerBound()) <= 1e-9 * max(1.0, abs(o.LowerBound()))
     finally:
         e.close()

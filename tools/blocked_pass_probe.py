@@ -1,6 +1,7 @@
 """Joined passes as one persistent chain launch with the Infinity-Cache ticket order: ms per pass on C3 for several
 (bands, lag, depth) against one launch per step.  python tools/blocked_pass_probe.py [grid] [passes] [configs...]
-config = bands:lag:depth (0 bands = automatic), or "off" """
+config = bands:lag:depth (0 bands = automatic; lag / depth "a" = the engine's own choice), tT:depth (tiled order, T blocks per tile),
+or "off" """
 import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -35,9 +36,14 @@ for c in cfgs:
     env = dict(os.environ, LPMP_ROT_VERBOSE="1")
     if c == "off":
         env["LPMP_NO_BLOCKED_PASSES"] = "1"
+    elif c.startswith("t"):
+        t, d = c[1:].split(":")
+        env.update(LPMP_ROT_TILES=t, LPMP_ROT_DEPTH=d)
     else:
         b, l, d = c.split(":")
-        env.update(LPMP_ROT_BANDS=b, LPMP_ROT_LAG=l, LPMP_ROT_DEPTH=d)
+        env.update(LPMP_ROT_BANDS=b)
+        if l != "a": env.update(LPMP_ROT_LAG=l)
+        if d != "a": env.update(LPMP_ROT_DEPTH=d)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     out = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": r.stderr[-400:]}
     out["chain"] = [l[6:] for l in r.stderr.splitlines() if l.startswith("lpmp: ")]
