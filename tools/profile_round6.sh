@@ -12,11 +12,11 @@ export TMPDIR=/tmp
 parts=${*:-counters probes solver sizes ranks}
 for part in $parts; do case $part in
 counters)
-  bash tools/profile_round.sh r06b --steps 20 --warmup 5
-  bash tools/profile_round.sh r06b_c4 --workload c4 --steps 10 --warmup 3
-  timeout 600 python bench.py --workload c5 --steps 10 --warmup 3 > gpurun_out/r06b_c5_bench_c5_default.json 2>/dev/null
-  timeout 600 python bench.py --workload c5 --c5-order colour_major --steps 20 --warmup 5 > gpurun_out/r06b_c5_bench_c5_colour_major.json 2>/dev/null
-  timeout 600 python bench.py --workload c5 --c5-order suggested --steps 20 --warmup 5 > gpurun_out/r06b_c5_bench_c5_suggested.json 2>/dev/null
+  bash tools/profile_round.sh r06c --steps 20 --warmup 5
+  bash tools/profile_round.sh r06c_c4 --workload c4 --steps 10 --warmup 3
+  timeout 600 python bench.py --workload c5 --steps 10 --warmup 3 > gpurun_out/r06c_c5_bench_c5_default.json 2>/dev/null
+  timeout 600 python bench.py --workload c5 --c5-order colour_major --steps 20 --warmup 5 > gpurun_out/r06c_c5_bench_c5_colour_major.json 2>/dev/null
+  timeout 600 python bench.py --workload c5 --c5-order suggested --steps 20 --warmup 5 > gpurun_out/r06c_c5_bench_c5_suggested.json 2>/dev/null
   timeout 600 python bench.py --grid 512 --labels 8 --pairwise potts --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r06_bench_c2.json 2>/dev/null
   timeout 600 python bench.py --order row_major --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r06_bench_c3_row_major.json 2> gpurun_out/r06_bench_c3_row_major.err
   ;;
@@ -41,6 +41,7 @@ sizes)
   for g in 1536 2048 3072; do LPMP_ROT_VERBOSE=1 timeout 900 python bench.py --grid $g --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r06_bench_c3_grid${g}.json 2> gpurun_out/r06_bench_c3_grid${g}.err; done
   for cfg in "1024 33" "1024 40" "1024 48" "1024 64" "768 96" "512 128" "256 256" "2048 16"; do set -- $cfg
     timeout 900 python bench.py --grid $1 --labels $2 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r06_bench_c3shape_grid$1_L$2.json 2>/dev/null; done
+  bash tools/tile_sweep.sh > gpurun_out/r06_tile_sweep.txt 2>&1
   timeout 1200 python bench.py --workload c4 --c4-nodes 8000000 --c4-edges 40000000 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/r06_bench_c4_x4_8M_40M.json 2>/dev/null
   for f in gpurun_out/r06_bench_c3_grid*.json gpurun_out/r06_bench_c3shape_*.json gpurun_out/r06_bench_c4_x4_8M_40M.json; do python - "$f" <<'PY'
 import json, sys
