@@ -962,7 +962,8 @@ constexpr int ROT_EXPLICIT_MAX = 7;
 // (window 336 MB: the reuse goes); 3072^2 (row 60 MB) 65.4 with lag 3 / depth 4 (57.2 launch by launch), 50.3 with lag 6 / depth 2
 // (46 = nine times; depth 3 and 4 with lags 5-6: 50.2-52.1).  So: a slack of 700 tickets behind the reach; depth 4 while
 // (reach + slack) * 4 stays under 275 MiB, else 2 (half of the second reads instead of three quarters, but they hit); the lag
-// stretched to a window of 200 MiB where the reach leaves room; no chain at all when even depth 2 cannot hold the window.
+// stretched to a window of 200 MiB where the reach leaves room; `fits` = false when even depth 2 cannot hold the window (then the
+// tiled order below, or one launch per step).
 struct RotGeometry { int bands = 1, lag = 3, depth = 4; bool fits = true; double reach_bytes = 0; };
 static RotGeometry rot_geometry(const lpmp_engine* e, const RotationInfo& ri) {
   RotGeometry g;
@@ -981,7 +982,7 @@ static RotGeometry rot_geometry(const lpmp_engine* e, const RotationInfo& ri) {
   g.fits = e->rot_depth_set || e->rot_lag_set || need * g.depth <= 1.25 * WINDOW_MAX;
   return g;
 }
-// Tiled ticket order (round 6, experiment: LPMP_ROT_TILES).  The band order walks a step's block list in memory order, so its lag has
+// Tiled ticket order (round 6; chosen in rotation_chain below, LPMP_ROT_TILES overrides).  The band order walks a step's block list in memory order, so its lag has
 // to cover how far ahead a block's predecessors lie IN THAT LIST — a grid row, a z-slice of a 3-D grid — whatever the distance in
 // the graph is.  Tiles are compact in the GRAPH instead: sets of about T blocks of either alternating step template (W and K; H and
 // T update K's factors), grown breadth-first over the block dependencies.  Inside a group of `depth` steps a block runs in the phase

@@ -12,11 +12,11 @@ export TMPDIR=/tmp
 parts=${*:-counters probes solver sizes ranks}
 for part in $parts; do case $part in
 counters)
-  bash tools/profile_round.sh r06c --steps 20 --warmup 5
-  bash tools/profile_round.sh r06c_c4 --workload c4 --steps 10 --warmup 3
-  timeout 600 python bench.py --workload c5 --steps 10 --warmup 3 > gpurun_out/r06c_c5_bench_c5_default.json 2>/dev/null
-  timeout 600 python bench.py --workload c5 --c5-order colour_major --steps 20 --warmup 5 > gpurun_out/r06c_c5_bench_c5_colour_major.json 2>/dev/null
-  timeout 600 python bench.py --workload c5 --c5-order suggested --steps 20 --warmup 5 > gpurun_out/r06c_c5_bench_c5_suggested.json 2>/dev/null
+  bash tools/profile_round.sh r06d --steps 20 --warmup 5
+  bash tools/profile_round.sh r06d_c4 --workload c4 --steps 10 --warmup 3
+  timeout 600 python bench.py --workload c5 --steps 10 --warmup 3 > gpurun_out/r06d_c5_bench_c5_default.json 2>/dev/null
+  timeout 600 python bench.py --workload c5 --c5-order colour_major --steps 20 --warmup 5 > gpurun_out/r06d_c5_bench_c5_colour_major.json 2>/dev/null
+  timeout 600 python bench.py --workload c5 --c5-order suggested --steps 20 --warmup 5 > gpurun_out/r06d_c5_bench_c5_suggested.json 2>/dev/null
   timeout 600 python bench.py --grid 512 --labels 8 --pairwise potts --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r06_bench_c2.json 2>/dev/null
   timeout 600 python bench.py --order row_major --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r06_bench_c3_row_major.json 2> gpurun_out/r06_bench_c3_row_major.err
   ;;
