@@ -1,8 +1,13 @@
-"""Round 6, on the GPU box: two PROCESSES hand DEVICE tensors to the collective backend — the code path of an RCCL run (device
-all-to-all-v; `--overlap-exchange`'s asynchronous exchange_begin / exchange_end) with real data between two ranks.  RCCL refuses two
-ranks on one device, so on the 1-GPU box the backend is gloo's own CUDA collectives (LPMP_DIST_DEVICE_COLLECTIVES=1: multi_gpu.DistComm
-stops staging through the host); everything above the backend — buffers, split sizes, stream ordering between the engine's kernels,
-pack / unpack and the collective — is what runs over RCCL."""
+"""Round 6, on the GPU box.
+* Two PROCESSES hand DEVICE tensors to the collective backend — the code path of an RCCL run (device all-to-all-v; `--overlap-exchange`'s
+  asynchronous exchange_begin / exchange_end) with real data between two ranks.  RCCL refuses two ranks on one device, so on the 1-GPU
+  box the backend is gloo's own CUDA collectives (LPMP_DIST_DEVICE_COLLECTIVES=1: multi_gpu.DistComm stops staging through the host);
+  everything above the backend — buffers, split sizes, stream ordering between the engine's kernels, pack / unpack and the
+  collective — is what runs over RCCL.
+* Hard constraints: +inf entries of pairwise tables, Potts differences of +inf.
+* The joined-pass launch away from the headline size: wide grids (lag and depth from the reach of the dependencies; the tiled ticket
+  order where no band order fits), the tiled order forced on small models.
+* More than 32 labels: every LDS size class of the streaming kernel, ragged label counts in one launch."""
 import json
 import os
 import subprocess
